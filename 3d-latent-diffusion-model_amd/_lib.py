@@ -1,0 +1,112 @@
+"""ctypes binding of libldm3d.so (C ABI: include/ldm3d.h).  Fails loudly: there is no fallback path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+LDM_MAX_LEVELS = 8
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libldm3d.so")
+
+
+class UNetCfg(C.Structure):
+    _fields_ = [("spatial_dims", C.c_int), ("in_channels", C.c_int), ("out_channels", C.c_int),
+                ("num_levels", C.c_int),
+                ("channels", C.c_int * LDM_MAX_LEVELS), ("attention_levels", C.c_int * LDM_MAX_LEVELS),
+                ("num_head_channels", C.c_int * LDM_MAX_LEVELS), ("num_res_blocks", C.c_int * LDM_MAX_LEVELS),
+                ("norm_num_groups", C.c_int), ("norm_eps", C.c_float)]
+
+
+class VaeCfg(C.Structure):
+    _fields_ = [("spatial_dims", C.c_int), ("in_channels", C.c_int), ("out_channels", C.c_int),
+                ("latent_channels", C.c_int), ("num_levels", C.c_int),
+                ("channels", C.c_int * LDM_MAX_LEVELS), ("num_res_blocks", C.c_int * LDM_MAX_LEVELS),
+                ("attention_levels", C.c_int * LDM_MAX_LEVELS),
+                ("norm_num_groups", C.c_int), ("norm_eps", C.c_float),
+                ("with_encoder_nonlocal_attn", C.c_int), ("with_decoder_nonlocal_attn", C.c_int)]
+
+
+# name -> (restype, argtypes); mirrors include/ldm3d.h one to one (tests/test_abi.py checks the header against it)
+_P = C.c_void_p
+_F = C.POINTER(C.c_float)
+SIGNATURES = {
+    "ldm_version": (C.c_int, []),
+    "ldm_last_error": (C.c_char_p, []),
+    "ldm_unet_create": (C.c_int, [C.POINTER(UNetCfg), C.POINTER(_P)]),
+    "ldm_vae_create": (C.c_int, [C.POINTER(VaeCfg), C.POINTER(_P)]),
+    "ldm_model_destroy": (None, [_P]),
+    "ldm_model_num_params": (C.c_int, [_P]),
+    "ldm_model_param_name": (C.c_char_p, [_P, C.c_int]),
+    "ldm_model_param_ndim": (C.c_int, [_P, C.c_int]),
+    "ldm_model_param_shape": (C.POINTER(C.c_int64), [_P, C.c_int]),
+    "ldm_model_load_param": (C.c_int, [_P, C.c_char_p, _P, C.c_size_t]),
+    "ldm_model_param_numel_total": (C.c_int64, [_P]),
+    "ldm_unet_workspace_bytes": (C.c_size_t, [_P, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "ldm_unet_forward": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   _P, C.c_size_t, _P]),
+    "ldm_vae_encode_workspace_bytes": (C.c_size_t, [_P, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "ldm_vae_decode_workspace_bytes": (C.c_size_t, [_P, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "ldm_vae_encode": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_size_t, _P]),
+    "ldm_vae_decode": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_size_t, _P]),
+    "ldm_ddpm_step": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
+                                C.c_float, C.c_int, _P]),
+    "ldm_ddim_step": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
+                                C.c_float, C.c_int, _P]),
+    "ldm_add_noise": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int64, _P]),
+    "ldm_scale": (C.c_int, [_P, _P, C.c_int64, C.c_float, _P]),
+    "ldm_op_conv3d": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P, _P, C.c_int, _P, C.c_int, _P, _P, _P, C.c_int, _P, _P, _P,
+                                C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                C.c_int, C.c_int, _P, C.c_size_t, _P]),
+    "ldm_op_group_norm_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "ldm_op_group_norm": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P, C.c_int, C.c_float, C.c_int, _P, C.c_int, C.c_int,
+                                    _P, C.c_size_t, _P]),
+    "ldm_op_attention": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "ldm_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "ldm_comm_init": (C.c_int, [C.c_int, C.c_int, C.c_char_p, C.POINTER(_P)]),
+    "ldm_comm_allreduce": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int, _P]),
+    "ldm_comm_broadcast": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int, _P]),
+    "ldm_comm_barrier": (C.c_int, [_P, _P]),
+    "ldm_comm_destroy": (None, [_P]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class LdmError(RuntimeError):
+    """Raised for every non-zero ldm_status (message from ldm_last_error)."""
+
+
+def lib() -> C.CDLL:
+    """Load libldm3d.so once.  Raises (never degrades) if it has not been built."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise LdmError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+                                   f"g.build()'` or `make -C {os.path.join(_HERE, 'csrc')}` (no CPU fallback exists)")
+                h = C.CDLL(LIB_PATH)
+                for name, (res, args) in SIGNATURES.items():
+                    fn = getattr(h, name)            # AttributeError = ABI mismatch: fail loudly
+                    fn.restype = res
+                    fn.argtypes = args
+                _lib = h
+    return _lib
+
+
+def check(status: int) -> None:
+    if status != 0:
+        msg = lib().ldm_last_error()
+        raise LdmError(f"libldm3d status {status}: {msg.decode() if msg else '?'}")
+
+
+def ptr(t) -> int | None:
+    """Device/host address of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,1208 @@
+// libldm3d.so - host side: launch plans, weight arena and the C ABI declared in include/ldm3d.h.
+//
+// The reference (sanazkaviani/3d-latent-diffusion-model) builds its networks by instantiating MONAI classes from
+// a JSON "_target_" (3d_ldm/utils.py:243-246) and runs them as a tree of nn.Modules.  Here a model is a flat,
+// static LAUNCH PLAN over NDHWC bf16 tensors in one caller-owned workspace: channel concat, nearest upsampling,
+// zero padding and 1x1 skip convolutions are addressing modes / extra K steps of the conv kernel, the time-
+// embedding bias, conv bias and residual add are conv epilogues, and every ResBlock's time projection is one
+// batched GEMV.  Plans are cached per input shape; nothing is allocated or synchronised on the step path.
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/ldm3d.h"
+#include "attention.h"
+#include "conv_igemm.h"
+#include "norm_elem.h"
+
+// ================================================================================================ errors
+static thread_local char g_err[1024] = "";
+static int fail(int code, const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
+    return code;
+}
+#define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) \
+    return fail(LDM_ERR_HIP, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+#define LDM_TRY(x) do { int r_ = (x); if (r_ != 0) return r_; } while (0)
+
+static inline int rup(int v, int m) { return (v + m - 1) / m * m; }
+static inline size_t rup_sz(size_t v, size_t m) { return (v + m - 1) / m * m; }
+
+static inline uint16_t host_f2bf(float f) {            // round-to-nearest-even, NaN stays NaN
+    uint32_t u; memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+// ================================================================================================ plan IR
+enum BaseId { BASE_NULL = 0, BASE_WS, BASE_W, BASE_IO0, BASE_IO1, BASE_IO2, BASE_IO3, BASE_IO4, BASE_IO5, BASE_COUNT };
+struct Ref { int base = BASE_NULL; size_t off = 0; };
+static inline Ref ws_ref(size_t off) { Ref r; r.base = BASE_WS; r.off = off; return r; }
+static inline Ref w_ref(size_t off) { Ref r; r.base = BASE_W; r.off = off; return r; }
+static inline Ref io_ref(int i) { Ref r; r.base = BASE_IO0 + i; r.off = 0; return r; }
+
+struct Act {                                         // NDHWC bf16 activation living in the workspace
+    size_t off = 0; int C = 0; int N = 0, D = 0, H = 0, W = 0; bool valid = false;
+    size_t bytes() const { return (size_t)N * D * H * W * C * 2; }
+    long rows() const { return (long)N * D * H * W; }
+};
+
+enum OpKind { OP_PACK, OP_CONV, OP_FINALIZE, OP_GN_STATS, OP_GN_FINALIZE, OP_GN_APPLY, OP_ATTN, OP_SINUSOID,
+              OP_GEMV, OP_VAE_HEADS };
+
+struct ConvCfg { int wgm, wgn, bk, splitk; };
+
+struct Op {
+    OpKind kind;
+    // generic refs; meaning depends on kind
+    Ref r[12];
+    int i[24];
+    float f[2];
+    ConvCfg cc;
+};
+
+struct Pool {                                        // plan-time workspace allocator (first fit + coalescing)
+    struct Blk { size_t off, size; };
+    std::vector<Blk> free_list;
+    std::map<size_t, size_t> live;
+    size_t top = 0, high = 0;
+    size_t alloc(size_t bytes) {
+        bytes = rup_sz(bytes, 256);
+        for (size_t k = 0; k < free_list.size(); ++k)
+            if (free_list[k].size >= bytes) {
+                size_t off = free_list[k].off;
+                if (free_list[k].size == bytes) free_list.erase(free_list.begin() + k);
+                else { free_list[k].off += bytes; free_list[k].size -= bytes; }
+                live[off] = bytes;
+                return off;
+            }
+        size_t off = top; top += bytes; high = std::max(high, top); live[off] = bytes;
+        return off;
+    }
+    void release(size_t off) {
+        auto it = live.find(off); if (it == live.end()) return;
+        Blk b{off, it->second}; live.erase(it);
+        free_list.push_back(b);
+        std::sort(free_list.begin(), free_list.end(), [](const Blk& a, const Blk& c) { return a.off < c.off; });
+        for (size_t k = 0; k + 1 < free_list.size();)
+            if (free_list[k].off + free_list[k].size == free_list[k + 1].off) {
+                free_list[k].size += free_list[k + 1].size; free_list.erase(free_list.begin() + k + 1);
+            } else ++k;
+        if (!free_list.empty() && free_list.back().off + free_list.back().size == top) {
+            top = free_list.back().off; free_list.pop_back();
+        }
+    }
+};
+
+struct Plan {
+    std::vector<Op> ops;
+    size_t ws_bytes = 0;
+};
+
+// ================================================================================================ parameters
+enum PackKind { PK_CONV_W, PK_VEC_F32, PK_LINEAR_W };
+struct ParamDesc {
+    std::string name; std::vector<int64_t> shape;
+    PackKind kind; size_t dst_off;                   // arena byte offset of the destination matrix / vector
+    int k = 1, cout = 0, cin = 0, cout_pad = 0, cin_s = 0, row_off = 0;
+    bool loaded = false;
+};
+
+struct ConvW { size_t w_off = 0; size_t b_off = 0; int cout = 0, cout_pad = 0, cin_s = 0, k = 1; bool has = false; };
+struct GnW { size_t g_off = 0, b_off = 0; int C = 0; };
+struct LinW { size_t w_off = 0, b_off = 0; int in = 0, out = 0; };
+
+struct ldm_model {
+    int type = 0;                                    // 0 = UNet, 1 = VAE
+    ldm_unet_cfg ucfg{}; ldm_vae_cfg vcfg{};
+    std::vector<ParamDesc> params;
+    std::map<std::string, int> pindex;
+    size_t arena_bytes = 8192;                       // first 8 KiB: the zero page (one padded input row, C <= 4096)
+    char* arena = nullptr;
+    int loaded_count = 0;
+    std::map<std::string, ConvW> convs; std::map<std::string, GnW> gns; std::map<std::string, LinW> lins;
+    std::map<std::string, std::shared_ptr<Plan>> plans;
+    // UNet: stacked time_emb_proj GEMV
+    size_t tproj_w_off = 0, tproj_b_off = 0; int tproj_rows = 0; std::map<std::string, int> tproj_row;
+
+    size_t arena_alloc(size_t bytes) { size_t o = arena_bytes; arena_bytes += rup_sz(bytes, 256); return o; }
+    void add_param(const ParamDesc& d) { pindex[d.name] = (int)params.size(); params.push_back(d); }
+
+    // conv registered under MONAI's Convolution wrapper: <name>.conv.{weight,bias}; several logical convs may
+    // share one destination matrix (fused q|k|v, mu|log_sigma) through row_off.
+    ConvW reg_conv_into(const std::string& pname, ConvW dst, int cin, int cout, int k, int row_off, bool lin_names) {
+        ParamDesc w; w.name = pname + (lin_names ? ".weight" : ".conv.weight");
+        if (k == 1 && lin_names) w.shape = {cout, cin}; else w.shape = {cout, cin, k, k, k};
+        w.kind = PK_CONV_W; w.dst_off = dst.w_off; w.k = k; w.cout = cout; w.cin = cin;
+        w.cout_pad = dst.cout_pad; w.cin_s = dst.cin_s; w.row_off = row_off;
+        add_param(w);
+        ParamDesc b; b.name = pname + (lin_names ? ".bias" : ".conv.bias"); b.shape = {cout};
+        b.kind = PK_VEC_F32; b.dst_off = dst.b_off + (size_t)row_off * 4; b.cout = cout;
+        add_param(b);
+        return dst;
+    }
+    ConvW new_conv_slot(int cin_s, int cout_total, int k) {
+        ConvW c; c.has = true; c.k = k; c.cout = cout_total; c.cout_pad = rup(cout_total, 64); c.cin_s = cin_s;
+        c.w_off = arena_alloc((size_t)k * k * k * c.cout_pad * cin_s * 2);
+        c.b_off = arena_alloc((size_t)c.cout_pad * 4);
+        return c;
+    }
+    void reg_conv(const std::string& name, int cin, int cin_s, int cout, int k) {
+        ConvW c = new_conv_slot(cin_s, cout, k);
+        reg_conv_into(name, c, cin, cout, k, 0, false);
+        convs[name] = c;
+    }
+    void reg_gn(const std::string& name, int C) {
+        GnW g; g.C = C; g.g_off = arena_alloc((size_t)C * 4); g.b_off = arena_alloc((size_t)C * 4);
+        ParamDesc w; w.name = name + ".weight"; w.shape = {C}; w.kind = PK_VEC_F32; w.dst_off = g.g_off; w.cout = C; add_param(w);
+        ParamDesc b; b.name = name + ".bias"; b.shape = {C}; b.kind = PK_VEC_F32; b.dst_off = g.b_off; b.cout = C; add_param(b);
+        gns[name] = g;
+    }
+    void reg_linear_at(const std::string& name, int in, int out, size_t w_off, size_t b_off) {
+        ParamDesc w; w.name = name + ".weight"; w.shape = {out, in}; w.kind = PK_LINEAR_W; w.dst_off = w_off; w.cout = out; w.cin = in; add_param(w);
+        ParamDesc b; b.name = name + ".bias"; b.shape = {out}; b.kind = PK_VEC_F32; b.dst_off = b_off; b.cout = out; add_param(b);
+    }
+    void reg_linear(const std::string& name, int in, int out) {
+        LinW l; l.in = in; l.out = out; l.w_off = arena_alloc((size_t)in * out * 2); l.b_off = arena_alloc((size_t)out * 4);
+        reg_linear_at(name, in, out, l.w_off, l.b_off);
+        lins[name] = l;
+    }
+    void reg_attn(const std::string& p, int C) {       // SpatialAttentionBlock: norm + fused q|k|v + out_proj
+        reg_gn(p + ".norm", C);
+        ConvW qkv = new_conv_slot(C, 3 * C, 1);
+        reg_conv_into(p + ".attn.to_q", qkv, C, C, 1, 0, true);
+        reg_conv_into(p + ".attn.to_k", qkv, C, C, 1, C, true);
+        reg_conv_into(p + ".attn.to_v", qkv, C, C, 1, 2 * C, true);
+        convs[p + ".attn.qkv"] = qkv;
+        ConvW o = new_conv_slot(C, C, 1);
+        reg_conv_into(p + ".attn.out_proj", o, C, C, 1, 0, true);
+        convs[p + ".attn.out_proj"] = o;
+    }
+};
+
+// ================================================================================================ builder
+struct Builder {
+    ldm_model* m; Plan* plan; Pool pool;
+    size_t partial_off = 0, partial_bytes = 0;       // shared split-K slab scratch (sized at the end)
+    size_t gnpart_off = 0, gnpart_bytes = 0;         // GroupNorm partial sums
+    size_t gnab_off = 0, gnab_bytes = 0;             // GroupNorm per-channel scale/shift
+    std::vector<size_t> partial_fixups, gnpart_fixups, gnab_fixups;   // op indices whose refs need final offsets
+    std::string err;
+
+    Act new_act(int N, int D, int H, int W, int C) {
+        Act a; a.N = N; a.D = D; a.H = H; a.W = W; a.C = C; a.valid = true; a.off = pool.alloc(a.bytes()); return a;
+    }
+    void free_act(Act& a) { if (a.valid) pool.release(a.off); a.valid = false; }
+
+    // ---- conv ---------------------------------------------------------------------------------------
+    struct ConvArgs {
+        Act xa, xb;                                   // group-0 sources (xb optional)
+        const ConvW* w = nullptr;
+        int k = 3, stride = 1, pad = 1, ups = 0;
+        int Do = 0, Ho = 0, Wo = 0;
+        Act g1a, g1b; const ConvW* w1 = nullptr;     // fused 1x1 skip (optional)
+        Ref temb; int temb_stride = 0;               // optional per-sample channel bias
+        Act residual;                                // optional
+        bool f32_out = false; Ref out_ref; int cout_real = 0;
+    };
+
+    static ConvCfg choose_cfg(long M, int cout_pad, int steps, int bk) {
+        ConvCfg best{2, 2, bk, 1}; double best_t = 1e30;
+        const int rb = bk * 2;
+        for (int wgn = 1; wgn <= 4; wgn *= 2) {
+            const int bn = 64 * wgn, bm = 64 * (4 / wgn);
+            if (cout_pad % bn) continue;
+            const long tiles = ((M + bm - 1) / bm) * (cout_pad / bn);
+            const double c_mfma = (double)bm * bn * bk * 2.0 / 4096.0;           // cycles at the per-CU MFMA peak
+            const double c_load = (double)(bm + bn) * rb / 28.0;                 // ~28 B/clk/CU global->LDS
+            const double c_step = std::max(c_mfma, c_load) + 60.0;
+            static const int splits[] = {1, 2, 3, 4, 6, 8, 9, 12, 16, 18, 24, 27, 32, 48, 64};
+            for (int sk : splits) {
+                if (sk > 1 && steps / sk < 6) break;
+                const long nwg = tiles * sk;
+                const int sps = (steps + sk - 1) / sk;
+                const double rounds = ceil((double)nwg / 256.0);
+                double t = rounds * (sps * c_step + 2500.0);
+                if (sk > 1) t += 6000.0 + (double)M * cout_pad * 4.0 * sk * 2.0 / 2500.0;   // slab write+read, ~2.5 KB/clk chip
+                if (t < best_t) { best_t = t; best = ConvCfg{4 / wgn, wgn, bk, sk}; }
+            }
+        }
+        return best;
+    }
+
+    Act conv(const ConvArgs& a, std::string tag = "") {
+        const ConvW& w = *a.w;
+        const int cin0 = a.xa.C + (a.xb.valid ? a.xb.C : 0);
+        int bk = 64;
+        if (a.xa.C % 64 || (a.xb.valid && a.xb.C % 64)) bk = 32;
+        int cin1 = 0;
+        if (a.w1) {
+            cin1 = a.g1a.C + (a.g1b.valid ? a.g1b.C : 0);
+            if (a.g1a.C % 64 || (a.g1b.valid && a.g1b.C % 64)) bk = 32;
+        }
+        if (cin0 != w.cin_s || (a.w1 && cin1 != a.w1->cin_s) || cin0 % 32 || cin1 % 32) {
+            err = "conv " + tag + ": channel bookkeeping mismatch"; return Act();
+        }
+        const int N = a.xa.N;
+        const long M = (long)N * a.Do * a.Ho * a.Wo;
+        const int taps = a.k * a.k * a.k;
+        const int nchunk0 = cin0 / bk, nchunk1 = cin1 / bk;
+        const int steps0 = taps * nchunk0, steps1 = nchunk1;
+        ConvCfg cc = choose_cfg(M, w.cout_pad, steps0 + steps1, bk);
+        const int bm = 64 * cc.wgm, bn = 64 * cc.wgn;
+        const int couts = a.f32_out ? 0 : rup(w.cout, 32);
+        Act out;
+        if (!a.f32_out) out = new_act(N, a.Do, a.Ho, a.Wo, couts);
+        Op op{}; op.kind = OP_CONV; op.cc = cc;
+        op.r[0] = ws_ref(a.xa.off); op.r[1] = a.xb.valid ? ws_ref(a.xb.off) : Ref();
+        op.r[2] = w_ref(w.w_off);
+        op.r[3] = a.w1 ? ws_ref(a.g1a.off) : Ref(); op.r[4] = (a.w1 && a.g1b.valid) ? ws_ref(a.g1b.off) : Ref();
+        op.r[5] = a.w1 ? w_ref(a.w1->w_off) : Ref();
+        op.r[6] = w_ref(w.b_off); op.r[7] = a.w1 ? w_ref(a.w1->b_off) : Ref();
+        op.r[8] = a.temb; op.r[9] = a.residual.valid ? ws_ref(a.residual.off) : Ref();
+        op.r[10] = a.f32_out ? a.out_ref : ws_ref(out.off);
+        op.r[11] = Ref();                                                     // partial slab (fixed up later)
+        int* i = op.i;
+        i[0] = a.xa.C; i[1] = a.xb.valid ? a.xb.C : 0; i[2] = a.w1 ? a.g1a.C : 0; i[3] = (a.w1 && a.g1b.valid) ? a.g1b.C : 0;
+        i[4] = N; i[5] = a.xa.D; i[6] = a.xa.H; i[7] = a.xa.W; i[8] = a.Do; i[9] = a.Ho; i[10] = a.Wo;
+        i[11] = a.k; i[12] = a.stride; i[13] = a.pad; i[14] = a.ups; i[15] = (int)M;
+        i[16] = a.f32_out ? rup(w.cout, 32) : couts; i[17] = w.cout_pad; i[18] = a.cout_real ? a.cout_real : w.cout;
+        i[19] = nchunk0; i[20] = nchunk1; i[21] = a.temb_stride; i[22] = a.f32_out ? 1 : 0;
+        i[23] = (int)((M + bm - 1) / bm);
+        if (M >= (1L << 31)) { err = "conv " + tag + ": M too large"; return Act(); }
+        if (cc.splitk > 1) {
+            partial_bytes = std::max(partial_bytes, (size_t)cc.splitk * M * w.cout_pad * 4);
+            partial_fixups.push_back(plan->ops.size());
+        }
+        (void)bn;
+        plan->ops.push_back(op);
+        if (cc.splitk > 1) {
+            Op f = op; f.kind = OP_FINALIZE;
+            partial_fixups.push_back(plan->ops.size());
+            plan->ops.push_back(f);
+        }
+        return out;
+    }
+
+    // ---- GroupNorm (+SiLU) over (xa | xb) -> contiguous bf16 --------------------------------------------
+    Act gn_apply(const GnW& g, const Act& xa, const Act& xb, int groups, float eps, bool silu) {
+        const int C = xa.C + (xb.valid ? xb.C : 0);
+        if (C != g.C || C % 8 || (C / groups) * groups != C || xa.C % 8) { err = "groupnorm: channel mismatch"; return Act(); }
+        const int DHW = xa.D * xa.H * xa.W, N = xa.N;
+        const int cvec = C / 8;
+        const int rows_par = std::max(1, 256 / cvec);
+        int nslab = std::min((DHW + rows_par - 1) / rows_par, std::max(1, 512 / N));
+        int rps = (DHW + nslab - 1) / nslab;
+        nslab = (DHW + rps - 1) / rps;
+        gnpart_bytes = std::max(gnpart_bytes, (size_t)N * nslab * C * 2 * 4);
+        gnab_bytes = std::max(gnab_bytes, (size_t)N * C * 2 * 4);
+        Op s{}; s.kind = OP_GN_STATS;
+        s.r[0] = ws_ref(xa.off); s.r[1] = xb.valid ? ws_ref(xb.off) : Ref();
+        s.i[0] = xa.C; s.i[1] = xb.valid ? xb.C : 0; s.i[2] = DHW; s.i[3] = nslab; s.i[4] = rps; s.i[5] = N;
+        gnpart_fixups.push_back(plan->ops.size()); plan->ops.push_back(s);
+        Op f{}; f.kind = OP_GN_FINALIZE;
+        f.r[1] = w_ref(g.g_off); f.r[2] = w_ref(g.b_off);
+        f.i[0] = nslab; f.i[1] = C; f.i[2] = groups; f.i[3] = DHW; f.i[4] = N; f.f[0] = eps;
+        gnpart_fixups.push_back(plan->ops.size()); gnab_fixups.push_back(plan->ops.size()); plan->ops.push_back(f);
+        Act out = new_act(N, xa.D, xa.H, xa.W, C);
+        Op ap{}; ap.kind = OP_GN_APPLY;
+        ap.r[0] = ws_ref(xa.off); ap.r[1] = xb.valid ? ws_ref(xb.off) : Ref(); ap.r[3] = ws_ref(out.off);
+        ap.i[0] = xa.C; ap.i[1] = xb.valid ? xb.C : 0; ap.i[2] = DHW; ap.i[3] = N; ap.i[4] = silu ? 1 : 0;
+        gnab_fixups.push_back(plan->ops.size()); plan->ops.push_back(ap);
+        return out;
+    }
+
+    // ---- blocks ---------------------------------------------------------------------------------------
+    Act conv3(const std::string& name, const Act& x, int stride = 1, int pad = 1, int ups = 0) {
+        ConvArgs a; a.xa = x; a.w = &m->convs.at(name); a.k = 3; a.stride = stride; a.pad = pad; a.ups = ups;
+        const int Du = x.D << ups, Hu = x.H << ups, Wu = x.W << ups;
+        if (stride == 1) { a.Do = Du; a.Ho = Hu; a.Wo = Wu; }
+        else if (pad == 1) { a.Do = (Du + 2 - 3) / 2 + 1; a.Ho = (Hu + 2 - 3) / 2 + 1; a.Wo = (Wu + 2 - 3) / 2 + 1; }
+        else { a.Do = (Du + 1 - 3) / 2 + 1; a.Ho = (Hu + 1 - 3) / 2 + 1; a.Wo = (Wu + 1 - 3) / 2 + 1; }   // F.pad(0,1) + s2 p0
+        return conv(a, name);
+    }
+
+    // ResBlock (UNet: with temb; VAE: without).  xb = skip tensor concatenated after xa (up path) or invalid.
+    Act resblock(const std::string& p, const Act& xa, const Act& xb, int cout, int groups, float eps,
+                 const std::string& skip_name, bool with_temb) {
+        const int cin = xa.C + (xb.valid ? xb.C : 0);
+        Act h0 = gn_apply(m->gns.at(p + ".norm1"), xa, xb, groups, eps, true);
+        if (!h0.valid) return Act();
+        ConvArgs c1; c1.xa = h0; c1.w = &m->convs.at(p + ".conv1"); c1.Do = xa.D; c1.Ho = xa.H; c1.Wo = xa.W;
+        if (with_temb) {
+            c1.temb = ws_ref(temb_all_off + (size_t)m->tproj_row.at(p) * 4); c1.temb_stride = tproj_stride;
+        }
+        Act h1 = conv(c1, p + ".conv1");
+        free_act(h0);
+        if (!h1.valid) return Act();
+        Act h2 = gn_apply(m->gns.at(p + ".norm2"), h1, Act(), groups, eps, true);
+        free_act(h1);
+        if (!h2.valid) return Act();
+        ConvArgs c2; c2.xa = h2; c2.w = &m->convs.at(p + ".conv2"); c2.Do = xa.D; c2.Ho = xa.H; c2.Wo = xa.W;
+        if (cin != cout) { c2.g1a = xa; c2.g1b = xb; c2.w1 = &m->convs.at(p + skip_name); }
+        else { if (xb.valid) { err = "resblock: identity skip with concat input"; return Act(); } c2.residual = xa; }
+        Act out = conv(c2, p + ".conv2");
+        free_act(h2);
+        return out;
+    }
+
+    Act attention(const std::string& p, const Act& x, int head_ch, int groups, float eps) {
+        const int C = x.C;
+        if (head_ch != 64 || C % 64) { err = "attention: only num_head_channels == 64 is implemented (" + p + ")"; return Act(); }
+        Act hn = gn_apply(m->gns.at(p + ".norm"), x, Act(), groups, eps, false);
+        if (!hn.valid) return Act();
+        ConvArgs q; q.xa = hn; q.w = &m->convs.at(p + ".attn.qkv"); q.k = 1; q.pad = 0; q.Do = x.D; q.Ho = x.H; q.Wo = x.W;
+        Act qkv = conv(q, p + ".qkv");
+        free_act(hn);
+        if (!qkv.valid) return Act();
+        Act o = new_act(x.N, x.D, x.H, x.W, C);
+        Op at{}; at.kind = OP_ATTN; at.r[0] = ws_ref(qkv.off); at.r[1] = ws_ref(o.off);
+        at.i[0] = x.N; at.i[1] = x.D * x.H * x.W; at.i[2] = C; at.i[3] = C / 64; at.f[0] = 1.0f / sqrtf(64.0f);
+        plan->ops.push_back(at);
+        free_act(qkv);
+        ConvArgs pr; pr.xa = o; pr.w = &m->convs.at(p + ".attn.out_proj"); pr.k = 1; pr.pad = 0;
+        pr.Do = x.D; pr.Ho = x.H; pr.Wo = x.W; pr.residual = x;
+        Act out = conv(pr, p + ".out_proj");
+        free_act(o);
+        return out;
+    }
+
+    size_t temb_all_off = 0; int tproj_stride = 0;
+
+    void finish() {
+        partial_off = partial_bytes ? pool.alloc(partial_bytes) : 0;
+        gnpart_off = gnpart_bytes ? pool.alloc(gnpart_bytes) : 0;
+        gnab_off = gnab_bytes ? pool.alloc(gnab_bytes) : 0;
+        for (size_t k : partial_fixups) plan->ops[k].r[11] = ws_ref(partial_off);
+        for (size_t k : gnpart_fixups) plan->ops[k].r[4] = ws_ref(gnpart_off);
+        for (size_t k : gnab_fixups) plan->ops[k].r[5] = ws_ref(gnab_off);
+        plan->ws_bytes = pool.high + 256;
+    }
+};
+
+// ================================================================================================ UNet
+static int unet_register(ldm_model* m) {
+    const ldm_unet_cfg& c = m->ucfg;
+    const int L = c.num_levels; const int* ch = c.channels;
+    const int temb = ch[0] * 4;
+    for (int i = 0; i < L; ++i) if (ch[i] % 32 || ch[i] % c.norm_num_groups)
+        return fail(LDM_ERR_UNSUPPORTED, "UNet channels must be multiples of 32 and of norm_num_groups (level %d: %d)", i, ch[i]);
+    std::vector<std::pair<std::string, int>> tprojs;        // (resblock prefix, cout) in registration order
+    auto reg_res = [&](const std::string& p, int cin, int cout) {
+        m->reg_gn(p + ".norm1", cin);
+        m->reg_conv(p + ".conv1", cin, cin, cout, 3);
+        tprojs.push_back({p, cout});
+        m->reg_gn(p + ".norm2", cout);
+        m->reg_conv(p + ".conv2", cout, cout, cout, 3);
+        if (cin != cout) m->reg_conv(p + ".skip_connection", cin, cin, cout, 1);
+    };
+    m->reg_conv("conv_in", c.in_channels, rup(c.in_channels, 32), ch[0], 3);
+    m->reg_linear("time_embed.0", ch[0], temb);
+    m->reg_linear("time_embed.2", temb, temb);
+    int oc = ch[0];
+    for (int i = 0; i < L; ++i) {
+        int ic = oc; oc = ch[i];
+        for (int j = 0; j < c.num_res_blocks[i]; ++j) {
+            char p[96]; snprintf(p, sizeof p, "down_blocks.%d.resnets.%d", i, j);
+            reg_res(p, j == 0 ? ic : oc, oc);
+            if (c.attention_levels[i]) { snprintf(p, sizeof p, "down_blocks.%d.attentions.%d", i, j); m->reg_attn(p, oc); }
+        }
+        if (i != L - 1) { char p[96]; snprintf(p, sizeof p, "down_blocks.%d.downsampler.op", i); m->reg_conv(p, oc, oc, oc, 3); }
+    }
+    reg_res("middle_block.resnet_1", ch[L - 1], ch[L - 1]);
+    m->reg_attn("middle_block.attention", ch[L - 1]);
+    reg_res("middle_block.resnet_2", ch[L - 1], ch[L - 1]);
+    oc = ch[L - 1];
+    for (int i = 0; i < L; ++i) {
+        const int lvl = L - 1 - i;
+        int prev = oc; oc = ch[lvl];
+        const int ic = ch[std::max(lvl - 1, 0)];
+        const int nres = c.num_res_blocks[lvl] + 1;
+        for (int j = 0; j < nres; ++j) {
+            const int skip_c = (j == nres - 1) ? ic : oc;
+            const int rin = (j == 0) ? prev : oc;
+            char p[96]; snprintf(p, sizeof p, "up_blocks.%d.resnets.%d", i, j);
+            reg_res(p, rin + skip_c, oc);
+            if (c.attention_levels[lvl]) { snprintf(p, sizeof p, "up_blocks.%d.attentions.%d", i, j); m->reg_attn(p, oc); }
+        }
+        if (i != L - 1) { char p[96]; snprintf(p, sizeof p, "up_blocks.%d.upsampler.conv", i); m->reg_conv(p, oc, oc, oc, 3); }
+    }
+    m->reg_gn("out.0", ch[0]);
+    m->reg_conv("out.2", ch[0], ch[0], c.out_channels, 3);
+    // stacked time_emb_proj: one GEMV for every ResBlock ([sum cout][temb] bf16)
+    int rows = 0; for (auto& t : tprojs) rows += t.second;
+    m->tproj_rows = rows;
+    m->tproj_w_off = m->arena_alloc((size_t)rows * temb * 2);
+    m->tproj_b_off = m->arena_alloc((size_t)rows * 4);
+    int r = 0;
+    for (auto& t : tprojs) {
+        m->tproj_row[t.first] = r;
+        m->reg_linear_at(t.first + ".time_emb_proj", temb, t.second, m->tproj_w_off + (size_t)r * temb * 2, m->tproj_b_off + (size_t)r * 4);
+        r += t.second;
+    }
+    return 0;
+}
+
+static int unet_build(ldm_model* m, int B, int D, int H, int W, Plan* plan) {
+    const ldm_unet_cfg& c = m->ucfg;
+    const int L = c.num_levels; const int* ch = c.channels;
+    const int temb = ch[0] * 4, G = c.norm_num_groups; const float eps = c.norm_eps;
+    Builder b; b.m = m; b.plan = plan;
+    // ---- time embedding: sinusoid -> Linear -> SiLU -> Linear -> (SiLU -> stacked projections)
+    const size_t sin_off = b.pool.alloc((size_t)B * ch[0] * 4);
+    const size_t e1_off = b.pool.alloc((size_t)B * temb * 4);
+    const size_t e2_off = b.pool.alloc((size_t)B * temb * 4);
+    b.tproj_stride = m->tproj_rows;
+    b.temb_all_off = b.pool.alloc(((size_t)B * m->tproj_rows + 256) * 4);
+    { Op o{}; o.kind = OP_SINUSOID; o.r[0] = io_ref(2); o.r[1] = ws_ref(sin_off); o.i[0] = B; o.i[1] = ch[0]; plan->ops.push_back(o); }
+    auto gemv = [&](size_t w_off, size_t b_off, size_t x_off, size_t y_off, int I, int O, int xs, int ys, int silu) {
+        Op o{}; o.kind = OP_GEMV; o.r[0] = w_ref(w_off); o.r[1] = w_ref(b_off); o.r[2] = ws_ref(x_off); o.r[3] = ws_ref(y_off);
+        o.i[0] = I; o.i[1] = O; o.i[2] = xs; o.i[3] = ys; o.i[4] = silu; o.i[5] = B; plan->ops.push_back(o);
+    };
+    const LinW& l0 = m->lins.at("time_embed.0"); const LinW& l2 = m->lins.at("time_embed.2");
+    gemv(l0.w_off, l0.b_off, sin_off, e1_off, ch[0], temb, ch[0], temb, 0);
+    gemv(l2.w_off, l2.b_off, e1_off, e2_off, temb, temb, temb, temb, 1);
+    gemv(m->tproj_w_off, m->tproj_b_off, e2_off, b.temb_all_off, temb, m->tproj_rows, temb, m->tproj_rows, 1);
+
+    // ---- pack input (x | cond) -> NDHWC bf16, channels padded to 32
+    const int cin_s = rup(c.in_channels, 32);
+    Act xin = b.new_act(B, D, H, W, cin_s);
+    { Op o{}; o.kind = OP_PACK; o.r[0] = io_ref(0); o.r[1] = io_ref(1); o.r[2] = ws_ref(xin.off);
+      o.i[0] = B; o.i[1] = c.in_channels; o.i[2] = cin_s; o.i[3] = D * H * W; plan->ops.push_back(o); }
+    Act h = b.conv3("conv_in", xin);
+    b.free_act(xin);
+    if (!h.valid) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
+    std::vector<Act> skips; skips.push_back(h);
+    char p[96];
+    for (int i = 0; i < L; ++i) {
+        for (int j = 0; j < c.num_res_blocks[i]; ++j) {
+            snprintf(p, sizeof p, "down_blocks.%d.resnets.%d", i, j);
+            Act hn = b.resblock(p, h, Act(), ch[i], G, eps, ".skip_connection", true);
+            if (!hn.valid) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
+            if (c.attention_levels[i]) {
+                snprintf(p, sizeof p, "down_blocks.%d.attentions.%d", i, j);
+                Act ha = b.attention(p, hn, c.num_head_channels[i], G, eps);
+                b.free_act(hn);
+                if (!ha.valid) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
+                hn = ha;
+            }
+            skips.push_back(hn); h = hn;
+        }
+        if (i != L - 1) {
+            if ((h.D | h.H | h.W) & 1) return fail(LDM_ERR_UNSUPPORTED, "odd spatial size %dx%dx%d at a UNet downsample", h.D, h.H, h.W);
+            snprintf(p, sizeof p, "down_blocks.%d.downsampler.op", i);
+            Act hd = b.conv3(p, h, 2, 1);
+            if (!hd.valid) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
+            skips.push_back(hd); h = hd;
+        }
+    }
+    {   // middle: Res, Attn, Res.  `h` is also the last skip and stays alive.
+        Act h1 = b.resblock("middle_block.resnet_1", h, Act(), ch[L - 1], G, eps, ".skip_connection", true);
+        if (!h1.valid) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
+        Act h2 = b.attention("middle_block.attention", h1, c.num_head_channels[L - 1], G, eps);
+        b.free_act(h1);
+        if (!h2.valid) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
+        Act h3 = b.resblock("middle_block.resnet_2", h2, Act(), ch[L - 1], G, eps, ".skip_connection", true);
+        b.free_act(h2);
+        if (!h3.valid) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
+        h = h3;
+    }
+    for (int i = 0; i < L; ++i) {
+        const int lvl = L - 1 - i;
+        for (int j = 0; j < c.num_res_blocks[lvl] + 1; ++j) {
+            Act s = skips.back(); skips.pop_back();
+            snprintf(p, sizeof p, "up_blocks.%d.resnets.%d", i, j);
+            Act hn = b.resblock(p, h, s, ch[lvl], G, eps, ".skip_connection", true);
+            b.free_act(h); b.free_act(s);
+            if (!hn.valid) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
+            if (c.attention_levels[lvl]) {
+                snprintf(p, sizeof p, "up_blocks.%d.attentions.%d", i, j);
+                Act ha = b.attention(p, hn, c.num_head_channels[lvl], G, eps);
+                b.free_act(hn);
+                if (!ha.valid) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
+                hn = ha;
+            }
+            h = hn;
+        }
+        if (i != L - 1) {
+            snprintf(p, sizeof p, "up_blocks.%d.upsampler.conv", i);
+            Act hu = b.conv3(p, h, 1, 1, 1);
+            b.free_act(h);
+            if (!hu.valid) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
+            h = hu;
+        }
+    }
+    Act hn = b.gn_apply(m->gns.at("out.0"), h, Act(), G, eps, true);
+    b.free_act(h);
+    if (!hn.valid) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
+    Builder::ConvArgs oa; oa.xa = hn; oa.w = &m->convs.at("out.2"); oa.Do = D; oa.Ho = H; oa.Wo = W;
+    oa.f32_out = true; oa.out_ref = io_ref(3); oa.cout_real = c.out_channels;
+    b.conv(oa, "out.2");
+    if (!b.err.empty()) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
+    b.finish();
+    return 0;
+}
+
+// ================================================================================================ VAE
+struct AeBlock { int kind; int a, b; };                 // 0 conv, 1 res, 2 attn, 3 down, 4 up, 5 gn
+static std::vector<AeBlock> ae_encoder_layout(const ldm_vae_cfg& c) {
+    std::vector<AeBlock> v; const int L = c.num_levels; const int* ch = c.channels;
+    v.push_back({0, c.in_channels, ch[0]});
+    int oc = ch[0];
+    for (int i = 0; i < L; ++i) {
+        int ic = oc; oc = ch[i];
+        for (int j = 0; j < c.num_res_blocks[i]; ++j) { v.push_back({1, ic, oc}); ic = oc; if (c.attention_levels[i]) v.push_back({2, ic, ic}); }
+        if (i != L - 1) v.push_back({3, ic, ic});
+    }
+    if (c.with_encoder_nonlocal_attn) { v.push_back({1, ch[L - 1], ch[L - 1]}); v.push_back({2, ch[L - 1], ch[L - 1]}); v.push_back({1, ch[L - 1], ch[L - 1]}); }
+    v.push_back({5, ch[L - 1], ch[L - 1]});
+    v.push_back({0, ch[L - 1], c.latent_channels});
+    return v;
+}
+static std::vector<AeBlock> ae_decoder_layout(const ldm_vae_cfg& c) {
+    std::vector<AeBlock> v; const int L = c.num_levels;
+    std::vector<int> rev(c.channels, c.channels + L); std::reverse(rev.begin(), rev.end());
+    v.push_back({0, c.latent_channels, rev[0]});
+    if (c.with_decoder_nonlocal_attn) { v.push_back({1, rev[0], rev[0]}); v.push_back({2, rev[0], rev[0]}); v.push_back({1, rev[0], rev[0]}); }
+    int oc = rev[0];
+    for (int i = 0; i < L; ++i) {
+        int ic = oc; oc = rev[i];
+        const int lvl = L - 1 - i;
+        for (int j = 0; j < c.num_res_blocks[lvl]; ++j) { v.push_back({1, ic, oc}); ic = oc; if (c.attention_levels[lvl]) v.push_back({2, ic, ic}); }
+        if (i != L - 1) v.push_back({4, ic, ic});
+    }
+    v.push_back({5, oc, oc});
+    v.push_back({0, oc, c.out_channels});
+    return v;
+}
+
+static int vae_register(ldm_model* m) {
+    const ldm_vae_cfg& c = m->vcfg;
+    for (int i = 0; i < c.num_levels; ++i) if (c.channels[i] % 32 || c.channels[i] % c.norm_num_groups)
+        return fail(LDM_ERR_UNSUPPORTED, "AutoencoderKL channels must be multiples of 32 and of norm_num_groups");
+    auto reg = [&](const char* prefix, const std::vector<AeBlock>& lay) -> int {
+        for (size_t k = 0; k < lay.size(); ++k) {
+            char p[96]; snprintf(p, sizeof p, "%s.blocks.%zu", prefix, k);
+            const AeBlock& bl = lay[k];
+            switch (bl.kind) {
+                case 0: {   // plain Convolution: keys <p>.conv.*
+                    ConvW cw = m->new_conv_slot(rup(bl.a, 32), bl.b, 3);
+                    m->reg_conv_into(p, cw, bl.a, bl.b, 3, 0, false); m->convs[p] = cw; break; }
+                case 1:
+                    m->reg_gn(std::string(p) + ".norm1", bl.a); m->reg_conv(std::string(p) + ".conv1", bl.a, bl.a, bl.b, 3);
+                    m->reg_gn(std::string(p) + ".norm2", bl.b); m->reg_conv(std::string(p) + ".conv2", bl.b, bl.b, bl.b, 3);
+                    if (bl.a != bl.b) m->reg_conv(std::string(p) + ".nin_shortcut", bl.a, bl.a, bl.b, 1);
+                    break;
+                case 2: return fail(LDM_ERR_UNSUPPORTED, "AutoencoderKL attention blocks (single head, d = C) are not implemented");
+                case 3: m->reg_conv(std::string(p) + ".conv", bl.a, bl.a, bl.a, 3); break;
+                case 4: m->reg_conv(std::string(p) + ".postconv", bl.a, bl.a, bl.a, 3); break;
+                case 5: m->reg_gn(p, bl.a); break;
+            }
+        }
+        return 0;
+    };
+    LDM_TRY(reg("encoder", ae_encoder_layout(c)));
+    LDM_TRY(reg("decoder", ae_decoder_layout(c)));
+    const int Lc = c.latent_channels, Ls = rup(Lc, 32);
+    ConvW heads = m->new_conv_slot(Ls, 2 * Lc, 1);                       // mu | log_sigma fused
+    m->reg_conv_into("quant_conv_mu", heads, Lc, Lc, 1, 0, false);
+    m->reg_conv_into("quant_conv_log_sigma", heads, Lc, Lc, 1, Lc, false);
+    m->convs["quant_heads"] = heads;
+    ConvW pq = m->new_conv_slot(Ls, Lc, 1);
+    m->reg_conv_into("post_quant_conv", pq, Lc, Lc, 1, 0, false);
+    m->convs["post_quant_conv"] = pq;
+    return 0;
+}
+
+static int vae_run_layout(Builder& b, const char* prefix, const std::vector<AeBlock>& lay, Act h, int G, float eps,
+                          bool last_f32, int io_out, Act* out) {
+    for (size_t k = 0; k < lay.size(); ++k) {
+        char p[96]; snprintf(p, sizeof p, "%s.blocks.%zu", prefix, k);
+        const AeBlock& bl = lay[k];
+        Act hn;
+        if (bl.kind == 0) {
+            const bool last = (k == lay.size() - 1);
+            if (last && last_f32) {
+                Builder::ConvArgs a; a.xa = h; a.w = &b.m->convs.at(p); a.Do = h.D; a.Ho = h.H; a.Wo = h.W;
+                a.f32_out = true; a.out_ref = io_ref(io_out); a.cout_real = bl.b;
+                b.conv(a, p); b.free_act(h);
+                if (!b.err.empty()) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
+                *out = Act(); return 0;
+            }
+            hn = b.conv3(p, h);
+        } else if (bl.kind == 1) {
+            hn = b.resblock(p, h, Act(), bl.b, G, eps, ".nin_shortcut", false);
+        } else if (bl.kind == 3) {
+            if ((h.D | h.H | h.W) & 1) return fail(LDM_ERR_UNSUPPORTED, "odd spatial size at an AutoencoderKL downsample");
+            hn = b.conv3(std::string(p) + ".conv", h, 2, 0);
+        } else if (bl.kind == 4) {
+            hn = b.conv3(std::string(p) + ".postconv", h, 1, 1, 1);
+        } else if (bl.kind == 5) {
+            hn = b.gn_apply(b.m->gns.at(p), h, Act(), G, eps, false);
+        } else return fail(LDM_ERR_UNSUPPORTED, "unsupported AutoencoderKL block");
+        b.free_act(h);
+        if (!hn.valid) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
+        h = hn;
+    }
+    *out = h;
+    return 0;
+}
+
+static int vae_build_encode(ldm_model* m, int B, int D, int H, int W, Plan* plan) {
+    const ldm_vae_cfg& c = m->vcfg;
+    Builder b; b.m = m; b.plan = plan;
+    const int cs = rup(c.in_channels, 32);
+    Act xin = b.new_act(B, D, H, W, cs);
+    { Op o{}; o.kind = OP_PACK; o.r[0] = io_ref(0); o.r[1] = Ref(); o.r[2] = ws_ref(xin.off);
+      o.i[0] = B; o.i[1] = c.in_channels; o.i[2] = cs; o.i[3] = D * H * W; plan->ops.push_back(o); }
+    Act h;
+    LDM_TRY(vae_run_layout(b, "encoder", ae_encoder_layout(c), xin, c.norm_num_groups, c.norm_eps, false, 0, &h));
+    // fused 1x1 heads -> fp32 [B][2L][dhw] scratch, then clamp/exp/sample
+    const int dhw = h.D * h.H * h.W;
+    const size_t ml_off = b.pool.alloc((size_t)B * 2 * c.latent_channels * dhw * 4);
+    Builder::ConvArgs a; a.xa = h; a.w = &m->convs.at("quant_heads"); a.k = 1; a.pad = 0; a.Do = h.D; a.Ho = h.H; a.Wo = h.W;
+    a.f32_out = true; a.out_ref = ws_ref(ml_off); a.cout_real = 2 * c.latent_channels;
+    b.conv(a, "quant_heads");
+    if (!b.err.empty()) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
+    b.free_act(h);
+    { Op o{}; o.kind = OP_VAE_HEADS; o.r[0] = ws_ref(ml_off); o.r[1] = io_ref(1); o.r[2] = io_ref(2); o.r[3] = io_ref(3); o.r[4] = io_ref(4);
+      o.i[0] = B; o.i[1] = c.latent_channels; o.i[2] = dhw; plan->ops.push_back(o); }
+    b.finish();
+    return 0;
+}
+
+static int vae_build_decode(ldm_model* m, int B, int d, int h_, int w, Plan* plan) {
+    const ldm_vae_cfg& c = m->vcfg;
+    Builder b; b.m = m; b.plan = plan;
+    const int ls = rup(c.latent_channels, 32);
+    Act zin = b.new_act(B, d, h_, w, ls);
+    { Op o{}; o.kind = OP_PACK; o.r[0] = io_ref(0); o.r[1] = Ref(); o.r[2] = ws_ref(zin.off);
+      o.i[0] = B; o.i[1] = c.latent_channels; o.i[2] = ls; o.i[3] = d * h_ * w; plan->ops.push_back(o); }
+    Builder::ConvArgs a; a.xa = zin; a.w = &m->convs.at("post_quant_conv"); a.k = 1; a.pad = 0; a.Do = d; a.Ho = h_; a.Wo = w;
+    Act z2 = b.conv(a, "post_quant_conv");
+    b.free_act(zin);
+    if (!z2.valid) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
+    Act out;
+    LDM_TRY(vae_run_layout(b, "decoder", ae_decoder_layout(c), z2, c.norm_num_groups, c.norm_eps, true, 1, &out));
+    b.finish();
+    return 0;
+}
+
+// ================================================================================================ launch
+struct Bases { char* p[BASE_COUNT]; };
+static inline char* rp(const Bases& b, const Ref& r) { return r.base == BASE_NULL ? nullptr : (b.p[r.base] ? b.p[r.base] + r.off : nullptr); }
+
+template <int WGM, int WGN, int BK>
+static int launch_conv_t(const ConvParams& p, hipStream_t s) {
+    constexpr int LDS = 2 * (64 * WGM + 64 * WGN) * BK * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<WGM, WGN, BK>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_set = true;
+    }
+    const int grid = p.mtiles * p.ntiles * p.splitk;
+    hipLaunchKernelGGL((conv_igemm_kernel<WGM, WGN, BK>), dim3(grid), dim3(256), LDS, s, p);
+    return 0;
+}
+
+static int launch_conv(const ConvParams& p, const ConvCfg& cc, hipStream_t s) {
+#define CASE(M_, N_, K_) if (cc.wgm == M_ && cc.wgn == N_ && cc.bk == K_) return launch_conv_t<M_, N_, K_>(p, s);
+    CASE(2, 2, 64) CASE(4, 1, 64) CASE(1, 4, 64) CASE(2, 2, 32) CASE(4, 1, 32) CASE(1, 4, 32)
+#undef CASE
+    return fail(LDM_ERR_BAD_ARG, "no conv kernel for tile config %dx%d bk %d", cc.wgm, cc.wgn, cc.bk);
+}
+
+static inline int grid_for(long total, int per_block = 256, int cap = 4096) {
+    long g = (total + per_block - 1) / per_block; if (g > cap) g = cap; if (g < 1) g = 1; return (int)g;
+}
+
+static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_t s) {
+    for (const Op& o : plan.ops) {
+        const int* i = o.i;
+        switch (o.kind) {
+            case OP_PACK: {
+                // two fp32 NCDHW sources (x | cond) -> one zero-padded NDHWC bf16 tensor
+                const long total = (long)i[0] * i[3] * i[2];
+                int cx = rt[0], cc = rt[1];
+                if (cx + cc != i[1]) return fail(LDM_ERR_BAD_ARG, "x_channels + cond_channels = %d, model expects %d", cx + cc, i[1]);
+                hipLaunchKernelGGL(pack2_ncdhw_kernel, dim3(grid_for(total)), dim3(256), 0, s, (const float*)rp(bs, o.r[0]), cx,
+                                   (const float*)rp(bs, o.r[1]), cc, (bf16_t*)rp(bs, o.r[2]), i[0], i[2], i[3]);
+                break; }
+            case OP_CONV: case OP_FINALIZE: {
+                ConvParams p{};
+                p.x0a = (const bf16_t*)rp(bs, o.r[0]); p.x0b = (const bf16_t*)rp(bs, o.r[1]); p.c0a = i[0]; p.c0b = i[1];
+                p.w0 = (const bf16_t*)rp(bs, o.r[2]);
+                p.x1a = (const bf16_t*)rp(bs, o.r[3]); p.x1b = (const bf16_t*)rp(bs, o.r[4]); p.c1a = i[2]; p.c1b = i[3];
+                p.w1 = (const bf16_t*)rp(bs, o.r[5]);
+                p.zero_page = (const bf16_t*)bs.p[BASE_W];
+                p.N = i[4]; p.Din = i[5]; p.Hin = i[6]; p.Win = i[7]; p.Dout = i[8]; p.Hout = i[9]; p.Wout = i[10];
+                p.ksize = i[11]; p.stride = i[12]; p.pad = i[13]; p.ups = i[14]; p.M = i[15];
+                p.CoutS = i[16]; p.CoutPad = i[17]; p.CoutReal = i[18]; p.nchunk0 = i[19]; p.nchunk1 = i[20];
+                p.steps0 = i[11] * i[11] * i[11] * i[19]; p.steps1 = i[20];
+                p.splitk = o.cc.splitk; p.steps_per_split = (p.steps0 + p.steps1 + p.splitk - 1) / p.splitk;
+                p.mtiles = i[23]; p.ntiles = p.CoutPad / (64 * o.cc.wgn);
+                p.bias = (const float*)rp(bs, o.r[6]); p.bias2 = (const float*)rp(bs, o.r[7]);
+                p.temb = (const float*)rp(bs, o.r[8]); p.temb_stride = i[21];
+                p.residual = (const bf16_t*)rp(bs, o.r[9]);
+                if (i[22]) { p.out_f32 = (float*)rp(bs, o.r[10]); p.out = nullptr; }
+                else { p.out = (bf16_t*)rp(bs, o.r[10]); p.out_f32 = nullptr; }
+                p.partial = (float*)rp(bs, o.r[11]);
+                if (o.kind == OP_CONV) { LDM_TRY(launch_conv(p, o.cc, s)); }
+                else {
+                    FinalizeParams f{}; f.partial = p.partial; f.splitk = p.splitk; f.M = p.M; f.CoutPad = p.CoutPad;
+                    f.CoutS = p.CoutS; f.CoutReal = p.CoutReal; f.DHWo = p.Dout * p.Hout * p.Wout;
+                    f.bias = p.bias; f.bias2 = p.bias2; f.temb = p.temb; f.temb_stride = p.temb_stride; f.residual = p.residual;
+                    f.out = p.out; f.out_f32 = p.out_f32;
+                    const long total = (long)p.M * (p.CoutS / 8);
+                    hipLaunchKernelGGL(splitk_finalize_kernel, dim3(grid_for(total)), dim3(256), 0, s, f);
+                }
+                break; }
+            case OP_GN_STATS: {
+                GnStatsParams p{}; p.xa = (const bf16_t*)rp(bs, o.r[0]); p.xb = (const bf16_t*)rp(bs, o.r[1]); p.ca = i[0]; p.cb = i[1];
+                p.DHW = i[2]; p.nslab = i[3]; p.rows_per_slab = i[4]; p.partial = (float*)rp(bs, o.r[4]);
+                hipLaunchKernelGGL(gn_stats_kernel, dim3(i[3], i[5]), dim3(256), 0, s, p);
+                break; }
+            case OP_GN_FINALIZE: {
+                GnFinalizeParams p{}; p.partial = (const float*)rp(bs, o.r[4]); p.nslab = i[0]; p.C = i[1]; p.Creal = i[1]; p.groups = i[2];
+                p.DHW = i[3]; p.eps = o.f[0]; p.gamma = (const float*)rp(bs, o.r[1]); p.beta = (const float*)rp(bs, o.r[2]);
+                p.ab = (float*)rp(bs, o.r[5]);
+                hipLaunchKernelGGL(gn_finalize_kernel, dim3(i[2], i[4]), dim3(64), 0, s, p);
+                break; }
+            case OP_GN_APPLY: {
+                GnApplyParams p{}; p.xa = (const bf16_t*)rp(bs, o.r[0]); p.xb = (const bf16_t*)rp(bs, o.r[1]); p.ca = i[0]; p.cb = i[1];
+                p.DHW = i[2]; p.N = i[3]; p.silu = i[4]; p.ab = (const float*)rp(bs, o.r[5]); p.out = (bf16_t*)rp(bs, o.r[3]);
+                const long total = (long)i[3] * i[2] * ((i[0] + i[1]) / 8);
+                hipLaunchKernelGGL(gn_apply_kernel, dim3(grid_for(total, 256, 2048)), dim3(256), 0, s, p);
+                break; }
+            case OP_ATTN: {
+                AttnParams p{}; p.qkv = (const bf16_t*)rp(bs, o.r[0]); p.out = (bf16_t*)rp(bs, o.r[1]);
+                p.B = i[0]; p.N = i[1]; p.C = i[2]; p.heads = i[3]; p.scale = o.f[0];
+                hipLaunchKernelGGL(attn_fwd_kernel, dim3((i[1] + 63) / 64, i[3], i[0]), dim3(256), 0, s, p);
+                break; }
+            case OP_SINUSOID:
+                hipLaunchKernelGGL(temb_sinusoid_kernel, dim3(grid_for((long)i[0] * i[1])), dim3(256), 0, s,
+                                   (const float*)rp(bs, o.r[0]), (float*)rp(bs, o.r[1]), i[0], i[1]);
+                break;
+            case OP_GEMV:
+                hipLaunchKernelGGL(gemv_bf16_kernel, dim3((i[1] + 3) / 4, i[5]), dim3(256), 0, s,
+                                   (const bf16_t*)rp(bs, o.r[0]), (const float*)rp(bs, o.r[1]), (const float*)rp(bs, o.r[2]),
+                                   (float*)rp(bs, o.r[3]), i[0], i[1], i[2], i[3], i[4]);
+                break;
+            case OP_VAE_HEADS: {
+                const long total = (long)i[0] * i[1] * i[2];
+                hipLaunchKernelGGL(vae_heads_kernel, dim3(grid_for(total)), dim3(256), 0, s, (const float*)rp(bs, o.r[0]),
+                                   (const float*)rp(bs, o.r[1]), (float*)rp(bs, o.r[2]), (float*)rp(bs, o.r[3]), (float*)rp(bs, o.r[4]),
+                                   i[0], i[1], i[2]);
+                break; }
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ================================================================================================ C ABI
+extern "C" {
+
+int ldm_version(void) { return LDM_ABI_VERSION; }
+const char* ldm_last_error(void) { return g_err; }
+
+int ldm_unet_create(const ldm_unet_cfg* cfg, ldm_model** out) {
+    if (!cfg || !out) return fail(LDM_ERR_BAD_ARG, "null argument");
+    if (cfg->spatial_dims != 3) return fail(LDM_ERR_UNSUPPORTED, "only spatial_dims == 3 is implemented");
+    if (cfg->num_levels < 1 || cfg->num_levels > LDM_MAX_LEVELS) return fail(LDM_ERR_BAD_ARG, "num_levels out of range");
+    if (cfg->in_channels < 1 || cfg->out_channels < 1 || cfg->norm_num_groups < 1) return fail(LDM_ERR_BAD_ARG, "bad channel counts");
+    for (int i = 0; i < cfg->num_levels; ++i) {
+        if (cfg->num_res_blocks[i] < 1) return fail(LDM_ERR_BAD_ARG, "num_res_blocks[%d] < 1", i);
+        if (cfg->attention_levels[i] && cfg->num_head_channels[i] != 64)
+            return fail(LDM_ERR_UNSUPPORTED, "attention level %d: num_head_channels must be 64 (got %d)", i, cfg->num_head_channels[i]);
+    }
+    if (cfg->num_head_channels[cfg->num_levels - 1] != 64)
+        return fail(LDM_ERR_UNSUPPORTED, "middle-block attention needs num_head_channels[-1] == 64");
+    std::unique_ptr<ldm_model> m(new ldm_model());
+    m->type = 0; m->ucfg = *cfg;
+    LDM_TRY(unet_register(m.get()));
+    *out = m.release();
+    return 0;
+}
+
+int ldm_vae_create(const ldm_vae_cfg* cfg, ldm_model** out) {
+    if (!cfg || !out) return fail(LDM_ERR_BAD_ARG, "null argument");
+    if (cfg->spatial_dims != 3) return fail(LDM_ERR_UNSUPPORTED, "only spatial_dims == 3 is implemented");
+    if (cfg->num_levels < 1 || cfg->num_levels > LDM_MAX_LEVELS) return fail(LDM_ERR_BAD_ARG, "num_levels out of range");
+    if (cfg->in_channels < 1 || cfg->out_channels < 1 || cfg->latent_channels < 1 || cfg->latent_channels > 16)
+        return fail(LDM_ERR_BAD_ARG, "bad channel counts");
+    std::unique_ptr<ldm_model> m(new ldm_model());
+    m->type = 1; m->vcfg = *cfg;
+    LDM_TRY(vae_register(m.get()));
+    *out = m.release();
+    return 0;
+}
+
+void ldm_model_destroy(ldm_model* m) {
+    if (!m) return;
+    if (m->arena) (void)hipFree(m->arena);
+    delete m;
+}
+
+int ldm_model_num_params(const ldm_model* m) { return m ? (int)m->params.size() : 0; }
+const char* ldm_model_param_name(const ldm_model* m, int i) {
+    return (m && i >= 0 && i < (int)m->params.size()) ? m->params[i].name.c_str() : nullptr;
+}
+int ldm_model_param_ndim(const ldm_model* m, int i) {
+    return (m && i >= 0 && i < (int)m->params.size()) ? (int)m->params[i].shape.size() : -1;
+}
+const int64_t* ldm_model_param_shape(const ldm_model* m, int i) {
+    return (m && i >= 0 && i < (int)m->params.size()) ? m->params[i].shape.data() : nullptr;
+}
+int64_t ldm_model_param_numel_total(const ldm_model* m) {
+    int64_t t = 0; if (!m) return 0;
+    for (auto& p : m->params) { int64_t n = 1; for (auto s : p.shape) n *= s; t += n; }
+    return t;
+}
+
+static int ensure_arena(ldm_model* m) {
+    if (m->arena) return 0;
+    HIP_TRY(hipMalloc((void**)&m->arena, m->arena_bytes));
+    HIP_TRY(hipMemset(m->arena, 0, m->arena_bytes));
+    return 0;
+}
+
+int ldm_model_load_param(ldm_model* m, const char* name, const float* src, size_t numel) {
+    if (!m || !name || !src) return fail(LDM_ERR_BAD_ARG, "null argument");
+    auto it = m->pindex.find(name);
+    if (it == m->pindex.end()) return fail(LDM_ERR_BAD_ARG, "unknown parameter '%s'", name);
+    ParamDesc& d = m->params[it->second];
+    size_t expect = 1; for (auto s : d.shape) expect *= (size_t)s;
+    if (expect != numel) return fail(LDM_ERR_BAD_ARG, "parameter '%s': expected %zu elements, got %zu", name, expect, numel);
+    LDM_TRY(ensure_arena(m));
+    if (d.kind == PK_VEC_F32) {
+        HIP_TRY(hipMemcpy(m->arena + d.dst_off, src, numel * 4, hipMemcpyHostToDevice));
+    } else if (d.kind == PK_LINEAR_W) {
+        std::vector<uint16_t> tmp(numel);
+        for (size_t k = 0; k < numel; ++k) tmp[k] = host_f2bf(src[k]);
+        HIP_TRY(hipMemcpy(m->arena + d.dst_off, tmp.data(), numel * 2, hipMemcpyHostToDevice));
+    } else {   // PK_CONV_W: [cout][cin][kd][kh][kw] fp32 -> [tap][cout_pad][cin_s] bf16 rows row_off..row_off+cout
+        const int taps = d.k * d.k * d.k;
+        std::vector<uint16_t> tmp((size_t)d.cout * d.cin_s);
+        for (int t = 0; t < taps; ++t) {
+            std::fill(tmp.begin(), tmp.end(), (uint16_t)0);
+            for (int co = 0; co < d.cout; ++co)
+                for (int ci = 0; ci < d.cin; ++ci)
+                    tmp[(size_t)co * d.cin_s + ci] = host_f2bf(src[((size_t)co * d.cin + ci) * taps + t]);
+            char* dst = m->arena + d.dst_off + ((size_t)t * d.cout_pad + d.row_off) * d.cin_s * 2;
+            HIP_TRY(hipMemcpy(dst, tmp.data(), tmp.size() * 2, hipMemcpyHostToDevice));
+        }
+    }
+    if (!d.loaded) { d.loaded = true; m->loaded_count++; }
+    return 0;
+}
+
+static int get_plan(ldm_model* m, const char* kind, int B, int D, int H, int W, std::shared_ptr<Plan>* out) {
+    if (B < 1 || D < 1 || H < 1 || W < 1 || D > 255 * 8 || H > 255 * 8 || W > 255 * 8) return fail(LDM_ERR_BAD_ARG, "bad shape");
+    char key[96]; snprintf(key, sizeof key, "%s:%d:%d:%d:%d", kind, B, D, H, W);
+    auto it = m->plans.find(key);
+    if (it != m->plans.end()) { *out = it->second; return 0; }
+    std::shared_ptr<Plan> p(new Plan());
+    if (m->type == 0) LDM_TRY(unet_build(m, B, D, H, W, p.get()));
+    else if (kind[0] == 'e') LDM_TRY(vae_build_encode(m, B, D, H, W, p.get()));
+    else LDM_TRY(vae_build_decode(m, B, D, H, W, p.get()));
+    m->plans[key] = p; *out = p;
+    return 0;
+}
+
+static int check_ready(ldm_model* m, const void* ws, size_t ws_bytes, const Plan& p) {
+    if (m->loaded_count != (int)m->params.size()) {
+        for (auto& d : m->params) if (!d.loaded)
+            return fail(LDM_ERR_NOT_LOADED, "parameter '%s' (and %d others) not uploaded", d.name.c_str(),
+                        (int)m->params.size() - m->loaded_count - 1);
+    }
+    if (!ws || ws_bytes < p.ws_bytes) return fail(LDM_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", p.ws_bytes, ws_bytes);
+    if (((uintptr_t)ws) & 255) return fail(LDM_ERR_BAD_ARG, "workspace must be 256-byte aligned");
+    return 0;
+}
+
+size_t ldm_unet_workspace_bytes(ldm_model* m, int B, int D, int H, int W) {
+    if (!m || m->type != 0) { fail(LDM_ERR_BAD_ARG, "not a UNet handle"); return 0; }
+    std::shared_ptr<Plan> p; if (get_plan(m, "unet", B, D, H, W, &p)) return 0;
+    return p->ws_bytes;
+}
+
+int ldm_unet_forward(ldm_model* m, const float* x, int x_channels, const float* cond, int cond_channels,
+                     const float* timesteps, float* out, int B, int D, int H, int W,
+                     void* workspace, size_t workspace_bytes, void* stream) {
+    if (!m || m->type != 0) return fail(LDM_ERR_BAD_ARG, "not a UNet handle");
+    if (!x || !timesteps || !out) return fail(LDM_ERR_BAD_ARG, "null tensor argument");
+    if (!cond) cond_channels = 0;
+    std::shared_ptr<Plan> p; LDM_TRY(get_plan(m, "unet", B, D, H, W, &p));
+    LDM_TRY(check_ready(m, workspace, workspace_bytes, *p));
+    Bases bs{}; bs.p[BASE_WS] = (char*)workspace; bs.p[BASE_W] = m->arena;
+    bs.p[BASE_IO0] = (char*)x; bs.p[BASE_IO1] = (char*)cond; bs.p[BASE_IO2] = (char*)timesteps; bs.p[BASE_IO3] = (char*)out;
+    const int rt[2] = {x_channels, cond_channels};
+    return run_plan(*p, bs, rt, (hipStream_t)stream);
+}
+
+static int vae_factor(const ldm_model* m) { return 1 << (m->vcfg.num_levels - 1); }
+
+size_t ldm_vae_encode_workspace_bytes(ldm_model* m, int B, int D, int H, int W) {
+    if (!m || m->type != 1) { fail(LDM_ERR_BAD_ARG, "not an AutoencoderKL handle"); return 0; }
+    std::shared_ptr<Plan> p; if (get_plan(m, "enc", B, D, H, W, &p)) return 0;
+    return p->ws_bytes;
+}
+size_t ldm_vae_decode_workspace_bytes(ldm_model* m, int B, int d, int h, int w) {
+    if (!m || m->type != 1) { fail(LDM_ERR_BAD_ARG, "not an AutoencoderKL handle"); return 0; }
+    std::shared_ptr<Plan> p; if (get_plan(m, "dec", B, d, h, w, &p)) return 0;
+    return p->ws_bytes;
+}
+
+int ldm_vae_encode(ldm_model* m, const float* x, const float* eps, float* z_mu, float* z_sigma, float* z,
+                   int B, int D, int H, int W, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!m || m->type != 1) return fail(LDM_ERR_BAD_ARG, "not an AutoencoderKL handle");
+    if (!x) return fail(LDM_ERR_BAD_ARG, "null tensor argument");
+    const int f = vae_factor(m);
+    if (D % f || H % f || W % f) return fail(LDM_ERR_UNSUPPORTED, "image size must be a multiple of %d", f);
+    std::shared_ptr<Plan> p; LDM_TRY(get_plan(m, "enc", B, D, H, W, &p));
+    LDM_TRY(check_ready(m, workspace, workspace_bytes, *p));
+    Bases bs{}; bs.p[BASE_WS] = (char*)workspace; bs.p[BASE_W] = m->arena;
+    bs.p[BASE_IO0] = (char*)x; bs.p[BASE_IO1] = (char*)eps; bs.p[BASE_IO2] = (char*)z_mu; bs.p[BASE_IO3] = (char*)z_sigma; bs.p[BASE_IO4] = (char*)z;
+    const int rt[2] = {m->vcfg.in_channels, 0};
+    return run_plan(*p, bs, rt, (hipStream_t)stream);
+}
+
+int ldm_vae_decode(ldm_model* m, const float* z, float* out, int B, int d, int h, int w,
+                   void* workspace, size_t workspace_bytes, void* stream) {
+    if (!m || m->type != 1) return fail(LDM_ERR_BAD_ARG, "not an AutoencoderKL handle");
+    if (!z || !out) return fail(LDM_ERR_BAD_ARG, "null tensor argument");
+    std::shared_ptr<Plan> p; LDM_TRY(get_plan(m, "dec", B, d, h, w, &p));
+    LDM_TRY(check_ready(m, workspace, workspace_bytes, *p));
+    Bases bs{}; bs.p[BASE_WS] = (char*)workspace; bs.p[BASE_W] = m->arena;
+    bs.p[BASE_IO0] = (char*)z; bs.p[BASE_IO1] = (char*)out;
+    const int rt[2] = {m->vcfg.latent_channels, 0};
+    return run_plan(*p, bs, rt, (hipStream_t)stream);
+}
+
+// ---- scheduler element-wise launches --------------------------------------------------------------------
+int ldm_ddpm_step(const float* eps, const float* x, const float* noise, float* prev, float* x0_out, int64_t n,
+                  float inv_sqrt_a, float sqrt_b, float c0, float c1, float sigma, int clip, void* stream) {
+    if (!eps || !x || !prev || n < 0) return fail(LDM_ERR_BAD_ARG, "bad argument");
+    StepCoef k{inv_sqrt_a, sqrt_b, c0, c1, sigma, 0.f, clip};
+    hipLaunchKernelGGL(ddpm_step_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, eps, x, noise, prev, x0_out, (long)n, k);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int ldm_ddim_step(const float* eps, const float* x, const float* noise, float* prev, float* x0_out, int64_t n,
+                  float inv_sqrt_a, float sqrt_b, float c0, float dir, float sigma, int clip, void* stream) {
+    if (!eps || !x || !prev || n < 0) return fail(LDM_ERR_BAD_ARG, "bad argument");
+    StepCoef k{inv_sqrt_a, sqrt_b, c0, 0.f, sigma, dir, clip};
+    hipLaunchKernelGGL(ddim_step_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, eps, x, noise, prev, x0_out, (long)n, k);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int ldm_add_noise(const float* x0, const float* eps, const float* sqrt_a, const float* sqrt_b, float* out,
+                  int B, int64_t per_sample, void* stream) {
+    if (!x0 || !eps || !sqrt_a || !sqrt_b || !out || B < 1 || per_sample < 0) return fail(LDM_ERR_BAD_ARG, "bad argument");
+    hipLaunchKernelGGL(add_noise_kernel, dim3(grid_for(per_sample * B)), dim3(256), 0, (hipStream_t)stream, x0, eps, sqrt_a, sqrt_b, out,
+                       (long)per_sample, B);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int ldm_scale(const float* x, float* y, int64_t n, float s, void* stream) {
+    if (!x || !y || n < 0) return fail(LDM_ERR_BAD_ARG, "bad argument");
+    hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, (long)n, s);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---- operator-level entry points (the same kernels the plans launch; used by per-kernel parity tests and
+//      micro-benchmarks).  Tensors are NDHWC bf16 device memory with C % 32 == 0. -------------------------------
+static char* g_zero_page = nullptr;
+static int ensure_zero_page() {
+    if (g_zero_page) return 0;
+    HIP_TRY(hipMalloc((void**)&g_zero_page, 8192));
+    HIP_TRY(hipMemset(g_zero_page, 0, 8192));
+    return 0;
+}
+
+int ldm_op_conv3d(const void* xa, int ca, const void* xb, int cb, const void* w, const float* bias,
+                  const void* x1a, int c1a, const void* x1b, int c1b, const void* w1, const float* bias2,
+                  const float* temb, int temb_stride, const void* residual, void* out_bf16, float* out_f32,
+                  int N, int Din, int Hin, int Win, int ksize, int stride, int pad, int ups,
+                  int cout, int cout_pad, int wgn, int splitk, void* scratch, size_t scratch_bytes, void* stream) {
+    if (!xa || !w || (!out_bf16 && !out_f32)) return fail(LDM_ERR_BAD_ARG, "null tensor argument");
+    if (!xb) cb = 0;
+    if (!x1a) { c1a = 0; c1b = 0; }
+    if (!x1b) c1b = 0;
+    const int cin0 = ca + cb, cin1 = c1a + c1b;
+    if (ca % 32 || cb % 32 || c1a % 32 || c1b % 32 || cout_pad % 64 || cout > cout_pad || cin0 > 4096 || cin1 > 4096)
+        return fail(LDM_ERR_BAD_ARG, "channel counts must be multiples of 32 (cout_pad of 64)");
+    if (ksize != 1 && ksize != 3) return fail(LDM_ERR_UNSUPPORTED, "ksize must be 1 or 3");
+    if (ups < 0 || ups > 1 || stride < 1 || stride > 2) return fail(LDM_ERR_UNSUPPORTED, "stride 1|2, ups 0|1");
+    LDM_TRY(ensure_zero_page());
+    int bk = 64;
+    if (ca % 64 || cb % 64 || c1a % 64 || c1b % 64) bk = 32;
+    const int Du = Din << ups, Hu = Hin << ups, Wu = Win << ups;
+    const int pad_total = (stride == 2 && pad == 0 && ksize == 3) ? 1 : 2 * pad;      // F.pad(0,1) form for s2 p0
+    const int Do = (Du + pad_total - ksize) / stride + 1, Ho = (Hu + pad_total - ksize) / stride + 1,
+              Wo = (Wu + pad_total - ksize) / stride + 1;
+    const long M = (long)N * Do * Ho * Wo;
+    if (M >= (1L << 31) || M < 1) return fail(LDM_ERR_BAD_ARG, "bad output size");
+    const int taps = ksize * ksize * ksize;
+    ConvParams p{};
+    p.x0a = (const bf16_t*)xa; p.x0b = (const bf16_t*)xb; p.c0a = ca; p.c0b = cb; p.w0 = (const bf16_t*)w;
+    p.x1a = (const bf16_t*)x1a; p.x1b = (const bf16_t*)x1b; p.c1a = c1a; p.c1b = c1b; p.w1 = (const bf16_t*)w1;
+    p.zero_page = (const bf16_t*)g_zero_page;
+    p.N = N; p.Din = Din; p.Hin = Hin; p.Win = Win; p.Dout = Do; p.Hout = Ho; p.Wout = Wo;
+    p.ksize = ksize; p.stride = stride; p.pad = pad; p.ups = ups; p.M = (int)M;
+    p.CoutS = rup(cout, 32); p.CoutPad = cout_pad; p.CoutReal = cout;
+    p.nchunk0 = cin0 / bk; p.nchunk1 = cin1 / bk; p.steps0 = taps * p.nchunk0; p.steps1 = p.nchunk1;
+    ConvCfg cc = Builder::choose_cfg(M, cout_pad, p.steps0 + p.steps1, bk);
+    if (wgn) { if ((wgn != 1 && wgn != 2 && wgn != 4) || cout_pad % (64 * wgn)) return fail(LDM_ERR_BAD_ARG, "bad wgn"); cc.wgn = wgn; cc.wgm = 4 / wgn; }
+    if (splitk) cc.splitk = splitk;
+    if (cc.splitk < 1 || cc.splitk > p.steps0 + p.steps1) return fail(LDM_ERR_BAD_ARG, "bad splitk");
+    p.splitk = cc.splitk; p.steps_per_split = (p.steps0 + p.steps1 + cc.splitk - 1) / cc.splitk;
+    p.mtiles = (int)((M + 64 * cc.wgm - 1) / (64 * cc.wgm)); p.ntiles = cout_pad / (64 * cc.wgn);
+    p.bias = bias; p.bias2 = bias2; p.temb = temb; p.temb_stride = temb_stride; p.residual = (const bf16_t*)residual;
+    p.out = out_f32 ? nullptr : (bf16_t*)out_bf16; p.out_f32 = out_f32;
+    if (cc.splitk > 1) {
+        const size_t need = (size_t)cc.splitk * M * cout_pad * 4;
+        if (!scratch || scratch_bytes < need) return fail(LDM_ERR_WORKSPACE, "split-K scratch too small: need %zu bytes", need);
+        p.partial = (float*)scratch;
+    }
+    LDM_TRY(launch_conv(p, cc, (hipStream_t)stream));
+    if (cc.splitk > 1) {
+        FinalizeParams f{}; f.partial = p.partial; f.splitk = p.splitk; f.M = p.M; f.CoutPad = p.CoutPad; f.CoutS = p.CoutS;
+        f.CoutReal = p.CoutReal; f.DHWo = Do * Ho * Wo; f.bias = bias; f.bias2 = bias2; f.temb = temb; f.temb_stride = temb_stride;
+        f.residual = p.residual; f.out = p.out; f.out_f32 = p.out_f32;
+        hipLaunchKernelGGL(splitk_finalize_kernel, dim3(grid_for((long)p.M * (p.CoutS / 8))), dim3(256), 0, (hipStream_t)stream, f);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+size_t ldm_op_group_norm_scratch_bytes(int N, int C, int DHW) {
+    const int cvec = C / 8, rows_par = std::max(1, 256 / std::max(1, cvec));
+    int nslab = std::min((DHW + rows_par - 1) / rows_par, std::max(1, 512 / N));
+    return ((size_t)N * nslab * C * 2 + (size_t)N * C * 2) * 4 + 512;
+}
+
+int ldm_op_group_norm(const void* xa, int ca, const void* xb, int cb, const float* gamma, const float* beta,
+                      int groups, float eps, int silu, void* out, int N, int DHW, void* scratch, size_t scratch_bytes,
+                      void* stream) {
+    if (!xa || !gamma || !beta || !out || !scratch) return fail(LDM_ERR_BAD_ARG, "null tensor argument");
+    if (!xb) cb = 0;
+    const int C = ca + cb;
+    if (C % 8 || ca % 8 || groups < 1 || C % groups) return fail(LDM_ERR_BAD_ARG, "bad channel / group counts");
+    if (scratch_bytes < ldm_op_group_norm_scratch_bytes(N, C, DHW)) return fail(LDM_ERR_WORKSPACE, "scratch too small");
+    const int cvec = C / 8, rows_par = std::max(1, 256 / cvec);
+    int nslab = std::min((DHW + rows_par - 1) / rows_par, std::max(1, 512 / N));
+    const int rps = (DHW + nslab - 1) / nslab; nslab = (DHW + rps - 1) / rps;
+    float* partial = (float*)scratch;
+    float* ab = partial + (size_t)N * nslab * C * 2;
+    hipStream_t s = (hipStream_t)stream;
+    GnStatsParams sp{}; sp.xa = (const bf16_t*)xa; sp.xb = (const bf16_t*)xb; sp.ca = ca; sp.cb = cb; sp.DHW = DHW; sp.nslab = nslab;
+    sp.rows_per_slab = rps; sp.partial = partial;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nslab, N), dim3(256), 0, s, sp);
+    GnFinalizeParams fp{}; fp.partial = partial; fp.nslab = nslab; fp.C = C; fp.Creal = C; fp.groups = groups; fp.DHW = DHW; fp.eps = eps;
+    fp.gamma = gamma; fp.beta = beta; fp.ab = ab;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, N), dim3(64), 0, s, fp);
+    GnApplyParams ap{}; ap.xa = sp.xa; ap.xb = sp.xb; ap.ca = ca; ap.cb = cb; ap.DHW = DHW; ap.N = N; ap.silu = silu; ap.ab = ab; ap.out = (bf16_t*)out;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(grid_for((long)N * DHW * cvec, 256, 2048)), dim3(256), 0, s, ap);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ldm_op_attention(const void* qkv, void* out, int B, int N, int C, void* stream) {
+    if (!qkv || !out || B < 1 || N < 1 || C < 64 || C % 64) return fail(LDM_ERR_BAD_ARG, "bad argument (head_dim is 64, C % 64 == 0)");
+    AttnParams p{}; p.qkv = (const bf16_t*)qkv; p.out = (bf16_t*)out; p.B = B; p.N = N; p.C = C; p.heads = C / 64; p.scale = 0.125f;
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3((N + 63) / 64, C / 64, B), dim3(256), 0, (hipStream_t)stream, p);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---- RCCL (loaded lazily so the library itself has no hard dependency on librccl) -----------------------
+typedef struct { char internal[128]; } rccl_uid;
+typedef void* rccl_comm_t;
+struct RcclApi {
+    void* lib = nullptr;
+    int (*GetUniqueId)(rccl_uid*) = nullptr;
+    int (*CommInitRank)(rccl_comm_t*, int, rccl_uid, int) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, rccl_comm_t, hipStream_t) = nullptr;
+    int (*Broadcast)(const void*, void*, size_t, int, int, rccl_comm_t, hipStream_t) = nullptr;
+    int (*CommDestroy)(rccl_comm_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+static RcclApi g_rccl;
+static int rccl_load() {
+    if (g_rccl.lib) return 0;
+    void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return fail(LDM_ERR_RCCL, "cannot load librccl.so: %s", dlerror());
+    g_rccl.GetUniqueId = (int (*)(rccl_uid*))dlsym(h, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (int (*)(rccl_comm_t*, int, rccl_uid, int))dlsym(h, "ncclCommInitRank");
+    g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, rccl_comm_t, hipStream_t))dlsym(h, "ncclAllReduce");
+    g_rccl.Broadcast = (int (*)(const void*, void*, size_t, int, int, rccl_comm_t, hipStream_t))dlsym(h, "ncclBroadcast");
+    g_rccl.CommDestroy = (int (*)(rccl_comm_t))dlsym(h, "ncclCommDestroy");
+    g_rccl.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.Broadcast || !g_rccl.CommDestroy)
+        return fail(LDM_ERR_RCCL, "librccl.so lacks a required symbol");
+    g_rccl.lib = h;
+    return 0;
+}
+#define RCCL_TRY(x) do { int r_ = (x); if (r_ != 0) return fail(LDM_ERR_RCCL, "%s failed: %s", #x, \
+    g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "?"); } while (0)
+
+struct ldm_comm { rccl_comm_t comm = nullptr; int rank = 0, world = 1; float* token = nullptr; };
+
+int ldm_comm_unique_id(char id[128]) {
+    if (!id) return fail(LDM_ERR_BAD_ARG, "null id");
+    LDM_TRY(rccl_load());
+    rccl_uid u; RCCL_TRY(g_rccl.GetUniqueId(&u)); memcpy(id, u.internal, 128);
+    return 0;
+}
+int ldm_comm_init(int rank, int world, const char id[128], ldm_comm** out) {
+    if (!id || !out || world < 1 || rank < 0 || rank >= world) return fail(LDM_ERR_BAD_ARG, "bad argument");
+    LDM_TRY(rccl_load());
+    std::unique_ptr<ldm_comm> c(new ldm_comm()); c->rank = rank; c->world = world;
+    rccl_uid u; memcpy(u.internal, id, 128);
+    RCCL_TRY(g_rccl.CommInitRank(&c->comm, world, u, rank));
+    HIP_TRY(hipMalloc((void**)&c->token, 256));
+    HIP_TRY(hipMemset(c->token, 0, 256));
+    *out = c.release();
+    return 0;
+}
+// ncclDataType: float32 = 7, bfloat16 = 9; ncclRedOp: sum = 0, avg = 4
+int ldm_comm_allreduce(ldm_comm* c, void* buf, int64_t count, int dtype, int op, void* stream) {
+    if (!c || !buf || count < 0 || dtype < 0 || dtype > 1 || op < 0 || op > 1) return fail(LDM_ERR_BAD_ARG, "bad argument");
+    RCCL_TRY(g_rccl.AllReduce(buf, buf, (size_t)count, dtype == 0 ? 7 : 9, op == 0 ? 0 : 4, c->comm, (hipStream_t)stream));
+    return 0;
+}
+int ldm_comm_broadcast(ldm_comm* c, void* buf, int64_t count, int dtype, int root, void* stream) {
+    if (!c || !buf || count < 0 || dtype < 0 || dtype > 1 || root < 0 || root >= c->world) return fail(LDM_ERR_BAD_ARG, "bad argument");
+    RCCL_TRY(g_rccl.Broadcast(buf, buf, (size_t)count, dtype == 0 ? 7 : 9, root, c->comm, (hipStream_t)stream));
+    return 0;
+}
+int ldm_comm_barrier(ldm_comm* c, void* stream) {
+    if (!c) return fail(LDM_ERR_BAD_ARG, "null comm");
+    RCCL_TRY(g_rccl.AllReduce(c->token, c->token, 1, 7, 0, c->comm, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+void ldm_comm_destroy(ldm_comm* c) {
+    if (!c) return;
+    if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+    if (c->token) (void)hipFree(c->token);
+    delete c;
+}
+
+}  // extern "C"

@@ -1,0 +1,272 @@
+// GroupNorm (+SiLU), layout packing, timestep-embedding MLP and scheduler step kernels (gfx950).
+//
+// These replace torch.nn.GroupNorm / SiLU / Linear and monai DDPMScheduler/DDIMScheduler element-wise math
+// that the reference reaches through MONAI (call sites 3d_ldm/inference.py:94-99,
+// 3d_ldm/train_diffusion.py:197-205).  All are HBM/L2-bound: 16-byte vector accesses, fp32 statistics,
+// wavefront shuffles + one LDS hop for the reductions.
+#pragma once
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm statistics, pass 1: per-(sample, channel) partial sum / sum-of-squares over a slab of voxels.
+// Input is the channel-concatenation (xa | xb) in NDHWC bf16.  Thread = 8 channels x strided voxels.
+// partial layout: [N][nslab][C][2] fp32.
+struct GnStatsParams {
+    const bf16_t* xa; const bf16_t* xb; int ca, cb;
+    int DHW; int nslab; int rows_per_slab;
+    float* partial;
+};
+
+__global__ __launch_bounds__(256) void gn_stats_kernel(const GnStatsParams p) {
+    __shared__ float red[256 * 16];
+    const int C = p.ca + p.cb;
+    const int cvec = C / 8;                       // 8-channel vectors per voxel
+    const int n = blockIdx.y, slab = blockIdx.x;
+    const int r0 = slab * p.rows_per_slab;
+    int r1 = r0 + p.rows_per_slab; if (r1 > p.DHW) r1 = p.DHW;
+    float s[8], q[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { s[k] = 0.f; q[k] = 0.f; }
+    // vector slots: cv = tid % cvp, row lane = tid / cvp, where cvp = cvec rounded up to a divisor-friendly stride
+    const int tid = threadIdx.x;
+    const int rows_par = 256 / cvec > 0 ? 256 / cvec : 1;   // voxels processed concurrently by the block
+    if (cvec <= 256) {
+        const int cv = tid % cvec, rl = tid / cvec;
+        if (rl < rows_par) {
+            const int c = cv * 8;
+            const bool second = c >= p.ca;
+            const bf16_t* base = second ? p.xb : p.xa;
+            const int cs = second ? p.cb : p.ca;
+            const int cc = second ? c - p.ca : c;
+            for (int r = r0 + rl; r < r1; r += rows_par) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(base + ((size_t)n * p.DHW + r) * cs + cc);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float lo = __uint_as_float(v[k] << 16), hi = __uint_as_float(v[k] & 0xffff0000u);
+                    s[2 * k] += lo; q[2 * k] += lo * lo; s[2 * k + 1] += hi; q[2 * k + 1] += hi * hi;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { red[tid * 16 + k] = s[k]; red[tid * 16 + 8 + k] = q[k]; }
+        __syncthreads();
+        // threads 0..cvec-1 fold the row lanes of their channel vector
+        if (tid < cvec) {
+            for (int rl2 = 1; rl2 < rows_par; ++rl2) {
+                const int t2 = rl2 * cvec + tid;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { s[k] += red[t2 * 16 + k]; q[k] += red[t2 * 16 + 8 + k]; }
+            }
+            float* dst = p.partial + (((size_t)n * p.nslab + slab) * C + tid * 8) * 2;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { dst[2 * k] = s[k]; dst[2 * k + 1] = q[k]; }
+        }
+    } else {
+        // very wide tensors (C > 2048): each thread walks several channel vectors, all rows of the slab
+        for (int cv = tid; cv < cvec; cv += 256) {
+            const int c = cv * 8;
+            const bool second = c >= p.ca;
+            const bf16_t* base = second ? p.xb : p.xa;
+            const int cs = second ? p.cb : p.ca;
+            const int cc = second ? c - p.ca : c;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { s[k] = 0.f; q[k] = 0.f; }
+            for (int r = r0; r < r1; ++r) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(base + ((size_t)n * p.DHW + r) * cs + cc);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float lo = __uint_as_float(v[k] << 16), hi = __uint_as_float(v[k] & 0xffff0000u);
+                    s[2 * k] += lo; q[2 * k] += lo * lo; s[2 * k + 1] += hi; q[2 * k + 1] += hi * hi;
+                }
+            }
+            float* dst = p.partial + (((size_t)n * p.nslab + slab) * C + c) * 2;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { dst[2 * k] = s[k]; dst[2 * k + 1] = q[k]; }
+        }
+    }
+}
+
+// Pass 2: one block per (sample, group): fold slabs and the group's channels in fp64, emit per-channel
+// scale/shift  a_c = gamma_c * rstd_g,  b_c = beta_c - mean_g * a_c   ->  ab[N][C][2].
+struct GnFinalizeParams {
+    const float* partial; int nslab; int C; int Creal; int groups; int DHW; float eps;
+    const float* gamma; const float* beta; float* ab;
+};
+
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const GnFinalizeParams p) {
+    const int n = blockIdx.y, g = blockIdx.x;
+    const int cpg = p.Creal / p.groups;
+    const int lane = threadIdx.x;
+    double s = 0.0, q = 0.0;
+    const int items = p.nslab * cpg;
+    for (int i = lane; i < items; i += 64) {
+        const int slab = i / cpg, c = g * cpg + (i - slab * cpg);
+        const float* src = p.partial + (((size_t)n * p.nslab + slab) * p.C + c) * 2;
+        s += (double)src[0]; q += (double)src[1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+    const double cnt = (double)cpg * (double)p.DHW;
+    const double mean = s / cnt;
+    double var = q / cnt - mean * mean; if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+    for (int c = g * cpg + lane; c < (g + 1) * cpg; c += 64) {
+        const float a = p.gamma[c] * rstd;
+        p.ab[((size_t)n * p.C + c) * 2] = a;
+        p.ab[((size_t)n * p.C + c) * 2 + 1] = p.beta[c] - (float)mean * a;
+    }
+}
+
+// Pass 3: y = silu?(x * a_c + b_c) -> contiguous bf16 NDHWC (materialises the concat for the next conv).
+struct GnApplyParams {
+    const bf16_t* xa; const bf16_t* xb; int ca, cb; int DHW; int N; int silu;
+    const float* ab; bf16_t* out;
+};
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const GnApplyParams p) {
+    const int C = p.ca + p.cb;
+    const int cvec = C / 8;
+    const long total = (long)p.N * p.DHW * cvec;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / cvec;
+        const int c = (int)(i - row * cvec) * 8;
+        const int n = (int)(row / p.DHW);
+        const bool second = c >= p.ca;
+        const bf16_t* src = second ? p.xb + row * p.cb + (c - p.ca) : p.xa + row * p.ca + c;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(src);
+        const float4* abp = reinterpret_cast<const float4*>(p.ab + ((size_t)n * C + c) * 2);
+        float y[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float4 ab = abp[k];
+            float lo = __uint_as_float(v[k] << 16) * ab.x + ab.y;
+            float hi = __uint_as_float(v[k] & 0xffff0000u) * ab.z + ab.w;
+            if (p.silu) { lo = silu_f(lo); hi = silu_f(hi); }
+            y[2 * k] = lo; y[2 * k + 1] = hi;
+        }
+        u32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = pack2bf(y[2 * k], y[2 * k + 1]);
+        *reinterpret_cast<u32x4*>(p.out + row * C + c) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp32 NCDHW (x | cond channel-concatenated) -> bf16 NDHWC with zero channel padding to Cs.  Once per forward.
+__global__ __launch_bounds__(256) void pack2_ncdhw_kernel(const float* __restrict__ x, int cx, const float* __restrict__ cond,
+                                                          int cc, bf16_t* __restrict__ out, int N, int Cs, int DHW) {
+    const long total = (long)N * DHW * Cs;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cs);
+        const long row = i / Cs;
+        const int n = (int)(row / DHW);
+        const int sp = (int)(row - (long)n * DHW);
+        float v = 0.f;
+        if (c < cx) v = x[((size_t)n * cx + c) * DHW + sp];
+        else if (c < cx + cc) v = cond[((size_t)n * cc + (c - cx)) * DHW + sp];
+        out[i] = f2bf(v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Timestep embedding + MLP:  emb = W2 silu(W1 [cos(t f), sin(t f)] + b1) + b2   (cos first).
+// GEMV with bf16 weights [out][in], fp32 activations; one wave per output row.
+__global__ __launch_bounds__(256) void temb_sinusoid_kernel(const float* __restrict__ t, float* __restrict__ out,
+                                                            int B, int dim) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int half = dim / 2;
+    if (i >= B * dim) return;
+    const int b = i / dim, k = i - b * dim;
+    const int j = k < half ? k : k - half;
+    const float f = expf((-logf(10000.0f) * (float)j) / (float)half);     // same op order as get_timestep_embedding
+    const float a = t[b] * f;
+    out[i] = (k < half) ? cosf(a) : ((k < 2 * half) ? sinf(a) : 0.f);
+}
+
+// y[b][o] = sum_i W[o][i] * act(x[b][i]) + bias[o];  act = SiLU when silu_in.  grid = (ceil(O/4), B).
+__global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16_t* __restrict__ W, const float* __restrict__ bias,
+                                                        const float* __restrict__ x, float* __restrict__ y,
+                                                        int I, int O, int x_stride, int y_stride, int silu_in) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int o = blockIdx.x * 4 + wave, b = blockIdx.y;
+    if (o >= O) return;
+    const bf16_t* wr = W + (size_t)o * I;
+    const float* xr = x + (size_t)b * x_stride;
+    float acc = 0.f;
+    for (int i = lane * 8; i < I; i += 64 * 8) {
+        const u32x4 w = *reinterpret_cast<const u32x4*>(wr + i);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float x0 = xr[i + 2 * k], x1 = xr[i + 2 * k + 1];
+            if (silu_in) { x0 = silu_f(x0); x1 = silu_f(x1); }
+            acc += __uint_as_float(w[k] << 16) * x0 + __uint_as_float(w[k] & 0xffff0000u) * x1;
+        }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) y[(size_t)b * y_stride + o] = acc + (bias ? bias[o] : 0.f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Scheduler steps (fp32, NCDHW flat).  Coefficients are computed on the host in fp32 exactly as MONAI does
+//  and passed by value, so the device side is a pure fused multiply-add pass.
+struct StepCoef { float inv_sqrt_a, sqrt_b, c0, c1, sigma, dir; int clip; };
+
+__global__ __launch_bounds__(256) void ddpm_step_kernel(const float* __restrict__ eps, const float* __restrict__ x,
+                                                        const float* __restrict__ z, float* __restrict__ prev,
+                                                        float* __restrict__ x0_out, long n, StepCoef k) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float x0 = (x[i] - k.sqrt_b * eps[i]) * k.inv_sqrt_a;
+        if (k.clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+        float pv = k.c0 * x0 + k.c1 * x[i];
+        if (z) pv += k.sigma * z[i];
+        prev[i] = pv;
+        if (x0_out) x0_out[i] = x0;
+    }
+}
+
+__global__ __launch_bounds__(256) void ddim_step_kernel(const float* __restrict__ eps, const float* __restrict__ x,
+                                                        const float* __restrict__ z, float* __restrict__ prev,
+                                                        float* __restrict__ x0_out, long n, StepCoef k) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float x0 = (x[i] - k.sqrt_b * eps[i]) * k.inv_sqrt_a;
+        if (k.clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+        float pv = k.c0 * x0 + k.dir * eps[i];          // c0 = sqrt(abar_prev), dir = sqrt(1 - abar_prev - sigma^2)
+        if (z) pv += k.sigma * z[i];
+        prev[i] = pv;
+        if (x0_out) x0_out[i] = x0;
+    }
+}
+
+// noisy = sa[b] * x0 + sb[b] * eps, per-sample coefficients read from device arrays.
+__global__ __launch_bounds__(256) void add_noise_kernel(const float* __restrict__ x0, const float* __restrict__ eps,
+                                                        const float* __restrict__ sa, const float* __restrict__ sb,
+                                                        float* __restrict__ out, long per_sample, int B) {
+    const long n = per_sample * B;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / per_sample);
+        out[i] = sa[b] * x0[i] + sb[b] * eps[i];
+    }
+}
+
+// VAE heads: input fp32 NCDHW [N][2L][DHW] (mu | log_var) -> z_mu, z_sigma (clamp [-30, 20], exp(./2)) and
+// optionally z = mu + sigma * eps.
+__global__ __launch_bounds__(256) void vae_heads_kernel(const float* __restrict__ ml, const float* __restrict__ eps,
+                                                        float* __restrict__ mu, float* __restrict__ sigma,
+                                                        float* __restrict__ z, int N, int L, int DHW) {
+    const long total = (long)N * L * DHW;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / ((long)L * DHW));
+        const long r = i - (long)n * L * DHW;
+        const float m = ml[(size_t)n * 2 * L * DHW + r];
+        float lv = ml[(size_t)n * 2 * L * DHW + (long)L * DHW + r];
+        lv = fminf(fmaxf(lv, -30.f), 20.f);
+        const float sg = expf(0.5f * lv);
+        if (mu) mu[i] = m;
+        if (sigma) sigma[i] = sg;
+        if (z) z[i] = m + sg * (eps ? eps[i] : 0.f);
+    }
+}
+
+__global__ __launch_bounds__(256) void scale_kernel(const float* __restrict__ x, float* __restrict__ y, long n, float s) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = x[i] * s;
+}

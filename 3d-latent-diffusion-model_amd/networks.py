@@ -1,0 +1,323 @@
+"""nn.Module shells over libldm3d.so: ``DiffusionModelUNet`` and ``AutoencoderKL``.
+
+Drop-in for the classes the reference instantiates from its JSON configs through ``define_instance``
+(3d_ldm/utils.py:243-246; ``_target_`` strings at 3d_ldm/config/config_train_16g.json:8,40 and
+config_train_32g.json:8,41) and then uses only through the nn.Module surface:
+``__call__(x=, timesteps=, context=None)``, ``encode_stage_2_inputs``, ``decode_stage_2_outputs``,
+``forward -> (recon, z_mu, z_sigma)``, ``state_dict`` / ``load_state_dict`` / ``parameters`` / ``to`` /
+``train`` / ``eval``.  Parameter names and shapes (the MONAI state_dict layout) are enumerated from the
+library, so there is one source of truth for them; parameters are ordinary fp32 nn.Parameters and are
+re-packed into the library's bf16 weight arena whenever they change.
+
+Inference only in this round: forward runs the hand-written HIP plan and returns tensors without grad_fn.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, Optional, Sequence, Union
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+class _Node(nn.Module):
+    """Anonymous container used to give parameters their dotted MONAI names."""
+
+
+def _per_level(v, n, name):
+    if isinstance(v, (int, bool)):
+        return [int(v)] * n
+    v = [int(a) for a in v]
+    if len(v) != n:
+        raise ValueError(f"{name} must have one entry per level ({n}), got {len(v)}")
+    return v
+
+
+class _LdmModule(nn.Module):
+    """Shared plumbing: C handle, parameter tree, weight upload, workspace cache."""
+
+    def __init__(self):
+        super().__init__()
+        self._h = C.c_void_p()
+        self._dirty = True
+        self._uploaded_versions: Dict[str, int] = {}
+        self._ws: Dict[tuple, torch.Tensor] = {}
+
+    # -- parameter tree -------------------------------------------------------------------------------
+    def _build_params(self):
+        L = _lib.lib()
+        n = L.ldm_model_num_params(self._h)
+        for i in range(n):
+            name = L.ldm_model_param_name(self._h, i).decode()
+            nd = L.ldm_model_param_ndim(self._h, i)
+            shp = L.ldm_model_param_shape(self._h, i)
+            shape = tuple(int(shp[k]) for k in range(nd))
+            parts = name.split(".")
+            node = self
+            for part in parts[:-1]:
+                if part not in node._modules:
+                    node.add_module(part, _Node())
+                node = node._modules[part]
+            node.register_parameter(parts[-1], nn.Parameter(torch.empty(shape, dtype=torch.float32)))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        """PyTorch-default init (what MONAI's Convolution / nn.Linear / nn.GroupNorm do) ..."""
+        params = dict(self.named_parameters())
+        for name, p in params.items():
+            with torch.no_grad():
+                if p.dim() == 1 and name.endswith(".weight"):
+                    p.fill_(1.0)                                  # GroupNorm gamma
+                elif p.dim() == 1:
+                    w = params.get(name[:-len("bias")] + "weight")
+                    if w is not None and w.dim() > 1:
+                        fan_in = w[0].numel()
+                        bound = 1.0 / math.sqrt(fan_in)
+                        p.uniform_(-bound, bound)
+                    else:
+                        p.zero_()                                 # GroupNorm beta
+                else:
+                    nn.init.kaiming_uniform_(p, a=math.sqrt(5))
+        self._zero_init()
+        self._dirty = True
+
+    def _zero_init(self):
+        pass
+
+    # -- keep the device arena in sync ------------------------------------------------------------------
+    def mark_weights_dirty(self):
+        self._dirty = True
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self._dirty = True
+        return r
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self._dirty = True
+        return r
+
+    def train(self, mode: bool = True):
+        self._dirty = True
+        return super().train(mode)
+
+    def _sync_weights(self):
+        if not (self._dirty or self.training):
+            return
+        L = _lib.lib()
+        for name, p in self.named_parameters():
+            v = p._version
+            if self._uploaded_versions.get(name) == (v, p.data_ptr()):
+                continue
+            host = p.detach().to(device="cpu", dtype=torch.float32).contiguous()
+            _lib.check(L.ldm_model_load_param(self._h, name.encode(), host.data_ptr(), host.numel()))
+            self._uploaded_versions[name] = (v, p.data_ptr())
+        self._dirty = False
+
+    def _workspace(self, key: tuple, nbytes: int, device) -> torch.Tensor:
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < nbytes or ws.device != device:
+            ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
+            self._ws[key] = ws
+        return ws
+
+    @staticmethod
+    def _need_cuda(t: torch.Tensor, what: str):
+        if not t.is_cuda:
+            raise _lib.LdmError(f"{what}: tensor is on {t.device}; this implementation runs on the GPU only "
+                                f"(no CPU fallback - the CPU oracle lives in oracle/ and is test infrastructure)")
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                _lib.lib().ldm_model_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+
+class DiffusionModelUNet(_LdmModule):
+    """MI355X-native DiffusionModelUNet (kwargs of ``diffusion_def``, 3d_ldm/config/config_train_16g.json:39-48)."""
+
+    def __init__(self, spatial_dims: int, in_channels: int, out_channels: int,
+                 num_res_blocks: Union[Sequence[int], int] = (2, 2, 2, 2),
+                 channels: Sequence[int] = (32, 64, 64, 64),
+                 attention_levels: Sequence[bool] = (False, False, True, True),
+                 norm_num_groups: int = 32, norm_eps: float = 1e-6, resblock_updown: bool = False,
+                 num_head_channels: Union[int, Sequence[int]] = 8, with_conditioning: bool = False,
+                 transformer_num_layers: int = 1, cross_attention_dim: Optional[int] = None,
+                 num_class_embeds: Optional[int] = None, upcast_attention: bool = False,
+                 dropout_cattn: float = 0.0, include_fc: bool = True, use_combined_linear: bool = False,
+                 use_flash_attention: bool = False):
+        super().__init__()
+        if with_conditioning or cross_attention_dim is not None or num_class_embeds is not None:
+            raise NotImplementedError("cross-attention / class conditioning is not on the reference's path "
+                                      "(with_conditioning=False everywhere; conditioning is channel concat)")
+        if resblock_updown or not include_fc or use_combined_linear:
+            raise NotImplementedError("resblock_updown / include_fc=False / use_combined_linear are not implemented")
+        n = len(channels)
+        if len(attention_levels) != n:
+            raise ValueError("attention_levels must have one entry per level")
+        cfg = _lib.UNetCfg()
+        cfg.spatial_dims, cfg.in_channels, cfg.out_channels, cfg.num_levels = spatial_dims, in_channels, out_channels, n
+        nrb = _per_level(num_res_blocks, n, "num_res_blocks")
+        nhc = _per_level(num_head_channels, n, "num_head_channels")
+        for i in range(n):
+            cfg.channels[i] = int(channels[i])
+            cfg.attention_levels[i] = int(bool(attention_levels[i]))
+            cfg.num_head_channels[i] = nhc[i]
+            cfg.num_res_blocks[i] = nrb[i]
+        cfg.norm_num_groups, cfg.norm_eps = int(norm_num_groups), float(norm_eps)
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.block_out_channels = list(channels)
+        _lib.check(_lib.lib().ldm_unet_create(C.byref(cfg), C.byref(self._h)))
+        self._build_params()
+
+    def _zero_init(self):
+        # MONAI zero_module(): every ResBlock conv2 and the output conv start at zero
+        with torch.no_grad():
+            for name, p in self.named_parameters():
+                if ".conv2.conv." in name or name.startswith("out.2.conv."):
+                    p.zero_()
+
+    def forward(self, x: torch.Tensor, timesteps: torch.Tensor, context: Optional[torch.Tensor] = None,
+                class_labels=None, down_block_additional_residuals=None, mid_block_additional_residual=None,
+                cond: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """eps_hat = UNet(x_t, t).  ``cond`` (extension) is a second tensor channel-concatenated after ``x``
+        inside the input packing kernel, so mode="concat" callers need no torch.cat."""
+        if context is not None or class_labels is not None or down_block_additional_residuals is not None \
+                or mid_block_additional_residual is not None:
+            raise NotImplementedError("context / class_labels / ControlNet residuals are not on the reference's path")
+        if torch.is_grad_enabled() and x.requires_grad:
+            raise NotImplementedError("backward through the HIP UNet is not implemented yet (inference only)")
+        self._need_cuda(x, "DiffusionModelUNet.forward")
+        if x.dim() != 5:
+            raise ValueError(f"expected [B, C, D, H, W], got {tuple(x.shape)}")
+        B, cx, D, H, W = x.shape
+        x = x.detach().to(torch.float32).contiguous()
+        cc = 0
+        if cond is not None:
+            cond = cond.detach().to(device=x.device, dtype=torch.float32).contiguous()
+            cc = cond.shape[1]
+        t = timesteps.detach().to(device=x.device, dtype=torch.float32).reshape(-1).contiguous()
+        if t.numel() != B:
+            raise ValueError(f"timesteps must have {B} entries, got {t.numel()}")
+        self._sync_weights()
+        L = _lib.lib()
+        nbytes = L.ldm_unet_workspace_bytes(self._h, B, D, H, W)
+        if nbytes == 0:
+            raise _lib.LdmError((L.ldm_last_error() or b"workspace query failed").decode())
+        ws = self._workspace(("unet", B, D, H, W), nbytes, x.device)
+        out = torch.empty((B, self.out_channels, D, H, W), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(L.ldm_unet_forward(self._h, x.data_ptr(), cx, _lib.ptr(cond), cc, t.data_ptr(), out.data_ptr(),
+                                          B, D, H, W, ws.data_ptr(), ws.numel(), _lib.current_stream()))
+        return out
+
+
+class AutoencoderKL(_LdmModule):
+    """MI355X-native AutoencoderKL (kwargs of ``autoencoder_def``, 3d_ldm/config/config_train_16g.json:7-28)."""
+
+    def __init__(self, spatial_dims: int, in_channels: int = 1, out_channels: int = 1,
+                 num_res_blocks: Union[Sequence[int], int] = (2, 2, 2, 2), channels: Sequence[int] = (32, 64, 64, 64),
+                 attention_levels: Sequence[bool] = (False, False, True, True), latent_channels: int = 3,
+                 norm_num_groups: int = 32, norm_eps: float = 1e-6, with_encoder_nonlocal_attn: bool = True,
+                 with_decoder_nonlocal_attn: bool = True, use_checkpoint: bool = False, use_convtranspose: bool = False,
+                 include_fc: bool = True, use_combined_linear: bool = False, use_flash_attention: bool = False):
+        super().__init__()
+        if use_convtranspose:
+            raise NotImplementedError("use_convtranspose is not on the reference's path")
+        n = len(channels)
+        cfg = _lib.VaeCfg()
+        cfg.spatial_dims, cfg.in_channels, cfg.out_channels = spatial_dims, in_channels, out_channels
+        cfg.latent_channels, cfg.num_levels = latent_channels, n
+        nrb = _per_level(num_res_blocks, n, "num_res_blocks")
+        for i in range(n):
+            cfg.channels[i] = int(channels[i])
+            cfg.num_res_blocks[i] = nrb[i]
+            cfg.attention_levels[i] = int(bool(attention_levels[i]))
+        cfg.norm_num_groups, cfg.norm_eps = int(norm_num_groups), float(norm_eps)
+        cfg.with_encoder_nonlocal_attn = int(bool(with_encoder_nonlocal_attn))
+        cfg.with_decoder_nonlocal_attn = int(bool(with_decoder_nonlocal_attn))
+        self.in_channels, self.out_channels, self.latent_channels = in_channels, out_channels, latent_channels
+        self.factor = 2 ** (n - 1)
+        _lib.check(_lib.lib().ldm_vae_create(C.byref(cfg), C.byref(self._h)))
+        self._build_params()
+
+    # -- encode ----------------------------------------------------------------------------------------
+    def _encode(self, x: torch.Tensor, eps: Optional[torch.Tensor], want_z: bool):
+        self._need_cuda(x, "AutoencoderKL.encode")
+        if torch.is_grad_enabled() and x.requires_grad:
+            raise NotImplementedError("backward through the HIP AutoencoderKL is not implemented yet (inference only)")
+        B, _, D, H, W = x.shape
+        x = x.detach().to(torch.float32).contiguous()
+        self._sync_weights()
+        L = _lib.lib()
+        nbytes = L.ldm_vae_encode_workspace_bytes(self._h, B, D, H, W)
+        if nbytes == 0:
+            raise _lib.LdmError((L.ldm_last_error() or b"workspace query failed").decode())
+        ws = self._workspace(("enc", B, D, H, W), nbytes, x.device)
+        f = self.factor
+        shp = (B, self.latent_channels, D // f, H // f, W // f)
+        z_mu = torch.empty(shp, dtype=torch.float32, device=x.device)
+        z_sigma = torch.empty_like(z_mu)
+        z = torch.empty_like(z_mu) if want_z else None
+        if eps is not None:
+            eps = eps.detach().to(device=x.device, dtype=torch.float32).contiguous()
+        with torch.cuda.device(x.device):
+            _lib.check(L.ldm_vae_encode(self._h, x.data_ptr(), _lib.ptr(eps), z_mu.data_ptr(), z_sigma.data_ptr(),
+                                        _lib.ptr(z), B, D, H, W, ws.data_ptr(), ws.numel(), _lib.current_stream()))
+        return z_mu, z_sigma, z
+
+    def encode(self, x: torch.Tensor):
+        z_mu, z_sigma, _ = self._encode(x, None, False)
+        return z_mu, z_sigma
+
+    def sampling(self, z_mu: torch.Tensor, z_sigma: torch.Tensor) -> torch.Tensor:
+        return z_mu + torch.randn_like(z_sigma) * z_sigma
+
+    def encode_stage_2_inputs(self, x: torch.Tensor, eps: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """z = mu + sigma * eps, eps ~ N(0, I) drawn with torch.randn_like unless given (tests pass it explicitly)."""
+        if eps is None:
+            B, _, D, H, W = x.shape
+            f = self.factor
+            eps = torch.randn((B, self.latent_channels, D // f, H // f, W // f), dtype=torch.float32, device=x.device)
+        return self._encode(x, eps, True)[2]
+
+    # -- decode ----------------------------------------------------------------------------------------
+    def decode(self, z: torch.Tensor) -> torch.Tensor:
+        self._need_cuda(z, "AutoencoderKL.decode")
+        if torch.is_grad_enabled() and z.requires_grad:
+            raise NotImplementedError("backward through the HIP AutoencoderKL is not implemented yet (inference only)")
+        B, _, d, h, w = z.shape
+        z = z.detach().to(torch.float32).contiguous()
+        self._sync_weights()
+        L = _lib.lib()
+        nbytes = L.ldm_vae_decode_workspace_bytes(self._h, B, d, h, w)
+        if nbytes == 0:
+            raise _lib.LdmError((L.ldm_last_error() or b"workspace query failed").decode())
+        ws = self._workspace(("dec", B, d, h, w), nbytes, z.device)
+        f = self.factor
+        out = torch.empty((B, self.out_channels, d * f, h * f, w * f), dtype=torch.float32, device=z.device)
+        with torch.cuda.device(z.device):
+            _lib.check(L.ldm_vae_decode(self._h, z.data_ptr(), out.data_ptr(), B, d, h, w, ws.data_ptr(), ws.numel(),
+                                        _lib.current_stream()))
+        return out
+
+    def decode_stage_2_outputs(self, z: torch.Tensor) -> torch.Tensor:
+        return self.decode(z)
+
+    def reconstruct(self, x: torch.Tensor) -> torch.Tensor:
+        return self.decode(self.encode(x)[0])
+
+    def forward(self, x: torch.Tensor):
+        """-> (reconstruction, z_mu, z_sigma)  (3d_ldm/train_autoencoder.py:366)."""
+        B, _, D, H, W = x.shape
+        f = self.factor
+        eps = torch.randn((B, self.latent_channels, D // f, H // f, W // f), dtype=torch.float32, device=x.device)
+        z_mu, z_sigma, z = self._encode(x, eps, True)
+        return self.decode(z), z_mu, z_sigma

@@ -1,0 +1,161 @@
+/* ldm3d.h - C ABI of libldm3d.so: the MI355X-native (gfx950) 3D latent-diffusion denoising path.
+ *
+ * This is the drop-in boundary for the hot path of sanazkaviani/3d-latent-diffusion-model.  The reference has
+ * no native code: its plug point is the JSON "_target_" class instantiated by define_instance
+ * (3d_ldm/utils.py:243-246) and then used through the nn.Module surface; each entry point below cites the
+ * reference call it serves.  The host-side mirror (the .py files of 3d-latent-diffusion-model_amd/, loaded with ctypes)
+ * exposes these as the same nn.Module / scheduler / inferer objects.  See INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative ldm_status; ldm_last_error() gives the message
+ *     (thread local).  Nothing aborts, nothing throws across the ABI.
+ *   - all tensor arguments are DEVICE pointers owned by the caller; image/latent tensors are fp32 NCDHW
+ *     (the reference's layout); the library converts to its internal NDHWC bf16 layout itself.
+ *   - the caller owns the workspace (size from *_workspace_bytes); the library owns weights and plans.
+ *     No allocation, no synchronisation on the forward/step path: every launch goes to `stream`
+ *     (a hipStream_t passed as void*), so calls may be captured into a hipGraph.
+ *   - handles are not thread safe; one process per GPU (torchrun model, 3d_ldm/train_diffusion.py:43-51).
+ */
+#ifndef LDM3D_H
+#define LDM3D_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LDM_MAX_LEVELS 8
+#define LDM_ABI_VERSION 1
+
+typedef enum {
+    LDM_OK = 0,
+    LDM_ERR_BAD_ARG = -1,
+    LDM_ERR_UNSUPPORTED = -2,     /* shape / config outside what the kernels implement */
+    LDM_ERR_HIP = -3,
+    LDM_ERR_NOT_LOADED = -4,      /* forward called before every parameter was uploaded */
+    LDM_ERR_WORKSPACE = -5,       /* workspace too small */
+    LDM_ERR_RCCL = -6
+} ldm_status;
+
+/* kwargs of "diffusion_def" (3d_ldm/config/config_train_16g.json:39-48); MONAI defaults norm_num_groups=32,
+ * norm_eps=1e-6 are filled by the host mirror. */
+typedef struct {
+    int spatial_dims;                         /* only 3 */
+    int in_channels, out_channels;
+    int num_levels;
+    int channels[LDM_MAX_LEVELS];
+    int attention_levels[LDM_MAX_LEVELS];
+    int num_head_channels[LDM_MAX_LEVELS];
+    int num_res_blocks[LDM_MAX_LEVELS];
+    int norm_num_groups;
+    float norm_eps;
+} ldm_unet_cfg;
+
+/* kwargs of "autoencoder_def" (3d_ldm/config/config_train_16g.json:7-28). */
+typedef struct {
+    int spatial_dims;                         /* only 3 */
+    int in_channels, out_channels, latent_channels;
+    int num_levels;
+    int channels[LDM_MAX_LEVELS];
+    int num_res_blocks[LDM_MAX_LEVELS];
+    int attention_levels[LDM_MAX_LEVELS];
+    int norm_num_groups;
+    float norm_eps;
+    int with_encoder_nonlocal_attn, with_decoder_nonlocal_attn;
+} ldm_vae_cfg;
+
+typedef struct ldm_model ldm_model;           /* a UNet or an AutoencoderKL: weights + cached launch plans */
+
+int ldm_version(void);
+const char* ldm_last_error(void);
+
+/* ---- construction (replaces define_instance(args, "diffusion_def" / "autoencoder_def"),
+ *      3d_ldm/utils.py:243-246, 3d_ldm/inference.py:71,75, 3d_ldm/train_diffusion.py:90,127) ------------ */
+int ldm_unet_create(const ldm_unet_cfg* cfg, ldm_model** out);
+int ldm_vae_create(const ldm_vae_cfg* cfg, ldm_model** out);
+void ldm_model_destroy(ldm_model* m);
+
+/* ---- parameters: MONAI-shaped state_dict (replaces load_state_dict, 3d_ldm/inference.py:73,77,
+ *      3d_ldm/train_diffusion.py:92-95,129-136).  Enumerate names/shapes, then upload fp32 HOST arrays. ----- */
+int ldm_model_num_params(const ldm_model* m);
+const char* ldm_model_param_name(const ldm_model* m, int i);
+int ldm_model_param_ndim(const ldm_model* m, int i);
+const int64_t* ldm_model_param_shape(const ldm_model* m, int i);
+int ldm_model_load_param(ldm_model* m, const char* name, const float* host_data, size_t numel);
+int64_t ldm_model_param_numel_total(const ldm_model* m);
+
+/* ---- DiffusionModelUNet.forward(x, timesteps, context=None)
+ *      (reached via inferer(...) 3d_ldm/train_diffusion.py:197-205,260-268 and inferer.sample(...)
+ *      3d_ldm/train_diffusion.py:326-333, 3d_ldm/inference.py:94-99).
+ *      x:[B,Cx,D,H,W], cond:[B,Cc,D,H,W] or NULL (mode="concat": Cx + Cc == in_channels), timesteps:[B] fp32,
+ *      out:[B,out_channels,D,H,W]; all fp32 NCDHW device memory. ---------------------------------------------- */
+size_t ldm_unet_workspace_bytes(ldm_model* m, int B, int D, int H, int W);
+int ldm_unet_forward(ldm_model* m, const float* x, int x_channels, const float* cond, int cond_channels,
+                     const float* timesteps, float* out, int B, int D, int H, int W,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- AutoencoderKL.encode / sampling / decode (3d_ldm/train_diffusion.py:104,180,195,249,258,310,324;
+ *      3d_ldm/train_autoencoder.py:366,579).  encode: x:[B,Cin,D,H,W] -> z_mu, z_sigma, z = mu + sigma*eps
+ *      (each [B,L,D/f,H/f,W/f], any of the three outputs may be NULL; eps NULL means eps = 0).
+ *      decode: z:[B,L,d,h,w] -> out:[B,Cout,d*f,h*f,w*f]. ------------------------------------------------------ */
+size_t ldm_vae_encode_workspace_bytes(ldm_model* m, int B, int D, int H, int W);
+size_t ldm_vae_decode_workspace_bytes(ldm_model* m, int B, int d, int h, int w);
+int ldm_vae_encode(ldm_model* m, const float* x, const float* eps, float* z_mu, float* z_sigma, float* z,
+                   int B, int D, int H, int W, void* workspace, size_t workspace_bytes, void* stream);
+int ldm_vae_decode(ldm_model* m, const float* z, float* out, int B, int d, int h, int w,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- scheduler arithmetic (monai DDPMScheduler / DDIMScheduler as built at 3d_ldm/inference.py:79-84,
+ *      3d_ldm/train_diffusion.py:140-145).  The host mirror keeps the fp32 beta / alpha-bar tables and passes
+ *      the per-step scalars; these launches are the element-wise part, n = number of elements.
+ *      ddpm:  x0 = (x - sqrt_b*eps)*inv_sqrt_a ; clip ; prev = c0*x0 + c1*x (+ sigma*noise)
+ *      ddim:  x0 likewise           ; prev = c0*x0 + dir*eps (+ sigma*noise)
+ *      noise / x0_out may be NULL. ---------------------------------------------------------------------------- */
+int ldm_ddpm_step(const float* eps, const float* x, const float* noise, float* prev, float* x0_out, int64_t n,
+                  float inv_sqrt_a, float sqrt_b, float c0, float c1, float sigma, int clip, void* stream);
+int ldm_ddim_step(const float* eps, const float* x, const float* noise, float* prev, float* x0_out, int64_t n,
+                  float inv_sqrt_a, float sqrt_b, float c0, float dir, float sigma, int clip, void* stream);
+/* add_noise: out = sqrt_a[b]*x0 + sqrt_b[b]*eps; sqrt_a, sqrt_b: [B] device fp32 (3d_ldm/train_diffusion.py:197-205) */
+int ldm_add_noise(const float* x0, const float* eps, const float* sqrt_a, const float* sqrt_b, float* out,
+                  int B, int64_t per_sample, void* stream);
+int ldm_scale(const float* x, float* y, int64_t n, float s, void* stream);
+
+/* ---- operator level: the kernels the plans are made of, on the library's internal layout (NDHWC bf16 device
+ *      tensors, C % 32 == 0).  They replace torch.nn.functional.conv3d / group_norm+silu / softmax-attention as
+ *      MONAI's blocks call them and exist for per-kernel parity tests and micro-benchmarks.
+ *      conv3d: out[m][co] = sum_tap sum_ci w[tap][co][ci] * cat(xa,xb)[voxel(m,tap)][ci]  (+ optional fused 1x1
+ *      conv over cat(x1a,x1b) with w1) + bias + bias2 + temb[n][co] + residual[m][co].  w: [k^3][cout_pad][ca+cb]
+ *      bf16, cout_pad % 64 == 0.  stride 2 with pad 0 means F.pad(x,(0,1)*3) then stride-2 conv (AEKLDownsample).
+ *      ups = 1 folds a nearest x2 upsample of the input into the loader.  Exactly one of out_bf16 ([M][rup32(cout)])
+ *      / out_f32 (NCDHW [N][cout][DHW]) is written.  wgn in {0 auto,1,2,4} picks the tile (BN = 64*wgn), splitk 0 =
+ *      auto; scratch holds the fp32 split-K slabs (splitk * M * cout_pad * 4 bytes). ------------------------------ */
+int ldm_op_conv3d(const void* xa, int ca, const void* xb, int cb, const void* w, const float* bias,
+                  const void* x1a, int c1a, const void* x1b, int c1b, const void* w1, const float* bias2,
+                  const float* temb, int temb_stride, const void* residual, void* out_bf16, float* out_f32,
+                  int N, int Din, int Hin, int Win, int ksize, int stride, int pad, int ups,
+                  int cout, int cout_pad, int wgn, int splitk, void* scratch, size_t scratch_bytes, void* stream);
+/* GroupNorm(groups, eps, affine) over cat(xa, xb), optional fused SiLU -> out [N*DHW][ca+cb] bf16. */
+size_t ldm_op_group_norm_scratch_bytes(int N, int C, int DHW);
+int ldm_op_group_norm(const void* xa, int ca, const void* xb, int cb, const float* gamma, const float* beta,
+                      int groups, float eps, int silu, void* out, int N, int DHW, void* scratch, size_t scratch_bytes,
+                      void* stream);
+/* softmax(q k^T / 8) v with head_dim 64: qkv [B*N][3C] bf16 (q|k|v, channel = head*64 + d) -> out [B*N][C] bf16. */
+int ldm_op_attention(const void* qkv, void* out, int B, int N, int C, void* stream);
+
+/* ---- data-parallel collectives (replaces init_process_group("nccl") + DDP all-reduce,
+ *      3d_ldm/utils.py:55-63, 3d_ldm/train_diffusion.py:121-123,147-149,281-283): RCCL over xGMI.
+ *      unique_id is the 128-byte ncclUniqueId produced by ldm_comm_unique_id on rank 0 and distributed
+ *      by the launcher's store.  dtype: 0 = fp32, 1 = bf16; op: 0 = sum, 1 = avg. ------------------------------ */
+typedef struct ldm_comm ldm_comm;
+int ldm_comm_unique_id(char id[128]);
+int ldm_comm_init(int rank, int world, const char id[128], ldm_comm** out);
+int ldm_comm_allreduce(ldm_comm* c, void* buf, int64_t count, int dtype, int op, void* stream);
+int ldm_comm_broadcast(ldm_comm* c, void* buf, int64_t count, int dtype, int root, void* stream);
+int ldm_comm_barrier(ldm_comm* c, void* stream);
+void ldm_comm_destroy(ldm_comm* c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LDM3D_H */

@@ -1,0 +1,22 @@
+"""Model definitions used across tests (shapes from 3d_ldm/config/config_train_16g.json, BASELINE.json)."""
+# benchmark UNet: diffusion_def of config_train_16g.json:39-48 with in = out = 4 latent channels (BASELINE.json)
+UNET_FULL = dict(spatial_dims=3, in_channels=4, out_channels=4, channels=[256, 256, 512],
+                 attention_levels=[False, True, True], num_head_channels=[0, 64, 64], num_res_blocks=2)
+# same topology, small enough for the CPU oracle to run in a second
+UNET_TINY = dict(spatial_dims=3, in_channels=4, out_channels=4, channels=[64, 64, 128],
+                 attention_levels=[False, True, True], num_head_channels=[0, 64, 64], num_res_blocks=2,
+                 norm_num_groups=32)
+# concat-conditioned variant (train_diffusion.py:197-205 mode="concat"): in = 2 x latent
+UNET_TINY_COND = dict(UNET_TINY, in_channels=8)
+# odd level structure: per-level res blocks, attention at level 0, 2 levels
+UNET_TINY_ALT = dict(spatial_dims=3, in_channels=3, out_channels=2, channels=[64, 128],
+                     attention_levels=[True, False], num_head_channels=64, num_res_blocks=[1, 2],
+                     norm_num_groups=16)
+# autoencoder_def of config_train_16g.json:7-28 with 1 image channel and 4 latent channels (BASELINE.json config 2)
+VAE_FULL = dict(spatial_dims=3, in_channels=1, out_channels=1, latent_channels=4, channels=[64, 128, 256],
+                num_res_blocks=2, norm_num_groups=32, norm_eps=1e-6, attention_levels=[False, False, False],
+                with_encoder_nonlocal_attn=False, with_decoder_nonlocal_attn=False)
+VAE_TINY = dict(spatial_dims=3, in_channels=2, out_channels=2, latent_channels=8, channels=[32, 64, 64],
+                num_res_blocks=[1, 2, 1], norm_num_groups=16, norm_eps=1e-6, attention_levels=[False, False, False],
+                with_encoder_nonlocal_attn=False, with_decoder_nonlocal_attn=False)
+SCHED = dict(num_train_timesteps=1000, schedule="scaled_linear_beta", beta_start=0.0015, beta_end=0.0195)

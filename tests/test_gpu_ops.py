@@ -1,0 +1,197 @@
+"""Per-kernel parity (-m gpu): every HIP kernel, called through the C ABI (ldm_op_*), against plain torch CPU fp32
+ops evaluated on the same bf16-rounded inputs.  Tolerance: fp32 accumulation-order noise plus one output rounding
+to bf16 -> rel-L2 <= 3e-3 against the UN-rounded fp32 result (a bf16 rounding alone is ~1.7e-3 rms... see below),
+and <= 2e-4 against the result rounded to bf16 the same way (the gate that matters: same rounding points)."""
+import itertools
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from util import bf16_round, from_ndhwc, pack_conv_weight, pad_vec, rel_l2, rup, to_ndhwc_bf16
+
+pytestmark = pytest.mark.gpu
+TOL_SAME_ROUNDING = 3e-4     # identical rounding points; remaining difference = fp32 summation order + rare bf16 ties
+TOL_FP32_OUT = 2e-5          # fp32 outputs (no output rounding)
+
+
+def _conv_case(cuda, lib, *, n=1, cin=(64, 0), cout=64, dims=(8, 8, 8), k=3, stride=1, pad=1, ups=0, wgn=0, splitk=0,
+               skip=None, temb=False, residual=False, f32_out=False, seed=0):
+    from ldm3d import _lib
+    g = torch.Generator().manual_seed(seed)
+    ca, cb = cin
+    c = ca + cb
+    cas, cbs = rup(ca, 32), (rup(cb, 32) if cb else 0)
+    assert cb == 0 or ca == cas, "dual source needs an unpadded first source"
+    x = torch.randn((n, c, *dims), generator=g)
+    w = torch.randn((cout, c, k, k, k), generator=g) / (c * k ** 3) ** 0.5
+    b = 0.1 * torch.randn((cout,), generator=g)
+    xr, wr = bf16_round(x), bf16_round(w)
+    xin = F.interpolate(xr, scale_factor=2.0, mode="nearest") if ups else xr
+    if stride == 2 and pad == 0:
+        xin = F.pad(xin, (0, 1, 0, 1, 0, 1))
+    ref = F.conv3d(xin, wr, b, stride=stride, padding=pad)
+    cout_pad = rup(cout, 64)
+    args = dict(x1a=None, c1a=0, x1b=None, c1b=0, w1=None, bias2=None)
+    keep = []
+    if skip is not None:                      # fused 1x1 conv over a (dual-source) tensor at output resolution
+        s_a, s_b = skip
+        xs = torch.randn((n, s_a + s_b, *ref.shape[2:]), generator=g)
+        ws = torch.randn((cout, s_a + s_b, 1, 1, 1), generator=g) / (s_a + s_b) ** 0.5
+        bs = 0.1 * torch.randn((cout,), generator=g)
+        ref = ref + F.conv3d(bf16_round(xs), bf16_round(ws), bs)
+        x1a = to_ndhwc_bf16(xs[:, :s_a]).to(cuda)
+        x1b = to_ndhwc_bf16(xs[:, s_a:]).to(cuda) if s_b else None
+        w1 = pack_conv_weight(ws, s_a + s_b, cout_pad).to(cuda)
+        b2 = pad_vec(bs, cout_pad).to(cuda)
+        keep += [x1a, x1b, w1, b2]
+        args = dict(x1a=x1a.data_ptr(), c1a=s_a, x1b=None if x1b is None else x1b.data_ptr(), c1b=s_b, w1=w1.data_ptr(),
+                    bias2=b2.data_ptr())
+    te = None
+    if temb:
+        tv = torch.randn((n, cout_pad), generator=g)
+        ref = ref + tv[:, :cout, None, None, None]
+        te = tv.to(cuda)
+    res = None
+    if residual:
+        rv = bf16_round(torch.randn(ref.shape, generator=g))
+        ref = ref + rv
+        res = to_ndhwc_bf16(rv).to(cuda)
+    xa = to_ndhwc_bf16(x[:, :ca]).to(cuda)
+    xb = to_ndhwc_bf16(x[:, ca:]).to(cuda) if cb else None
+    wp = pack_conv_weight(w, cas + cbs, cout_pad).to(cuda)
+    bp = pad_vec(b, cout_pad).to(cuda)
+    do, ho, wo = ref.shape[2:]
+    m = n * do * ho * wo
+    couts = rup(cout, 32)
+    out_bf = torch.empty((n, do, ho, wo, couts), dtype=torch.bfloat16, device=cuda)
+    out_f = torch.empty((n, cout, do, ho, wo), dtype=torch.float32, device=cuda)
+    scratch = torch.empty((max(1, splitk or 64) * m * cout_pad * 4 + 256,), dtype=torch.uint8, device=cuda)
+    st = lib.ldm_op_conv3d(xa.data_ptr(), cas, None if xb is None else xb.data_ptr(), cbs, wp.data_ptr(), bp.data_ptr(),
+                           args["x1a"], args["c1a"], args["x1b"], args["c1b"], args["w1"], args["bias2"],
+                           None if te is None else te.data_ptr(), cout_pad, None if res is None else res.data_ptr(),
+                           None if f32_out else out_bf.data_ptr(), out_f.data_ptr() if f32_out else None,
+                           n, *dims, k, stride, pad, ups, cout, cout_pad, wgn, splitk, scratch.data_ptr(), scratch.numel(),
+                           torch.cuda.current_stream().cuda_stream)
+    _lib.check(st)
+    torch.cuda.synchronize()
+    if f32_out:
+        return rel_l2(out_f.cpu(), ref), TOL_FP32_OUT
+    got = from_ndhwc(out_bf.cpu(), cout)
+    if couts > cout:
+        assert float(out_bf[..., cout:].float().abs().max()) == 0.0, "channel padding must be written as zeros"
+    return rel_l2(got, bf16_round(ref)), TOL_SAME_ROUNDING
+
+
+@pytest.mark.parametrize("wgn,splitk", [(1, 1), (2, 1), (4, 1), (2, 3), (1, 9), (4, 4)])
+def test_conv3_tiles_and_splitk(cuda, built_lib, wgn, splitk):
+    err, tol = _conv_case(cuda, built_lib, cin=(256, 0), cout=256, dims=(6, 6, 6), wgn=wgn, splitk=splitk)
+    assert err <= tol, (wgn, splitk, err)
+
+
+@pytest.mark.parametrize("cin,cout", [((4, 0), 64), ((32, 0), 4), ((96, 0), 32), ((64, 0), 1), ((128, 64), 128), ((64, 96), 64)])
+def test_conv3_channel_shapes(cuda, built_lib, cin, cout):
+    """Tiny / padded channel counts, BK=32 path, dual-source concat."""
+    err, tol = _conv_case(cuda, built_lib, cin=cin, cout=cout, dims=(5, 7, 6), n=2)
+    assert err <= tol, (cin, cout, err)
+
+
+def test_conv3_ragged_edges(cuda, built_lib):
+    """M not a multiple of any tile, batch 3, non-cubic volume."""
+    err, tol = _conv_case(cuda, built_lib, cin=(64, 0), cout=96, dims=(3, 5, 7), n=3)
+    assert err <= tol, err
+
+
+def test_conv3_stride2_pad1(cuda, built_lib):
+    err, tol = _conv_case(cuda, built_lib, cin=(64, 0), cout=64, dims=(8, 8, 8), stride=2, pad=1)
+    assert err <= tol, err
+
+
+def test_conv3_stride2_asym_pad(cuda, built_lib):
+    """AEKLDownsample: F.pad (0,1) per dim then stride-2 conv without padding."""
+    err, tol = _conv_case(cuda, built_lib, cin=(64, 0), cout=64, dims=(8, 6, 10), stride=2, pad=0)
+    assert err <= tol, err
+
+
+def test_conv3_fused_nearest_upsample(cuda, built_lib):
+    err, tol = _conv_case(cuda, built_lib, cin=(64, 0), cout=64, dims=(4, 5, 3), ups=1)
+    assert err <= tol, err
+
+
+def test_conv1x1(cuda, built_lib):
+    err, tol = _conv_case(cuda, built_lib, cin=(128, 0), cout=384, dims=(6, 6, 6), k=1, pad=0)
+    assert err <= tol, err
+
+
+def test_conv_epilogue_temb_residual(cuda, built_lib):
+    err, tol = _conv_case(cuda, built_lib, cin=(64, 0), cout=64, dims=(6, 6, 6), n=2, temb=True, residual=True)
+    assert err <= tol, err
+
+
+@pytest.mark.parametrize("splitk", [1, 4])
+def test_conv_fused_skip_1x1_dual_source(cuda, built_lib, splitk):
+    """ResBlock conv2 with the 1x1 skip over cat(h, skip) appended as extra K steps."""
+    err, tol = _conv_case(cuda, built_lib, cin=(64, 0), cout=64, dims=(6, 6, 6), skip=(64, 32), splitk=splitk)
+    assert err <= tol, err
+
+
+@pytest.mark.parametrize("splitk", [1, 3])
+def test_conv_f32_ncdhw_output(cuda, built_lib, splitk):
+    err, tol = _conv_case(cuda, built_lib, cin=(64, 0), cout=4, dims=(6, 6, 6), n=2, f32_out=True, splitk=splitk)
+    assert err <= tol, err
+
+
+def test_conv_big_level0_shape(cuda, built_lib):
+    """The dominant shape of the benchmark UNet: 256 -> 256 @ 24^3."""
+    err, tol = _conv_case(cuda, built_lib, cin=(256, 0), cout=256, dims=(24, 24, 24))
+    assert err <= tol, err
+
+
+@pytest.mark.parametrize("c,groups,dual,silu", [(64, 32, 0, 1), (256, 32, 0, 1), (768, 32, 512, 1), (96, 8, 32, 0), (1024, 32, 512, 1)])
+def test_group_norm_silu(cuda, built_lib, c, groups, dual, silu):
+    from ldm3d import _lib
+    g = torch.Generator().manual_seed(c)
+    n, dims = 2, (5, 6, 7)
+    x = bf16_round(torch.randn((n, c, *dims), generator=g) * 1.5 + 0.3)
+    gamma = 1 + 0.1 * torch.randn((c,), generator=g)
+    beta = 0.1 * torch.randn((c,), generator=g)
+    ref = F.group_norm(x, groups, gamma, beta, 1e-6)
+    if silu:
+        ref = F.silu(ref)
+    ca = dual if dual else c
+    xa = to_ndhwc_bf16(x[:, :ca], ca).to(cuda)
+    xb = to_ndhwc_bf16(x[:, ca:], c - ca).to(cuda) if dual else None
+    dhw = dims[0] * dims[1] * dims[2]
+    out = torch.empty((n, *dims, c), dtype=torch.bfloat16, device=cuda)
+    sb = built_lib.ldm_op_group_norm_scratch_bytes(n, c, dhw)
+    scratch = torch.empty((sb,), dtype=torch.uint8, device=cuda)
+    gd, bd = gamma.to(cuda), beta.to(cuda)
+    _lib.check(built_lib.ldm_op_group_norm(xa.data_ptr(), ca, None if xb is None else xb.data_ptr(), c - ca, gd.data_ptr(),
+                                           bd.data_ptr(), groups, 1e-6, silu, out.data_ptr(), n, dhw, scratch.data_ptr(),
+                                           scratch.numel(), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    err = rel_l2(from_ndhwc(out.cpu(), c), bf16_round(ref))
+    assert err <= TOL_SAME_ROUNDING, err
+
+
+@pytest.mark.parametrize("b,n,c", [(1, 216, 512), (2, 64, 64), (1, 1728, 256), (1, 100, 128)])
+def test_attention(cuda, built_lib, b, n, c):
+    """softmax(q k^T / 8) v, head_dim 64; compared with fp32 softmax attention on the same bf16 q, k, v."""
+    from ldm3d import _lib
+    g = torch.Generator().manual_seed(n)
+    qkv = bf16_round(torch.randn((b, n, 3 * c), generator=g))
+    qkv[..., :2 * c] *= 1.7                       # peaky-ish scores
+    h = c // 64
+
+    def split(z):
+        return z.reshape(b, n, h, 64).permute(0, 2, 1, 3)
+    q, k, v = split(qkv[..., :c]), split(qkv[..., c:2 * c]), split(qkv[..., 2 * c:])
+    a = torch.softmax(q @ k.transpose(-1, -2) * 0.125, dim=-1)
+    ref = (a @ v).permute(0, 2, 1, 3).reshape(b, n, c)
+    dq = qkv.to(torch.bfloat16).to(cuda)
+    out = torch.empty((b, n, c), dtype=torch.bfloat16, device=cuda)
+    _lib.check(built_lib.ldm_op_attention(dq.data_ptr(), out.data_ptr(), b, n, c, torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    err = rel_l2(out.float().cpu(), ref)
+    # P is rounded to bf16 before P.V and the output to bf16: ~2^-9 relative each
+    assert err <= 4e-3, err
