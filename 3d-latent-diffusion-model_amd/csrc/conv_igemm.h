@@ -182,7 +182,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     // stage and runs the MFMAs of step s (iteration s_begin-1 only primes the pipe).
     for (int s = s_begin - 1; s < s_end; ++s) {
         const int buf = (s - s_begin) & 1;
-        __syncthreads();                               // stage `buf` landed (vmcnt(0)); stage buf^1 is free again
+        // hipcc does not count LDS-DMA in the waits it emits for __syncthreads(): drain this wave's copies by hand,
+        // then the barrier makes every wave's copies of stage `buf` visible and frees stage buf^1.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
         if (s + 1 < s_end) {
             const int ibuf = buf ^ 1;
             const int ca = ld_grp ? c1a : c0a, cb = ld_grp ? c1b : c0b;

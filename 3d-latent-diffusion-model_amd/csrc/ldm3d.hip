@@ -380,9 +380,13 @@ struct Builder {
     size_t temb_all_off = 0; int tproj_stride = 0;
 
     void finish() {
-        partial_off = partial_bytes ? pool.alloc(partial_bytes) : 0;
-        gnpart_off = gnpart_bytes ? pool.alloc(gnpart_bytes) : 0;
-        gnab_off = gnab_bytes ? pool.alloc(gnab_bytes) : 0;
+        // shared scratch lives ABOVE the activation pool's high-water mark: it is used throughout the plan, so it
+        // must never alias a (temporarily freed) activation block
+        size_t top = rup_sz(pool.high, 256);
+        partial_off = top; top += rup_sz(partial_bytes, 256);
+        gnpart_off = top; top += rup_sz(gnpart_bytes, 256);
+        gnab_off = top; top += rup_sz(gnab_bytes, 256);
+        pool.high = top;
         for (size_t k : partial_fixups) plan->ops[k].r[11] = ws_ref(partial_off);
         for (size_t k : gnpart_fixups) plan->ops[k].r[4] = ws_ref(gnpart_off);
         for (size_t k : gnab_fixups) plan->ops[k].r[5] = ws_ref(gnab_off);
