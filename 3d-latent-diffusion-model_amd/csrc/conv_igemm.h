@@ -47,6 +47,7 @@ struct ConvParams {
     bf16_t* out;                      // [M][CoutS] bf16 NDHWC            (mode 0)
     float* out_f32;                   // [N][CoutReal][Dout*Hout*Wout]    (mode 1)
     float* partial;                   // [splitk][M][CoutPad] fp32 slabs  (splitk > 1)
+    int dbg;                          // timing experiments only (LDM_CONV_DBG): 1 = all voxel rows from the zero page, 2 = all weight rows = row 0
 };
 
 // Bijective XCD-aware remap: blocks b, b+8, b+16.. share an XCD (observed round-robin dispatch); give each
@@ -62,23 +63,34 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-template <int WGM, int WGN, int BK>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) {
+template <int WGM, int WGN, int BK, int NS, int NG>
+__global__ __launch_bounds__(256 * NG, 2) void conv_igemm_kernel(const ConvParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the body uses gfx950-only types (buffer resources); the host pass only needs the stub
     constexpr int BM = 64 * WGM, BN = 64 * WGN;
     constexpr int RB = BK * 2;                 // bytes per LDS row
     constexpr int CPR = RB / 16;               // 16-byte chunks per row (4 | 8)
     constexpr int RPP = 1024 / RB;             // rows per LDS-DMA piece (16 | 8)
-    constexpr int PA = BM / RPP / 4;           // voxel pieces per wave
-    constexpr int PB = BN / RPP / 4;           // weight pieces per wave
-    constexpr int STAGE = (BM + BN) * RB;      // bytes per pipeline stage
+    constexpr int NW = 4 * NG;                 // waves per workgroup
+    constexpr int PA = BM / RPP / NW;          // voxel pieces per wave
+    constexpr int PB = BN / RPP / NW;          // weight pieces per wave
+    constexpr int STAGE = (BM + BN) * RB;      // bytes per ring slot
     constexpr int SWZ_SHIFT = (CPR == 8) ? 1 : 2;
-    constexpr int KS = BK / 32;                // MFMA k-substeps per stage
+    constexpr int KS = BK / 32;                // MFMA k-substeps per K step
+    constexpr int PF = NS - 1;                 // K steps in flight beyond the one being computed
+    constexpr int LPS = PA + PB;               // LDS-DMA instructions per wave per K step
+    static_assert(PA >= 1 && PB >= 1, "tile too small for this many waves");
+    static_assert(KS == NG, "each wave group computes exactly one 32-deep k-substep per K step");
+    static_assert((PF - 1) * LPS <= 63 && PF * LPS <= 63, "vmcnt is a 6-bit counter");
+    static_assert(NG == 1 || NS * STAGE >= 65536, "the accumulator exchange needs 64 KiB of LDS");
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave % WGM, wn = wave / WGM;
+    const int grp = wave >> 2;                 // wave group: 0 = waves 0-3, 1 = waves 4-7 (second wave of each SIMD)
+    const int wq = wave & 3;
+    const int wm = wq % WGM, wn = wq / WGM;
 
     // ---- block -> (split, ntile, mtile); mtile fastest so one XCD streams one weight panel
     const int nwg = gridDim.x;
@@ -90,21 +102,24 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     const int steps_total = p.steps0 + p.steps1;
     const int s_begin = split * p.steps_per_split;
     int s_end = s_begin + p.steps_per_split; if (s_end > steps_total) s_end = steps_total;
+    const int nsteps = s_end - s_begin;
+    const int dbg = p.dbg;
 
-    // ---- per-lane loader state -----------------------------------------------------------------
+    // ---- per-lane loader constants ------------------------------------------------------------
     const int prow = lane / CPR;                       // row inside a piece
     const int pchunk = lane % CPR;                     // physical 16-B chunk this lane fills
     const int DHWo = p.Dout * p.Hout * p.Wout;
     const int HWo = p.Hout * p.Wout;
     const int DinU = p.Din << p.ups, HinU = p.Hin << p.ups, WinU = p.Win << p.ups;
+    const int rows_in0 = p.N * p.Din * p.Hin * p.Win;  // voxel rows of the group-0 source
 
-    int a_id0[PA], a_ih0[PA], a_iw0[PA], a_nbase[PA], a_m[PA], a_koff[PA];
+    int a_id0[PA], a_ih0[PA], a_iw0[PA], a_nbase[PA], a_m[PA], a_kb[PA];
 #pragma unroll
     for (int j = 0; j < PA; ++j) {
         const int row = (wave * PA + j) * RPP + prow;  // voxel row inside the tile
         const int m = m0 + row;
         const int swz = (row >> SWZ_SHIFT) & (CPR - 1);
-        a_koff[j] = ((pchunk ^ swz) * 8);              // logical channel offset inside the BK chunk
+        a_kb[j] = (pchunk ^ swz) * 16;                 // byte offset of this lane's logical chunk inside the BK chunk
         if (m < p.M) {
             const int n = m / DHWo; int r = m - n * DHWo;
             const int od = r / HWo; r -= od * HWo;
@@ -116,61 +131,116 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
             a_id0[j] = -(1 << 20); a_ih0[j] = 0; a_iw0[j] = 0; a_nbase[j] = 0; a_m[j] = -1;
         }
     }
-    int b_row[PB], b_koff[PB];
+    int b_row[PB], b_kb[PB];
 #pragma unroll
     for (int j = 0; j < PB; ++j) {
         const int R = (wave * PB + j) * RPP + prow;    // LDS row inside the weight tile
         const int swz = (R >> SWZ_SHIFT) & (CPR - 1);
-        b_koff[j] = ((pchunk ^ swz) * 8);
+        b_kb[j] = (pchunk ^ swz) * 16;
         // LDS row (64q + 16nt + i) holds cout 64q + 16(i>>2) + 4nt + (i&3): after the MFMA a lane owns 16
         // consecutive couts (accumulator row 4g+r of tile nt  <->  cout 16g + 4nt + r).
         const int q = R >> 6, nt = (R >> 4) & 3, i = R & 15;
-        b_row[j] = n0 + 64 * q + 16 * (i >> 2) + 4 * nt + (i & 3);
+        b_row[j] = ((dbg & 2) ? 0 : n0 + 64 * q + 16 * (i >> 2) + 4 * nt + (i & 3));
     }
 
-    // Loader state machine.  The K loop visits steps s = (group, tap, chunk) in order; the loader runs one step
-    // ahead of the MFMAs.  Row pointers are recomputed only when the tap or the concat source changes; inside
-    // a (tap, source) run each step is one 64-bit add per row (padded rows point into the zero page, which is
-    // at least one full row long, so the same add is harmless there).
-    const int taps_k = p.ksize, c0a = p.c0a, c0b = p.c0b, c1a = p.c1a, c1b = p.c1b;
-    const int steps0 = p.steps0, nchunk0 = p.nchunk0;
-    const bf16_t* const x0a = p.x0a; const bf16_t* const x0b = p.x0b;
-    const bf16_t* const x1a = p.x1a; const bf16_t* const x1b = p.x1b;
-    const bf16_t* const zp = p.zero_page;
-    const int upsh = p.ups, Hin = p.Hin, Win = p.Win, CoutPad = p.CoutPad, nchunk1 = p.nchunk1;
-    const bf16_t* const w0p = p.w0; const bf16_t* const w1p = p.w1;
+    // ---- loader: the K loop is a sequence of SEGMENTS = (group, tap, concat source) runs of cs/BK steps.  Inside a
+    // segment every copy is  buffer_load_dwordx4 ... lds  with a per-lane byte offset that stays fixed (voxel row of
+    // the shifted tap; 0xFFFFFFFF for zero padding: the buffer range check then writes zeros) and a SCALAR offset
+    // that advances by BK*2 bytes per step, so a step costs one m0 write + one instruction per piece.  The address
+    // arithmetic (15 VALU per row) runs once per segment.
+    int sg_grp, sg_tap, sg_kd, sg_kh, sg_kw, sg_src, sg_left;      // scalar segment state
+    unsigned soff_a = 0, soff_b = 0;
+    unsigned a_vo[PA], b_vo[PB];
+    __amdgpu_buffer_rsrc_t rs_a, rs_b;
+    int ld_s = s_begin;
+    {
+        int chunk;
+        if (ld_s < p.steps0) {
+            sg_grp = 0; sg_tap = ld_s / p.nchunk0; chunk = ld_s - sg_tap * p.nchunk0;
+            const int kk = p.ksize * p.ksize;
+            sg_kd = sg_tap / kk; sg_kh = (sg_tap - sg_kd * kk) / p.ksize; sg_kw = sg_tap - sg_kd * kk - sg_kh * p.ksize;
+        } else { sg_grp = 1; sg_tap = 0; chunk = ld_s - p.steps0; sg_kd = sg_kh = sg_kw = 0; }
+        const int ca = sg_grp ? p.c1a : p.c0a;
+        sg_src = (chunk * BK >= ca) ? 1 : 0;
+        sg_left = -1 - (sg_src ? chunk - ca / BK : chunk);         // negative: "enter the segment at chunk -sg_left-1"
+    }
 
-    int ld_s = s_begin;                                // next step to load
-    int ld_grp, ld_tap, ld_chunk, ld_kd, ld_kh, ld_kw;
-    if (ld_s < steps0) {
-        ld_grp = 0; ld_tap = ld_s / nchunk0; ld_chunk = ld_s - ld_tap * nchunk0;
-        const int kk = taps_k * taps_k;
-        ld_kd = ld_tap / kk; ld_kh = (ld_tap - ld_kd * kk) / taps_k; ld_kw = ld_tap - ld_kd * kk - ld_kh * taps_k;
-    } else { ld_grp = 1; ld_tap = 0; ld_chunk = ld_s - steps0; ld_kd = ld_kh = ld_kw = 0; }
-    int ld_src = -1;                                   // concat source the cached pointers belong to (-1: stale)
-    int a_voff[PA];
-    const char* a_ptr[PA];
-    const char* b_ptr[PB];
-#pragma unroll
-    for (int j = 0; j < PA; ++j) { a_voff[j] = -1; a_ptr[j] = nullptr; }
-#pragma unroll
-    for (int j = 0; j < PB; ++j) b_ptr[j] = nullptr;
-    bool voff_stale = true;
+#define LDM_SEG_SETUP(CIS) do {                                                                               \
+        const int ca_ = sg_grp ? p.c1a : p.c0a, cb_ = sg_grp ? p.c1b : p.c0b;                                 \
+        const int cin_ = ca_ + cb_, cs_ = sg_src ? cb_ : ca_;                                                 \
+        const bf16_t* xs_ = sg_grp ? (sg_src ? p.x1b : p.x1a) : (sg_src ? p.x0b : p.x0a);                     \
+        const unsigned rows_ = sg_grp ? (unsigned)p.M : (unsigned)rows_in0;                                   \
+        rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)xs_, 0, (int)(rows_ * (unsigned)cs_ * 2u), 0x00020000);\
+        _Pragma("unroll") for (int j = 0; j < PA; ++j) {                                                      \
+            int v_;                                                                                           \
+            if (sg_grp == 0) {                                                                                \
+                const int id = a_id0[j] + sg_kd, ih = a_ih0[j] + sg_kh, iw = a_iw0[j] + sg_kw;                \
+                const bool ok = ((unsigned)id < (unsigned)DinU) & ((unsigned)ih < (unsigned)HinU) &          \
+                                ((unsigned)iw < (unsigned)WinU);                                              \
+                v_ = a_nbase[j] + ((id >> p.ups) * p.Hin + (ih >> p.ups)) * p.Win + (iw >> p.ups);            \
+                v_ = ok ? v_ : -1;                                                                            \
+            } else v_ = a_m[j];                                                                               \
+            if (dbg & 1) v_ = -1;                                                                             \
+            a_vo[j] = (v_ >= 0) ? (unsigned)v_ * (unsigned)(cs_ * 2) + (unsigned)a_kb[j] : 0xFFFFFFFFu;       \
+        }                                                                                                     \
+        const bf16_t* wp_ = sg_grp ? p.w1 : p.w0;                                                             \
+        const unsigned wbytes_ = (unsigned)(sg_grp ? 1 : p.ksize * p.ksize * p.ksize) * (unsigned)p.CoutPad * \
+                                 (unsigned)cin_ * 2u;                                                         \
+        rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)wp_, 0, (int)wbytes_, 0x00020000);                    \
+        _Pragma("unroll") for (int j = 0; j < PB; ++j)                                                        \
+            b_vo[j] = (unsigned)b_row[j] * (unsigned)(cin_ * 2) + (unsigned)b_kb[j];                          \
+        soff_a = (unsigned)(CIS) * (BK * 2);                                                                  \
+        soff_b = (unsigned)sg_tap * (unsigned)p.CoutPad * (unsigned)(cin_ * 2) +                              \
+                 (unsigned)((sg_src ? ca_ : 0) + (CIS) * BK) * 2u;                                            \
+        sg_left = cs_ / BK - (CIS);                                                                           \
+    } while (0)
 
-    // ---- fragment read addresses (swizzled) -----------------------------------------------------
+    // issue the copies of step ld_s into ring slot (ld_s - s_begin) % NS and advance the scalar state
+#define LDM_SEG_ADVANCE() do {                                                                                \
+        if (sg_left <= 0) {                                                                                   \
+            if (sg_left < 0) { const int cis_ = -sg_left - 1; LDM_SEG_SETUP(cis_); }   /* first segment */     \
+            else {                                                                                            \
+                const int cb_nx = sg_grp ? p.c1b : p.c0b;                                                     \
+                if (sg_src == 0 && cb_nx > 0) sg_src = 1;                                                     \
+                else {                                                                                        \
+                    sg_src = 0;                                                                               \
+                    if (sg_grp == 0) {                                                                        \
+                        ++sg_tap;                                                                             \
+                        if (++sg_kw == p.ksize) { sg_kw = 0; if (++sg_kh == p.ksize) { sg_kh = 0; ++sg_kd; } }\
+                        if (ld_s >= p.steps0) { sg_grp = 1; sg_tap = 0; }                                     \
+                    }                                                                                         \
+                }                                                                                             \
+                LDM_SEG_SETUP(0);                                                                             \
+            }                                                                                                 \
+        }                                                                                                     \
+    } while (0)
+    // the LPS copies of step ld_s (no control flow: this is part of the hot block)
+#define LDM_DMA_RAW() do {                                                                                    \
+        {                                                                                                     \
+            char* st_ = smem + ((ld_s - s_begin) % NS) * STAGE;                                               \
+            _Pragma("unroll") for (int j = 0; j < PA; ++j)                                                    \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr_t)(st_ + (wave * PA + j) * 1024), 16, \
+                                                         a_vo[j], soff_a, 0, 0);                              \
+            _Pragma("unroll") for (int j = 0; j < PB; ++j)                                                    \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr_t)(st_ + BM * RB + (wave * PB + j) * 1024), \
+                                                         16, b_vo[j], soff_b, 0, 0);                          \
+        }                                                                                                     \
+        soff_a += BK * 2; soff_b += BK * 2; --sg_left; ++ld_s;                                                \
+    } while (0)
+#define LDM_DMA() do {                                                                                        \
+        if (!(dbg & 4)) LDM_DMA_RAW();                                                                        \
+        else { soff_a += BK * 2; soff_b += BK * 2; --sg_left; ++ld_s; }                                       \
+    } while (0)
+    // issue the copies of step ld_s into ring slot (ld_s - s_begin) % NS and advance the scalar state
+#define LDM_ISSUE() do { LDM_SEG_ADVANCE(); LDM_DMA(); } while (0)
+
+    // ---- fragment reads: one 32-deep k-substep per wave group.  Row swizzle bits do not depend on the 16-row tile
+    //      index t, so tile t sits at a constant +t*16*RB from the wave's base address (immediate offsets). ------
     const int fr = lane & 15, fg = lane >> 4;
-    int a_rd[4][KS], b_rd[4][KS];                     // byte offsets inside a stage
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int ra = wm * 64 + t * 16 + fr;
-        const int rb = wn * 64 + t * 16 + fr;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int c = ks * 4 + fg;
-            a_rd[t][ks] = ra * RB + ((c ^ ((ra >> SWZ_SHIFT) & (CPR - 1))) << 4);
-            b_rd[t][ks] = BM * RB + rb * RB + ((c ^ ((rb >> SWZ_SHIFT) & (CPR - 1))) << 4);
-        }
-    }
+    const int ra0 = wm * 64 + fr, rb0 = wn * 64 + fr;
+    const int cfrag = grp * 4 + fg;                     // 16-byte chunk of this lane's 8 k-values (ks = grp)
+    const int a_rd0 = ra0 * RB + ((cfrag ^ ((ra0 >> SWZ_SHIFT) & (CPR - 1))) << 4);
+    const int b_rd0 = BM * RB + rb0 * RB + ((cfrag ^ ((rb0 >> SWZ_SHIFT) & (CPR - 1))) << 4);
 
     f32x4 acc[4][4];                                   // [cout tile nt][voxel tile mt]
 #pragma unroll
@@ -178,98 +248,156 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // Software pipeline, one barrier per K step: iteration s issues the loads of step s+1 into the other
-    // stage and runs the MFMAs of step s (iteration s_begin-1 only primes the pipe).
-    for (int s = s_begin - 1; s < s_end; ++s) {
-        const int buf = (s - s_begin) & 1;
-        // hipcc does not count LDS-DMA in the waits it emits for __syncthreads(): drain this wave's copies by hand,
-        // then the barrier makes every wave's copies of stage `buf` visible and frees stage buf^1.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    bf16x8 wfA[4], afA[4], wfB[4], afB[4];             // two fragment sets: one feeds the MFMAs while the other loads
+
+#define LDM_READ_FRAGS_RAW(WF, AF, SLOT) do {                                                       \
+        {                                                                                           \
+            const char* sb_ = smem + (SLOT) * STAGE;                                                \
+            _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                         \
+                WF[t] = *reinterpret_cast<const bf16x8*>(sb_ + b_rd0 + t * 16 * RB);                \
+                AF[t] = *reinterpret_cast<const bf16x8*>(sb_ + a_rd0 + t * 16 * RB);                \
+            }                                                                                       \
+        }                                                                                           \
+    } while (0)
+#define LDM_READ_FRAGS(WF, AF, SLOT) do { if (!(dbg & 16)) LDM_READ_FRAGS_RAW(WF, AF, SLOT); } while (0)
+#define LDM_MFMA16_RAW(WF, AF) do {                                                                 \
+        {                                                                                           \
+            _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                        \
+                _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                    \
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[nt], AF[mt], acc[nt][mt], 0, 0, 0); \
+        }                                                                                           \
+    } while (0)
+#define LDM_MFMA16(WF, AF) do { if (!(dbg & 8)) LDM_MFMA16_RAW(WF, AF); } while (0)
+    // Step S+1 ready: counted vmcnt (hipcc does not track LDS-DMA, every wait on it is hand written; a plain
+    // __syncthreads() would drain vmcnt(0) and with it the whole prefetch ring), then a RAW barrier: every wave's
+    // copies of step S+1 are visible and every wave holds its fragments of step S in registers, so ring slot S % NS
+    // may be refilled.  The empty asm statements pin LDS reads behind the barrier.
+#define LDM_NEXT_STEP_READY(S) do {                                                                 \
+        if ((S) + PF < s_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF - 1) * LPS) : "memory"); \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                       \
+        __builtin_amdgcn_s_barrier();                                                               \
+        asm volatile("" ::: "memory");                                                              \
+    } while (0)
+    // One K step: CUR fragments are (being) loaded, NXT get loaded behind the barrier while CUR feeds the MFMAs.
+    // lgkmcnt(0) goes through the builtin (0xC07F = lgkmcnt 0 only) so that hipcc's wait insertion KNOWS set CUR
+    // has arrived and does not re-wait behind the reads of NXT.  Group 0 issues its copies before its MFMAs, group 1
+    // after: on every SIMD one wave is in its matrix phase while its partner is in its copy phase.
+#define LDM_HALF(S, WC, AC, WN, AN) do {                                                            \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                                         \
+        if ((S) + 1 < s_end) {                                                                      \
+            LDM_NEXT_STEP_READY(S);                                                                 \
+            if (grp == 0 && ld_s < s_end) LDM_ISSUE();                                              \
+            LDM_READ_FRAGS(WN, AN, ((S) + 1 - s_begin) % NS);                                       \
+        }                                                                                           \
+        LDM_MFMA16(WC, AC);                                                                         \
+        if (grp == 1 && (S) + 1 < s_end && ld_s < s_end) LDM_ISSUE();                              \
+    } while (0)
+
+    // ---- prologue: fill the ring (NS steps in flight), wait for the first step ----------------------------------
+    if (nsteps > 0) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) if (i < nsteps) LDM_ISSUE();
+        if (nsteps > PF) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PF * LPS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        LDM_READ_FRAGS(wfA, afA, 0);
+    }
+    // Steady state: one hot basic block per K step.  The segment change (rare, VALU heavy) runs BEFORE the wait; the
+    // copies of step s+NS, the fragment reads of step s+1 and the 16 MFMAs of step s then sit in one scheduling
+    // region and sched_group_barrier interleaves them (an MFMA occupies the matrix pipe for 16 cycles but the issue
+    // port for ~8: one copy / LDS read rides in the shadow of each MFMA instead of in front of all of them).
+#define LDM_FAST_HALF(S, WC, AC, WN, AN) do {                                                       \
+        LDM_SEG_ADVANCE();                                                                          \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                                         \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF - 1) * LPS) : "memory");                       \
+        __builtin_amdgcn_s_barrier();                                                               \
+        asm volatile("" ::: "memory");                                                              \
+        LDM_DMA_RAW();                                                                              \
+        LDM_READ_FRAGS_RAW(WN, AN, ((S) + 1 - s_begin) % NS);                                       \
+        LDM_MFMA16_RAW(WC, AC);                                                                     \
+        _Pragma("unroll") for (int i_ = 0; i_ < LPS; ++i_) {                                        \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   /* 1 MFMA */                       \
+            __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);   /* m0 / offset SALU */             \
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   /* 1 LDS-DMA copy (VMEM read) */   \
+        }                                                                                           \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                          \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   /* 1 MFMA */                       \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   /* 1 ds_read_b128 */               \
+        }                                                                                           \
+        __builtin_amdgcn_sched_group_barrier(0x008, 16 - LPS - 8 > 0 ? 16 - LPS - 8 : 0, 0);        \
+    } while (0)
+
+    int s = s_begin;
+    if (dbg == 0) {                                   // (timing experiments run the generic loop)
+        while (s + 1 + NS < s_end) {
+            LDM_FAST_HALF(s, wfA, afA, wfB, afB);
+            LDM_FAST_HALF(s + 1, wfB, afB, wfA, afA);
+            s += 2;
+        }
+    }
+    for (; s < s_end; s += 2) {                       // generic tail (and the whole loop for short K ranges)
+        LDM_HALF(s, wfA, afA, wfB, afB);
+        if (s + 1 >= s_end) break;
+        LDM_HALF(s + 1, wfB, afB, wfA, afA);
+    }
+#undef LDM_FAST_HALF
+#undef LDM_HALF
+#undef LDM_NEXT_STEP_READY
+#undef LDM_MFMA16
+#undef LDM_READ_FRAGS
+#undef LDM_ISSUE
+#undef LDM_DMA
+#undef LDM_DMA_RAW
+#undef LDM_READ_FRAGS_RAW
+#undef LDM_MFMA16_RAW
+#undef LDM_SEG_ADVANCE
+#undef LDM_SEG_SETUP
+
+    // ---- intra-workgroup K reduction: group g keeps voxel tiles mt in {2g, 2g+1} and receives its partner's
+    //      partial sums for them through LDS (the ring is dead by now). --------------------------------------------
+    constexpr int MT0 = 0, MTN = (NG == 2) ? 2 : 4;
+    const int mt_base = (NG == 2) ? 2 * grp : 0;
+    if constexpr (NG == 2) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();
-        if (s + 1 < s_end) {
-            const int ibuf = buf ^ 1;
-            const int ca = ld_grp ? c1a : c0a, cb = ld_grp ? c1b : c0b;
-            const int ch = ld_chunk * BK;                  // first channel of this chunk in the concatenated input
-            const int src = (ch >= ca) ? 1 : 0;
-            if (voff_stale) {                              // wave-uniform: new tap (or group) -> new voxel offsets
-                voff_stale = false; ld_src = -1;
-                if (ld_grp == 0) {
+        float* xch = reinterpret_cast<float*>(smem);
+        const int dst = 1 - grp;                       // partner group owns mt in {2*dst, 2*dst+1}
 #pragma unroll
-                    for (int j = 0; j < PA; ++j) {
-                        const int id = a_id0[j] + ld_kd, ih = a_ih0[j] + ld_kh, iw = a_iw0[j] + ld_kw;
-                        const bool ok = ((unsigned)id < (unsigned)DinU) & ((unsigned)ih < (unsigned)HinU) &
-                                        ((unsigned)iw < (unsigned)WinU);
-                        const int v = a_nbase[j] + ((id >> upsh) * Hin + (ih >> upsh)) * Win + (iw >> upsh);
-                        a_voff[j] = ok ? v : -1;
-                    }
-                } else {
+        for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-                    for (int j = 0; j < PA; ++j) a_voff[j] = a_m[j];
+            for (int ml = 0; ml < 2; ++ml)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    xch[(((dst * 4 + wq) * 32) + (nt * 2 + ml) * 4 + r) * 64 + lane] =
+                        (grp == 0) ? acc[nt][2 + ml][r] : acc[nt][ml][r];
+        __syncthreads();
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int ml = 0; ml < 2; ++ml)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = xch[(((grp * 4 + wq) * 32) + (nt * 2 + ml) * 4 + r) * 64 + lane];
+                    if (grp == 0) acc[nt][ml][r] += v; else acc[nt][2 + ml][r] += v;
                 }
-                const int cin = ca + cb;
-                const bf16_t* wb = ld_grp ? w1p : w0p + (size_t)ld_tap * CoutPad * cin;
-#pragma unroll
-                for (int j = 0; j < PB; ++j)
-                    b_ptr[j] = reinterpret_cast<const char*>(wb + (size_t)b_row[j] * cin + b_koff[j]);
-            }
-            if (src != ld_src) {                           // wave-uniform: (re)base the row pointers on this source
-                ld_src = src;
-                const bf16_t* xs = ld_grp ? (src ? x1b : x1a) : (src ? x0b : x0a);
-                const int cs = src ? cb : ca;
-#pragma unroll
-                for (int j = 0; j < PA; ++j) {
-                    const bool ok = a_voff[j] >= 0;
-                    const bf16_t* rowp = xs + (size_t)(ok ? a_voff[j] : 0) * cs;
-                    a_ptr[j] = reinterpret_cast<const char*>((ok ? rowp : zp) + a_koff[j]);
-                }
-            }
-            const int chs = src ? ch - ca : ch;
-            char* stage = smem + ibuf * STAGE;
-#pragma unroll
-            for (int j = 0; j < PA; ++j) glds16(a_ptr[j] + chs * 2, stage + (wave * PA + j) * 1024);
-#pragma unroll
-            for (int j = 0; j < PB; ++j) glds16(b_ptr[j] + ch * 2, stage + BM * RB + (wave * PB + j) * 1024);
-            // advance to the next step
-            ++ld_s; ++ld_chunk;
-            const int nch = ld_grp ? nchunk1 : nchunk0;
-            if (ld_chunk == nch) {
-                ld_chunk = 0; voff_stale = true;
-                if (ld_grp == 0) {
-                    ++ld_tap;
-                    if (++ld_kw == taps_k) { ld_kw = 0; if (++ld_kh == taps_k) { ld_kh = 0; ++ld_kd; } }
-                    if (ld_s >= steps0) { ld_grp = 1; ld_tap = 0; }
-                }
-            }
-        }
-        if (s < s_begin) continue;
-        const char* stage = smem + buf * STAGE;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            bf16x8 wf[4], af[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                wf[t] = *reinterpret_cast<const bf16x8*>(stage + b_rd[t][ks]);
-                af[t] = *reinterpret_cast<const bf16x8*>(stage + a_rd[t][ks]);
-            }
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc[nt][mt], 0, 0, 0);
-        }
     }
 
     // ---- epilogue -------------------------------------------------------------------------------
     const int cbase = n0 + wn * 64 + 16 * fg;          // this lane's 16 consecutive couts
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int m = m0 + wm * 64 + mt * 16 + fr;
+    for (int ml = MT0; ml < MTN; ++ml) {
+        const int mt = (NG == 2) ? ml : ml;            // index into acc resolved below
+        const int m = m0 + wm * 64 + (mt_base + ml) * 16 + fr;
         if (m >= p.M) continue;
         float v[16];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[nt * 4 + r] = acc[nt][mt][r];
+            for (int r = 0; r < 4; ++r) {
+                if constexpr (NG == 2) v[nt * 4 + r] = (grp == 0) ? acc[nt][ml][r] : acc[nt][2 + ml][r];
+                else v[nt * 4 + r] = acc[nt][mt][r];
+            }
         if (p.splitk > 1) {
             float* dst = p.partial + ((size_t)split * p.M + m) * p.CoutPad + cbase;
 #pragma unroll
@@ -320,6 +448,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
             op[h] = o;
         }
     }
+#endif  // __HIP_DEVICE_COMPILE__
 }
 
 // Sums split-K slabs and applies the same epilogue as the fused path.  One thread per (voxel, 8 channels).

@@ -11,6 +11,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -23,6 +24,10 @@
 #include "attention.h"
 #include "conv_igemm.h"
 #include "norm_elem.h"
+
+#ifndef CONV_STAGES
+#define CONV_STAGES 4     // depth of the conv kernel's LDS ring (prefetch distance = stages - 1 K steps)
+#endif
 
 // ================================================================================================ errors
 static thread_local char g_err[1024] = "";
@@ -708,19 +713,49 @@ static inline char* rp(const Bases& b, const Ref& r) { return r.base == BASE_NUL
 
 template <int WGM, int WGN, int BK>
 static int launch_conv_t(const ConvParams& p, hipStream_t s) {
-    constexpr int LDS = 2 * (64 * WGM + 64 * WGN) * BK * 2;
+    // 128 KiB-class LDS ring; BK = 64 tiles run 8 waves (two per SIMD, intra-workgroup K split)
+    constexpr int STAGE = (64 * WGM + 64 * WGN) * BK * 2;
+    constexpr int NG = (BK == 64) ? 2 : 1;
+    constexpr int NS = (STAGE * 4 <= 131072) ? 4 : 3;
+    constexpr int LDS = NS * STAGE;
     static bool attr_set = false;
     if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<WGM, WGN, BK>),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<WGM, WGN, BK, NS, NG>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr_set = true;
     }
     const int grid = p.mtiles * p.ntiles * p.splitk;
-    hipLaunchKernelGGL((conv_igemm_kernel<WGM, WGN, BK>), dim3(grid), dim3(256), LDS, s, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<WGM, WGN, BK, NS, NG>), dim3(grid), dim3(256 * NG), LDS, s, p);
     return 0;
 }
 
+// ---- optional HIP-event instrumentation of one conv tile configuration (bench.py's roofline leg) ----------
+struct ProfState {
+    bool on = false; int wgm = 0, wgn = 0, bk = 0;
+    std::vector<hipEvent_t> ev; size_t used = 0;          // pairs (start, stop)
+    std::vector<double> flops;                            // algorithmic FLOPs of each instrumented launch
+    double flops_all = 0.0; long launches_all = 0;        // every conv launch while profiling is on
+};
+static ProfState g_prof;
+
+static double conv_algorithmic_flops(const ConvParams& p) {
+    // 2 * M * Cout_real * (k^3 * Cin0 + Cin1); input channels as stored (only the two stem convs are padded, 4 -> 32)
+    const double taps = (double)p.ksize * p.ksize * p.ksize;
+    return 2.0 * (double)p.M * (double)p.CoutReal * (taps * (double)(p.c0a + p.c0b) + (double)(p.c1a + p.c1b));
+}
+
+static int launch_conv_impl(const ConvParams& p, const ConvCfg& cc, hipStream_t s);
 static int launch_conv(const ConvParams& p, const ConvCfg& cc, hipStream_t s) {
+    if (!g_prof.on) return launch_conv_impl(p, cc, s);
+    g_prof.flops_all += conv_algorithmic_flops(p); g_prof.launches_all++;
+    const bool hit = cc.wgm == g_prof.wgm && cc.wgn == g_prof.wgn && cc.bk == g_prof.bk && g_prof.used + 2 <= g_prof.ev.size();
+    if (hit) HIP_TRY(hipEventRecord(g_prof.ev[g_prof.used], s));
+    LDM_TRY(launch_conv_impl(p, cc, s));
+    if (hit) { HIP_TRY(hipEventRecord(g_prof.ev[g_prof.used + 1], s)); g_prof.used += 2; g_prof.flops.push_back(conv_algorithmic_flops(p)); }
+    return 0;
+}
+
+static int launch_conv_impl(const ConvParams& p, const ConvCfg& cc, hipStream_t s) {
 #define CASE(M_, N_, K_) if (cc.wgm == M_ && cc.wgn == N_ && cc.bk == K_) return launch_conv_t<M_, N_, K_>(p, s);
     CASE(2, 2, 64) CASE(4, 1, 64) CASE(1, 4, 64) CASE(2, 2, 32) CASE(4, 1, 32) CASE(1, 4, 32)
 #undef CASE
@@ -1027,6 +1062,44 @@ int ldm_scale(const float* x, float* y, int64_t n, float s, void* stream) {
     return 0;
 }
 
+// ---- profiling: HIP events around every launch of one conv tile configuration ------------------------------
+int ldm_profile_start(int wgm, int wgn, int bk, int max_launches) {
+    if (max_launches < 1) return fail(LDM_ERR_BAD_ARG, "max_launches < 1");
+    for (auto e : g_prof.ev) (void)hipEventDestroy(e);
+    g_prof = ProfState();
+    g_prof.ev.resize((size_t)max_launches * 2);
+    for (auto& e : g_prof.ev) HIP_TRY(hipEventCreate(&e));
+    g_prof.wgm = wgm; g_prof.wgn = wgn; g_prof.bk = bk; g_prof.on = true;
+    return 0;
+}
+/* out[0] = instrumented launches, out[1] = their total ms, out[2] = their total algorithmic FLOPs,
+ * out[3] = all conv launches seen, out[4] = algorithmic FLOPs of all conv launches seen */
+int ldm_profile_stop(double out[5]) {
+    if (!out) return fail(LDM_ERR_BAD_ARG, "null out");
+    g_prof.on = false;
+    double ms = 0.0, fl = 0.0;
+    for (size_t k = 0; k + 1 < g_prof.used + 1 && k < g_prof.used; k += 2) {
+        HIP_TRY(hipEventSynchronize(g_prof.ev[k + 1]));
+        float t = 0.f; HIP_TRY(hipEventElapsedTime(&t, g_prof.ev[k], g_prof.ev[k + 1]));
+        ms += t; fl += g_prof.flops[k / 2];
+    }
+    out[0] = (double)(g_prof.used / 2); out[1] = ms; out[2] = fl; out[3] = (double)g_prof.launches_all; out[4] = g_prof.flops_all;
+    for (auto e : g_prof.ev) (void)hipEventDestroy(e);
+    g_prof.ev.clear(); g_prof.used = 0; g_prof.flops.clear();
+    return 0;
+}
+/* Tile configuration the planner chose for each conv of a cached plan: fills cfgs[4*i..] = {wgm, wgn, bk, splitk} */
+int ldm_model_plan_conv_cfgs(ldm_model* m, const char* kind, int B, int D, int H, int W, int* cfgs, int max_convs) {
+    if (!m || !kind) return fail(LDM_ERR_BAD_ARG, "null argument");
+    std::shared_ptr<Plan> p; LDM_TRY(get_plan(m, kind, B, D, H, W, &p));
+    int n = 0;
+    for (const Op& o : p->ops) if (o.kind == OP_CONV) {
+        if (cfgs && n < max_convs) { cfgs[4 * n] = o.cc.wgm; cfgs[4 * n + 1] = o.cc.wgn; cfgs[4 * n + 2] = o.cc.bk; cfgs[4 * n + 3] = o.cc.splitk; }
+        ++n;
+    }
+    return n;
+}
+
 // ---- operator-level entry points (the same kernels the plans launch; used by per-kernel parity tests and
 //      micro-benchmarks).  Tensors are NDHWC bf16 device memory with C % 32 == 0. -------------------------------
 static char* g_zero_page = nullptr;
@@ -1082,6 +1155,7 @@ int ldm_op_conv3d(const void* xa, int ca, const void* xb, int cb, const void* w,
         if (!scratch || scratch_bytes < need) return fail(LDM_ERR_WORKSPACE, "split-K scratch too small: need %zu bytes", need);
         p.partial = (float*)scratch;
     }
+    { const char* e = getenv("LDM_CONV_DBG"); p.dbg = e ? atoi(e) : 0; }
     LDM_TRY(launch_conv(p, cc, (hipStream_t)stream));
     if (cc.splitk > 1) {
         FinalizeParams f{}; f.partial = p.partial; f.splitk = p.splitk; f.M = p.M; f.CoutPad = p.CoutPad; f.CoutS = p.CoutS;

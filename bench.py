@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py - UNet denoising steps/s on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one DiffusionModelUNet forward + one DDPM scheduler step (fresh N(0,1) noise drawn on the device) on a
+synthetic 1x4x24x24x24 fp32 latent: BASELINE.json configs[2] (benchmark UNet = diffusion_def of
+3d_ldm/config/config_train_16g.json:39-48 with 4 latent channels, DDPM schedule of :56-60), random-init weights.
+With N > 1 every rank drives its own independent reverse chain on its own GPU (the sampling path has no exchange
+step: inference.py has no distributed code) -> weak scaling, no data-path collective; the only collectives are the
+timing barrier and the MAX over ranks.
+
+Also reported on the same JSON line:
+  roofline     - the dominant kernel (implicit-GEMM conv, 128x128x64 tile) timed live with HIP events on the launch
+                 stream over the timed region: algorithmic FLOPs / measured kernel time vs the dense bf16 MFMA peak.
+  cpu_baseline - the CPU oracle (fp32 torch ops, all host cores) timed on a bounded sample of the same workload.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0         # /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
+UNET_STEP_GFLOP = 889.1                      # SURVEY.md section 8d / BASELINE.md section 3 (2*MAC, real channel counts)
+DOMINANT_TILE = (2, 2, 64)                   # conv_igemm_kernel<2,2,64>: 128 voxels x 128 couts x K 64
+
+
+def make_unet(dev, seed=0):
+    import torch
+    import cfgs
+    from ldm3d.networks import DiffusionModelUNet
+    m = DiffusionModelUNet(**cfgs.UNET_FULL)
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():                     # random init everywhere (MONAI zero-inits conv2/out: zeros would flatter DVFS)
+        for name, p in m.named_parameters():
+            if p.dim() > 1:
+                fan_in = p[0].numel()
+                p.copy_(torch.randn(p.shape, generator=g) / fan_in ** 0.5)
+            elif name.endswith(".weight"):
+                p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g))
+            else:
+                p.copy_(0.05 * torch.randn(p.shape, generator=g))
+    return m.to(dev).eval()
+
+
+def host_cores():
+    """CPU share of this container (cgroup quota / affinity), not the host's core count."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return max(1, min(n, 16))               # a 1-GPU box's CPU share is 16 cores
+
+
+def cpu_baseline(steps=3):
+    """Oracle (test infrastructure) as the CPU baseline: fp32 torch ops, all host cores, same UNet, same latent."""
+    import torch
+    import cfgs
+    from oracle import unet as ou
+    from oracle.schedulers import OracleDDPM
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    sd = ou.init_state_dict(ou.unet_param_shapes(cfgs.UNET_FULL), 0)
+    sch = OracleDDPM(**cfgs.SCHED)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn((1, 4, 24, 24, 24), generator=g)
+
+    def one(t, x):
+        eps = ou.unet_forward(sd, cfgs.UNET_FULL, x, torch.tensor([float(t)]))
+        return sch.step(eps, t, x, torch.randn(x.shape, generator=g))[0]
+    with torch.no_grad():
+        tw = time.perf_counter()
+        x = one(999, x)                       # warm-up (oneDNN primitive creation)
+        if time.perf_counter() - tw > 15.0:   # keep the default run within minutes on a slow host
+            steps = 1
+        t0 = time.perf_counter()
+        for i in range(steps):
+            x = one(998 - i, x)
+        dt = time.perf_counter() - t0
+    return {"value": steps / dt, "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} DDPM steps (UNet fwd + scheduler step) on 1x4x24^3 after 1 warm-up step, fp32 torch-CPU oracle"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", init_method="env://", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    import cfgs
+    from ldm3d import _lib
+    from ldm3d.schedulers import DDPMScheduler
+    L = _lib.lib()
+    unet = make_unet(dev, seed=rank)
+    sch = DDPMScheduler(**cfgs.SCHED)
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    x = torch.randn((1, 4, 24, 24, 24), device=dev, generator=gen)
+    tbuf = torch.empty((1,), dtype=torch.float32, device=dev)
+    T = sch.num_train_timesteps
+
+    def step(i, x):
+        t = (T - 1 - i) % T
+        tbuf.fill_(float(t))
+        eps = unet(x=x, timesteps=tbuf)
+        return sch.step(eps, t, x, generator=gen)[0]
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for i in range(args.warmup):
+            x = step(i, x)
+        profile = (not args.no_roofline) and rank == 0
+        if profile:
+            _lib.check(L.ldm_profile_start(*DOMINANT_TILE, 64 * args.steps + 64))
+        fence()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            x = step(args.warmup + i, x)
+        fence()
+        dt = time.perf_counter() - t0
+        prof = (C.c_double * 5)()
+        if profile:
+            _lib.check(L.ldm_profile_stop(prof))
+    assert torch.isfinite(x).all()
+
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = dt / args.steps * 1e3
+    out = {
+        "metric": "UNet denoising steps/sec (bf16, 1x4x24x24x24 latent; whole job = sum over GPUs)",
+        "value": world * args.steps / dt, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "DiffusionModelUNet (channels 256/256/512, attn at 12^3 and 6^3, 191.18 M params) fwd + DDPM "
+                               "step on 1x4x24^3, 1000-step schedule scaled_linear_beta 0.0015-0.0195 (BASELINE configs[2])",
+                   "per_gpu_batch": 1, "parallelism": f"replicas x{world} (independent chains, no collective)",
+                   "weights": "random init, seeded", "launch": "eager (one C-ABI call per forward, ~215 kernel launches)"},
+        "steps_per_s_per_gpu": args.steps / dt,
+        "unet_step_tflops": UNET_STEP_GFLOP / ms_per_step,
+    }
+    if profile and prof[0] > 0:
+        achieved = prof[2] / (prof[1] * 1e-3) / 1e12
+        out["roofline"] = {
+            "bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": None,
+            "kernel": "conv_igemm_kernel<2,2,64> (implicit-GEMM conv3d, 128x128x64 tile, bf16 MFMA 16x16x32)",
+            "launches": int(prof[0]), "avg_launch_us": prof[1] * 1e3 / prof[0],
+            "algorithmic_gflop_per_launch": prof[2] / prof[0] / 1e9,
+            "share_of_conv_flops": prof[2] / prof[4] if prof[4] else None,
+            "whole_step_frac_of_mfma_peak": UNET_STEP_GFLOP / ms_per_step / MFMA_BF16_DENSE_PEAK_TFLOPS,
+        }
+    if not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline()
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

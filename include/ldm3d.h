@@ -143,6 +143,14 @@ int ldm_op_group_norm(const void* xa, int ca, const void* xb, int cb, const floa
 /* softmax(q k^T / 8) v with head_dim 64: qkv [B*N][3C] bf16 (q|k|v, channel = head*64 + d) -> out [B*N][C] bf16. */
 int ldm_op_attention(const void* qkv, void* out, int B, int N, int C, void* stream);
 
+/* ---- measurement support (bench.py): HIP events around every launch of ONE conv tile configuration
+ *      (wgm x wgn waves, K depth bk), recorded on the launch stream.  stop() fills
+ *      out = {instrumented launches, their total ms, their algorithmic FLOPs, all conv launches, all conv FLOPs}.
+ *      plan_conv_cfgs lists the {wgm, wgn, bk, splitk} the planner chose per conv of a plan ("unet"|"enc"|"dec"). -- */
+int ldm_profile_start(int wgm, int wgn, int bk, int max_launches);
+int ldm_profile_stop(double out[5]);
+int ldm_model_plan_conv_cfgs(ldm_model* m, const char* kind, int B, int D, int H, int W, int* cfgs, int max_convs);
+
 /* ---- data-parallel collectives (replaces init_process_group("nccl") + DDP all-reduce,
  *      3d_ldm/utils.py:55-63, 3d_ldm/train_diffusion.py:121-123,147-149,281-283): RCCL over xGMI.
  *      unique_id is the 128-byte ncclUniqueId produced by ldm_comm_unique_id on rank 0 and distributed
