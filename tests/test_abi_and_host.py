@@ -1,0 +1,142 @@
+"""CPU-side checks (no GPU, no compute calls): the C-ABI library loads and exports every symbol include/ldm3d.h
+declares; the host mirror (config resolver, scheduler tables, module shells) behaves like the reference's objects."""
+import ctypes
+import json
+import os
+import re
+import types
+
+import pytest
+import torch
+
+import cfgs
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "ldm3d.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ldm_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    from ldm3d import _lib
+    names = header_functions()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(built_lib, n), f"{n} declared in include/ldm3d.h but not exported"
+    assert sorted(_lib.SIGNATURES) == names, "ctypes signature table and header disagree"
+    assert built_lib.ldm_version() == 1
+
+
+def test_error_reporting_never_throws(built_lib):
+    from ldm3d import _lib
+    h = ctypes.c_void_p()
+    cfg = _lib.UNetCfg()
+    cfg.spatial_dims = 2
+    assert built_lib.ldm_unet_create(ctypes.byref(cfg), ctypes.byref(h)) == -2            # LDM_ERR_UNSUPPORTED
+    assert b"spatial_dims" in built_lib.ldm_last_error()
+    assert built_lib.ldm_unet_create(None, ctypes.byref(h)) == -1                        # LDM_ERR_BAD_ARG
+    with pytest.raises(_lib.LdmError):
+        _lib.check(-1)
+
+
+def test_param_layout_matches_independent_oracle_layout(built_lib):
+    """The library enumerates MONAI-shaped state_dict names; the oracle derives them independently."""
+    from ldm3d.networks import AutoencoderKL, DiffusionModelUNet
+    from oracle import autoencoder as oa
+    from oracle import unet as ou
+    for cfg in (cfgs.UNET_FULL, cfgs.UNET_TINY, cfgs.UNET_TINY_ALT, cfgs.UNET_TINY_COND):
+        m = DiffusionModelUNet(**cfg)
+        sd, ref = m.state_dict(), ou.unet_param_shapes(cfg)
+        assert set(sd) == set(ref)
+        assert all(tuple(sd[k].shape) == tuple(ref[k]) for k in ref)
+    for cfg in (cfgs.VAE_FULL, cfgs.VAE_TINY):
+        m = AutoencoderKL(**cfg)
+        sd, ref = m.state_dict(), oa.ae_param_shapes(cfg)
+        assert set(sd) == set(ref)
+        assert all(tuple(sd[k].shape) == tuple(ref[k]) for k in ref)
+
+
+def test_module_surface_the_reference_relies_on(built_lib):
+    """state_dict round trip, .parameters(), train()/eval(), DDP-style .module unwrap, MONAI zero init
+    (3d_ldm/train_diffusion.py:129-149,291-303)."""
+    from ldm3d.networks import DiffusionModelUNet
+    m = DiffusionModelUNet(**cfgs.UNET_TINY)
+    sd = m.state_dict()
+    assert float(sd["out.2.conv.weight"].abs().max()) == 0.0 and float(sd["down_blocks.0.resnets.0.conv2.conv.weight"].abs().max()) == 0.0
+    assert float(sd["down_blocks.0.resnets.0.conv1.conv.weight"].abs().max()) > 0.0
+    m2 = DiffusionModelUNet(**cfgs.UNET_TINY)
+    m2.load_state_dict({k: v + 1 for k, v in sd.items()})
+    assert torch.equal(m2.state_dict()["conv_in.conv.bias"], sd["conv_in.conv.bias"] + 1)
+    wrapper = types.SimpleNamespace(module=m)
+    assert wrapper.module.state_dict().keys() == sd.keys()
+    assert m.train().training and not m.eval().training
+    assert sum(p.numel() for p in m.parameters()) == sum(v.numel() for v in sd.values())
+    with pytest.raises(Exception):                                                       # no CPU fallback
+        m(x=torch.zeros((1, 4, 8, 8, 8)), timesteps=torch.zeros(1))
+
+
+def test_unsupported_configs_fail_loudly(built_lib):
+    from ldm3d import _lib
+    from ldm3d.networks import AutoencoderKL, DiffusionModelUNet
+    with pytest.raises(NotImplementedError):
+        DiffusionModelUNet(**dict(cfgs.UNET_TINY, with_conditioning=True, cross_attention_dim=64))
+    with pytest.raises(_lib.LdmError):
+        DiffusionModelUNet(**dict(cfgs.UNET_TINY, num_head_channels=[0, 32, 32]))       # head_dim 64 only
+    with pytest.raises(_lib.LdmError):
+        AutoencoderKL(**dict(cfgs.VAE_TINY, attention_levels=[False, False, True]))
+
+
+REFERENCE_STYLE_CONFIG = {
+    # same schema as 3d_ldm/config/config_train_16g.json (values reduced): "_target_", "@ref", "$@ref"
+    "spatial_dims": 3, "image_channels": 2, "latent_channels": 8,
+    "autoencoder_def": {"_target_": "networks.AutoencoderKL", "spatial_dims": "@spatial_dims",
+                        "in_channels": "$@image_channels", "out_channels": "@image_channels",
+                        "latent_channels": "@latent_channels", "channels": [32, 64, 64], "num_res_blocks": 2,
+                        "norm_num_groups": 32, "norm_eps": 1e-06, "attention_levels": [False, False, False],
+                        "with_encoder_nonlocal_attn": False, "with_decoder_nonlocal_attn": False},
+    "diffusion_def": {"_target_": "monai.networks.nets.DiffusionModelUNet", "spatial_dims": "@spatial_dims",
+                      "in_channels": "$@latent_channels * 2", "out_channels": "@latent_channels",
+                      "channels": [64, 64, 128], "attention_levels": [False, True, True],
+                      "num_head_channels": [0, 64, 64], "num_res_blocks": 2},
+    "NoiseScheduler": {"num_train_timesteps": 1000, "beta_start": 0.0015, "beta_end": 0.0195},
+}
+
+
+def test_define_instance_resolves_reference_schema(built_lib, tmp_path):
+    from ldm3d.config import define_instance, load_config_namespace
+    from ldm3d.networks import AutoencoderKL, DiffusionModelUNet
+    (tmp_path / "c.json").write_text(json.dumps(REFERENCE_STYLE_CONFIG))
+    (tmp_path / "e.json").write_text(json.dumps({"model_dir": "./m", "output_dir": "./o"}))
+    args = load_config_namespace(str(tmp_path / "e.json"), str(tmp_path / "c.json"), gpus=1)
+    ae = define_instance(args, "autoencoder_def")
+    un = define_instance(args, "diffusion_def")
+    assert isinstance(ae, AutoencoderKL) and isinstance(un, DiffusionModelUNet)
+    assert ae.in_channels == 2 and ae.latent_channels == 8 and un.in_channels == 16 and un.out_channels == 8
+    assert args.model_dir == "./m" and args.NoiseScheduler["beta_end"] == 0.0195
+    with pytest.raises(ImportError):
+        define_instance({"x": {"_target_": "no.such.Class"}}, "x")
+    with pytest.raises(KeyError):
+        define_instance({"x": {"_target_": "networks.AutoencoderKL", "spatial_dims": "@missing"}}, "x")
+
+
+def test_host_scheduler_tables_equal_oracle(built_lib):
+    from ldm3d.schedulers import DDIMScheduler, DDPMScheduler
+    from oracle.schedulers import OracleDDPM
+    d, o = DDPMScheduler(**cfgs.SCHED), OracleDDPM(**cfgs.SCHED)
+    assert torch.equal(d.betas, o.betas) and torch.equal(d.alphas_cumprod, o.alphas_cumprod)
+    assert d.num_train_timesteps == 1000 and d.timesteps.tolist() == o.timesteps.tolist()
+    for t in (0, 1, 500, 999):                                                           # per-step scalars as MONAI computes them
+        a_t = o.alphas_cumprod[t]
+        a_p = o.alphas_cumprod[t - 1] if t > 0 else o.one
+        assert d._c0[t] == pytest.approx(float(a_p ** 0.5 * o.betas[t] / (1 - a_t)), rel=1e-6)
+        assert d._c1[t] == pytest.approx(float(o.alphas[t] ** 0.5 * (1 - a_p) / (1 - a_t)), rel=1e-6, abs=1e-12)
+    i = DDIMScheduler(**cfgs.SCHED)
+    i.set_timesteps(50)
+    assert i.timesteps.tolist() == list(range(980, -1, -20))
+    with pytest.raises(ValueError):
+        i.set_timesteps(1001)
+    with pytest.raises(Exception):                                                       # CUDA tensors only
+        d.step(torch.zeros(2), 5, torch.zeros(2))
