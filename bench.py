@@ -69,6 +69,20 @@ def host_cores():
     return max(1, min(n, 16))               # a 1-GPU box's CPU share is 16 cores
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (None if absent)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")))
+    for f in reversed(files):
+        try:
+            t = json.load(open(f)).get("conv_hbm_traffic_bytes_per_launch")
+            if t:
+                return t["total"]
+        except (OSError, ValueError):
+            pass
+    return None
+
+
 def cpu_baseline(steps=3):
     """Oracle (test infrastructure) as the CPU baseline: fp32 torch ops, all host cores, same UNet, same latent."""
     import torch
@@ -145,17 +159,21 @@ def main():
     with torch.no_grad():
         for i in range(args.warmup):
             x = step(i, x)
-        profile = (not args.no_roofline) and rank == 0
-        if profile:
-            _lib.check(L.ldm_profile_start(*DOMINANT_TILE, 64 * args.steps + 64))
         fence()
         t0 = time.perf_counter()
         for i in range(args.steps):
             x = step(args.warmup + i, x)
         fence()
         dt = time.perf_counter() - t0
+        # Roofline leg: the SAME K steps once more with HIP events recorded on the launch stream around every launch
+        # of the dominant kernel (kept out of the timed region above: 2 events x ~60 launches per step cost ~25 %).
+        profile = (not args.no_roofline) and rank == 0
         prof = (C.c_double * 5)()
         if profile:
+            _lib.check(L.ldm_profile_start(*DOMINANT_TILE, 64 * args.steps + 64))
+            for i in range(args.steps):
+                x = step(args.warmup + args.steps + i, x)
+            torch.cuda.synchronize()
             _lib.check(L.ldm_profile_stop(prof))
     assert torch.isfinite(x).all()
 
@@ -185,12 +203,15 @@ def main():
         achieved = prof[2] / (prof[1] * 1e-3) / 1e12
         out["roofline"] = {
             "bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": None,
+            "frac": achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": pmc_traffic(),
             "kernel": "conv_igemm_kernel<2,2,64> (implicit-GEMM conv3d, 128x128x64 tile, bf16 MFMA 16x16x32)",
             "launches": int(prof[0]), "avg_launch_us": prof[1] * 1e3 / prof[0],
             "algorithmic_gflop_per_launch": prof[2] / prof[0] / 1e9,
             "share_of_conv_flops": prof[2] / prof[4] if prof[4] else None,
             "whole_step_frac_of_mfma_peak": UNET_STEP_GFLOP / ms_per_step / MFMA_BF16_DENSE_PEAK_TFLOPS,
+            "how": "HIP events on the launch stream around every launch of this kernel, second pass of the same K steps; "
+                   "traffic = HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), read side x2 per "
+                   "the gfx950 FETCH_SIZE correction",
         }
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline()
