@@ -24,7 +24,7 @@ f = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
 rows = list(csv.DictReader(open(f)))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 bench = json.loads(open(os.path.join(src, "bench_trace.json")).read().strip().splitlines()[-1])
-nsteps = bench["steps"] + bench["warmup"]
+nsteps = bench["warmup"] + bench["steps"] * (2 if bench.get("roofline") else 1)   # roofline leg repeats the K steps
 out["bench_under_profiler"] = {k: bench[k] for k in ("value", "ms_per_step", "steps", "warmup")}
 out["bench_roofline_hip_events"] = bench.get("roofline")
 out["kernels"] = [{"name": short(r["Name"]), "calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3,
