@@ -48,6 +48,7 @@ struct ConvParams {
     float* out_f32;                   // [N][CoutReal][Dout*Hout*Wout]    (mode 1)
     float* partial;                   // [splitk][M][CoutPad] fp32 slabs  (splitk > 1)
     float* stats;                     // GroupNorm partials of the OUTPUT: [ceil(M/32)][CoutS][2] (sum, sum sq) or null
+    unsigned long long* stamps;       // diagnostic (dbg & 512): per-workgroup s_memrealtime stamps [nwg][8]
     int dbg;                          // timing experiments only (LDM_CONV_DBG): 1 = all voxel rows from the zero page, 2 = all weight rows = row 0
 };
 
@@ -83,6 +84,7 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_igemm_kernel(const ConvParam
     static_assert(KS == NG, "each wave group computes exactly one 32-deep k-substep per K step");
     static_assert((PF - 1) * LPS <= 63 && PF * LPS <= 63, "vmcnt is a 6-bit counter");
     static_assert(NG == 1 || NS * STAGE >= 65536, "the accumulator exchange needs 64 KiB of LDS");
+    static_assert(NS * STAGE + 28 * BM * 4 <= 160 * 1024, "ring + tap table must fit the 160 KiB LDS");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
@@ -105,6 +107,9 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_igemm_kernel(const ConvParam
     int s_end = s_begin + p.steps_per_split; if (s_end > steps_total) s_end = steps_total;
     const int nsteps = s_end - s_begin;
     const int dbg = p.dbg;
+    if (dbg & 128) return;                             // timing experiment: launch cost only
+#define LDM_STAMP(I) do { if ((dbg & 512) && tid == 0) p.stamps[(size_t)blockIdx.x * 8 + (I)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    LDM_STAMP(0);
 
     // ---- per-lane loader constants ------------------------------------------------------------
     const int prow = lane / CPR;                       // row inside a piece
@@ -114,23 +119,39 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_igemm_kernel(const ConvParam
     const int DinU = p.Din << p.ups, HinU = p.Hin << p.ups, WinU = p.Win << p.ups;
     const int rows_in0 = p.N * p.Din * p.Hin * p.Win;  // voxel rows of the group-0 source
 
-    int a_id0[PA], a_ih0[PA], a_iw0[PA], a_nbase[PA], a_m[PA], a_kb[PA];
+    // (tap, row) -> source voxel table in LDS, built once by the whole workgroup: entry = voxel index of the shifted tap
+    // (covers stride, asymmetric padding and the folded x2 upsample: src = (o*stride + k - pad) >> ups) or -1 where
+    // the tap falls into the zero padding / the row is beyond M.  A tap change in the K loop is then one ds_read_b32
+    // per copied row instead of ~100 serialized instructions on every wave.
+    int* const tapv = reinterpret_cast<int*>(smem + NS * STAGE);
+    {
+        constexpr int TPR = (256 * NG) / BM;           // threads per row
+        const int row = tid / TPR, part = tid % TPR;
+        const int m = m0 + row;
+        const int taps = p.ksize * p.ksize * p.ksize;
+        if (row < BM) {
+            int n = 0, od = 0, oh = 0, ow = 0;
+            if (m < p.M) { n = m / DHWo; int r = m - n * DHWo; od = r / HWo; r -= od * HWo; oh = r / p.Wout; ow = r - oh * p.Wout; }
+            const int nb = n * p.Din * p.Hin * p.Win;
+            if (part == 0) tapv[taps * BM + row] = -1;             // sentinel row read by the one-tap-ahead prefetch
+            for (int tap = part; tap < taps; tap += TPR) {
+                int kd = 0, kh = 0, kw = 0;
+                if (p.ksize == 3) { kd = tap / 9; kh = (tap - kd * 9) / 3; kw = tap - kd * 9 - kh * 3; }
+                const int id = od * p.stride + kd - p.pad, ih = oh * p.stride + kh - p.pad, iw = ow * p.stride + kw - p.pad;
+                const bool ok = (m < p.M) & ((unsigned)id < (unsigned)DinU) & ((unsigned)ih < (unsigned)HinU) &
+                                ((unsigned)iw < (unsigned)WinU) & !(dbg & 1);
+                tapv[tap * BM + row] = ok ? nb + ((id >> p.ups) * p.Hin + (ih >> p.ups)) * p.Win + (iw >> p.ups) : -1;
+            }
+        }
+    }
+    int a_row[PA], a_m[PA], a_kb[PA];                  // per copied voxel row: row in tile, output row (group 1), chunk byte
 #pragma unroll
     for (int j = 0; j < PA; ++j) {
-        const int row = (wave * PA + j) * RPP + prow;  // voxel row inside the tile
-        const int m = m0 + row;
+        const int row = (wave * PA + j) * RPP + prow;
         const int swz = (row >> SWZ_SHIFT) & (CPR - 1);
         a_kb[j] = (pchunk ^ swz) * 16;                 // byte offset of this lane's logical chunk inside the BK chunk
-        if (m < p.M) {
-            const int n = m / DHWo; int r = m - n * DHWo;
-            const int od = r / HWo; r -= od * HWo;
-            const int oh = r / p.Wout; const int ow = r - oh * p.Wout;
-            a_id0[j] = od * p.stride - p.pad; a_ih0[j] = oh * p.stride - p.pad; a_iw0[j] = ow * p.stride - p.pad;
-            a_nbase[j] = n * p.Din * p.Hin * p.Win;
-            a_m[j] = m;
-        } else {
-            a_id0[j] = -(1 << 20); a_ih0[j] = 0; a_iw0[j] = 0; a_nbase[j] = 0; a_m[j] = -1;
-        }
+        a_row[j] = row;
+        a_m[j] = (m0 + row < p.M && !(dbg & 1)) ? m0 + row : -1;
     }
     int b_row[PB], b_kb[PB];
 #pragma unroll
@@ -147,71 +168,68 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_igemm_kernel(const ConvParam
     // ---- loader: the K loop is a sequence of SEGMENTS = (group, tap, concat source) runs of cs/BK steps.  Inside a
     // segment every copy is  buffer_load_dwordx4 ... lds  with a per-lane byte offset that stays fixed (voxel row of
     // the shifted tap; 0xFFFFFFFF for zero padding: the buffer range check then writes zeros) and a SCALAR offset
-    // that advances by BK*2 bytes per step, so a step costs one m0 write + one instruction per piece.  The address
-    // arithmetic (15 VALU per row) runs once per segment.
-    int sg_grp, sg_tap, sg_kd, sg_kh, sg_kw, sg_src, sg_left;      // scalar segment state
+    // that advances by BK*2 bytes per step, so a step costs one m0 write + one instruction per piece.  Three tiers
+    // keep the rare work rare: per GROUP (descriptors, weight row offsets), per TAP (voxel index from the packed
+    // candidates: ~10 VALU per row), per SOURCE (row byte offset = voxel * channels).
+    int sg_grp, sg_tap, sg_src, sg_left;                           // scalar segment state
+    int g_ca = 0, g_cb = 0;                                        // channels of the current group's two sources
+    unsigned g_wtap = 0;                                           // bytes between two taps of the weight tensor
     unsigned soff_a = 0, soff_b = 0;
+    int a_v[PA];                                                   // source voxel of the current tap (-1: padding)
     unsigned a_vo[PA], b_vo[PB];
-    __amdgpu_buffer_rsrc_t rs_a, rs_b;
+    __amdgpu_buffer_rsrc_t rs_a, rs_a0, rs_a1, rs_b;
     int ld_s = s_begin;
+    int first_cis;                                                 // chunk inside the source where this K range starts
     {
         int chunk;
         if (ld_s < p.steps0) {
             sg_grp = 0; sg_tap = ld_s / p.nchunk0; chunk = ld_s - sg_tap * p.nchunk0;
-            const int kk = p.ksize * p.ksize;
-            sg_kd = sg_tap / kk; sg_kh = (sg_tap - sg_kd * kk) / p.ksize; sg_kw = sg_tap - sg_kd * kk - sg_kh * p.ksize;
-        } else { sg_grp = 1; sg_tap = 0; chunk = ld_s - p.steps0; sg_kd = sg_kh = sg_kw = 0; }
+        } else { sg_grp = 1; sg_tap = 0; chunk = ld_s - p.steps0; }
         const int ca = sg_grp ? p.c1a : p.c0a;
         sg_src = (chunk * BK >= ca) ? 1 : 0;
-        sg_left = -1 - (sg_src ? chunk - ca / BK : chunk);         // negative: "enter the segment at chunk -sg_left-1"
+        first_cis = sg_src ? chunk - ca / BK : chunk;
+        sg_left = -1;                                              // "state not set up yet"
     }
 
-#define LDM_SEG_SETUP(CIS) do {                                                                               \
-        const int ca_ = sg_grp ? p.c1a : p.c0a, cb_ = sg_grp ? p.c1b : p.c0b;                                 \
-        const int cin_ = ca_ + cb_, cs_ = sg_src ? cb_ : ca_;                                                 \
-        const bf16_t* xs_ = sg_grp ? (sg_src ? p.x1b : p.x1a) : (sg_src ? p.x0b : p.x0a);                     \
+#define LDM_GROUP_SETUP() do {                                                                                \
+        g_ca = sg_grp ? p.c1a : p.c0a; g_cb = sg_grp ? p.c1b : p.c0b;                                         \
+        const int cin_ = g_ca + g_cb;                                                                         \
         const unsigned rows_ = sg_grp ? (unsigned)p.M : (unsigned)rows_in0;                                   \
-        rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)xs_, 0, (int)(rows_ * (unsigned)cs_ * 2u), 0x00020000);\
-        _Pragma("unroll") for (int j = 0; j < PA; ++j) {                                                      \
-            int v_;                                                                                           \
-            if (sg_grp == 0) {                                                                                \
-                const int id = a_id0[j] + sg_kd, ih = a_ih0[j] + sg_kh, iw = a_iw0[j] + sg_kw;                \
-                const bool ok = ((unsigned)id < (unsigned)DinU) & ((unsigned)ih < (unsigned)HinU) &          \
-                                ((unsigned)iw < (unsigned)WinU);                                              \
-                v_ = a_nbase[j] + ((id >> p.ups) * p.Hin + (ih >> p.ups)) * p.Win + (iw >> p.ups);            \
-                v_ = ok ? v_ : -1;                                                                            \
-            } else v_ = a_m[j];                                                                               \
-            if (dbg & 1) v_ = -1;                                                                             \
-            a_vo[j] = (v_ >= 0) ? (unsigned)v_ * (unsigned)(cs_ * 2) + (unsigned)a_kb[j] : 0xFFFFFFFFu;       \
-        }                                                                                                     \
-        const bf16_t* wp_ = sg_grp ? p.w1 : p.w0;                                                             \
-        const unsigned wbytes_ = (unsigned)(sg_grp ? 1 : p.ksize * p.ksize * p.ksize) * (unsigned)p.CoutPad * \
-                                 (unsigned)cin_ * 2u;                                                         \
-        rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)wp_, 0, (int)wbytes_, 0x00020000);                    \
+        rs_a0 = __builtin_amdgcn_make_buffer_rsrc((void*)(sg_grp ? p.x1a : p.x0a), 0, (int)(rows_ * (unsigned)g_ca * 2u), 0x00020000); \
+        rs_a1 = __builtin_amdgcn_make_buffer_rsrc((void*)(sg_grp ? p.x1b : p.x0b), 0, (int)(rows_ * (unsigned)g_cb * 2u), 0x00020000); \
+        g_wtap = (unsigned)p.CoutPad * (unsigned)cin_ * 2u;                                                   \
+        rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)(sg_grp ? p.w1 : p.w0), 0,                            \
+                                                 (int)((unsigned)(sg_grp ? 1 : p.ksize * p.ksize * p.ksize) * g_wtap), 0x00020000); \
         _Pragma("unroll") for (int j = 0; j < PB; ++j)                                                        \
             b_vo[j] = (unsigned)b_row[j] * (unsigned)(cin_ * 2) + (unsigned)b_kb[j];                          \
-        soff_a = (unsigned)(CIS) * (BK * 2);                                                                  \
-        soff_b = (unsigned)sg_tap * (unsigned)p.CoutPad * (unsigned)(cin_ * 2) +                              \
-                 (unsigned)((sg_src ? ca_ : 0) + (CIS) * BK) * 2u;                                            \
-        sg_left = cs_ / BK - (CIS);                                                                           \
     } while (0)
-
-    // issue the copies of step ld_s into ring slot (ld_s - s_begin) % NS and advance the scalar state
+#define LDM_TAP_SETUP() do {                                                                                  \
+        _Pragma("unroll") for (int j = 0; j < PA; ++j)                                                        \
+            a_v[j] = (sg_grp == 0) ? tapv[sg_tap * BM + a_row[j]] : a_m[j];                                   \
+    } while (0)
+#define LDM_SRC_SETUP() do {                                                                                  \
+        const unsigned cs2_ = (unsigned)(sg_src ? g_cb : g_ca) * 2u;                                          \
+        rs_a = sg_src ? rs_a1 : rs_a0;                                                                        \
+        _Pragma("unroll") for (int j = 0; j < PA; ++j)                                                        \
+            a_vo[j] = (a_v[j] >= 0) ? (unsigned)a_v[j] * cs2_ + (unsigned)a_kb[j] : 0xFFFFFFFFu;              \
+    } while (0)
+    // move to the segment that contains step ld_s (called when the current one is exhausted, or not yet set up)
 #define LDM_SEG_ADVANCE() do {                                                                                \
         if (sg_left <= 0) {                                                                                   \
-            if (sg_left < 0) { const int cis_ = -sg_left - 1; LDM_SEG_SETUP(cis_); }   /* first segment */     \
-            else {                                                                                            \
-                const int cb_nx = sg_grp ? p.c1b : p.c0b;                                                     \
-                if (sg_src == 0 && cb_nx > 0) sg_src = 1;                                                     \
-                else {                                                                                        \
-                    sg_src = 0;                                                                               \
-                    if (sg_grp == 0) {                                                                        \
-                        ++sg_tap;                                                                             \
-                        if (++sg_kw == p.ksize) { sg_kw = 0; if (++sg_kh == p.ksize) { sg_kh = 0; ++sg_kd; } }\
-                        if (ld_s >= p.steps0) { sg_grp = 1; sg_tap = 0; }                                     \
-                    }                                                                                         \
-                }                                                                                             \
-                LDM_SEG_SETUP(0);                                                                             \
+            if (sg_left < 0) {                                         /* first call: enter mid-segment */     \
+                LDM_GROUP_SETUP(); LDM_TAP_SETUP(); LDM_SRC_SETUP();                                          \
+                soff_a = (unsigned)first_cis * (BK * 2);                                                      \
+                soff_b = (unsigned)sg_tap * g_wtap + (unsigned)((sg_src ? g_ca : 0) + first_cis * BK) * 2u;   \
+                sg_left = (sg_src ? g_cb : g_ca) / BK - first_cis;                                            \
+            } else if (sg_src == 0 && g_cb > 0) {                      /* second concat source, same tap */    \
+                sg_src = 1; LDM_SRC_SETUP();                                                                  \
+                soff_a = 0; sg_left = g_cb / BK;                       /* soff_b simply keeps running */       \
+            } else {                                                   /* next tap (or the fused 1x1 group) */ \
+                sg_src = 0;                                                                                   \
+                if (sg_grp == 0 && ld_s >= p.steps0) { sg_grp = 1; sg_tap = 0; LDM_GROUP_SETUP(); }           \
+                else ++sg_tap;                                                                                  \
+                LDM_TAP_SETUP(); LDM_SRC_SETUP();                                                             \
+                soff_a = 0; soff_b = (unsigned)sg_tap * g_wtap; sg_left = g_ca / BK;                          \
             }                                                                                                 \
         }                                                                                                     \
     } while (0)
@@ -284,6 +302,7 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_igemm_kernel(const ConvParam
     // has arrived and does not re-wait behind the reads of NXT.  Group 0 issues its copies before its MFMAs, group 1
     // after: on every SIMD one wave is in its matrix phase while its partner is in its copy phase.
 #define LDM_HALF(S, WC, AC, WN, AN) do {                                                            \
+        LDM_ST2(S, 0);                                                                              \
         __builtin_amdgcn_s_waitcnt(0xC07F);                                                         \
         if ((S) + 1 < s_end) {                                                                      \
             LDM_NEXT_STEP_READY(S);                                                                 \
@@ -294,7 +313,10 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_igemm_kernel(const ConvParam
         if (grp == 1 && (S) + 1 < s_end && ld_s < s_end) LDM_ISSUE();                              \
     } while (0)
 
+    LDM_STAMP(1);
+    if (dbg & 256) return;                             // timing experiment: setup only
     // ---- prologue: fill the ring (NS steps in flight), wait for the first step ----------------------------------
+    __syncthreads();                                   // tap table complete
     if (nsteps > 0) {
 #pragma unroll
         for (int i = 0; i < NS; ++i) if (i < nsteps) LDM_ISSUE();
@@ -304,17 +326,17 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_igemm_kernel(const ConvParam
         asm volatile("" ::: "memory");
         LDM_READ_FRAGS(wfA, afA, 0);
     }
+    LDM_STAMP(2);
     // Steady state: one hot basic block per K step.  The segment change (rare, VALU heavy) runs BEFORE the wait; the
     // copies of step s+NS, the fragment reads of step s+1 and the 16 MFMAs of step s then sit in one scheduling
     // region and sched_group_barrier interleaves them (an MFMA occupies the matrix pipe for 16 cycles but the issue
     // port for ~8: one copy / LDS read rides in the shadow of each MFMA instead of in front of all of them).
-#define LDM_FAST_HALF(S, WC, AC, WN, AN) do {                                                       \
-        LDM_SEG_ADVANCE();                                                                          \
-        __builtin_amdgcn_s_waitcnt(0xC07F);                                                         \
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF - 1) * LPS) : "memory");                       \
-        __builtin_amdgcn_s_barrier();                                                               \
-        asm volatile("" ::: "memory");                                                              \
-        LDM_DMA_RAW();                                                                              \
+#define LDM_ST2(S, K) do { if ((dbg & 1024) && tid == 0 && (S) - s_begin < 120) p.stamps[(size_t)gridDim.x * 8 + (size_t)blockIdx.x * 512 + ((S) - s_begin) * 4 + (K)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    // Branch-free: valid while the loader stays inside group 0 with a single source (every 3^3 conv of the UNet: the
+    // concat is materialised by GroupNorm; the fused 1x1 skip steps at the end run through the generic loop below).
+    // Tap changes are handled by selects: a_nx[] always holds the row offsets of tap f_tap+1 (read from the LDS table
+    // one step ahead), the scalar offsets wrap with s_cselect.
+#define LDM_FAST_TAIL(WC, AC, WN, AN, S) \
         LDM_READ_FRAGS_RAW(WN, AN, ((S) + 1 - s_begin) % NS);                                       \
         LDM_MFMA16_RAW(WC, AC);                                                                     \
         _Pragma("unroll") for (int i_ = 0; i_ < LPS; ++i_) {                                        \
@@ -326,23 +348,97 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_igemm_kernel(const ConvParam
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   /* 1 MFMA */                       \
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   /* 1 ds_read_b128 */               \
         }                                                                                           \
-        __builtin_amdgcn_sched_group_barrier(0x008, 16 - LPS - 8 > 0 ? 16 - LPS - 8 : 0, 0);        \
+        __builtin_amdgcn_sched_group_barrier(0x008, 16 - LPS - 8 > 0 ? 16 - LPS - 8 : 0, 0);
+#define LDM_FAST_SYNC(S) \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                                         \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF - 1) * LPS) : "memory");                       \
+        LDM_ST2(S, 2);                                                                              \
+        __builtin_amdgcn_s_barrier();                                                               \
+        asm volatile("" ::: "memory");                                                              \
+        LDM_ST2(S, 3);
+#define LDM_FAST_COPIES() \
+            char* st_ = smem + ((ld_s - s_begin) % NS) * STAGE;                                     \
+            _Pragma("unroll") for (int j = 0; j < PA; ++j)                                          \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr_t)(st_ + (wave * PA + j) * 1024), 16, \
+                                                         a_vo[j], soff_a, 0, 0);                    \
+            _Pragma("unroll") for (int j = 0; j < PB; ++j)                                          \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr_t)(st_ + BM * RB + (wave * PB + j) * 1024), \
+                                                         16, b_vo[j], soff_b, 0, 0);
+    // Variant A (few chunks per tap, e.g. the 64/128-channel VAE convs): tap changes by selects inside the hot block.
+#define LDM_FAST_HALF(S, WC, AC, WN, AN) do {                                                       \
+        LDM_ST2(S, 0);                                                                              \
+        LDM_FAST_SYNC(S)                                                                            \
+        {                                                                                           \
+            LDM_FAST_COPIES()                                                                       \
+            const bool last_ = (sg_left == 1);                                                      \
+            soff_a = last_ ? 0u : soff_a + BK * 2;                                                  \
+            soff_b += BK * 2 + (last_ ? f_wjump : 0u);                                              \
+            sg_left = last_ ? f_nch : sg_left - 1;                                                  \
+            sg_tap += last_ ? 1 : 0;                                                                \
+            ++ld_s;                                                                                 \
+            _Pragma("unroll") for (int j = 0; j < PA; ++j) {                                        \
+                /* a_vr[] was read from the table one step ago (no LDS wait inside the hot block) */ \
+                const unsigned nx_ = (a_vr[j] >= 0) ? (unsigned)a_vr[j] * f_cs2 + (unsigned)a_kb[j] : 0xFFFFFFFFu; \
+                a_vo[j] = last_ ? nx_ : a_vo[j];                                                    \
+                a_vr[j] = tapv[(sg_tap + 1) * BM + a_row[j]];                                       \
+            }                                                                                       \
+        }                                                                                           \
+        LDM_FAST_TAIL(WC, AC, WN, AN, S)                                                            \
+    } while (0)
+    // Variant B (many chunks per tap, the UNet convs): the hot block carries nothing extra; a tap change is one short
+    // uniform branch in front of the waits (table read + multiply-add per copied row).
+#define LDM_FAST_HALF_B(S, WC, AC, WN, AN) do {                                                     \
+        LDM_ST2(S, 0);                                                                              \
+        if (sg_left == 0) {                                                                         \
+            ++sg_tap; soff_a = 0; soff_b = (unsigned)sg_tap * g_wtap; sg_left = f_nch;              \
+            _Pragma("unroll") for (int j = 0; j < PA; ++j) {                                        \
+                const int v_ = tapv[sg_tap * BM + a_row[j]];                                        \
+                a_vo[j] = (v_ >= 0) ? (unsigned)v_ * f_cs2 + (unsigned)a_kb[j] : 0xFFFFFFFFu;       \
+            }                                                                                       \
+        }                                                                                           \
+        LDM_FAST_SYNC(S)                                                                            \
+        {                                                                                           \
+            LDM_FAST_COPIES()                                                                       \
+            soff_a += BK * 2; soff_b += BK * 2; --sg_left; ++ld_s;                                  \
+        }                                                                                           \
+        LDM_FAST_TAIL(WC, AC, WN, AN, S)                                                            \
     } while (0)
 
     int s = s_begin;
-    if (dbg == 0) {                                   // (timing experiments run the generic loop)
-        while (s + 1 + NS < s_end) {
-            LDM_FAST_HALF(s, wfA, afA, wfB, afB);
-            LDM_FAST_HALF(s + 1, wfB, afB, wfA, afA);
-            s += 2;
+    const int f_lim = (s_end < p.steps0) ? s_end : p.steps0;      // fast loop: only group-0 steps are issued
+    if ((dbg & ~(512 | 1024 | 3)) == 0 && p.c0b == 0 && s + 1 + NS < f_lim) {
+        LDM_SEG_ADVANCE();                                          // make sure a segment is set up (sg_left >= 1)
+        const unsigned f_cs2 = (unsigned)g_ca * 2u;
+        const unsigned f_wjump = g_wtap - (unsigned)g_ca * 2u;     // from the end of a tap's channel run to the next tap
+        const int f_nch = g_ca / BK;
+        if (f_nch <= 3) {
+            int a_vr[PA];                                           // voxel of each copied row under tap sg_tap + 1
+#pragma unroll
+            for (int j = 0; j < PA; ++j) a_vr[j] = tapv[(sg_tap + 1) * BM + a_row[j]];
+            while (s + 1 + NS < f_lim) {
+                LDM_FAST_HALF(s, wfA, afA, wfB, afB);
+                LDM_FAST_HALF(s + 1, wfB, afB, wfA, afA);
+                s += 2;
+            }
+        } else {
+            while (s + 1 + NS < f_lim) {
+                LDM_FAST_HALF_B(s, wfA, afA, wfB, afB);
+                LDM_FAST_HALF_B(s + 1, wfB, afB, wfA, afA);
+                s += 2;
+            }
         }
+        if (ld_s >= p.steps0) { sg_left = 0; sg_tap = p.ksize * p.ksize * p.ksize - 1; }   // group 0 exhausted: let the generic advance switch groups
     }
-    for (; s < s_end; s += 2) {                       // generic tail (and the whole loop for short K ranges)
+    for (; s < s_end; s += 2) {                       // generic loop: prologue-sized K ranges, dual sources, fused skip, tail
         LDM_HALF(s, wfA, afA, wfB, afB);
         if (s + 1 >= s_end) break;
         LDM_HALF(s + 1, wfB, afB, wfA, afA);
     }
 #undef LDM_FAST_HALF
+#undef LDM_FAST_HALF_B
+#undef LDM_FAST_TAIL
+#undef LDM_FAST_SYNC
+#undef LDM_FAST_COPIES
 #undef LDM_HALF
 #undef LDM_NEXT_STEP_READY
 #undef LDM_MFMA16
@@ -353,8 +449,12 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_igemm_kernel(const ConvParam
 #undef LDM_READ_FRAGS_RAW
 #undef LDM_MFMA16_RAW
 #undef LDM_SEG_ADVANCE
-#undef LDM_SEG_SETUP
+#undef LDM_GROUP_SETUP
+#undef LDM_TAP_SETUP
+#undef LDM_SRC_SETUP
 
+    LDM_STAMP(3);
+    if (dbg & 64) return;                              // timing experiment: no reduction / epilogue
     // ---- intra-workgroup K reduction: group g keeps voxel tiles mt in {2g, 2g+1} and receives its partner's
     //      partial sums for them through LDS (the ring is dead by now). --------------------------------------------
     constexpr int MTN = (NG == 2) ? 2 : 4;           // 16-row tiles this wave finishes
@@ -384,6 +484,7 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_igemm_kernel(const ConvParam
                 }
     }
 
+    LDM_STAMP(4);
     // ---- epilogue -------------------------------------------------------------------------------
     // Per lane: 16 consecutive couts of one voxel per 16-row tile.  Optionally also the GroupNorm partial sums of
     // the (bf16-rounded) output over each 32-row block, written to a slab (no atomics -> bitwise reproducible).
@@ -480,6 +581,8 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_igemm_kernel(const ConvParam
             }
         }
     }
+    LDM_STAMP(5);
+#undef LDM_STAMP
 #endif  // __HIP_DEVICE_COMPILE__
 }
 

@@ -740,7 +740,7 @@ static int launch_conv_t(const ConvParams& p, hipStream_t s) {
     constexpr int STAGE = (64 * WGM + 64 * WGN) * BK * 2;
     constexpr int NG = (BK == 64) ? 2 : 1;
     constexpr int NS = (STAGE * 4 <= 131072) ? 4 : 3;
-    constexpr int LDS = NS * STAGE;
+    constexpr int LDS = NS * STAGE + 28 * 64 * WGM * 4;       // ring + (tap, row) -> voxel table (+1 sentinel tap)
     static bool attr_set = false;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<WGM, WGN, BK, NS, NG>),
@@ -1185,6 +1185,10 @@ int ldm_op_conv3d(const void* xa, int ca, const void* xb, int cb, const void* w,
         p.partial = (float*)scratch;
     }
     { const char* e = getenv("LDM_CONV_DBG"); p.dbg = e ? atoi(e) : 0; }
+    if (p.dbg & 512) {                          // diagnostic stamps go to the caller's scratch (needs nwg * 64 bytes)
+        if (cc.splitk > 1 || !scratch || scratch_bytes < (size_t)p.mtiles * p.ntiles * (64 + 4096)) return fail(LDM_ERR_BAD_ARG, "stamps need scratch and splitk 1");
+        p.stamps = (unsigned long long*)scratch;
+    }
     LDM_TRY(launch_conv(p, cc, (hipStream_t)stream));
     if (cc.splitk > 1) {
         FinalizeParams f{}; f.partial = p.partial; f.splitk = p.splitk; f.M = p.M; f.CoutPad = p.CoutPad; f.CoutS = p.CoutS;
