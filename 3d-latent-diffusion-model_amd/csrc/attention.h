@@ -11,7 +11,7 @@
 //   S^T = K Q^T        : MFMA A = K tile rows (LDS, swizzled ds_read_b128), B = Q fragments (registers)
 //                        -> a lane holds 16 scores of ONE query (col = lane&15): row max/sum need 2 shuffles.
 //   O^T += V^T P^T     : P stays in registers as the B operand (k order permuted identically on both operands),
-//                        A = V^T rows read from a transposed LDS image (ds_read_b64, padded rows).
+//                        A = V^T fragments read from the row-major V image with ds_read_b64_tr_b16 (hardware transpose).
 #pragma once
 #include "common.h"
 
@@ -22,10 +22,8 @@ struct AttnParams {
 
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     constexpr int D = 64, KT = 64;
-    constexpr int VROW = 136;                         // bytes per V^T row (64 keys * 2 B + 8 B pad: conflict-free b64 reads)
-    __shared__ __attribute__((aligned(16))) char smem[KT * 128 + D * VROW];
-    char* ks = smem;                                  // K tile  [64 keys][64 d] bf16, 16-B chunks XOR-swizzled
-    char* vs = smem + KT * 128;                       // V^T tile [64 d][64 keys] bf16
+    constexpr int TILE = KT * 128 + KT * 128;         // one K image + one V image (both row-major [key][d], swizzled)
+    __shared__ __attribute__((aligned(16))) char smem[2 * TILE];   // double buffered
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
@@ -49,28 +47,41 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     for (int i = 0; i < 4; ++i) ot[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float mrun = -INFINITY, lrun = 0.f;               // running max / per-lane partial row sum
 
-    const int ntile = (p.N + KT - 1) / KT;
-    for (int t = 0; t < ntile; ++t) {
-        const int k0 = t * KT;
-        __syncthreads();                              // previous tile fully consumed
-        // ---- stage K (row-major, swizzled) and V^T ------------------------------------------------
+    // staging split (issue early / write late): the global loads of tile t+1 are issued before the MFMAs of tile t and
+    // written to the other LDS image after them, so their latency hides under the compute; one barrier per tile.
+    u32x4 kreg[2], vreg[2];
+    auto stage_load = [&](int k0) {
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int idx = tid + it * 256;           // 512 (row, chunk) pairs
             const int row = idx >> 3, ch = idx & 7;
             int kr = k0 + row; if (kr >= p.N) kr = p.N - 1;
             const bf16_t* tok = base + (size_t)kr * ld + hoff + ch * 8;
-            const u32x4 kv = *reinterpret_cast<const u32x4*>(tok + p.C);
-            const u32x4 vv = *reinterpret_cast<const u32x4*>(tok + 2 * p.C);
-            *reinterpret_cast<u32x4*>(ks + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)) = kv;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int d = ch * 8 + 2 * e;
-                *reinterpret_cast<bf16_t*>(vs + d * VROW + row * 2) = (bf16_t)(vv[e] & 0xffff);
-                *reinterpret_cast<bf16_t*>(vs + (d + 1) * VROW + row * 2) = (bf16_t)(vv[e] >> 16);
-            }
+            kreg[it] = *reinterpret_cast<const u32x4*>(tok + p.C);
+            vreg[it] = *reinterpret_cast<const u32x4*>(tok + 2 * p.C);
         }
-        __syncthreads();
+    };
+    auto stage_write = [&](char* ks, char* vs) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int idx = tid + it * 256;
+            const int row = idx >> 3, ch = idx & 7;
+            *reinterpret_cast<u32x4*>(ks + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)) = kreg[it];
+            // V stays row-major; its 32-byte blocks are XOR-swizzled by (row>>1)&3 so that the transposed reads
+            // (4 rows x 16 columns per 16-lane group) are bank-conflict free
+            *reinterpret_cast<u32x4*>(vs + row * 128 + ((ch ^ (((row >> 1) & 3) << 1)) << 4)) = vreg[it];
+        }
+    };
+
+    const int ntile = (p.N + KT - 1) / KT;
+    stage_load(0);
+    stage_write(smem, smem + KT * 128);
+    __syncthreads();
+    for (int t = 0; t < ntile; ++t) {
+        const int k0 = t * KT;
+        const char* ks = smem + (t & 1) * TILE;       // K tile  [64 keys][64 d] bf16, 16-B chunks XOR-swizzled
+        const char* vs = ks + KT * 128;               // V tile  [64 keys][64 d] bf16, read transposed (ds_read_b64_tr_b16)
+        if (t + 1 < ntile) stage_load(k0 + KT);
 
         // ---- S^T = K Q^T : st[j][r] = S[q = fr][key = k0 + 16 j + 4 fg + r] ------------------------
         f32x4 st[4];
@@ -92,9 +103,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = k0 + 16 * j + 4 * fg + r;
-                const float s = (key < p.N) ? st[j][r] * p.scale : -INFINITY;
-                st[j][r] = s;
-                tmax = fmaxf(tmax, s);
+                const float sv = (key < p.N) ? st[j][r] * p.scale : -INFINITY;
+                st[j][r] = sv;
+                tmax = fmaxf(tmax, sv);
             }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
@@ -123,19 +134,31 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) ot[dt][r] *= alpha;
         }
-        // ---- O^T += V^T P^T ------------------------------------------------------------------------
+        // ---- O^T += V^T P^T : the A operand V^T[d][key] comes from the row-major V image through the hardware
+        //      transpose read: lane 4q+p of a 16-lane group addresses row (key) q, columns (d) 4p..4p+3 of a 4 x 16 block
+        //      and lane i receives column i of the 4 rows (probed: tools/probe/ds_read_tr_probe.hip). ------------------
+        typedef __attribute__((ext_vector_type(4))) short s16x4;
+        typedef __attribute__((address_space(3))) s16x4* lds_s16x4_t;
+        const int tq = fr >> 2, tp = fr & 3;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-            const char* vrow = vs + (dt * 16 + fr) * VROW;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const u32x2 lo = *reinterpret_cast<const u32x2*>(vrow + ((2 * h) * 16 + 4 * fg) * 2);
-                const u32x2 hi = *reinterpret_cast<const u32x2*>(vrow + ((2 * h + 1) * 16 + 4 * fg) * 2);
-                u32x4 vv = {lo[0], lo[1], hi[0], hi[1]};
-                const bf16x8 vf = *reinterpret_cast<bf16x8*>(&vv);
+                const int rlo = (2 * h) * 16 + 4 * fg + tq, rhi = rlo + 16;       // key rows this lane addresses
+                const char* alo = vs + rlo * 128 + ((dt ^ ((rlo >> 1) & 3)) << 5) + tp * 8;
+                const char* ahi = vs + rhi * 128 + ((dt ^ ((rhi >> 1) & 3)) << 5) + tp * 8;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)alo);
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)ahi);
+                const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[h], ot[dt], 0, 0, 0);
             }
         }
+        // ---- late write of tile t+1 into the other image (its last readers finished before the previous barrier) ----
+        if (t + 1 < ntile) {
+            char* nk = smem + ((t + 1) & 1) * TILE;
+            stage_write(nk, nk + KT * 128);
+        }
+        __syncthreads();
     }
     // ---- normalise and store ------------------------------------------------------------------------
     lrun += __shfl_xor(lrun, 16, 64);
