@@ -31,6 +31,8 @@ struct ConvParams {
     int N, Din, Hin, Win;             // group-0 source dims (before the optional x2 upsample)
     int Dout, Hout, Wout;
     int ksize, stride, pad, ups;      // ups = 0/1 : nearest-neighbour x2 upsample folded into the loader
+    int exact;                        // with ups = 1: tap positions must be EVEN (source = pos / 2), odd ones read zero:
+                                      // the transposed (data-gradient) form of a stride-2 convolution
     int M;                            // N * Dout * Hout * Wout
     int CoutS;                        // stored output channels (multiple of 32, >= real Cout)
     int CoutPad;                      // weight rows (multiple of 64 and of BN)
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_igemm_kernel(const ConvParam
                 if (p.ksize == 3) { kd = tap / 9; kh = (tap - kd * 9) / 3; kw = tap - kd * 9 - kh * 3; }
                 const int id = od * p.stride + kd - p.pad, ih = oh * p.stride + kh - p.pad, iw = ow * p.stride + kw - p.pad;
                 const bool ok = (m < p.M) & ((unsigned)id < (unsigned)DinU) & ((unsigned)ih < (unsigned)HinU) &
-                                ((unsigned)iw < (unsigned)WinU) & !(dbg & 1);
+                                ((unsigned)iw < (unsigned)WinU) & !(dbg & 1) & !(p.exact & (id | ih | iw) & 1);
                 tapv[tap * BM + row] = ok ? nb + ((id >> p.ups) * p.Hin + (ih >> p.ups)) * p.Win + (iw >> p.ups) : -1;
             }
         }

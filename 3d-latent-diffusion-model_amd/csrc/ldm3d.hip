@@ -1152,7 +1152,9 @@ int ldm_op_conv3d(const void* xa, int ca, const void* xb, int cb, const void* w,
     if (ca % 32 || cb % 32 || c1a % 32 || c1b % 32 || cout_pad % 64 || cout > cout_pad || cin0 > 4096 || cin1 > 4096)
         return fail(LDM_ERR_BAD_ARG, "channel counts must be multiples of 32 (cout_pad of 64)");
     if (ksize != 1 && ksize != 3) return fail(LDM_ERR_UNSUPPORTED, "ksize must be 1 or 3");
-    if (ups < 0 || ups > 1 || stride < 1 || stride > 2) return fail(LDM_ERR_UNSUPPORTED, "stride 1|2, ups 0|1");
+    int exact = 0;
+    if (ups == 2) { ups = 1; exact = 1; }            // ups = 2: zero-insertion upsample (transposed stride-2 conv)
+    if (ups < 0 || ups > 1 || stride < 1 || stride > 2) return fail(LDM_ERR_UNSUPPORTED, "stride 1|2, ups 0|1|2");
     LDM_TRY(ensure_zero_page());
     int bk = 64;
     if (ca % 64 || cb % 64 || c1a % 64 || c1b % 64) bk = 32;
@@ -1168,7 +1170,7 @@ int ldm_op_conv3d(const void* xa, int ca, const void* xb, int cb, const void* w,
     p.x1a = (const bf16_t*)x1a; p.x1b = (const bf16_t*)x1b; p.c1a = c1a; p.c1b = c1b; p.w1 = (const bf16_t*)w1;
     p.zero_page = (const bf16_t*)g_zero_page;
     p.N = N; p.Din = Din; p.Hin = Hin; p.Win = Win; p.Dout = Do; p.Hout = Ho; p.Wout = Wo;
-    p.ksize = ksize; p.stride = stride; p.pad = pad; p.ups = ups; p.M = (int)M;
+    p.ksize = ksize; p.stride = stride; p.pad = pad; p.ups = ups; p.exact = exact; p.M = (int)M;
     p.CoutS = rup(cout, 32); p.CoutPad = cout_pad; p.CoutReal = cout;
     p.nchunk0 = cin0 / bk; p.nchunk1 = cin1 / bk; p.steps0 = taps * p.nchunk0; p.steps1 = p.nchunk1;
     ConvCfg cc = Builder::choose_cfg(M, cout_pad, p.steps0 + p.steps1, bk);
@@ -1228,6 +1230,17 @@ int ldm_op_group_norm(const void* xa, int ca, const void* xb, int cb, const floa
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, N), dim3(64), 0, s, fp);
     GnApplyParams ap{}; ap.xa = sp.xa; ap.xb = sp.xb; ap.ca = ca; ap.cb = cb; ap.DHW = DHW; ap.N = N; ap.silu = silu; ap.ab = ab; ap.out = (bf16_t*)out;
     hipLaunchKernelGGL(gn_apply_kernel, dim3(grid_for((long)N * DHW * cvec, 256, 2048)), dim3(256), 0, s, ap);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+/* Weights of the data-gradient conv: wt[tap'][ci][co] = w[taps-1-tap'][co][ci].  w: [taps][cout_pad][cin] bf16,
+ * wt: [taps][round64(cin)][round32(cout)] bf16 (device memory, caller allocated). */
+int ldm_op_weight_flip_transpose(const void* w, void* wt, int ksize, int cout, int cout_pad, int cin, void* stream) {
+    if (!w || !wt || (ksize != 1 && ksize != 3) || cout < 1 || cin < 1 || cout_pad < cout) return fail(LDM_ERR_BAD_ARG, "bad argument");
+    const int taps = ksize * ksize * ksize, rows = rup(cin, 64), cols = rup(cout, 32);
+    hipLaunchKernelGGL(weight_flip_transpose_kernel, dim3(grid_for((long)taps * rows * cols)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)w, (bf16_t*)wt, taps, cout, cout_pad, cin, rows);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -309,3 +309,23 @@ __global__ __launch_bounds__(256) void vae_heads_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void scale_kernel(const float* __restrict__ x, float* __restrict__ y, long n, float s) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = x[i] * s;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Training support.
+// Weights for the data-gradient convolution: Wt[tap'][ci][co] = W[taps-1-tap'][co][ci]  (flip + transpose), both in the
+// arena layout [tap][rows padded][cols]; zero rows / columns in the padding.
+__global__ __launch_bounds__(256) void weight_flip_transpose_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ wt,
+                                                                    int taps, int cout, int cout_pad, int cin, int cin_pad_rows) {
+    // wt: [taps][cin_pad_rows][cout_pad_cols = round32(cout)]
+    const int cols = (cout + 31) / 32 * 32;
+    const long total = (long)taps * cin_pad_rows * cols;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int co = (int)(i % cols);
+        const long r = i / cols;
+        const int ci = (int)(r % cin_pad_rows);
+        const int tp = (int)(r / cin_pad_rows);
+        bf16_t v = 0;
+        if (co < cout && ci < cin) v = w[((size_t)(taps - 1 - tp) * cout_pad + co) * cin + ci];
+        wt[i] = v;
+    }
+}

@@ -135,6 +135,10 @@ int ldm_op_conv3d(const void* xa, int ca, const void* xb, int cb, const void* w,
                   const float* temb, int temb_stride, const void* residual, void* out_bf16, float* out_f32,
                   int N, int Din, int Hin, int Win, int ksize, int stride, int pad, int ups,
                   int cout, int cout_pad, int wgn, int splitk, void* scratch, size_t scratch_bytes, void* stream);
+/* ---- training building blocks (backward of train_diffusion.py:207-219) ----------------
+ *      data gradient of a conv = ldm_op_conv3d on dY with flipped + transposed weights (ldm_op_weight_flip_transpose),
+ *      pad' = k-1-pad; for a stride-2 forward conv pass ups = 2 (zero-insertion upsample: odd tap positions read 0). */
+int ldm_op_weight_flip_transpose(const void* w, void* wt, int ksize, int cout, int cout_pad, int cin, void* stream);
 /* GroupNorm(groups, eps, affine) over cat(xa, xb), optional fused SiLU -> out [N*DHW][ca+cb] bf16. */
 size_t ldm_op_group_norm_scratch_bytes(int N, int C, int DHW);
 int ldm_op_group_norm(const void* xa, int ca, const void* xb, int cb, const float* gamma, const float* beta,

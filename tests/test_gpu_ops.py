@@ -195,3 +195,37 @@ def test_attention(cuda, built_lib, b, n, c):
     err = rel_l2(out.float().cpu(), ref)
     # P is rounded to bf16 before P.V and the output to bf16: ~2^-9 relative each
     assert err <= 8e-3, err
+
+
+# ------------------------------------------------------------------------------------------------ training blocks
+def _dgrad_case(cuda, lib, cin, cout, dims, k, stride, pad, seed=0):
+    """dX of y = conv3d(x, w, stride, pad) for a given dY, as one more conv launch on flipped/transposed weights."""
+    from ldm3d import _lib
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn((1, cin, *dims), generator=g, requires_grad=True)
+    w = bf16_round(torch.randn((cout, cin, k, k, k), generator=g) / (cin * k ** 3) ** 0.5)
+    y = F.conv3d(x, w, None, stride=stride, padding=pad)
+    dy = bf16_round(torch.randn(y.shape, generator=g))
+    (ref,) = torch.autograd.grad(y, x, dy)
+    cout_pad, cin_pad = rup(cout, 64), rup(cin, 64)
+    wp = pack_conv_weight(w, cin, cout_pad).to(cuda)                       # forward arena layout [taps][cout_pad][cin]
+    wt = torch.empty((k ** 3, cin_pad, rup(cout, 32)), dtype=torch.bfloat16, device=cuda)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.ldm_op_weight_flip_transpose(wp.data_ptr(), wt.data_ptr(), k, cout, cout_pad, cin, st))
+    dyd = to_ndhwc_bf16(dy).to(cuda)                                       # channels padded to round32(cout)
+    out = torch.empty((1, *dims, rup(cin, 32)), dtype=torch.bfloat16, device=cuda)
+    scratch = torch.empty((64 << 20,), dtype=torch.uint8, device=cuda)
+    zero_bias = torch.zeros((cin_pad,), device=cuda)
+    _lib.check(lib.ldm_op_conv3d(dyd.data_ptr(), rup(cout, 32), None, 0, wt.data_ptr(), zero_bias.data_ptr(), None, 0, None, 0, None,
+                                 None, None, 0, None, out.data_ptr(), None, 1, *y.shape[2:], k, 1, k - 1 - pad,
+                                 2 if stride == 2 else 0, cin, cin_pad, 0, 0, scratch.data_ptr(), scratch.numel(), st))
+    torch.cuda.synchronize()
+    return rel_l2(from_ndhwc(out.cpu(), cin), bf16_round(ref))
+
+
+@pytest.mark.parametrize("cin,cout,dims,k,stride,pad", [(64, 64, (6, 6, 6), 3, 1, 1), (128, 64, (5, 7, 6), 3, 1, 1),
+                                                        (64, 128, (6, 6, 6), 1, 1, 0), (64, 64, (8, 8, 8), 3, 2, 1),
+                                                        (32, 96, (12, 8, 4), 3, 2, 1)])
+def test_conv_dgrad(cuda, built_lib, cin, cout, dims, k, stride, pad):
+    err = _dgrad_case(cuda, built_lib, cin, cout, dims, k, stride, pad)
+    assert err <= TOL_SAME_ROUNDING, err
