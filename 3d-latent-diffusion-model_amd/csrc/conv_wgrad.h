@@ -1,0 +1,190 @@
+// Weight gradient of the 3D convolution (training; reference call site: loss.backward()
+// at 3d_ldm/train_diffusion.py:214 reaching every nn.Conv3d / nn.Linear of the UNet).
+//
+//   dW[tap][co][ci] = sum over output voxels m of  dY[m][co] * X[src(m, tap)][ci]
+//
+// One GEMM per tap that contracts over VOXELS: both operands are stored voxel-major (NDHWC rows), i.e. K is the slow
+// dimension, so the MFMA fragments (8 consecutive k per lane) are read from LDS with the hardware transpose
+// ds_read_b64_tr_b16 (4 voxel rows x 16 channels per 16-lane group).  Workgroup = 128 couts x 128 cins of ONE tap,
+// 8 waves as two groups that each take one 32-voxel half of every 64-voxel K step (same pipeline as the forward kernel:
+// 4-slot LDS ring filled by buffer_load ... lds, counted vmcnt, raw barrier, double-buffered register fragments).
+// Output fp32 [taps][Cout][Cin] (deterministic: no atomics; the voxel range is not split across workgroups).
+#pragma once
+#include "common.h"
+
+struct WgradParams {
+    const bf16_t* dy; int cdy;        // [M][cdy]   output-gradient, NDHWC bf16 (cdy = stored channels of the conv output)
+    const bf16_t* x; int cx;          // [rows_in][cx] conv input (single source)
+    float* dw;                        // [taps][Cout][Cin] fp32
+    int Cout, Cin;                    // real channel counts written
+    int N, Din, Hin, Win, Dout, Hout, Wout, ksize, stride, pad, ups;
+    int M, co_tiles, ci_tiles;
+};
+
+__global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int KV = 64;                     // voxels per K step
+    constexpr int TR = 256;                    // bytes per LDS row (128 channels)
+    constexpr int STAGE = 2 * KV * TR;         // dY tile + X tile = 32 KiB
+    constexpr int NS = 4, PF = NS - 1, LPS = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    typedef __attribute__((address_space(3))) s16x4* lds_s16x4_t;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wq = wave & 3;
+    const int wa = wq & 1, wb = wq >> 1;       // wave tile: couts [64 wa, +64) x cins [64 wb, +64)
+    int bid = blockIdx.x;
+    const int ci_t = bid % p.ci_tiles; bid /= p.ci_tiles;
+    const int co_t = bid % p.co_tiles; const int tap = bid / p.co_tiles;
+    const int kk = p.ksize * p.ksize;
+    const int kd = tap / kk, kh = (tap - kd * kk) / p.ksize, kw = tap - kd * kk - kh * p.ksize;
+    const int DinU = p.Din << p.ups, HinU = p.Hin << p.ups, WinU = p.Win << p.ups;
+    const int HWo = p.Hout * p.Wout, DHWo = p.Dout * HWo;
+    const int nsteps = (p.M + KV - 1) / KV;
+
+    // ---- loader: each wave copies 2 pieces (4 voxel rows x 256 B) of the dY tile and 2 of the X tile per step.
+    // lane -> (row = lane / 16 inside the piece, physical 16-B chunk = lane % 16); 32-byte blocks are XOR-swizzled by
+    // f(row) = (row & 3) + 4 * ((row >> 3) & 1) so the transposed reads below are bank-conflict free.
+    const int prow = lane >> 4, pch = lane & 15;
+    int l_row[2], l_kb[2];                     // voxel row inside the step, logical channel byte this lane fetches
+    int vw[2], vh[2], vd[2], vn[2];            // output coordinates of that row at the current step (updated incrementally)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = (wave * 2 + j) * 4 + prow;
+        const int f = (row & 3) + 4 * ((row >> 3) & 1);
+        l_row[j] = row;
+        l_kb[j] = ((((pch >> 1) ^ f) << 1) | (pch & 1)) * 16;
+        int m = row;                           // step 0
+        vn[j] = m / DHWo; m -= vn[j] * DHWo; vd[j] = m / HWo; m -= vd[j] * HWo; vh[j] = m / p.Wout; vw[j] = m - vh[j] * p.Wout;
+    }
+    // 64 voxels ahead, decomposed once (each component is smaller than its extent, so every carry wraps at most once)
+    const int q_d = KV / HWo, q_h = (KV - q_d * HWo) / p.Wout, q_w = KV - q_d * HWo - q_h * p.Wout;
+    __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (int)((unsigned)p.M * (unsigned)p.cdy * 2u), 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.x, 0, (int)((unsigned)(p.N * p.Din * p.Hin * p.Win) * (unsigned)p.cx * 2u), 0x00020000);
+    const unsigned dy_cb = (unsigned)co_t * 256u, x_cb = (unsigned)ci_t * 256u;   // byte offset of the channel tile
+    int ld_s = 0;
+
+#define WG_ISSUE() do {                                                                                       \
+        char* st_ = smem + (ld_s % NS) * STAGE;                                                               \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                       \
+            const int m_ = ld_s * KV + l_row[j];                                                              \
+            /* dY row m (rows beyond M and channels beyond the tensor fall outside the buffer -> zeros) */     \
+            const bool okc_ = (dy_cb + (unsigned)l_kb[j]) < (unsigned)p.cdy * 2u;                              \
+            const unsigned vo_dy = (m_ < p.M && okc_) ? (unsigned)m_ * (unsigned)(p.cdy * 2) + dy_cb + (unsigned)l_kb[j] : 0xFFFFFFFFu; \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, (lds_ptr_t)(st_ + (wave * 2 + j) * 1024), 16, vo_dy, 0, 0, 0); \
+            /* X row src(m, tap) */                                                                            \
+            const int id = vd[j] * p.stride + kd - p.pad, ih = vh[j] * p.stride + kh - p.pad, iw = vw[j] * p.stride + kw - p.pad; \
+            const bool ok_ = (m_ < p.M) & ((unsigned)id < (unsigned)DinU) & ((unsigned)ih < (unsigned)HinU) & ((unsigned)iw < (unsigned)WinU) & \
+                             ((x_cb + (unsigned)l_kb[j]) < (unsigned)p.cx * 2u);                               \
+            const int src_ = ((vn[j] * p.Din + (id >> p.ups)) * p.Hin + (ih >> p.ups)) * p.Win + (iw >> p.ups); \
+            const unsigned vo_x = ok_ ? (unsigned)src_ * (unsigned)(p.cx * 2) + x_cb + (unsigned)l_kb[j] : 0xFFFFFFFFu; \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(st_ + KV * TR + (wave * 2 + j) * 1024), 16, vo_x, 0, 0, 0); \
+            /* advance this row by 64 output voxels */                                                         \
+            vw[j] += q_w; if (vw[j] >= p.Wout) { vw[j] -= p.Wout; ++vh[j]; }                                   \
+            vh[j] += q_h; if (vh[j] >= p.Hout) { vh[j] -= p.Hout; ++vd[j]; }                                   \
+            vd[j] += q_d; if (vd[j] >= p.Dout) { vd[j] -= p.Dout; ++vn[j]; }                                   \
+        }                                                                                                     \
+        ++ld_s;                                                                                               \
+    } while (0)
+
+    // ---- fragments: this wave group's 32 voxels of the step are rows [32 grp, 32 grp + 32).  Lane (i = lane & 15,
+    //      g = lane >> 4) gets k = 8g .. 8g+7 of column i: two transposed reads (rows 8g..8g+3 and 8g+4..8g+7).
+    const int fi = lane & 15, fg = lane >> 4, tq = fi >> 2, tp = fi & 3;
+    const int r_lo = 32 * grp + 8 * fg + tq, r_hi = r_lo + 4;            // voxel rows this lane ADDRESSES
+    const int f_lo = (r_lo & 3) + 4 * ((r_lo >> 3) & 1), f_hi = (r_hi & 3) + 4 * ((r_hi >> 3) & 1);
+    int a_lo[4], a_hi[4], b_lo[4], b_hi[4];                              // byte offsets inside a ring slot
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int ca = wa * 4 + t, cb = wb * 4 + t;                      // 32-byte column block (16 channels) in the tile
+        a_lo[t] = r_lo * TR + ((ca ^ f_lo) << 5) + tp * 8;
+        a_hi[t] = r_hi * TR + ((ca ^ f_hi) << 5) + tp * 8;
+        b_lo[t] = KV * TR + r_lo * TR + ((cb ^ f_lo) << 5) + tp * 8;
+        b_hi[t] = KV * TR + r_hi * TR + ((cb ^ f_hi) << 5) + tp * 8;
+    }
+    f32x4 acc[4][4];                                                     // [cout tile][cin tile]
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 afA[4], bfA[4], afB[4], bfB[4];
+#define WG_READ(AF, BF, SLOT) do {                                                                  \
+        const char* sb_ = smem + (SLOT) * STAGE;                                                    \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                             \
+            const s16x4 al_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(sb_ + a_lo[t])); \
+            const s16x4 ah_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(sb_ + a_hi[t])); \
+            const s16x4 bl_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(sb_ + b_lo[t])); \
+            const s16x4 bh_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(sb_ + b_hi[t])); \
+            AF[t] = (bf16x8){al_[0], al_[1], al_[2], al_[3], ah_[0], ah_[1], ah_[2], ah_[3]};       \
+            BF[t] = (bf16x8){bl_[0], bl_[1], bl_[2], bl_[3], bh_[0], bh_[1], bh_[2], bh_[3]};       \
+        }                                                                                           \
+    } while (0)
+#define WG_MFMA(AF, BF) do {                                                                        \
+        _Pragma("unroll") for (int a = 0; a < 4; ++a)                                               \
+            _Pragma("unroll") for (int b = 0; b < 4; ++b)                                           \
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[a], BF[b], acc[a][b], 0, 0, 0); \
+    } while (0)
+#define WG_HALF(S, AC, BC, AN, BN) do {                                                             \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                                         \
+        if ((S) + 1 < nsteps) {                                                                     \
+            if ((S) + PF < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF - 1) * LPS) : "memory"); \
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                   \
+            __builtin_amdgcn_s_barrier();                                                           \
+            asm volatile("" ::: "memory");                                                          \
+            if (ld_s < nsteps) WG_ISSUE();                                                          \
+            WG_READ(AN, BN, ((S) + 1) % NS);                                                        \
+        }                                                                                           \
+        WG_MFMA(AC, BC);                                                                            \
+    } while (0)
+
+#pragma unroll
+    for (int i = 0; i < NS; ++i) if (i < nsteps) WG_ISSUE();
+    if (nsteps > PF) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PF * LPS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    WG_READ(afA, bfA, 0);
+    for (int s = 0; s < nsteps; s += 2) {
+        WG_HALF(s, afA, bfA, afB, bfB);
+        if (s + 1 >= nsteps) break;
+        WG_HALF(s + 1, afB, bfB, afA, bfA);
+    }
+#undef WG_HALF
+#undef WG_MFMA
+#undef WG_READ
+#undef WG_ISSUE
+
+    // ---- reduce the two wave groups through LDS (group 1 -> group 0), then group 0 stores ------------------------
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    float* xch = reinterpret_cast<float*>(smem);
+    if (grp == 1) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xch[((wq * 64) + (a * 4 + b) * 4 + r) * 64 + lane] = acc[a][b][r];
+    }
+    __syncthreads();
+    if (grp == 0) {
+        // accumulator: col = lane & 15 -> cin, row = 4 fg + r -> cout
+        const size_t tap_off = (size_t)tap * p.Cout * p.Cin;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int ci = ci_t * 128 + wb * 64 + b * 16 + fi;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = co_t * 128 + wa * 64 + a * 16 + 4 * fg + r;
+                    const float v = acc[a][b][r] + xch[((wq * 64) + (a * 4 + b) * 4 + r) * 64 + lane];
+                    if (co < p.Cout && ci < p.Cin) p.dw[tap_off + (size_t)co * p.Cin + ci] = v;
+                }
+            }
+    }
+#endif
+}

@@ -23,6 +23,7 @@
 #include "../../include/ldm3d.h"
 #include "attention.h"
 #include "conv_igemm.h"
+#include "conv_wgrad.h"
 #include "norm_elem.h"
 
 #ifndef CONV_STAGES
@@ -1241,6 +1242,29 @@ int ldm_op_weight_flip_transpose(const void* w, void* wt, int ksize, int cout, i
     const int taps = ksize * ksize * ksize, rows = rup(cin, 64), cols = rup(cout, 32);
     hipLaunchKernelGGL(weight_flip_transpose_kernel, dim3(grid_for((long)taps * rows * cols)), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)w, (bf16_t*)wt, taps, cout, cout_pad, cin, rows);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+/* dW[tap][co][ci] (fp32, [k^3][cout][cin]) of y = conv3d(x, w): dy [M][cdy] and x [rows][cx] are NDHWC bf16. */
+int ldm_op_conv3d_wgrad(const void* dy, int cdy, const void* x, int cx, float* dw, int cout, int cin,
+                        int N, int Din, int Hin, int Win, int ksize, int stride, int pad, int ups, void* stream) {
+    if (!dy || !x || !dw) return fail(LDM_ERR_BAD_ARG, "null tensor argument");
+    if (cdy % 32 || cx % 32 || cout < 1 || cin < 1 || cout > cdy || cin > cx) return fail(LDM_ERR_BAD_ARG, "bad channel counts");
+    if ((ksize != 1 && ksize != 3) || stride < 1 || stride > 2 || ups < 0 || ups > 1) return fail(LDM_ERR_UNSUPPORTED, "ksize 1|3, stride 1|2, ups 0|1");
+    const int Du = Din << ups, Hu = Hin << ups, Wu = Win << ups;
+    const int pad_total = (stride == 2 && pad == 0 && ksize == 3) ? 1 : 2 * pad;
+    const int Do = (Du + pad_total - ksize) / stride + 1, Ho = (Hu + pad_total - ksize) / stride + 1, Wo = (Wu + pad_total - ksize) / stride + 1;
+    const long M = (long)N * Do * Ho * Wo;
+    if (M < 1 || M >= (1L << 31) || (long)Do * Ho * Wo < 64) return fail(LDM_ERR_UNSUPPORTED, "output volume must hold at least 64 voxels");
+    if ((long)M * cdy * 2 >= (1L << 32) || (long)N * Din * Hin * Win * cx * 2 >= (1L << 32)) return fail(LDM_ERR_UNSUPPORTED, "tensor exceeds 4 GiB");
+    WgradParams p{}; p.dy = (const bf16_t*)dy; p.cdy = cdy; p.x = (const bf16_t*)x; p.cx = cx; p.dw = dw; p.Cout = cout; p.Cin = cin;
+    p.N = N; p.Din = Din; p.Hin = Hin; p.Win = Win; p.Dout = Do; p.Hout = Ho; p.Wout = Wo; p.ksize = ksize; p.stride = stride; p.pad = pad; p.ups = ups;
+    p.M = (int)M; p.co_tiles = (cout + 127) / 128; p.ci_tiles = (cin + 127) / 128;
+    constexpr int LDS = 4 * 2 * 64 * 256;
+    static bool attr_set = false;
+    if (!attr_set) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr_set = true; }
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(p.co_tiles * p.ci_tiles * ksize * ksize * ksize), dim3(512), LDS, (hipStream_t)stream, p);
     HIP_TRY(hipGetLastError());
     return 0;
 }

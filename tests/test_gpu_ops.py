@@ -229,3 +229,32 @@ def _dgrad_case(cuda, lib, cin, cout, dims, k, stride, pad, seed=0):
 def test_conv_dgrad(cuda, built_lib, cin, cout, dims, k, stride, pad):
     err = _dgrad_case(cuda, built_lib, cin, cout, dims, k, stride, pad)
     assert err <= TOL_SAME_ROUNDING, err
+
+
+def _wgrad_case(cuda, lib, cin, cout, dims, k, stride, pad, n=1, ups=0, seed=0):
+    from ldm3d import _lib
+    g = torch.Generator().manual_seed(seed)
+    x = bf16_round(torch.randn((n, cin, *dims), generator=g))
+    w = torch.randn((cout, cin, k, k, k), generator=g, requires_grad=True)
+    xin = F.interpolate(x, scale_factor=2.0, mode="nearest") if ups else x
+    y = F.conv3d(xin, w, None, stride=stride, padding=pad)
+    dy = bf16_round(torch.randn(y.shape, generator=g))
+    (ref,) = torch.autograd.grad(y, w, dy)                                  # [cout][cin][k][k][k]
+    ref = ref.reshape(cout, cin, k ** 3).permute(2, 0, 1).contiguous()       # -> [taps][cout][cin]
+    xd, dyd = to_ndhwc_bf16(x).to(cuda), to_ndhwc_bf16(dy).to(cuda)
+    dw = torch.full((k ** 3, cout, cin), float("nan"), dtype=torch.float32, device=cuda)
+    _lib.check(lib.ldm_op_conv3d_wgrad(dyd.data_ptr(), dyd.shape[-1], xd.data_ptr(), xd.shape[-1], dw.data_ptr(), cout, cin,
+                                       n, *dims, k, stride, pad, ups, torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert torch.isfinite(dw).all()
+    return rel_l2(dw.cpu(), ref)
+
+
+@pytest.mark.parametrize("cin,cout,dims,k,stride,pad,n,ups", [
+    (64, 64, (6, 6, 6), 3, 1, 1, 1, 0), (128, 256, (5, 7, 6), 3, 1, 1, 2, 0), (256, 128, (8, 8, 8), 1, 1, 0, 1, 0),
+    (64, 64, (8, 8, 8), 3, 2, 1, 1, 0), (4, 64, (8, 8, 8), 3, 1, 1, 1, 0), (64, 4, (6, 6, 6), 3, 1, 1, 1, 0),
+    (64, 64, (4, 4, 4), 3, 1, 1, 1, 1), (96, 160, (6, 6, 6), 3, 1, 1, 1, 0)])
+def test_conv_wgrad(cuda, built_lib, cin, cout, dims, k, stride, pad, n, ups):
+    """fp32 output, fp32 accumulation over voxels: only summation order separates it from autograd."""
+    err = _wgrad_case(cuda, built_lib, cin, cout, dims, k, stride, pad, n, ups)
+    assert err <= 2e-5, err
