@@ -91,6 +91,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnStatsParams p) {
 struct GnFinalizeParams {
     const float* partial; int nslab; int C; int Creal; int groups; int DHW; float eps;
     const float* gamma; const float* beta; float* ab;
+    float* mr;                                     // optional [N][groups][2] mean, rstd (saved for the backward pass)
 };
 
 __global__ __launch_bounds__(64) void gn_finalize_kernel(const GnFinalizeParams p) {   // fallback path only
@@ -110,6 +111,7 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const GnFinalizeParams 
     const double mean = s / cnt;
     double var = q / cnt - mean * mean; if (var < 0.0) var = 0.0;
     const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+    if (p.mr && lane == 0) { p.mr[((size_t)n * p.groups + g) * 2] = (float)mean; p.mr[((size_t)n * p.groups + g) * 2 + 1] = rstd; }
     for (int c = g * cpg + lane; c < (g + 1) * cpg; c += 64) {
         const float a = p.gamma[c] * rstd;
         p.ab[((size_t)n * p.C + c) * 2] = a;
@@ -123,6 +125,7 @@ struct GnPrepParams {
     const float* sa; const float* sb; int ca, cb;      // slabs of the two concatenated sources (sb may be null)
     int nrb_per_sample; int groups; int DHW; float eps;
     const float* gamma; const float* beta; float* ab;
+    float* mr;                                     // optional [N][groups][2] mean, rstd (saved for the backward pass)
 };
 
 __global__ __launch_bounds__(256) void gn_prep_kernel(const GnPrepParams p) {
@@ -149,6 +152,7 @@ __global__ __launch_bounds__(256) void gn_prep_kernel(const GnPrepParams p) {
     const double mean = rs[0] / cnt;
     double var = rq[0] / cnt - mean * mean; if (var < 0.0) var = 0.0;
     const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+    if (p.mr && tid == 0) { p.mr[((size_t)n * p.groups + g) * 2] = (float)mean; p.mr[((size_t)n * p.groups + g) * 2 + 1] = rstd; }
     for (int c = g * cpg + tid; c < (g + 1) * cpg; c += 256) {
         const float a = p.gamma[c] * rstd;
         p.ab[((size_t)n * C + c) * 2] = a;
@@ -328,4 +332,262 @@ __global__ __launch_bounds__(256) void weight_flip_transpose_kernel(const bf16_t
         if (co < cout && ci < cin) v = w[((size_t)(taps - 1 - tp) * cout_pad + co) * cin + ci];
         wt[i] = v;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm (+SiLU) backward.  Forward: y = act(u), u = gamma_c * xhat + beta_c, xhat = (x - mean_g) * rstd_g.
+// With g = dy * act'(u):  dgamma_c = sum g*xhat,  dbeta_c = sum g,
+//   dx = rstd_g * (gamma_c * g - mean_grp(gamma*g) - xhat * mean_grp(gamma*g*xhat))   (means over the group's cpg*DHW elements).
+// Pass 1: per-(sample, channel) partial sums of g and g*xhat over voxel slabs (same structure as gn_stats_kernel).
+struct GnBwdParams {
+    const bf16_t* dy;                              // [N*DHW][C] gradient w.r.t. the GroupNorm(+SiLU) output
+    const bf16_t* xa; const bf16_t* xb; int ca, cb; // saved forward input (channel-concatenated sources)
+    const float* ab;                               // [N][C][2] forward scale/shift (u = a*x + b)
+    const float* mr;                               // [N][G][2] forward mean, rstd
+    const float* gamma;
+    int groups, DHW, N, silu, nslab, rows_per_slab;
+    float* partial;                                // [N][nslab][C][2]
+    float* gsum;                                   // [N][G][2]  mean_grp(gamma*g), mean_grp(gamma*g*xhat)
+    float* dgamma_n; float* dbeta_n;               // [N][C] per-sample parameter gradients (summed over N by the caller)
+    const bf16_t* acc_a; const bf16_t* acc_b;      // optional gradients to add to dx (residual / skip paths), same split
+    bf16_t* dxa; bf16_t* dxb;                      // outputs [N*DHW][ca], [N*DHW][cb]
+};
+
+__device__ __forceinline__ float gn_bwd_g(float dy, float u, int silu) {
+    if (!silu) return dy;
+    const float sg = 1.0f / (1.0f + __expf(-u));
+    return dy * sg * (1.0f + u * (1.0f - sg));
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const GnBwdParams p) {
+    __shared__ float red[256 * 16];
+    const int C = p.ca + p.cb, cvec = C / 8, cpg = C / p.groups;
+    const int n = blockIdx.y, slab = blockIdx.x, tid = threadIdx.x;
+    const int r0 = slab * p.rows_per_slab;
+    int r1 = r0 + p.rows_per_slab; if (r1 > p.DHW) r1 = p.DHW;
+    const int rows_par = 256 / cvec > 0 ? 256 / cvec : 1;
+    for (int cv0 = 0; cv0 < cvec; cv0 += 256) {
+        const int cw = cvec - cv0 < 256 ? cvec - cv0 : 256;
+        const int rp = 256 / cw;
+        const int cv = tid % cw, rl = tid / cw;
+        float s1[8], s2[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
+        if (rl < rp) {
+            const int c = (cv0 + cv) * 8;
+            const bool second = c >= p.ca;
+            const bf16_t* xb_ = second ? p.xb : p.xa;
+            const int cs = second ? p.cb : p.ca, cc = second ? c - p.ca : c;
+            float a[8], b[8], mean[8], rstd[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                a[k] = p.ab[((size_t)n * C + c + k) * 2]; b[k] = p.ab[((size_t)n * C + c + k) * 2 + 1];
+                const int g = (c + k) / cpg;
+                mean[k] = p.mr[((size_t)n * p.groups + g) * 2]; rstd[k] = p.mr[((size_t)n * p.groups + g) * 2 + 1];
+            }
+            for (int r = r0 + rl; r < r1; r += rp) {
+                const size_t row = (size_t)n * p.DHW + r;
+                const u32x4 xv = *reinterpret_cast<const u32x4*>(xb_ + row * cs + cc);
+                const u32x4 dv = *reinterpret_cast<const u32x4*>(p.dy + row * C + c);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float x = __uint_as_float((k & 1) ? (xv[k >> 1] & 0xffff0000u) : (xv[k >> 1] << 16));
+                    const float dy = __uint_as_float((k & 1) ? (dv[k >> 1] & 0xffff0000u) : (dv[k >> 1] << 16));
+                    const float g = gn_bwd_g(dy, a[k] * x + b[k], p.silu);
+                    s1[k] += g; s2[k] += g * (x - mean[k]) * rstd[k];
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { red[tid * 16 + k] = s1[k]; red[tid * 16 + 8 + k] = s2[k]; }
+        __syncthreads();
+        if (tid < cw) {
+            for (int r2 = 1; r2 < rp; ++r2) {
+                const int t2 = r2 * cw + tid;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { s1[k] += red[t2 * 16 + k]; s2[k] += red[t2 * 16 + 8 + k]; }
+            }
+            float* dst = p.partial + (((size_t)n * p.nslab + slab) * C + (cv0 + tid) * 8) * 2;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { dst[2 * k] = s1[k]; dst[2 * k + 1] = s2[k]; }
+        }
+    }
+    (void)rows_par;
+}
+
+// Pass 2: one block per (sample, group): per-channel totals -> dgamma/dbeta (per sample), group means of gamma*g(.xhat).
+__global__ __launch_bounds__(64) void gn_bwd_finalize_kernel(const GnBwdParams p) {
+    const int n = blockIdx.y, g = blockIdx.x, lane = threadIdx.x;
+    const int C = p.ca + p.cb, cpg = C / p.groups;
+    double S1 = 0.0, S2 = 0.0;
+    for (int c = g * cpg + lane; c < (g + 1) * cpg; c += 64) {
+        double t1 = 0.0, t2 = 0.0;
+        for (int s = 0; s < p.nslab; ++s) {
+            const float* src = p.partial + (((size_t)n * p.nslab + s) * C + c) * 2;
+            t1 += (double)src[0]; t2 += (double)src[1];
+        }
+        p.dbeta_n[(size_t)n * C + c] = (float)t1;
+        p.dgamma_n[(size_t)n * C + c] = (float)t2;
+        S1 += (double)p.gamma[c] * t1; S2 += (double)p.gamma[c] * t2;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { S1 += __shfl_xor(S1, o, 64); S2 += __shfl_xor(S2, o, 64); }
+    if (lane == 0) {
+        const double cnt = (double)cpg * (double)p.DHW;
+        p.gsum[((size_t)n * p.groups + g) * 2] = (float)(S1 / cnt);
+        p.gsum[((size_t)n * p.groups + g) * 2 + 1] = (float)(S2 / cnt);
+    }
+}
+
+// Pass 3: dx (+ accumulated residual gradient) -> bf16, split back into the two concatenated sources.
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GnBwdParams p) {
+    const int C = p.ca + p.cb, cvec = C / 8, cpg = C / p.groups;
+    const long total = (long)p.N * p.DHW * cvec;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / cvec;
+        const int c = (int)(i - row * cvec) * 8;
+        const int n = (int)(row / p.DHW);
+        const bool second = c >= p.ca;
+        const int cs = second ? p.cb : p.ca, cc = second ? c - p.ca : c;
+        const u32x4 xv = *reinterpret_cast<const u32x4*>((second ? p.xb : p.xa) + row * cs + cc);
+        const u32x4 dv = *reinterpret_cast<const u32x4*>(p.dy + row * C + c);
+        const bf16_t* accp = second ? p.acc_b : p.acc_a;
+        u32x4 av = {0u, 0u, 0u, 0u};
+        if (accp) av = *reinterpret_cast<const u32x4*>(accp + row * cs + cc);
+        float out[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float x = __uint_as_float((k & 1) ? (xv[k >> 1] & 0xffff0000u) : (xv[k >> 1] << 16));
+            const float dy = __uint_as_float((k & 1) ? (dv[k >> 1] & 0xffff0000u) : (dv[k >> 1] << 16));
+            const float ac = __uint_as_float((k & 1) ? (av[k >> 1] & 0xffff0000u) : (av[k >> 1] << 16));
+            const float a = p.ab[((size_t)n * C + c + k) * 2], b = p.ab[((size_t)n * C + c + k) * 2 + 1];
+            const int g = (c + k) / cpg;
+            const float mean = p.mr[((size_t)n * p.groups + g) * 2], rstd = p.mr[((size_t)n * p.groups + g) * 2 + 1];
+            const float m1 = p.gsum[((size_t)n * p.groups + g) * 2], m2 = p.gsum[((size_t)n * p.groups + g) * 2 + 1];
+            const float gg = gn_bwd_g(dy, a * x + b, p.silu);
+            const float xh = (x - mean) * rstd;
+            out[k] = rstd * (p.gamma[c + k] * gg - m1 - xh * m2) + ac;
+        }
+        u32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = pack2bf(out[2 * k], out[2 * k + 1]);
+        *reinterpret_cast<u32x4*>((second ? p.dxb : p.dxa) + row * cs + cc) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Small training kernels.
+// MSE loss gradient: d/dpred mean((pred - target)^2) = 2 (pred - target) / numel, fp32 NCDHW -> bf16 NDHWC (padded);
+// also accumulates the loss (one atomicAdd per block; the value is only reported, never fed back).
+__global__ __launch_bounds__(256) void mse_grad_pack_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                            bf16_t* __restrict__ dy, float* __restrict__ loss,
+                                                            int N, int C, int Cs, int DHW) {
+    const long total = (long)N * DHW * Cs;
+    const float inv = 1.0f / (float)((long)N * C * DHW);
+    float lsum = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cs);
+        const long row = i / Cs;
+        const int n = (int)(row / DHW);
+        const int sp = (int)(row - (long)n * DHW);
+        float g = 0.f;
+        if (c < C) {
+            const size_t j = ((size_t)n * C + c) * DHW + sp;
+            const float d = pred[j] - target[j];
+            g = 2.0f * d * inv; lsum += d * d * inv;
+        }
+        dy[i] = f2bf(g);
+    }
+    lsum = wave_sum(lsum);
+    if (loss && (threadIdx.x & 63) == 0) atomicAdd(loss, lsum);
+}
+
+// Per-(sample, channel) column sums of an NDHWC bf16 tensor from gn_stats-style partials: out[n][c] = sum_slab partial[..][0]
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                              int N, int nslab, int C, int accumulate_over_n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (accumulate_over_n) {                            // bias gradient: also sum over the batch
+        if (i >= C) return;
+        double t = 0.0;
+        for (int n = 0; n < N; ++n)
+            for (int s = 0; s < nslab; ++s) t += (double)partial[(((size_t)n * nslab + s) * C + i) * 2];
+        out[i] = (float)t;
+    } else {
+        if (i >= N * C) return;
+        const int n = i / C, c = i - n * C;
+        double t = 0.0;
+        for (int s = 0; s < nslab; ++s) t += (double)partial[(((size_t)n * nslab + s) * C + c) * 2];
+        out[i] = (float)t;
+    }
+}
+
+// 2x2x2 sum pooling (adjoint of the nearest x2 upsample): out[n][d][h][w][c] = sum of the 8 fine voxels, bf16 NDHWC.
+__global__ __launch_bounds__(256) void sumpool2_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out,
+                                                       int N, int D, int H, int W, int C) {   // D,H,W = COARSE dims
+    const int cvec = C / 8;
+    const long total = (long)N * D * H * W * cvec;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % cvec);
+        long r = i / cvec;
+        const int w = (int)(r % W); r /= W; const int h = (int)(r % H); r /= H; const int d = (int)(r % D); const int n = (int)(r / D);
+        float s[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s[k] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const size_t row = (((size_t)n * 2 * D + 2 * d + (t >> 2)) * 2 * H + 2 * h + ((t >> 1) & 1)) * 2 * W + 2 * w + (t & 1);
+            const u32x4 v = *reinterpret_cast<const u32x4*>(x + row * C + cv * 8);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { s[2 * k] += __uint_as_float(v[k] << 16); s[2 * k + 1] += __uint_as_float(v[k] & 0xffff0000u); }
+        }
+        u32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = pack2bf(s[2 * k], s[2 * k + 1]);
+        *reinterpret_cast<u32x4*>(out + (size_t)i * 8) = o;
+    }
+}
+
+// Linear layers of the time-embedding path (tiny: batch x <= 1024 features), fp32 activations, bf16-rounded weights.
+//   dx[b][i] = act'(x_pre[b][i]) * sum_o W[o][i] dy[b][o]      (act = SiLU applied to the layer INPUT when silu_in)
+//   dW[o][i] = sum_b dy[b][o] * act(x_pre[b][i]);  db[o] = sum_b dy[b][o]
+__global__ __launch_bounds__(256) void linear_bwd_dx_kernel(const bf16_t* __restrict__ W, const float* __restrict__ dy,
+                                                            const float* __restrict__ x_pre, float* __restrict__ dx,
+                                                            int I, int O, int dy_stride, int x_stride, int silu_in) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (i >= I) return;
+    float acc = 0.f;
+    for (int o = 0; o < O; ++o) acc += bf2f(W[(size_t)o * I + i]) * dy[(size_t)b * dy_stride + o];
+    if (silu_in) {
+        const float u = x_pre[(size_t)b * x_stride + i];
+        const float sg = 1.0f / (1.0f + __expf(-u));
+        acc *= sg * (1.0f + u * (1.0f - sg));
+    }
+    dx[(size_t)b * x_stride + i] = acc;
+}
+
+__global__ __launch_bounds__(256) void linear_bwd_dw_kernel(const float* __restrict__ dy, const float* __restrict__ x_pre,
+                                                            float* __restrict__ dW, float* __restrict__ db,
+                                                            int B, int I, int O, int dy_stride, int x_stride, int silu_in) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)O * I) return;
+    const int o = (int)(idx / I), i = (int)(idx - (long)o * I);
+    float acc = 0.f, bsum = 0.f;
+    for (int b = 0; b < B; ++b) {
+        float xv = x_pre[(size_t)b * x_stride + i];
+        if (silu_in) xv = silu_f(xv);
+        const float d = dy[(size_t)b * dy_stride + o];
+        acc += d * xv; bsum += d;
+    }
+    dW[idx] = acc;
+    if (i == 0 && db) db[o] = bsum;
+}
+
+// out[c] = sum_n in[n][c]
+__global__ __launch_bounds__(256) void rowsum_n_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float t = 0.f;
+    for (int n = 0; n < N; ++n) t += in[(size_t)n * C + c];
+    out[c] = t;
 }

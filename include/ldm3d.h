@@ -142,6 +142,11 @@ int ldm_op_weight_flip_transpose(const void* w, void* wt, int ksize, int cout, i
 /*      weight gradient: dw[tap][co][ci] (fp32) = sum_m dy[m][co] * x[src(m, tap)][ci]; deterministic (no atomics). */
 int ldm_op_conv3d_wgrad(const void* dy, int cdy, const void* x, int cx, float* dw, int cout, int cin,
                         int N, int Din, int Hin, int Win, int ksize, int stride, int pad, int ups, void* stream);
+/*      backward of y = act(GroupNorm(cat(xa, xb))): dxa, dxb (bf16 NDHWC, plus acc_a / acc_b when given), dgamma, dbeta (fp32). */
+size_t ldm_op_group_norm_bwd_scratch_bytes(int N, int C, int DHW, int groups);
+int ldm_op_group_norm_bwd(const void* dy, const void* xa, int ca, const void* xb, int cb, const float* gamma, const float* beta,
+                          int groups, float eps, int silu, const void* acc_a, const void* acc_b, void* dxa, void* dxb,
+                          float* dgamma, float* dbeta, int N, int DHW, void* scratch, size_t scratch_bytes, void* stream);
 /* GroupNorm(groups, eps, affine) over cat(xa, xb), optional fused SiLU -> out [N*DHW][ca+cb] bf16. */
 size_t ldm_op_group_norm_scratch_bytes(int N, int C, int DHW);
 int ldm_op_group_norm(const void* xa, int ca, const void* xb, int cb, const float* gamma, const float* beta,

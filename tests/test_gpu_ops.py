@@ -258,3 +258,45 @@ def test_conv_wgrad(cuda, built_lib, cin, cout, dims, k, stride, pad, n, ups):
     """fp32 output, fp32 accumulation over voxels: only summation order separates it from autograd."""
     err = _wgrad_case(cuda, built_lib, cin, cout, dims, k, stride, pad, n, ups)
     assert err <= 2e-5, err
+
+
+@pytest.mark.parametrize("c,groups,dual,silu,n", [(64, 32, 0, 1, 1), (256, 32, 0, 1, 2), (768, 32, 512, 1, 1), (96, 8, 32, 0, 2)])
+def test_group_norm_silu_backward(cuda, built_lib, c, groups, dual, silu, n):
+    """dx (+ accumulated residual gradient), dgamma, dbeta of act(GroupNorm(cat(xa, xb))) against torch autograd on the
+    same bf16-rounded inputs; dx is rounded to bf16 by the kernel."""
+    from ldm3d import _lib
+    g = torch.Generator().manual_seed(c + n)
+    dims = (4, 6, 5)
+    x = bf16_round(torch.randn((n, c, *dims), generator=g) * 1.3 + 0.2).requires_grad_(True)
+    gamma = (1 + 0.1 * torch.randn((c,), generator=g)).requires_grad_(True)
+    beta = (0.1 * torch.randn((c,), generator=g)).requires_grad_(True)
+    y = F.group_norm(x, groups, gamma, beta, 1e-6)
+    if silu:
+        y = F.silu(y)
+    dy = bf16_round(torch.randn(y.shape, generator=g))
+    acc = bf16_round(torch.randn(y.shape, generator=g))
+    dx_ref, dg_ref, db_ref = torch.autograd.grad(y, (x, gamma, beta), dy)
+    dx_ref = dx_ref + acc
+    ca = dual if dual else c
+    xd = x.detach()
+    xa = to_ndhwc_bf16(xd[:, :ca], ca).to(cuda)
+    xb = to_ndhwc_bf16(xd[:, ca:], c - ca).to(cuda) if dual else None
+    aa = to_ndhwc_bf16(acc[:, :ca], ca).to(cuda)
+    ab_ = to_ndhwc_bf16(acc[:, ca:], c - ca).to(cuda) if dual else None
+    dyd = to_ndhwc_bf16(dy, c).to(cuda)
+    dhw = dims[0] * dims[1] * dims[2]
+    dxa = torch.empty((n, *dims, ca), dtype=torch.bfloat16, device=cuda)
+    dxb = torch.empty((n, *dims, c - ca), dtype=torch.bfloat16, device=cuda) if dual else None
+    dgam, dbet = torch.empty((c,), device=cuda), torch.empty((c,), device=cuda)
+    scratch = torch.empty((built_lib.ldm_op_group_norm_bwd_scratch_bytes(n, c, dhw, groups),), dtype=torch.uint8, device=cuda)
+    gd, bd = gamma.detach().to(cuda), beta.detach().to(cuda)
+    P = lambda t: None if t is None else t.data_ptr()
+    _lib.check(built_lib.ldm_op_group_norm_bwd(dyd.data_ptr(), xa.data_ptr(), ca, P(xb), c - ca, gd.data_ptr(), bd.data_ptr(), groups,
+                                               1e-6, silu, aa.data_ptr(), P(ab_), dxa.data_ptr(), P(dxb), dgam.data_ptr(), dbet.data_ptr(),
+                                               n, dhw, scratch.data_ptr(), scratch.numel(), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    got = from_ndhwc(dxa.cpu(), ca)
+    if dual:
+        got = torch.cat([got, from_ndhwc(dxb.cpu(), c - ca)], 1)
+    assert rel_l2(got, bf16_round(dx_ref)) <= 5e-4
+    assert rel_l2(dgam.cpu(), dg_ref) <= 1e-4 and rel_l2(dbet.cpu(), db_ref) <= 1e-4
