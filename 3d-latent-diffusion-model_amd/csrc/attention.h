@@ -18,6 +18,7 @@
 struct AttnParams {
     const bf16_t* qkv; bf16_t* out;
     int B, N, C, heads; float scale;
+    float* lse;                       // optional [B][heads][N]: log-sum-exp of the scaled scores (saved for the backward pass)
 };
 
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
@@ -165,6 +166,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     lrun += __shfl_xor(lrun, 32, 64);
     const float inv = 1.0f / lrun;
     const int qr = q0 + fr;
+    if (p.lse && qr < p.N && fg == 0) p.lse[((size_t)b * p.heads + head) * p.N + qr] = mrun + __logf(lrun);
     if (qr < p.N) {
         bf16_t* orow = p.out + ((size_t)b * p.N + qr) * p.C + hoff;
 #pragma unroll
@@ -173,6 +175,243 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
             o[0] = pack2bf(ot[dt][0] * inv, ot[dt][1] * inv);
             o[1] = pack2bf(ot[dt][2] * inv, ot[dt][3] * inv);
             *reinterpret_cast<u32x2*>(orow + dt * 16 + 4 * fg) = o;
+        }
+    }
+}
+
+
+// ================================================================================================ backward
+// Given dO:  delta_i = sum_d dO_id O_id ;  P_ij = exp(scale q_i.k_j - LSE_i) ;  dV_j = sum_i P_ij dO_i ;
+//            dP_ij = dO_i . V_j ;  dS_ij = P_ij (dP_ij - delta_i) ;  dQ_i = scale sum_j dS_ij K_j ;  dK_j = scale sum_i dS_ij Q_i.
+// Two kernels so that every output row is owned by exactly one wave (no atomics, bitwise reproducible):
+//   attn_bwd_dq_kernel  : workgroup = 64 query rows of one (batch, head), loops over key tiles   -> dQ
+//   attn_bwd_dkv_kernel : workgroup = 64 key rows of one (batch, head), loops over query tiles   -> dK, dV
+// Same MFMA idioms as the forward: scores are produced with the reduction-free index on the lane, P / dS go straight
+// back in as B operands with the k order permuted identically on both operands, transposed operands come from
+// row-major LDS images through ds_read_b64_tr_b16.
+struct AttnBwdParams {
+    const bf16_t* qkv; const bf16_t* o; const bf16_t* d_o; const float* lse;
+    float* delta;                     // [B][heads][N] scratch
+    bf16_t* dqkv;                     // [B*N][3C]  (dq | dk | dv)
+    int B, N, C, heads; float scale;
+};
+
+// delta[b][h][i] = sum_d dO[i][h*64+d] * O[i][h*64+d]; one wave per (token, head) pair of 64 channels... 16 lanes x 4 elems
+__global__ __launch_bounds__(256) void attn_delta_kernel(const AttnBwdParams p) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;             // one thread per (token, head, 16-byte chunk of 8 d)
+    const long total = (long)p.B * p.N * p.heads * 8;
+    float s = 0.f;
+    long tok = 0; int head = 0;
+    if (idx < total) {
+        const int ch = (int)(idx & 7);
+        const long th = idx >> 3;
+        head = (int)(th % p.heads); tok = th / p.heads;
+        const u32x4 a = *reinterpret_cast<const u32x4*>(p.o + tok * p.C + head * 64 + ch * 8);
+        const u32x4 b = *reinterpret_cast<const u32x4*>(p.d_o + tok * p.C + head * 64 + ch * 8);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            s += __uint_as_float(a[k] << 16) * __uint_as_float(b[k] << 16) +
+                 __uint_as_float(a[k] & 0xffff0000u) * __uint_as_float(b[k] & 0xffff0000u);
+    }
+    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+    if (idx < total && (idx & 7) == 0) {
+        const long bb = tok / p.N, i = tok - bb * p.N;
+        p.delta[((size_t)bb * p.heads + head) * p.N + i] = s;
+    }
+}
+
+typedef __attribute__((ext_vector_type(4))) short attn_s16x4;
+typedef __attribute__((address_space(3))) attn_s16x4* attn_lds_s16x4_t;
+
+// LDS image helpers: 64 rows x 64 bf16 (128-byte rows).  ROW image: 16-byte chunks XOR (row>>1)&7 (ds_read_b128 row reads);
+// TR image: 32-byte blocks XOR (row>>1)&3 (transposed reads).
+__device__ __forceinline__ int attn_row_off(int row, int ch) { return row * 128 + ((ch ^ ((row >> 1) & 7)) << 4); }
+__device__ __forceinline__ int attn_tr_off(int row, int ch) { return row * 128 + ((ch ^ (((row >> 1) & 3) << 1)) << 4); }
+// fragment of the TRANSPOSED tile for MFMA rows dt*16.., k-slots of half h: lane (fr, fg) -> 8 values
+__device__ __forceinline__ bf16x8 attn_tr_frag(const char* img, int dt, int h, int fr, int fg) {
+    const int tq = fr >> 2, tp = fr & 3;
+    const int rlo = (2 * h) * 16 + 4 * fg + tq, rhi = rlo + 16;
+    const attn_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((attn_lds_s16x4_t)(img + rlo * 128 + ((dt ^ ((rlo >> 1) & 3)) << 5) + tp * 8));
+    const attn_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((attn_lds_s16x4_t)(img + rhi * 128 + ((dt ^ ((rhi >> 1) & 3)) << 5) + tp * 8));
+    return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdParams p) {
+    constexpr int D = 64, KT = 64;
+    __shared__ __attribute__((aligned(16))) char smem[3 * KT * 128];    // K row image, K tr image, V row image
+    char* k_row = smem; char* k_tr = smem + KT * 128; char* v_row = smem + 2 * KT * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int b = blockIdx.z, head = blockIdx.y;
+    const int q0 = blockIdx.x * 64 + wave * 16;
+    const int ld = 3 * p.C, hoff = head * D;
+    const bf16_t* base = p.qkv + (size_t)b * p.N * ld;
+    int qr = q0 + fr; const bool qok = qr < p.N; if (!qok) qr = p.N - 1;
+    bf16x8 qf[2], dof[2];                              // B operands: Q[q][d], dO[q][d] with d = k2*32 + 8 fg ..
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) {
+        qf[k2] = *reinterpret_cast<const bf16x8*>(base + (size_t)qr * ld + hoff + k2 * 32 + 8 * fg);
+        dof[k2] = *reinterpret_cast<const bf16x8*>(p.d_o + ((size_t)b * p.N + qr) * p.C + hoff + k2 * 32 + 8 * fg);
+    }
+    const float lse = p.lse[((size_t)b * p.heads + head) * p.N + qr];
+    const float dlt = p.delta[((size_t)b * p.heads + head) * p.N + qr];
+    f32x4 dq[4];                                       // dQ^T: dq[dt][r] = dQ[q = fr][d = dt*16 + 4 fg + r]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dq[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int ntile = (p.N + KT - 1) / KT;
+    for (int t = 0; t < ntile; ++t) {
+        const int k0 = t * KT;
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int idx = tid + it * 256, row = idx >> 3, ch = idx & 7;
+            int kr = k0 + row; if (kr >= p.N) kr = p.N - 1;
+            const bf16_t* tok = base + (size_t)kr * ld + hoff + ch * 8;
+            const u32x4 kv = *reinterpret_cast<const u32x4*>(tok + p.C);
+            const u32x4 vv = *reinterpret_cast<const u32x4*>(tok + 2 * p.C);
+            *reinterpret_cast<u32x4*>(k_row + attn_row_off(row, ch)) = kv;
+            *reinterpret_cast<u32x4*>(k_tr + attn_tr_off(row, ch)) = kv;
+            *reinterpret_cast<u32x4*>(v_row + attn_row_off(row, ch)) = vv;
+        }
+        __syncthreads();
+        bf16x8 dsf[2];                                 // dS^T fragments (B operand of the dQ product)
+        f32x4 st[4], dp[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            st[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int row = j * 16 + fr;
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(k_row + attn_row_off(row, k2 * 4 + fg));
+                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(v_row + attn_row_off(row, k2 * 4 + fg));
+                st[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[k2], st[j], 0, 0, 0);    // S^T[key][q]
+                dp[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[k2], dp[j], 0, 0, 0);   // dP^T[key][q]
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float dsv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int j = 2 * h + (e >> 2), r = e & 3;
+                const int key = k0 + 16 * j + 4 * fg + r;
+                const float pe = (key < p.N) ? __expf(st[j][r] * p.scale - lse) : 0.f;
+                dsv[e] = pe * (dp[j][r] - dlt);
+            }
+            u32x4 pk;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pk[e] = pack2bf(dsv[2 * e], dsv[2 * e + 1]);
+            dsf[h] = *reinterpret_cast<bf16x8*>(&pk);
+        }
+        // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(attn_tr_frag(k_tr, dt, h, fr, fg), dsf[h], dq[dt], 0, 0, 0);
+    }
+    if (qok) {
+        bf16_t* orow = p.dqkv + ((size_t)b * p.N + qr) * ld + hoff;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            u32x2 o;
+            o[0] = pack2bf(dq[dt][0] * p.scale, dq[dt][1] * p.scale);
+            o[1] = pack2bf(dq[dt][2] * p.scale, dq[dt][3] * p.scale);
+            *reinterpret_cast<u32x2*>(orow + dt * 16 + 4 * fg) = o;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdParams p) {
+    constexpr int D = 64, QT = 64;
+    __shared__ __attribute__((aligned(16))) char smem[4 * QT * 128 + 2 * QT * 4];   // Q row/tr, dO row/tr images, LSE, delta
+    char* q_row = smem; char* q_tr = smem + QT * 128; char* do_row = smem + 2 * QT * 128; char* do_tr = smem + 3 * QT * 128;
+    float* s_lse = reinterpret_cast<float*>(smem + 4 * QT * 128); float* s_dlt = s_lse + QT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int b = blockIdx.z, head = blockIdx.y;
+    const int kv0 = blockIdx.x * 64 + wave * 16;
+    const int ld = 3 * p.C, hoff = head * D;
+    const bf16_t* base = p.qkv + (size_t)b * p.N * ld;
+    int kr = kv0 + fr; const bool kok = kr < p.N; if (!kok) kr = p.N - 1;
+    bf16x8 kf[2], vf[2];                               // B operands: K[key][d], V[key][d] of this wave's 16 keys
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) {
+        kf[k2] = *reinterpret_cast<const bf16x8*>(base + (size_t)kr * ld + p.C + hoff + k2 * 32 + 8 * fg);
+        vf[k2] = *reinterpret_cast<const bf16x8*>(base + (size_t)kr * ld + 2 * p.C + hoff + k2 * 32 + 8 * fg);
+    }
+    f32x4 dk[4], dv[4];                                // dK^T, dV^T: [dt][r] = d?[key = fr][d = dt*16 + 4 fg + r]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { dk[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    const int ntile = (p.N + QT - 1) / QT;
+    for (int t = 0; t < ntile; ++t) {
+        const int q0 = t * QT;
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int idx = tid + it * 256, row = idx >> 3, ch = idx & 7;
+            int qr = q0 + row; if (qr >= p.N) qr = p.N - 1;
+            const u32x4 qv = *reinterpret_cast<const u32x4*>(base + (size_t)qr * ld + hoff + ch * 8);
+            const u32x4 ov = *reinterpret_cast<const u32x4*>(p.d_o + ((size_t)b * p.N + qr) * p.C + hoff + ch * 8);
+            *reinterpret_cast<u32x4*>(q_row + attn_row_off(row, ch)) = qv;
+            *reinterpret_cast<u32x4*>(q_tr + attn_tr_off(row, ch)) = qv;
+            *reinterpret_cast<u32x4*>(do_row + attn_row_off(row, ch)) = ov;
+            *reinterpret_cast<u32x4*>(do_tr + attn_tr_off(row, ch)) = ov;
+        }
+        if (tid < QT) {
+            int qr = q0 + tid; const bool ok = qr < p.N; if (!ok) qr = p.N - 1;
+            s_lse[tid] = ok ? p.lse[((size_t)b * p.heads + head) * p.N + qr] : INFINITY;      // exp(s - inf) = 0 masks the row
+            s_dlt[tid] = p.delta[((size_t)b * p.heads + head) * p.N + qr];
+        }
+        __syncthreads();
+        // S[q][key] = Q K^T and dP[q][key] = dO V^T with the key on the lane (col = fr), q = 16 j + 4 fg + r
+        f32x4 st[4], dp[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            st[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int row = j * 16 + fr;
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                const bf16x8 qf = *reinterpret_cast<const bf16x8*>(q_row + attn_row_off(row, k2 * 4 + fg));
+                const bf16x8 of = *reinterpret_cast<const bf16x8*>(do_row + attn_row_off(row, k2 * 4 + fg));
+                st[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf[k2], st[j], 0, 0, 0);
+                dp[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(of, vf[k2], dp[j], 0, 0, 0);
+            }
+        }
+        bf16x8 pf[2], dsf[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float pv[8], dsv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int j = 2 * h + (e >> 2), r = e & 3;
+                const int ql = 16 * j + 4 * fg + r;
+                const float pe = __expf(st[j][r] * p.scale - s_lse[ql]);
+                pv[e] = pe; dsv[e] = pe * (dp[j][r] - s_dlt[ql]);
+            }
+            u32x4 pk, dk_;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { pk[e] = pack2bf(pv[2 * e], pv[2 * e + 1]); dk_[e] = pack2bf(dsv[2 * e], dsv[2 * e + 1]); }
+            pf[h] = *reinterpret_cast<bf16x8*>(&pk); dsf[h] = *reinterpret_cast<bf16x8*>(&dk_);
+        }
+        // dV^T[d][key] += dO^T[d][q] P[q][key] ;  dK^T[d][key] += Q^T[d][q] dS[q][key]
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(attn_tr_frag(do_tr, dt, h, fr, fg), pf[h], dv[dt], 0, 0, 0);
+                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(attn_tr_frag(q_tr, dt, h, fr, fg), dsf[h], dk[dt], 0, 0, 0);
+            }
+    }
+    if (kok) {
+        bf16_t* orow = p.dqkv + ((size_t)b * p.N + kr) * ld + hoff;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            u32x2 o;
+            o[0] = pack2bf(dk[dt][0] * p.scale, dk[dt][1] * p.scale); o[1] = pack2bf(dk[dt][2] * p.scale, dk[dt][3] * p.scale);
+            *reinterpret_cast<u32x2*>(orow + p.C + dt * 16 + 4 * fg) = o;
+            o[0] = pack2bf(dv[dt][0], dv[dt][1]); o[1] = pack2bf(dv[dt][2], dv[dt][3]);
+            *reinterpret_cast<u32x2*>(orow + 2 * p.C + dt * 16 + 4 * fg) = o;
         }
     }
 }

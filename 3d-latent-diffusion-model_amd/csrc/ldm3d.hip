@@ -856,7 +856,7 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                 break; }
             case OP_ATTN: {
                 AttnParams p{}; p.qkv = (const bf16_t*)rp(bs, o.r[0]); p.out = (bf16_t*)rp(bs, o.r[1]);
-                p.B = i[0]; p.N = i[1]; p.C = i[2]; p.heads = i[3]; p.scale = o.f[0];
+                p.B = i[0]; p.N = i[1]; p.C = i[2]; p.heads = i[3]; p.scale = o.f[0]; p.lse = (float*)rp(bs, o.r[2]);
                 hipLaunchKernelGGL(attn_fwd_kernel, dim3((i[1] + 63) / 64, i[3], i[0]), dim3(256), 0, s, p);
                 break; }
             case OP_SINUSOID:
@@ -1314,8 +1314,29 @@ int ldm_op_group_norm_bwd(const void* dy, const void* xa, int ca, const void* xb
 
 int ldm_op_attention(const void* qkv, void* out, int B, int N, int C, void* stream) {
     if (!qkv || !out || B < 1 || N < 1 || C < 64 || C % 64) return fail(LDM_ERR_BAD_ARG, "bad argument (head_dim is 64, C % 64 == 0)");
-    AttnParams p{}; p.qkv = (const bf16_t*)qkv; p.out = (bf16_t*)out; p.B = B; p.N = N; p.C = C; p.heads = C / 64; p.scale = 0.125f;
+    AttnParams p{}; p.qkv = (const bf16_t*)qkv; p.out = (bf16_t*)out; p.B = B; p.N = N; p.C = C; p.heads = C / 64; p.scale = 0.125f; p.lse = nullptr;
     hipLaunchKernelGGL(attn_fwd_kernel, dim3((N + 63) / 64, C / 64, B), dim3(256), 0, (hipStream_t)stream, p);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+/* attention forward that also saves the log-sum-exp rows, and its backward: dqkv [B*N][3C] from dO [B*N][C]. */
+int ldm_op_attention_train(const void* qkv, void* out, float* lse, int B, int N, int C, void* stream) {
+    if (!qkv || !out || !lse || B < 1 || N < 1 || C < 64 || C % 64) return fail(LDM_ERR_BAD_ARG, "bad argument");
+    AttnParams p{}; p.qkv = (const bf16_t*)qkv; p.out = (bf16_t*)out; p.B = B; p.N = N; p.C = C; p.heads = C / 64; p.scale = 0.125f; p.lse = lse;
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3((N + 63) / 64, C / 64, B), dim3(256), 0, (hipStream_t)stream, p);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int ldm_op_attention_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta_scratch, void* dqkv,
+                         int B, int N, int C, void* stream) {
+    if (!qkv || !o || !d_o || !lse || !delta_scratch || !dqkv || B < 1 || N < 1 || C < 64 || C % 64) return fail(LDM_ERR_BAD_ARG, "bad argument");
+    AttnBwdParams p{}; p.qkv = (const bf16_t*)qkv; p.o = (const bf16_t*)o; p.d_o = (const bf16_t*)d_o; p.lse = lse; p.delta = delta_scratch;
+    p.dqkv = (bf16_t*)dqkv; p.B = B; p.N = N; p.C = C; p.heads = C / 64; p.scale = 0.125f;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3(grid_for((long)B * N * p.heads * 8, 256, 1 << 20)), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((N + 63) / 64, p.heads, B), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((N + 63) / 64, p.heads, B), dim3(256), 0, s, p);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -154,6 +154,11 @@ int ldm_op_group_norm(const void* xa, int ca, const void* xb, int cb, const floa
                       void* stream);
 /* softmax(q k^T / 8) v with head_dim 64: qkv [B*N][3C] bf16 (q|k|v, channel = head*64 + d) -> out [B*N][C] bf16. */
 int ldm_op_attention(const void* qkv, void* out, int B, int N, int C, void* stream);
+/*      training form (also writes lse [B][C/64][N] fp32) and backward: dqkv [B*N][3C] bf16 from d_o [B*N][C] bf16;
+ *      delta_scratch: B * (C/64) * N floats. */
+int ldm_op_attention_train(const void* qkv, void* out, float* lse, int B, int N, int C, void* stream);
+int ldm_op_attention_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta_scratch, void* dqkv,
+                         int B, int N, int C, void* stream);
 
 /* ---- measurement support (bench.py): HIP events around every launch of ONE conv tile configuration
  *      (wgm x wgn waves, K depth bk), recorded on the launch stream.  stop() fills

@@ -179,8 +179,9 @@ def test_attention(cuda, built_lib, b, n, c):
     """softmax(q k^T / 8) v, head_dim 64; compared with fp32 softmax attention on the same bf16 q, k, v."""
     from ldm3d import _lib
     g = torch.Generator().manual_seed(n)
-    qkv = bf16_round(torch.randn((b, n, 3 * c), generator=g))
+    qkv = torch.randn((b, n, 3 * c), generator=g)
     qkv[..., :2 * c] *= 1.7                       # peaky-ish scores
+    qkv = bf16_round(qkv)
     h = c // 64
 
     def split(z):
@@ -300,3 +301,40 @@ def test_group_norm_silu_backward(cuda, built_lib, c, groups, dual, silu, n):
         got = torch.cat([got, from_ndhwc(dxb.cpu(), c - ca)], 1)
     assert rel_l2(got, bf16_round(dx_ref)) <= 5e-4
     assert rel_l2(dgam.cpu(), dg_ref) <= 1e-4 and rel_l2(dbet.cpu(), db_ref) <= 1e-4
+
+
+@pytest.mark.parametrize("b,n,c", [(1, 216, 128), (2, 64, 64), (1, 1000, 256)])
+def test_attention_backward(cuda, built_lib, b, n, c):
+    """dq | dk | dv against torch autograd of fp32 softmax attention on the same bf16 q, k, v, dO (P and dS are rounded to
+    bf16 inside the kernels, outputs are bf16: ~2^-9 relative each)."""
+    from ldm3d import _lib
+    g = torch.Generator().manual_seed(n + c)
+    qkv = torch.randn((b, n, 3 * c), generator=g)
+    qkv[..., :2 * c] *= 1.5
+    qkv = bf16_round(qkv).requires_grad_(True)
+    h = c // 64
+
+    def split(z):
+        return z.reshape(b, n, h, 64).permute(0, 2, 1, 3)
+    q, k, v = split(qkv[..., :c]), split(qkv[..., c:2 * c]), split(qkv[..., 2 * c:])
+    o = (torch.softmax(q @ k.transpose(-1, -2) * 0.125, dim=-1) @ v).permute(0, 2, 1, 3).reshape(b, n, c)
+    do = bf16_round(torch.randn(o.shape, generator=g))
+    (ref,) = torch.autograd.grad(o, qkv, do)
+    st = torch.cuda.current_stream().cuda_stream
+    dq = qkv.detach().to(torch.bfloat16).to(cuda)
+    out = torch.empty((b, n, c), dtype=torch.bfloat16, device=cuda)
+    lse = torch.empty((b, h, n), dtype=torch.float32, device=cuda)
+    _lib.check(built_lib.ldm_op_attention_train(dq.data_ptr(), out.data_ptr(), lse.data_ptr(), b, n, c, st))
+    dod = do.to(torch.bfloat16).to(cuda)
+    delta = torch.empty((b, h, n), dtype=torch.float32, device=cuda)
+    dqkv = torch.full((b, n, 3 * c), float("nan"), dtype=torch.bfloat16, device=cuda)
+    _lib.check(built_lib.ldm_op_attention_bwd(dq.data_ptr(), out.data_ptr(), dod.data_ptr(), lse.data_ptr(), delta.data_ptr(),
+                                              dqkv.data_ptr(), b, n, c, st))
+    torch.cuda.synchronize()
+    assert rel_l2(out.float().cpu(), o.detach()) <= 8e-3
+    ref_lse = torch.logsumexp(q.detach() @ k.detach().transpose(-1, -2) * 0.125, dim=-1)
+    assert rel_l2(lse.cpu(), ref_lse) <= 1e-5
+    got = dqkv.float().cpu()
+    for name, sl in (("dq", slice(0, c)), ("dk", slice(c, 2 * c)), ("dv", slice(2 * c, 3 * c))):
+        e = rel_l2(got[..., sl], ref[..., sl])
+        assert e <= 1.5e-2, (name, e)
