@@ -8,15 +8,16 @@
 // ds_read_b64_tr_b16 (4 voxel rows x 16 channels per 16-lane group).  Workgroup = 128 couts x 128 cins of ONE tap,
 // 8 waves as two groups that each take one 32-voxel half of every 64-voxel K step (same pipeline as the forward kernel:
 // 4-slot LDS ring filled by buffer_load ... lds, counted vmcnt, raw barrier, double-buffered register fragments).
-// Output fp32 [taps][Cout][Cin] (deterministic: no atomics; the voxel range is not split across workgroups).
+// Output fp32 [taps][Cout][ld] (deterministic: no atomics; the voxel range is not split across workgroups).
 #pragma once
 #include "common.h"
 
 struct WgradParams {
     const bf16_t* dy; int cdy;        // [M][cdy]   output-gradient, NDHWC bf16 (cdy = stored channels of the conv output)
     const bf16_t* x; int cx;          // [rows_in][cx] conv input (single source)
-    float* dw;                        // [taps][Cout][Cin] fp32
+    float* dw;                        // [taps][Cout][dw_ld] fp32; this launch writes columns [dw_ci_off, dw_ci_off + Cin)
     int Cout, Cin;                    // real channel counts written
+    int dw_ld, dw_ci_off;             // row length / first column (dual-source convs are two launches into one matrix)
     int N, Din, Hin, Win, Dout, Hout, Wout, ksize, stride, pad, ups;
     int M, co_tiles, ci_tiles;
 };
@@ -60,7 +61,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradParams p)
         int m = row;                           // step 0
         vn[j] = m / DHWo; m -= vn[j] * DHWo; vd[j] = m / HWo; m -= vd[j] * HWo; vh[j] = m / p.Wout; vw[j] = m - vh[j] * p.Wout;
     }
-    // 64 voxels ahead, decomposed once (each component is smaller than its extent, so every carry wraps at most once)
+    // 64 voxels ahead, decomposed once (q_w < Wout and q_h < Hout, so those carries wrap at most once; volumes smaller
+    // than 64 voxels make q_d >= Dout, hence the loop on the depth carry)
     const int q_d = KV / HWo, q_h = (KV - q_d * HWo) / p.Wout, q_w = KV - q_d * HWo - q_h * p.Wout;
     __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (int)((unsigned)p.M * (unsigned)p.cdy * 2u), 0x00020000);
     __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradParams p)
             /* advance this row by 64 output voxels */                                                         \
             vw[j] += q_w; if (vw[j] >= p.Wout) { vw[j] -= p.Wout; ++vh[j]; }                                   \
             vh[j] += q_h; if (vh[j] >= p.Hout) { vh[j] -= p.Hout; ++vd[j]; }                                   \
-            vd[j] += q_d; if (vd[j] >= p.Dout) { vd[j] -= p.Dout; ++vn[j]; }                                   \
+            vd[j] += q_d; while (vd[j] >= p.Dout) { vd[j] -= p.Dout; ++vn[j]; }                                   \
         }                                                                                                     \
         ++ld_s;                                                                                               \
     } while (0)
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradParams p)
     __syncthreads();
     if (grp == 0) {
         // accumulator: col = lane & 15 -> cin, row = 4 fg + r -> cout
-        const size_t tap_off = (size_t)tap * p.Cout * p.Cin;
+        const size_t tap_off = (size_t)tap * p.Cout * p.dw_ld + p.dw_ci_off;
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradParams p)
                 for (int r = 0; r < 4; ++r) {
                     const int co = co_t * 128 + wa * 64 + a * 16 + 4 * fg + r;
                     const float v = acc[a][b][r] + xch[((wq * 64) + (a * 4 + b) * 4 + r) * 64 + lane];
-                    if (co < p.Cout && ci < p.Cin) p.dw[tap_off + (size_t)co * p.Cin + ci] = v;
+                    if (co < p.Cout && ci < p.Cin) p.dw[tap_off + (size_t)co * p.dw_ld + ci] = v;
                 }
             }
     }

@@ -65,7 +65,9 @@ struct Act {                                         // NDHWC bf16 activation li
 };
 
 enum OpKind { OP_PACK, OP_CONV, OP_FINALIZE, OP_GN_STATS, OP_GN_FINALIZE, OP_GN_PREP, OP_GN_APPLY, OP_ATTN, OP_SINUSOID,
-              OP_GEMV, OP_VAE_HEADS };
+              OP_GEMV, OP_VAE_HEADS,
+              // backward (training plans only)
+              OP_WT, OP_WGRAD, OP_EXPORT, OP_COLSUM, OP_GNB, OP_ATTN_BWD, OP_ADD, OP_SUMPOOL, OP_LIN_DX, OP_LIN_DW };
 
 struct ConvCfg { int wgm, wgn, bk, splitk; };
 
@@ -114,6 +116,8 @@ struct Pool {                                        // plan-time workspace allo
 struct Plan {
     std::vector<Op> ops;
     size_t ws_bytes = 0;
+    size_t bwd_begin = 0;                            // training plans: ops [0, bwd_begin) = forward, the rest = backward
+    bool train = false;
 };
 
 // ================================================================================================ parameters
@@ -122,6 +126,7 @@ struct ParamDesc {
     std::string name; std::vector<int64_t> shape;
     PackKind kind; size_t dst_off;                   // arena byte offset of the destination matrix / vector
     int k = 1, cout = 0, cin = 0, cout_pad = 0, cin_s = 0, row_off = 0;
+    int64_t flat_off = 0;                            // element offset in the flat fp32 gradient buffer (parameter order)
     bool loaded = false;
 };
 
@@ -143,7 +148,13 @@ struct ldm_model {
     size_t tproj_w_off = 0, tproj_b_off = 0; int tproj_rows = 0; std::map<std::string, int> tproj_row;
 
     size_t arena_alloc(size_t bytes) { size_t o = arena_bytes; arena_bytes += rup_sz(bytes, 256); return o; }
-    void add_param(const ParamDesc& d) { pindex[d.name] = (int)params.size(); params.push_back(d); }
+    int64_t flat_total = 0;
+    void add_param(const ParamDesc& d) {
+        pindex[d.name] = (int)params.size(); params.push_back(d);
+        ParamDesc& q = params.back(); q.flat_off = flat_total;
+        int64_t n = 1; for (auto v : q.shape) n *= v;
+        flat_total += n;
+    }
 
     // conv registered under MONAI's Convolution wrapper: <name>.conv.{weight,bias}; several logical convs may
     // share one destination matrix (fused q|k|v, mu|log_sigma) through row_off.
@@ -210,9 +221,11 @@ struct Builder {
         Act a; a.N = N; a.D = D; a.H = H; a.W = W; a.C = C; a.valid = true; a.off = pool.alloc(a.bytes()); return a;
     }
     void free_act(Act& a) {
+        if (train) return;                            // training plans keep every activation for the backward pass
         if (a.valid) { pool.release(a.off); if (a.has_stats) pool.release(a.stats_off); }
         a.valid = false; a.has_stats = false;
     }
+    bool train = false, recording = false;
 
     // ---- conv ---------------------------------------------------------------------------------------
     struct ConvArgs {
@@ -225,7 +238,17 @@ struct Builder {
         Act residual;                                // optional
         bool f32_out = false; Ref out_ref; int cout_real = 0;
         bool want_stats = true;                       // also emit the output's GroupNorm partials
+        // backward-pass uses of the same kernel (data gradients)
+        Ref w_over; bool no_bias = false; int exact = 0;   // weights from the workspace; zero-insertion upsample
+        int temb_row = -1;                            // first row of this ResBlock in the stacked time projection
     };
+    struct Tape {                                    // one differentiable forward op, recorded in training plans
+        int kind = 0;                                 // 0 conv, 1 GroupNorm(+SiLU), 2 attention
+        ConvArgs c; Act out; bool leaf_input = false;
+        const GnW* g = nullptr; Act xa, xb; size_t ab_off = 0, mr_off = 0; int groups = 0; bool silu = false;
+        Act qkv, o; size_t lse_off = 0;
+    };
+    std::vector<Tape> tape;
 
     static ConvCfg choose_cfg(long M, int cout_pad, int steps, int bk) {
         ConvCfg best{2, 2, bk, 1}; double best_t = 1e30;
@@ -282,10 +305,10 @@ struct Builder {
         }
         Op op{}; op.kind = OP_CONV; op.cc = cc;
         op.r[0] = ws_ref(a.xa.off); op.r[1] = a.xb.valid ? ws_ref(a.xb.off) : Ref();
-        op.r[2] = w_ref(w.w_off);
+        op.r[2] = a.w_over.base != BASE_NULL ? a.w_over : w_ref(w.w_off);
         op.r[3] = a.w1 ? ws_ref(a.g1a.off) : Ref(); op.r[4] = (a.w1 && a.g1b.valid) ? ws_ref(a.g1b.off) : Ref();
         op.r[5] = a.w1 ? w_ref(a.w1->w_off) : Ref();
-        op.r[6] = w_ref(w.b_off); op.r[7] = a.w1 ? w_ref(a.w1->b_off) : Ref();
+        op.r[6] = a.no_bias ? Ref() : w_ref(w.b_off); op.r[7] = a.w1 ? w_ref(a.w1->b_off) : Ref();
         op.r[8] = a.temb; op.r[9] = a.residual.valid ? ws_ref(a.residual.off) : Ref();
         op.r[10] = a.f32_out ? a.out_ref : ws_ref(out.off);
         op.r[11] = Ref();                                                     // partial slab (fixed up later)
@@ -293,7 +316,7 @@ struct Builder {
         int* i = op.i;
         i[0] = a.xa.C; i[1] = a.xb.valid ? a.xb.C : 0; i[2] = a.w1 ? a.g1a.C : 0; i[3] = (a.w1 && a.g1b.valid) ? a.g1b.C : 0;
         i[4] = N; i[5] = a.xa.D; i[6] = a.xa.H; i[7] = a.xa.W; i[8] = a.Do; i[9] = a.Ho; i[10] = a.Wo;
-        i[11] = a.k; i[12] = a.stride; i[13] = a.pad; i[14] = a.ups; i[15] = (int)M;
+        i[11] = a.k; i[12] = a.stride; i[13] = a.pad; i[14] = a.ups | (a.exact << 1); i[15] = (int)M;
         i[16] = a.f32_out ? rup(w.cout, 32) : couts; i[17] = w.cout_pad; i[18] = a.cout_real ? a.cout_real : w.cout;
         i[19] = nchunk0; i[20] = nchunk1; i[21] = a.temb_stride; i[22] = a.f32_out ? 1 : 0;
         i[23] = (int)((M + bm - 1) / bm);
@@ -309,6 +332,7 @@ struct Builder {
             partial_fixups.push_back(plan->ops.size());
             plan->ops.push_back(f);
         }
+        if (recording) { Tape t; t.kind = 0; t.c = a; t.out = out; tape.push_back(t); }
         return out;
     }
 
@@ -317,7 +341,13 @@ struct Builder {
         const int C = xa.C + (xb.valid ? xb.C : 0);
         if (C != g.C || C % 8 || (C / groups) * groups != C || xa.C % 8) { err = "groupnorm: channel mismatch"; return Act(); }
         const int DHW = xa.D * xa.H * xa.W, N = xa.N;
-        gnab_bytes = std::max(gnab_bytes, (size_t)N * C * 2 * 4);
+        size_t ab_off = 0, mr_off = 0;               // training: scale/shift and mean/rstd are saved per instance
+        if (train) { ab_off = pool.alloc((size_t)N * C * 2 * 4); mr_off = pool.alloc((size_t)N * groups * 2 * 4); }
+        else gnab_bytes = std::max(gnab_bytes, (size_t)N * C * 2 * 4);
+        auto ab_ref = [&](Op& o_) {
+            if (train) { o_.r[5] = ws_ref(ab_off); if (o_.kind != OP_GN_APPLY) o_.r[6] = ws_ref(mr_off); }
+            else gnab_fixups.push_back(plan->ops.size());
+        };
         const bool fused = xa.has_stats && (!xb.valid || xb.has_stats) && (N == 1 || DHW % 32 == 0);
         if (fused) {                                   // partials came with the tensors: one small reduce
             Op f{}; f.kind = OP_GN_PREP;
@@ -325,7 +355,7 @@ struct Builder {
             f.r[2] = w_ref(g.g_off); f.r[3] = w_ref(g.b_off);
             f.i[0] = xa.C; f.i[1] = xb.valid ? xb.C : 0; f.i[2] = (N == 1) ? (DHW + 31) / 32 : DHW / 32; f.i[3] = groups;
             f.i[4] = DHW; f.i[5] = N; f.f[0] = eps;
-            gnab_fixups.push_back(plan->ops.size()); plan->ops.push_back(f);
+            ab_ref(f); plan->ops.push_back(f);
         } else {
             const int cvec = C / 8;
             const int rows_par = std::max(1, 256 / cvec);
@@ -340,13 +370,17 @@ struct Builder {
             Op f{}; f.kind = OP_GN_FINALIZE;
             f.r[1] = w_ref(g.g_off); f.r[2] = w_ref(g.b_off);
             f.i[0] = nslab; f.i[1] = C; f.i[2] = groups; f.i[3] = DHW; f.i[4] = N; f.f[0] = eps;
-            gnpart_fixups.push_back(plan->ops.size()); gnab_fixups.push_back(plan->ops.size()); plan->ops.push_back(f);
+            gnpart_fixups.push_back(plan->ops.size()); ab_ref(f); plan->ops.push_back(f);
         }
         Act out = new_act(N, xa.D, xa.H, xa.W, C);
         Op ap{}; ap.kind = OP_GN_APPLY;
         ap.r[0] = ws_ref(xa.off); ap.r[1] = xb.valid ? ws_ref(xb.off) : Ref(); ap.r[3] = ws_ref(out.off);
         ap.i[0] = xa.C; ap.i[1] = xb.valid ? xb.C : 0; ap.i[2] = DHW; ap.i[3] = N; ap.i[4] = silu ? 1 : 0;
-        gnab_fixups.push_back(plan->ops.size()); plan->ops.push_back(ap);
+        ab_ref(ap); plan->ops.push_back(ap);
+        if (recording) {
+            Tape t; t.kind = 1; t.g = &g; t.xa = xa; t.xb = xb; t.out = out; t.ab_off = ab_off; t.mr_off = mr_off;
+            t.groups = groups; t.silu = silu; tape.push_back(t);
+        }
         return out;
     }
 
@@ -369,6 +403,7 @@ struct Builder {
         ConvArgs c1; c1.xa = h0; c1.w = &m->convs.at(p + ".conv1"); c1.Do = xa.D; c1.Ho = xa.H; c1.Wo = xa.W;
         if (with_temb) {
             c1.temb = ws_ref(temb_all_off + (size_t)m->tproj_row.at(p) * 4); c1.temb_stride = tproj_stride;
+            c1.temb_row = m->tproj_row.at(p);
         }
         Act h1 = conv(c1, p + ".conv1");
         free_act(h0);
@@ -397,13 +432,209 @@ struct Builder {
         Act o = new_act(x.N, x.D, x.H, x.W, C);
         Op at{}; at.kind = OP_ATTN; at.r[0] = ws_ref(qkv.off); at.r[1] = ws_ref(o.off);
         at.i[0] = x.N; at.i[1] = x.D * x.H * x.W; at.i[2] = C; at.i[3] = C / 64; at.f[0] = 1.0f / sqrtf(64.0f);
+        size_t lse_off = 0;
+        if (train) { lse_off = pool.alloc((size_t)x.N * (C / 64) * at.i[1] * 4); at.r[2] = ws_ref(lse_off); }
         plan->ops.push_back(at);
+        if (recording) { Tape t; t.kind = 2; t.qkv = qkv; t.o = o; t.lse_off = lse_off; tape.push_back(t); }
         free_act(qkv);
         ConvArgs pr; pr.xa = o; pr.w = &m->convs.at(p + ".attn.out_proj"); pr.k = 1; pr.pad = 0;
         pr.Do = x.D; pr.Ho = x.H; pr.Wo = x.W; pr.residual = x;
         Act out = conv(pr, p + ".out_proj");
         free_act(o);
         return out;
+    }
+
+
+    // ---- backward pass (training plans) -------------------------------------------------------------------
+    // Gradients w.r.t. activations are bf16 NDHWC tensors in the same workspace; gslot maps a forward activation
+    // (by offset) to the tensor holding the sum of the contributions emitted so far.  Kernels that can add an
+    // incoming gradient while they write (conv epilogue `residual`, GroupNorm backward `acc`) always write to a
+    // fresh buffer; plain pass-through contributions (identity skips) alias the producer's buffer.
+    // Parameter gradients go to one flat fp32 buffer (BASE_IO4) in parameter order, MONAI tensor layouts.
+    std::map<size_t, Act> gslot;
+    size_t wt_off = 0, dw_off = 0, vec_off = 0, dtemb_off = 0;
+    size_t sin_off = 0, e1_off = 0, e2_off = 0;      // saved time-embedding MLP activations
+    static Ref grad_ref(int64_t elem_off) { Ref r; r.base = BASE_IO4; r.off = (size_t)elem_off * 4; return r; }
+
+    Act take_grad(const Act& a) const { auto it = gslot.find(a.off); return it == gslot.end() ? Act() : it->second; }
+    void add_grad_alias(const Act& target, const Act& g) {
+        Act cur = take_grad(target);
+        if (!cur.valid) { gslot[target.off] = g; return; }
+        Act sum = new_act(g.N, g.D, g.H, g.W, g.C);
+        Op o{}; o.kind = OP_ADD; o.r[0] = ws_ref(cur.off); o.r[1] = ws_ref(g.off); o.r[2] = ws_ref(sum.off);
+        o.i[0] = (int)(g.rows() * g.C / 8);
+        plan->ops.push_back(o);
+        gslot[target.off] = sum;
+    }
+    void emit_export(size_t src_off, int taps, int rows_total, int ld, int row_off, int col_off, int cout, int cin, int64_t flat_off) {
+        Op o{}; o.kind = OP_EXPORT; o.r[0] = ws_ref(src_off); o.r[1] = grad_ref(flat_off);
+        o.i[0] = taps; o.i[1] = rows_total; o.i[2] = ld; o.i[3] = row_off; o.i[4] = col_off; o.i[5] = cout; o.i[6] = cin;
+        plan->ops.push_back(o);
+    }
+    void export_conv_weights(const ConvW& w, int ld) {           // staging [taps][w.cout][ld] -> every parameter of the slot
+        for (const ParamDesc& d : m->params)
+            if ((d.kind == PK_CONV_W) && d.dst_off == w.w_off)
+                emit_export(dw_off, d.k * d.k * d.k, w.cout, ld, d.row_off, 0, d.cout, d.cin, d.flat_off);
+    }
+    void export_bias(const ConvW& w) {                           // staging vector [couts] -> bias parameter(s) of the slot
+        for (const ParamDesc& d : m->params)
+            if (d.kind == PK_VEC_F32 && d.dst_off >= w.b_off && d.dst_off < w.b_off + (size_t)w.cout_pad * 4)
+                emit_export(vec_off, 1, 1, 0, 0, (int)((d.dst_off - w.b_off) / 4), 1, d.cout, d.flat_off);
+    }
+    // column sums of a bf16 gradient tensor: slab partials (shared scratch) + fold
+    void emit_colsum(const Act& g, bool per_sample, Ref out, int count, int out_stride) {
+        const int C = g.C, DHW = g.D * g.H * g.W, N = g.N;
+        const int cvec = C / 8, rows_par = std::max(1, 256 / cvec);
+        int nslab = std::min((DHW + rows_par - 1) / rows_par, std::max(1, 512 / N));
+        const int rps = (DHW + nslab - 1) / nslab; nslab = (DHW + rps - 1) / rps;
+        gnpart_bytes = std::max(gnpart_bytes, (size_t)N * nslab * C * 2 * 4);
+        Op st{}; st.kind = OP_GN_STATS; st.r[0] = ws_ref(g.off);
+        st.i[0] = C; st.i[1] = 0; st.i[2] = DHW; st.i[3] = nslab; st.i[4] = rps; st.i[5] = N;
+        gnpart_fixups.push_back(plan->ops.size()); plan->ops.push_back(st);
+        Op cs{}; cs.kind = OP_COLSUM; cs.r[0] = out;
+        cs.i[0] = N; cs.i[1] = nslab; cs.i[2] = C; cs.i[3] = per_sample ? 0 : 1; cs.i[4] = count; cs.i[5] = out_stride;
+        gnpart_fixups.push_back(plan->ops.size()); plan->ops.push_back(cs);
+    }
+    void emit_wgrad(const Act& dy, const Act& x, int cout, int cin, int ld, int ci_off, int k, int stride, int pad, int ups) {
+        Op o{}; o.kind = OP_WGRAD; o.r[0] = ws_ref(dy.off); o.r[1] = ws_ref(x.off); o.r[2] = ws_ref(dw_off);
+        int* i = o.i;
+        i[0] = dy.C; i[1] = x.C; i[2] = cout; i[3] = cin; i[4] = ld; i[5] = ci_off; i[6] = x.N; i[7] = x.D; i[8] = x.H; i[9] = x.W;
+        i[10] = dy.D; i[11] = dy.H; i[12] = dy.W; i[13] = k; i[14] = stride; i[15] = pad; i[16] = ups; i[17] = (int)dy.rows();
+        plan->ops.push_back(o);
+    }
+    // dX of one source tensor `src` (channels [ci_off, ci_off + src.C) of the conv input) given dY.
+    bool emit_dgrad(const Act& dy, const Act& src, const ConvW& w, int ci_off, int k, int stride, int pad, int ups) {
+        if (stride == 2 && !(k == 3 && pad == 1)) { err = "backward of a stride-2 conv needs k = 3, pad = 1"; return false; }
+        const int taps = k * k * k;
+        Op t{}; t.kind = OP_WT; t.r[0] = w_ref(w.w_off); t.r[1] = ws_ref(wt_off);
+        t.i[0] = taps; t.i[1] = w.cout; t.i[2] = w.cout_pad; t.i[3] = w.cin_s; t.i[4] = rup(src.C, 64); t.i[5] = ci_off; t.i[6] = src.C;
+        plan->ops.push_back(t);
+        ConvW syn; syn.has = true; syn.k = k; syn.cout = src.C; syn.cout_pad = rup(src.C, 64); syn.cin_s = dy.C;
+        ConvArgs d; d.xa = dy; d.w = &syn; d.w_over = ws_ref(wt_off); d.no_bias = true; d.k = k; d.stride = 1; d.pad = k - 1 - pad;
+        if (stride == 2) { d.ups = 1; d.exact = 1; }
+        d.Do = src.D << ups; d.Ho = src.H << ups; d.Wo = src.W << ups;
+        d.want_stats = false;
+        if (!ups) d.residual = take_grad(src);
+        Act g = conv(d, "dgrad");
+        if (!g.valid) return false;
+        if (ups) {                                      // adjoint of the fused nearest x2 upsample
+            Act gc = new_act(src.N, src.D, src.H, src.W, src.C);
+            Op sp{}; sp.kind = OP_SUMPOOL; sp.r[0] = ws_ref(g.off); sp.r[1] = ws_ref(gc.off);
+            sp.i[0] = src.N; sp.i[1] = src.D; sp.i[2] = src.H; sp.i[3] = src.W; sp.i[4] = src.C;
+            plan->ops.push_back(sp);
+            add_grad_alias(src, gc);
+        } else gslot[src.off] = g;
+        return true;
+    }
+    bool backward_conv(const Tape& t, const Act& dout) {
+        const ConvArgs& a = t.c; const ConvW& w = *a.w;
+        int cin_real = 0;
+        for (const ParamDesc& d : m->params) if (d.kind == PK_CONV_W && d.dst_off == w.w_off) cin_real = d.cin;
+        if (!cin_real) { err = "backward: conv slot without parameters"; return false; }
+        if (dout.C != rup(w.cout, 32)) { err = "backward: gradient channel mismatch"; return false; }
+        // bias (both biases of a conv with a fused 1x1 skip see the same column sums) and the time-embedding rows
+        emit_colsum(dout, false, ws_ref(vec_off), dout.C, 0);
+        export_bias(w);
+        if (a.w1) export_bias(*a.w1);
+        if (a.temb_row >= 0) emit_colsum(dout, true, ws_ref(dtemb_off + (size_t)a.temb_row * 4), w.cout, tproj_stride);
+        // weights
+        if (a.xb.valid) {
+            emit_wgrad(dout, a.xa, w.cout, a.xa.C, cin_real, 0, a.k, a.stride, a.pad, a.ups);
+            emit_wgrad(dout, a.xb, w.cout, a.xb.C, cin_real, a.xa.C, a.k, a.stride, a.pad, a.ups);
+        } else emit_wgrad(dout, a.xa, w.cout, cin_real, cin_real, 0, a.k, a.stride, a.pad, a.ups);
+        export_conv_weights(w, cin_real);
+        if (a.w1) {
+            const int c1 = a.g1a.C + (a.g1b.valid ? a.g1b.C : 0);
+            emit_wgrad(dout, a.g1a, a.w1->cout, a.g1a.C, c1, 0, 1, 1, 0, 0);
+            if (a.g1b.valid) emit_wgrad(dout, a.g1b, a.w1->cout, a.g1b.C, c1, a.g1a.C, 1, 1, 0, 0);
+            export_conv_weights(*a.w1, c1);
+        }
+        // data
+        if (!t.leaf_input) {
+            if (!emit_dgrad(dout, a.xa, w, 0, a.k, a.stride, a.pad, a.ups)) return false;
+            if (a.xb.valid && !emit_dgrad(dout, a.xb, w, a.xa.C, a.k, a.stride, a.pad, a.ups)) return false;
+        }
+        if (a.w1) {
+            if (!emit_dgrad(dout, a.g1a, *a.w1, 0, 1, 1, 0, 0)) return false;
+            if (a.g1b.valid && !emit_dgrad(dout, a.g1b, *a.w1, a.g1a.C, 1, 1, 0, 0)) return false;
+        }
+        if (a.residual.valid) add_grad_alias(a.residual, dout);
+        return true;
+    }
+    bool backward_gn(const Tape& t) {
+        Act dy = take_grad(t.out);
+        if (!dy.valid) { err = "backward: GroupNorm output without a gradient"; return false; }
+        const Act& xa = t.xa; const Act& xb = t.xb;
+        const int C = t.g->C, DHW = xa.D * xa.H * xa.W, N = xa.N;
+        const int cvec = C / 8, rows_par = std::max(1, 256 / cvec);
+        int nslab = std::min((DHW + rows_par - 1) / rows_par, std::max(1, 512 / N));
+        const int rps = (DHW + nslab - 1) / nslab; nslab = (DHW + rps - 1) / rps;
+        gnpart_bytes = std::max(gnpart_bytes, (size_t)N * nslab * C * 2 * 4);
+        const size_t gsum = pool.alloc((size_t)N * t.groups * 2 * 4), dgn = pool.alloc((size_t)N * C * 4), dbn = pool.alloc((size_t)N * C * 4);
+        Act acc_a = take_grad(xa), acc_b = xb.valid ? take_grad(xb) : Act();
+        Act dxa = new_act(xa.N, xa.D, xa.H, xa.W, xa.C), dxb;
+        if (xb.valid) dxb = new_act(xb.N, xb.D, xb.H, xb.W, xb.C);
+        int64_t go = -1, bo = -1;
+        for (const ParamDesc& d : m->params) {
+            if (d.kind == PK_VEC_F32 && d.dst_off == t.g->g_off) go = d.flat_off;
+            if (d.kind == PK_VEC_F32 && d.dst_off == t.g->b_off) bo = d.flat_off;
+        }
+        if (go < 0 || bo < 0) { err = "backward: GroupNorm parameters not found"; return false; }
+        Op o{}; o.kind = OP_GNB;
+        o.r[0] = ws_ref(dy.off); o.r[1] = ws_ref(xa.off); o.r[2] = xb.valid ? ws_ref(xb.off) : Ref(); o.r[3] = ws_ref(t.ab_off);
+        o.r[5] = ws_ref(t.mr_off); o.r[6] = w_ref(t.g->g_off); o.r[7] = ws_ref(gsum); o.r[8] = ws_ref(dgn); o.r[9] = ws_ref(dbn);
+        o.r[10] = acc_a.valid ? ws_ref(acc_a.off) : Ref(); o.r[11] = acc_b.valid ? ws_ref(acc_b.off) : Ref();
+        o.r[12] = ws_ref(dxa.off); o.r[13] = xb.valid ? ws_ref(dxb.off) : Ref();
+        int* i = o.i;
+        i[0] = xa.C; i[1] = xb.valid ? xb.C : 0; i[2] = t.groups; i[3] = DHW; i[4] = N; i[5] = t.silu ? 1 : 0; i[6] = nslab; i[7] = rps;
+        i[8] = (int)go; i[9] = (int)bo;
+        gnpart_fixups.push_back(plan->ops.size()); plan->ops.push_back(o);
+        gslot[xa.off] = dxa;
+        if (xb.valid) gslot[xb.off] = dxb;
+        return true;
+    }
+    bool backward_attn(const Tape& t) {
+        Act d_o = take_grad(t.o);
+        if (!d_o.valid) { err = "backward: attention output without a gradient"; return false; }
+        const Act& q = t.qkv;
+        const int C = t.o.C, N = q.D * q.H * q.W;
+        Act dqkv = new_act(q.N, q.D, q.H, q.W, q.C);
+        const size_t delta = pool.alloc((size_t)q.N * (C / 64) * N * 4);
+        Op o{}; o.kind = OP_ATTN_BWD;
+        o.r[0] = ws_ref(q.off); o.r[1] = ws_ref(t.o.off); o.r[2] = ws_ref(d_o.off); o.r[3] = ws_ref(t.lse_off); o.r[4] = ws_ref(delta);
+        o.r[5] = ws_ref(dqkv.off);
+        o.i[0] = q.N; o.i[1] = N; o.i[2] = C; o.f[0] = 1.0f / sqrtf(64.0f);
+        plan->ops.push_back(o);
+        gslot[q.off] = dqkv;
+        return true;
+    }
+    void emit_lin_dw(Ref dy, Ref x_pre, Ref dW, Ref db, int B, int I, int O, int dy_stride, int x_stride, int silu) {
+        Op o{}; o.kind = OP_LIN_DW; o.r[0] = dy; o.r[1] = x_pre; o.r[2] = dW; o.r[3] = db;
+        o.i[0] = B; o.i[1] = I; o.i[2] = O; o.i[3] = dy_stride; o.i[4] = x_stride; o.i[5] = silu;
+        plan->ops.push_back(o);
+    }
+    void emit_lin_dx(Ref W, Ref dy, Ref x_pre, Ref dx, int B, int I, int O, int dy_stride, int x_stride, int silu) {
+        const int nz = std::max(1, std::min(64, O / 64));
+        const size_t part = pool.alloc((size_t)nz * B * I * 4);
+        Op o{}; o.kind = OP_LIN_DX; o.r[0] = W; o.r[1] = dy; o.r[2] = x_pre; o.r[3] = dx; o.r[4] = ws_ref(part);
+        o.i[0] = B; o.i[1] = I; o.i[2] = O; o.i[3] = dy_stride; o.i[4] = x_stride; o.i[5] = silu; o.i[6] = nz;
+        plan->ops.push_back(o);
+    }
+    // Walk the tape backwards.  `dout_final` = the packed gradient of the network output (the last conv writes fp32
+    // NCDHW straight to the caller, so its gradient arrives through the I/O table).
+    bool backward_all(const Act& dout_final) {
+        for (size_t k = tape.size(); k-- > 0;) {
+            const Tape& t = tape[k];
+            bool ok = true;
+            if (t.kind == 0) {
+                Act dout = t.c.f32_out ? dout_final : take_grad(t.out);
+                if (!dout.valid) { err = "backward: conv output without a gradient"; return false; }
+                ok = backward_conv(t, dout);
+            } else if (t.kind == 1) ok = backward_gn(t);
+            else ok = backward_attn(t);
+            if (!ok) return false;
+        }
+        return true;
     }
 
     size_t temb_all_off = 0; int tproj_stride = 0;
@@ -486,11 +717,11 @@ static int unet_register(ldm_model* m) {
     return 0;
 }
 
-static int unet_build(ldm_model* m, int B, int D, int H, int W, Plan* plan) {
+static int unet_build(ldm_model* m, int B, int D, int H, int W, Plan* plan, bool train) {
     const ldm_unet_cfg& c = m->ucfg;
     const int L = c.num_levels; const int* ch = c.channels;
     const int temb = ch[0] * 4, G = c.norm_num_groups; const float eps = c.norm_eps;
-    Builder b; b.m = m; b.plan = plan;
+    Builder b; b.m = m; b.plan = plan; b.train = train; b.recording = train;
     // ---- time embedding: sinusoid -> Linear -> SiLU -> Linear -> (SiLU -> stacked projections)
     const size_t sin_off = b.pool.alloc((size_t)B * ch[0] * 4);
     const size_t e1_off = b.pool.alloc((size_t)B * temb * 4);
@@ -513,6 +744,7 @@ static int unet_build(ldm_model* m, int B, int D, int H, int W, Plan* plan) {
     { Op o{}; o.kind = OP_PACK; o.r[0] = io_ref(0); o.r[1] = io_ref(1); o.r[2] = ws_ref(xin.off);
       o.i[0] = B; o.i[1] = c.in_channels; o.i[2] = cin_s; o.i[3] = D * H * W; plan->ops.push_back(o); }
     Act h = b.conv3("conv_in", xin);
+    if (train && !b.tape.empty()) b.tape.back().leaf_input = true;        // no gradient w.r.t. the network input
     b.free_act(xin);
     if (!h.valid) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
     std::vector<Act> skips; skips.push_back(h);
@@ -582,6 +814,45 @@ static int unet_build(ldm_model* m, int B, int D, int H, int W, Plan* plan) {
     oa.f32_out = true; oa.out_ref = io_ref(3); oa.cout_real = c.out_channels;
     b.conv(oa, "out.2");
     if (!b.err.empty()) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
+    if (train) {
+        // ================= backward: reverse walk over the tape, then the time-embedding MLP =================
+        plan->train = true; plan->bwd_begin = plan->ops.size();
+        b.recording = false;
+        const int rows = m->tproj_rows;
+        size_t max_wt = 0, max_dw = (size_t)rows * temb * 4;
+        for (auto& kv : m->convs) {
+            const ConvW& w = kv.second; const size_t taps = (size_t)w.k * w.k * w.k;
+            max_wt = std::max(max_wt, taps * rup(w.cin_s, 64) * rup(w.cout, 32) * 2);
+            max_dw = std::max(max_dw, taps * w.cout * w.cin_s * 4);
+        }
+        b.wt_off = b.pool.alloc(max_wt); b.dw_off = b.pool.alloc(max_dw);
+        b.vec_off = b.pool.alloc((size_t)std::max(4096, rows) * 4);
+        b.dtemb_off = b.pool.alloc(((size_t)B * rows + 256) * 4);
+        const int cos_ = rup(c.out_channels, 32);
+        Act dout = b.new_act(B, D, H, W, cos_);
+        { Op o{}; o.kind = OP_PACK; o.r[0] = io_ref(0); o.r[1] = Ref(); o.r[2] = ws_ref(dout.off);
+          o.i[0] = B; o.i[1] = c.out_channels; o.i[2] = cos_; o.i[3] = D * H * W; plan->ops.push_back(o); }
+        if (!b.backward_all(dout)) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
+        // stacked projections  temb_all = Wt silu(e2) + bt
+        const Ref dtemb = ws_ref(b.dtemb_off);
+        b.emit_lin_dw(dtemb, ws_ref(e2_off), ws_ref(b.dw_off), ws_ref(b.vec_off), B, temb, rows, rows, temb, 1);
+        for (const ParamDesc& d : m->params) {
+            if (d.kind == PK_LINEAR_W && d.dst_off >= m->tproj_w_off && d.dst_off < m->tproj_w_off + (size_t)rows * temb * 2)
+                b.emit_export(b.dw_off, 1, rows, temb, (int)((d.dst_off - m->tproj_w_off) / ((size_t)temb * 2)), 0, d.cout, d.cin, d.flat_off);
+            if (d.kind == PK_VEC_F32 && d.dst_off >= m->tproj_b_off && d.dst_off < m->tproj_b_off + (size_t)rows * 4)
+                b.emit_export(b.vec_off, 1, 1, 0, 0, (int)((d.dst_off - m->tproj_b_off) / 4), 1, d.cout, d.flat_off);
+        }
+        const size_t de2 = b.pool.alloc((size_t)B * temb * 4), de1 = b.pool.alloc((size_t)B * temb * 4);
+        b.emit_lin_dx(w_ref(m->tproj_w_off), dtemb, ws_ref(e2_off), ws_ref(de2), B, temb, rows, rows, temb, 1);
+        auto P = [&](const char* n) { return m->params[m->pindex.at(n)].flat_off; };
+        // time_embed.2: e2 = L2 silu(e1) + b2;  time_embed.0: e1 = L0 sinusoid + b0
+        b.emit_lin_dw(ws_ref(de2), ws_ref(e1_off), Builder::grad_ref(P("time_embed.2.weight")), Builder::grad_ref(P("time_embed.2.bias")),
+                      B, temb, temb, temb, temb, 1);
+        b.emit_lin_dx(w_ref(l2.w_off), ws_ref(de2), ws_ref(e1_off), ws_ref(de1), B, temb, temb, temb, temb, 1);
+        b.emit_lin_dw(ws_ref(de1), ws_ref(sin_off), Builder::grad_ref(P("time_embed.0.weight")), Builder::grad_ref(P("time_embed.0.bias")),
+                      B, ch[0], temb, temb, ch[0], 0);
+        if (!b.err.empty()) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
+    }
     b.finish();
     return 0;
 }
@@ -790,8 +1061,18 @@ static inline int grid_for(long total, int per_block = 256, int cap = 4096) {
     long g = (total + per_block - 1) / per_block; if (g > cap) g = cap; if (g < 1) g = 1; return (int)g;
 }
 
-static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_t s) {
-    for (const Op& o : plan.ops) {
+static int launch_wgrad(const WgradParams& p, hipStream_t s) {
+    constexpr int LDS = 4 * 2 * 64 * 256;
+    static bool attr_set = false;
+    if (!attr_set) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr_set = true; }
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(p.co_tiles * p.ci_tiles * p.ksize * p.ksize * p.ksize), dim3(512), LDS, s, p);
+    return 0;
+}
+
+static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_t s, size_t begin = 0, size_t end = (size_t)-1) {
+    if (end > plan.ops.size()) end = plan.ops.size();
+    for (size_t oi = begin; oi < end; ++oi) {
+        const Op& o = plan.ops[oi];
         const int* i = o.i;
         switch (o.kind) {
             case OP_PACK: {
@@ -810,7 +1091,7 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                 p.w1 = (const bf16_t*)rp(bs, o.r[5]);
                 p.zero_page = (const bf16_t*)bs.p[BASE_W];
                 p.N = i[4]; p.Din = i[5]; p.Hin = i[6]; p.Win = i[7]; p.Dout = i[8]; p.Hout = i[9]; p.Wout = i[10];
-                p.ksize = i[11]; p.stride = i[12]; p.pad = i[13]; p.ups = i[14]; p.M = i[15];
+                p.ksize = i[11]; p.stride = i[12]; p.pad = i[13]; p.ups = i[14] & 1; p.exact = i[14] >> 1; p.M = i[15];
                 p.CoutS = i[16]; p.CoutPad = i[17]; p.CoutReal = i[18]; p.nchunk0 = i[19]; p.nchunk1 = i[20];
                 p.steps0 = i[11] * i[11] * i[11] * i[19]; p.steps1 = i[20];
                 p.splitk = o.cc.splitk; p.steps_per_split = (p.steps0 + p.steps1 + p.splitk - 1) / p.splitk;
@@ -839,13 +1120,13 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
             case OP_GN_FINALIZE: {
                 GnFinalizeParams p{}; p.partial = (const float*)rp(bs, o.r[4]); p.nslab = i[0]; p.C = i[1]; p.Creal = i[1]; p.groups = i[2];
                 p.DHW = i[3]; p.eps = o.f[0]; p.gamma = (const float*)rp(bs, o.r[1]); p.beta = (const float*)rp(bs, o.r[2]);
-                p.ab = (float*)rp(bs, o.r[5]);
+                p.ab = (float*)rp(bs, o.r[5]); p.mr = (float*)rp(bs, o.r[6]);
                 hipLaunchKernelGGL(gn_finalize_kernel, dim3(i[2], i[4]), dim3(64), 0, s, p);
                 break; }
             case OP_GN_PREP: {
                 GnPrepParams p{}; p.sa = (const float*)rp(bs, o.r[0]); p.sb = (const float*)rp(bs, o.r[1]); p.ca = i[0]; p.cb = i[1];
                 p.nrb_per_sample = i[2]; p.groups = i[3]; p.DHW = i[4]; p.eps = o.f[0];
-                p.gamma = (const float*)rp(bs, o.r[2]); p.beta = (const float*)rp(bs, o.r[3]); p.ab = (float*)rp(bs, o.r[5]);
+                p.gamma = (const float*)rp(bs, o.r[2]); p.beta = (const float*)rp(bs, o.r[3]); p.ab = (float*)rp(bs, o.r[5]); p.mr = (float*)rp(bs, o.r[6]);
                 hipLaunchKernelGGL(gn_prep_kernel, dim3(i[3], i[5]), dim3(256), 0, s, p);
                 break; }
             case OP_GN_APPLY: {
@@ -874,6 +1155,75 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                                    (const float*)rp(bs, o.r[1]), (float*)rp(bs, o.r[2]), (float*)rp(bs, o.r[3]), (float*)rp(bs, o.r[4]),
                                    i[0], i[1], i[2]);
                 break; }
+            // ------------------------------------------------------------------ backward ops
+            case OP_WT: {
+                const int cols = rup(i[1], 32);
+                hipLaunchKernelGGL(weight_flip_transpose_kernel, dim3(grid_for((long)i[0] * i[4] * cols)), dim3(256), 0, s,
+                                   (const bf16_t*)rp(bs, o.r[0]), (bf16_t*)rp(bs, o.r[1]), i[0], i[1], i[2], i[3], i[4], i[5], i[6]);
+                break; }
+            case OP_WGRAD: {
+                WgradParams p{}; p.dy = (const bf16_t*)rp(bs, o.r[0]); p.cdy = i[0]; p.x = (const bf16_t*)rp(bs, o.r[1]); p.cx = i[1];
+                p.dw = (float*)rp(bs, o.r[2]); p.Cout = i[2]; p.Cin = i[3]; p.dw_ld = i[4]; p.dw_ci_off = i[5];
+                p.N = i[6]; p.Din = i[7]; p.Hin = i[8]; p.Win = i[9]; p.Dout = i[10]; p.Hout = i[11]; p.Wout = i[12];
+                p.ksize = i[13]; p.stride = i[14]; p.pad = i[15]; p.ups = i[16]; p.M = i[17];
+                p.co_tiles = (p.Cout + 127) / 128; p.ci_tiles = (p.Cin + 127) / 128;
+                if ((long)p.M * p.cdy * 2 >= (1L << 32) || (long)p.N * p.Din * p.Hin * p.Win * p.cx * 2 >= (1L << 32))
+                    return fail(LDM_ERR_UNSUPPORTED, "weight gradient: tensor exceeds 4 GiB");
+                LDM_TRY(launch_wgrad(p, s));
+                break; }
+            case OP_EXPORT:
+                hipLaunchKernelGGL(grad_export_kernel, dim3((i[6] + 63) / 64, i[5]), dim3(256), 0, s, (const float*)rp(bs, o.r[0]),
+                                   (float*)rp(bs, o.r[1]), i[0], i[1], i[2], i[3], i[4], i[5], i[6]);
+                break;
+            case OP_COLSUM: {
+                const int n = i[3] ? i[4] : i[0] * i[4];
+                hipLaunchKernelGGL(colsum_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const float*)rp(bs, o.r[4]),
+                                   (float*)rp(bs, o.r[0]), i[0], i[1], i[2], i[3], i[4], i[5]);
+                break; }
+            case OP_GNB: {
+                GnBwdParams p{}; p.dy = (const bf16_t*)rp(bs, o.r[0]); p.xa = (const bf16_t*)rp(bs, o.r[1]); p.xb = (const bf16_t*)rp(bs, o.r[2]);
+                p.ca = i[0]; p.cb = i[1]; p.ab = (const float*)rp(bs, o.r[3]); p.mr = (const float*)rp(bs, o.r[5]);
+                p.gamma = (const float*)rp(bs, o.r[6]); p.groups = i[2]; p.DHW = i[3]; p.N = i[4]; p.silu = i[5]; p.nslab = i[6];
+                p.rows_per_slab = i[7]; p.partial = (float*)rp(bs, o.r[4]); p.gsum = (float*)rp(bs, o.r[7]);
+                p.dgamma_n = (float*)rp(bs, o.r[8]); p.dbeta_n = (float*)rp(bs, o.r[9]);
+                p.acc_a = (const bf16_t*)rp(bs, o.r[10]); p.acc_b = (const bf16_t*)rp(bs, o.r[11]);
+                p.dxa = (bf16_t*)rp(bs, o.r[12]); p.dxb = (bf16_t*)rp(bs, o.r[13]);
+                const int C = i[0] + i[1];
+                float* flat = (float*)bs.p[BASE_IO4];
+                if (!flat) return fail(LDM_ERR_BAD_ARG, "backward without a gradient buffer");
+                hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(i[6], i[4]), dim3(256), 0, s, p);
+                hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(i[2], i[4]), dim3(64), 0, s, p);
+                hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid_for((long)i[4] * i[3] * (C / 8), 256, 2048)), dim3(256), 0, s, p);
+                hipLaunchKernelGGL(rowsum_n_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)p.dgamma_n, flat + i[8], i[4], C);
+                hipLaunchKernelGGL(rowsum_n_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)p.dbeta_n, flat + i[9], i[4], C);
+                break; }
+            case OP_ATTN_BWD: {
+                AttnBwdParams p{}; p.qkv = (const bf16_t*)rp(bs, o.r[0]); p.o = (const bf16_t*)rp(bs, o.r[1]); p.d_o = (const bf16_t*)rp(bs, o.r[2]);
+                p.lse = (const float*)rp(bs, o.r[3]); p.delta = (float*)rp(bs, o.r[4]); p.dqkv = (bf16_t*)rp(bs, o.r[5]);
+                p.B = i[0]; p.N = i[1]; p.C = i[2]; p.heads = i[2] / 64; p.scale = o.f[0];
+                hipLaunchKernelGGL(attn_delta_kernel, dim3(grid_for((long)p.B * p.N * p.heads * 8, 256, 1 << 20)), dim3(256), 0, s, p);
+                hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((p.N + 63) / 64, p.heads, p.B), dim3(256), 0, s, p);
+                hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((p.N + 63) / 64, p.heads, p.B), dim3(256), 0, s, p);
+                break; }
+            case OP_ADD:
+                hipLaunchKernelGGL(add_bf16_kernel, dim3(grid_for(i[0], 256, 2048)), dim3(256), 0, s, (const bf16_t*)rp(bs, o.r[0]),
+                                   (const bf16_t*)rp(bs, o.r[1]), (bf16_t*)rp(bs, o.r[2]), (long)i[0]);
+                break;
+            case OP_SUMPOOL:
+                hipLaunchKernelGGL(sumpool2_kernel, dim3(grid_for((long)i[0] * i[1] * i[2] * i[3] * (i[4] / 8), 256, 2048)), dim3(256), 0, s,
+                                   (const bf16_t*)rp(bs, o.r[0]), (bf16_t*)rp(bs, o.r[1]), i[0], i[1], i[2], i[3], i[4]);
+                break;
+            case OP_LIN_DX: {       // i: B, I, O, dy_stride, x_stride, silu, nz
+                hipLaunchKernelGGL(linear_bwd_dx_part_kernel, dim3((i[1] + 255) / 256, i[0], i[6]), dim3(256), 0, s, (const bf16_t*)rp(bs, o.r[0]),
+                                   (const float*)rp(bs, o.r[1]), (float*)rp(bs, o.r[4]), i[1], i[2], i[3], i[0]);
+                hipLaunchKernelGGL(linear_bwd_dx_fold_kernel, dim3((i[1] + 255) / 256, i[0]), dim3(256), 0, s, (const float*)rp(bs, o.r[4]),
+                                   (const float*)rp(bs, o.r[2]), (float*)rp(bs, o.r[3]), i[1], i[6], i[4], i[0], i[5]);
+                break; }
+            case OP_LIN_DW:         // i: B, I, O, dy_stride, x_stride, silu
+                hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3(grid_for((long)i[2] * i[1], 256, 1 << 24)), dim3(256), 0, s,
+                                   (const float*)rp(bs, o.r[0]), (const float*)rp(bs, o.r[1]), (float*)rp(bs, o.r[2]), (float*)rp(bs, o.r[3]),
+                                   i[0], i[1], i[2], i[3], i[4], i[5]);
+                break;
         }
     }
     HIP_TRY(hipGetLastError());
@@ -983,7 +1333,7 @@ static int get_plan(ldm_model* m, const char* kind, int B, int D, int H, int W, 
     auto it = m->plans.find(key);
     if (it != m->plans.end()) { *out = it->second; return 0; }
     std::shared_ptr<Plan> p(new Plan());
-    if (m->type == 0) LDM_TRY(unet_build(m, B, D, H, W, p.get()));
+    if (m->type == 0) LDM_TRY(unet_build(m, B, D, H, W, p.get(), kind[0] == 't'));
     else if (kind[0] == 'e') LDM_TRY(vae_build_encode(m, B, D, H, W, p.get()));
     else LDM_TRY(vae_build_decode(m, B, D, H, W, p.get()));
     m->plans[key] = p; *out = p;
@@ -1019,6 +1369,93 @@ int ldm_unet_forward(ldm_model* m, const float* x, int x_channels, const float* 
     bs.p[BASE_IO0] = (char*)x; bs.p[BASE_IO1] = (char*)cond; bs.p[BASE_IO2] = (char*)timesteps; bs.p[BASE_IO3] = (char*)out;
     const int rt[2] = {x_channels, cond_channels};
     return run_plan(*p, bs, rt, (hipStream_t)stream);
+}
+
+// ---- training: forward that keeps the tape, backward into one flat fp32 gradient buffer --------------------------
+int64_t ldm_model_param_offset(const ldm_model* m, int i) {
+    return (m && i >= 0 && i < (int)m->params.size()) ? m->params[i].flat_off : -1;
+}
+
+/* Re-pack every parameter from device fp32 tensors (MONAI layouts, library parameter order) into the bf16 arena:
+ * what an optimizer step is followed by.  ptrs is a HOST array of n device pointers. */
+int ldm_model_load_params_device(ldm_model* m, const float* const* ptrs, int n, void* stream) {
+    if (!m || !ptrs) return fail(LDM_ERR_BAD_ARG, "null argument");
+    if (n != (int)m->params.size()) return fail(LDM_ERR_BAD_ARG, "expected %d parameter pointers, got %d", (int)m->params.size(), n);
+    LDM_TRY(ensure_arena(m));
+    hipStream_t s = (hipStream_t)stream;
+    for (int k = 0; k < n; ++k) {
+        ParamDesc& d = m->params[k];
+        if (!ptrs[k]) return fail(LDM_ERR_BAD_ARG, "parameter '%s': null pointer", d.name.c_str());
+        if (d.kind == PK_VEC_F32) {
+            HIP_TRY(hipMemcpyAsync(m->arena + d.dst_off, ptrs[k], (size_t)d.cout * 4, hipMemcpyDeviceToDevice, s));
+        } else if (d.kind == PK_LINEAR_W) {
+            hipLaunchKernelGGL(param_pack_kernel, dim3((d.cin + 63) / 64, d.cout), dim3(256), 0, s, ptrs[k], (bf16_t*)(m->arena + d.dst_off),
+                               1, d.cout, d.cin, d.cin, d.cout, 0);
+        } else {
+            hipLaunchKernelGGL(param_pack_kernel, dim3((d.cin_s + 63) / 64, d.cout), dim3(256), 0, s, ptrs[k], (bf16_t*)(m->arena + d.dst_off),
+                               d.k * d.k * d.k, d.cout, d.cin, d.cin_s, d.cout_pad, d.row_off);
+        }
+        if (!d.loaded) { d.loaded = true; m->loaded_count++; }
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+size_t ldm_unet_train_workspace_bytes(ldm_model* m, int B, int D, int H, int W) {
+    if (!m || m->type != 0) { fail(LDM_ERR_BAD_ARG, "not a UNet handle"); return 0; }
+    std::shared_ptr<Plan> p; if (get_plan(m, "train", B, D, H, W, &p)) return 0;
+    return p->ws_bytes;
+}
+
+/* Same result as ldm_unet_forward; additionally leaves every activation, GroupNorm statistic and attention
+ * log-sum-exp row in `workspace`, which must reach ldm_unet_train_backward untouched. */
+int ldm_unet_train_forward(ldm_model* m, const float* x, int x_channels, const float* cond, int cond_channels,
+                           const float* timesteps, float* out, int B, int D, int H, int W,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+    if (!m || m->type != 0) return fail(LDM_ERR_BAD_ARG, "not a UNet handle");
+    if (!x || !timesteps || !out) return fail(LDM_ERR_BAD_ARG, "null tensor argument");
+    if (!cond) cond_channels = 0;
+    std::shared_ptr<Plan> p; LDM_TRY(get_plan(m, "train", B, D, H, W, &p));
+    LDM_TRY(check_ready(m, workspace, workspace_bytes, *p));
+    Bases bs{}; bs.p[BASE_WS] = (char*)workspace; bs.p[BASE_W] = m->arena;
+    bs.p[BASE_IO0] = (char*)x; bs.p[BASE_IO1] = (char*)cond; bs.p[BASE_IO2] = (char*)timesteps; bs.p[BASE_IO3] = (char*)out;
+    const int rt[2] = {x_channels, cond_channels};
+    return run_plan(*p, bs, rt, (hipStream_t)stream, 0, p->bwd_begin);
+}
+
+/* grad_out: fp32 [B][out_channels][D][H][W] (dLoss/d eps_hat).  flat_grads: fp32 [ldm_model_param_numel_total], every
+ * element is overwritten with dLoss/dparam (parameter i at ldm_model_param_offset(i), its MONAI tensor layout). */
+int ldm_unet_train_backward(ldm_model* m, const float* grad_out, float* flat_grads, int B, int D, int H, int W,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+    if (!m || m->type != 0) return fail(LDM_ERR_BAD_ARG, "not a UNet handle");
+    if (!grad_out || !flat_grads) return fail(LDM_ERR_BAD_ARG, "null tensor argument");
+    std::shared_ptr<Plan> p; LDM_TRY(get_plan(m, "train", B, D, H, W, &p));
+    LDM_TRY(check_ready(m, workspace, workspace_bytes, *p));
+    Bases bs{}; bs.p[BASE_WS] = (char*)workspace; bs.p[BASE_W] = m->arena;
+    bs.p[BASE_IO0] = (char*)grad_out; bs.p[BASE_IO4] = (char*)flat_grads;
+    const int rt[2] = {m->ucfg.out_channels, 0};
+    return run_plan(*p, bs, rt, (hipStream_t)stream, p->bwd_begin, p->ops.size());
+}
+
+static float* g_norm_parts = nullptr;
+int ldm_grad_sq_norm(const float* flat_grads, int64_t n, float* out, void* stream) {
+    if (!flat_grads || !out || n < 0) return fail(LDM_ERR_BAD_ARG, "bad argument");
+    if (((uintptr_t)flat_grads) & 15) return fail(LDM_ERR_BAD_ARG, "gradient buffer must be 16-byte aligned");
+    if (!g_norm_parts) HIP_TRY(hipMalloc((void**)&g_norm_parts, 2048 * 4));
+    const int nb = grid_for((n + 3) / 4, 256, 2048);
+    hipLaunchKernelGGL(sq_norm_part_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, flat_grads, (long)n, g_norm_parts);
+    hipLaunchKernelGGL(sq_norm_fold_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)g_norm_parts, nb, out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int ldm_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                  float beta2, float eps, int step, const float* sq_norm, float max_norm, void* stream) {
+    if (!params || !grads || !exp_avg || !exp_avg_sq || n < 0 || step < 1) return fail(LDM_ERR_BAD_ARG, "bad argument");
+    AdamCoef k{lr, beta1, beta2, eps, 1.0f - powf(beta1, (float)step), sqrtf(1.0f - powf(beta2, (float)step)), max_norm};
+    hipLaunchKernelGGL(adam_step_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq,
+                       (long)n, k, sq_norm);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 static int vae_factor(const ldm_model* m) { return 1 << (m->vcfg.num_levels - 1); }
@@ -1241,7 +1678,7 @@ int ldm_op_weight_flip_transpose(const void* w, void* wt, int ksize, int cout, i
     if (!w || !wt || (ksize != 1 && ksize != 3) || cout < 1 || cin < 1 || cout_pad < cout) return fail(LDM_ERR_BAD_ARG, "bad argument");
     const int taps = ksize * ksize * ksize, rows = rup(cin, 64), cols = rup(cout, 32);
     hipLaunchKernelGGL(weight_flip_transpose_kernel, dim3(grid_for((long)taps * rows * cols)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)w, (bf16_t*)wt, taps, cout, cout_pad, cin, rows);
+                       (const bf16_t*)w, (bf16_t*)wt, taps, cout, cout_pad, cin, rows, 0, cin);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1256,15 +1693,12 @@ int ldm_op_conv3d_wgrad(const void* dy, int cdy, const void* x, int cx, float* d
     const int pad_total = (stride == 2 && pad == 0 && ksize == 3) ? 1 : 2 * pad;
     const int Do = (Du + pad_total - ksize) / stride + 1, Ho = (Hu + pad_total - ksize) / stride + 1, Wo = (Wu + pad_total - ksize) / stride + 1;
     const long M = (long)N * Do * Ho * Wo;
-    if (M < 1 || M >= (1L << 31) || (long)Do * Ho * Wo < 64) return fail(LDM_ERR_UNSUPPORTED, "output volume must hold at least 64 voxels");
+    if (M < 1 || M >= (1L << 31)) return fail(LDM_ERR_BAD_ARG, "bad output size");
     if ((long)M * cdy * 2 >= (1L << 32) || (long)N * Din * Hin * Win * cx * 2 >= (1L << 32)) return fail(LDM_ERR_UNSUPPORTED, "tensor exceeds 4 GiB");
-    WgradParams p{}; p.dy = (const bf16_t*)dy; p.cdy = cdy; p.x = (const bf16_t*)x; p.cx = cx; p.dw = dw; p.Cout = cout; p.Cin = cin;
+    WgradParams p{}; p.dy = (const bf16_t*)dy; p.cdy = cdy; p.x = (const bf16_t*)x; p.cx = cx; p.dw = dw; p.Cout = cout; p.Cin = cin; p.dw_ld = cin; p.dw_ci_off = 0;
     p.N = N; p.Din = Din; p.Hin = Hin; p.Win = Win; p.Dout = Do; p.Hout = Ho; p.Wout = Wo; p.ksize = ksize; p.stride = stride; p.pad = pad; p.ups = ups;
     p.M = (int)M; p.co_tiles = (cout + 127) / 128; p.ci_tiles = (cin + 127) / 128;
-    constexpr int LDS = 4 * 2 * 64 * 256;
-    static bool attr_set = false;
-    if (!attr_set) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr_set = true; }
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(p.co_tiles * p.ci_tiles * ksize * ksize * ksize), dim3(512), LDS, (hipStream_t)stream, p);
+    LDM_TRY(launch_wgrad(p, (hipStream_t)stream));
     HIP_TRY(hipGetLastError());
     return 0;
 }

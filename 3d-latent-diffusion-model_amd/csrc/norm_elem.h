@@ -319,8 +319,10 @@ __global__ __launch_bounds__(256) void scale_kernel(const float* __restrict__ x,
 // Weights for the data-gradient convolution: Wt[tap'][ci][co] = W[taps-1-tap'][co][ci]  (flip + transpose), both in the
 // arena layout [tap][rows padded][cols]; zero rows / columns in the padding.
 __global__ __launch_bounds__(256) void weight_flip_transpose_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ wt,
-                                                                    int taps, int cout, int cout_pad, int cin, int cin_pad_rows) {
-    // wt: [taps][cin_pad_rows][cout_pad_cols = round32(cout)]
+                                                                    int taps, int cout, int cout_pad, int cin, int cin_pad_rows,
+                                                                    int ci_off, int ci_cnt) {
+    // w: [taps][cout_pad][cin];  wt: [taps][cin_pad_rows][round32(cout)] holding input channels [ci_off, ci_off + ci_cnt)
+    // (one matrix per source tensor of a channel-concatenated conv input)
     const int cols = (cout + 31) / 32 * 32;
     const long total = (long)taps * cin_pad_rows * cols;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -329,7 +331,7 @@ __global__ __launch_bounds__(256) void weight_flip_transpose_kernel(const bf16_t
         const int ci = (int)(r % cin_pad_rows);
         const int tp = (int)(r / cin_pad_rows);
         bf16_t v = 0;
-        if (co < cout && ci < cin) v = w[((size_t)(taps - 1 - tp) * cout_pad + co) * cin + ci];
+        if (co < cout && ci < ci_cnt) v = w[((size_t)(taps - 1 - tp) * cout_pad + co) * cin + ci_off + ci];
         wt[i] = v;
     }
 }
@@ -503,22 +505,24 @@ __global__ __launch_bounds__(256) void mse_grad_pack_kernel(const float* __restr
     if (loss && (threadIdx.x & 63) == 0) atomicAdd(loss, lsum);
 }
 
-// Per-(sample, channel) column sums of an NDHWC bf16 tensor from gn_stats-style partials: out[n][c] = sum_slab partial[..][0]
+// Per-(sample, channel) column sums of an NDHWC bf16 tensor from gn_stats-style partials [N][nslab][C][2]:
+//   accumulate_over_n: out[c] = sum_n sum_slab (bias gradient);  else out[n * out_stride + c] = sum_slab (time-embedding
+//   gradient).  Only the first `count` channels are written.
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partial, float* __restrict__ out,
-                                                              int N, int nslab, int C, int accumulate_over_n) {
+                                                              int N, int nslab, int C, int accumulate_over_n, int count, int out_stride) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (accumulate_over_n) {                            // bias gradient: also sum over the batch
-        if (i >= C) return;
+    if (accumulate_over_n) {
+        if (i >= count) return;
         double t = 0.0;
         for (int n = 0; n < N; ++n)
             for (int s = 0; s < nslab; ++s) t += (double)partial[(((size_t)n * nslab + s) * C + i) * 2];
         out[i] = (float)t;
     } else {
-        if (i >= N * C) return;
-        const int n = i / C, c = i - n * C;
+        if (i >= N * count) return;
+        const int n = i / count, c = i - n * count;
         double t = 0.0;
         for (int s = 0; s < nslab; ++s) t += (double)partial[(((size_t)n * nslab + s) * C + c) * 2];
-        out[i] = (float)t;
+        out[(size_t)n * out_stride + c] = (float)t;
     }
 }
 
@@ -566,6 +570,33 @@ __global__ __launch_bounds__(256) void linear_bwd_dx_kernel(const bf16_t* __rest
     dx[(size_t)b * x_stride + i] = acc;
 }
 
+// The same in two stages for tall matrices (the stacked time_emb_proj: O ~ 6400): stage 1 sums a slice of the output rows
+// (blockIdx.z) into part[z][b][i]; stage 2 folds the slices in a fixed order and applies act'.
+__global__ __launch_bounds__(256) void linear_bwd_dx_part_kernel(const bf16_t* __restrict__ W, const float* __restrict__ dy,
+                                                                 float* __restrict__ part, int I, int O, int dy_stride, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y, z = blockIdx.z, nz = gridDim.z;
+    if (i >= I) return;
+    const int per = (O + nz - 1) / nz, o0 = z * per;
+    int o1 = o0 + per; if (o1 > O) o1 = O;
+    float acc = 0.f;
+#pragma unroll 4
+    for (int o = o0; o < o1; ++o) acc += bf2f(W[(size_t)o * I + i]) * dy[(size_t)b * dy_stride + o];
+    part[((size_t)z * B + b) * I + i] = acc;
+}
+__global__ __launch_bounds__(256) void linear_bwd_dx_fold_kernel(const float* __restrict__ part, const float* __restrict__ x_pre,
+                                                                 float* __restrict__ dx, int I, int nz, int x_stride, int B, int silu_in) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (i >= I) return;
+    float acc = 0.f;
+    for (int z = 0; z < nz; ++z) acc += part[((size_t)z * B + b) * I + i];
+    if (silu_in) {
+        const float u = x_pre[(size_t)b * x_stride + i];
+        const float sg = 1.0f / (1.0f + __expf(-u));
+        acc *= sg * (1.0f + u * (1.0f - sg));
+    }
+    dx[(size_t)b * x_stride + i] = acc;
+}
+
 __global__ __launch_bounds__(256) void linear_bwd_dw_kernel(const float* __restrict__ dy, const float* __restrict__ x_pre,
                                                             float* __restrict__ dW, float* __restrict__ db,
                                                             int B, int I, int O, int dy_stride, int x_stride, int silu_in) {
@@ -590,4 +621,91 @@ __global__ __launch_bounds__(256) void rowsum_n_kernel(const float* __restrict__
     float t = 0.f;
     for (int n = 0; n < N; ++n) t += in[(size_t)n * C + c];
     out[c] = t;
+}
+
+// out = a + b (bf16 NDHWC gradients meeting at a tensor with two consumers), 8 elements per thread.
+__global__ __launch_bounds__(256) void add_bf16_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
+                                                       bf16_t* __restrict__ out, long nvec) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+        const u32x4 va = reinterpret_cast<const u32x4*>(a)[i], vb = reinterpret_cast<const u32x4*>(b)[i];
+        u32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            o[k] = pack2bf(__uint_as_float(va[k] << 16) + __uint_as_float(vb[k] << 16),
+                           __uint_as_float(va[k] & 0xffff0000u) + __uint_as_float(vb[k] & 0xffff0000u));
+        reinterpret_cast<u32x4*>(out)[i] = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Parameter traffic between the caller's fp32 tensors (MONAI state_dict layout) and the library's device layouts.
+// Pack:   src [cout][cin][taps] fp32  ->  dst [taps][cout_pad][cin_s] bf16, rows row_off .. row_off + cout, zero channel padding.
+// Export: src [taps][rows_total][ld] fp32 (wgrad output), rows row_off.., columns col_off..  ->  dst [cout][cin][taps] fp32.
+// One block per (64-channel chunk, cout row): the [64][taps] tile goes through LDS so both sides are coalesced.
+__global__ __launch_bounds__(256) void param_pack_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst,
+                                                         int taps, int cout, int cin, int cin_s, int cout_pad, int row_off) {
+    __shared__ float tile[64 * 27];
+    const int co = blockIdx.y, ci0 = blockIdx.x * 64, tid = threadIdx.x;
+    int nci = cin - ci0; if (nci > 64) nci = 64; if (nci < 0) nci = 0;
+    const float* s = src + ((size_t)co * cin + ci0) * taps;
+    for (int i = tid; i < nci * taps; i += 256) tile[i] = s[i];
+    __syncthreads();
+    for (int i = tid; i < taps * 64; i += 256) {
+        const int t = i >> 6, c = i & 63, ci = ci0 + c;
+        if (ci < cin_s) dst[((size_t)t * cout_pad + row_off + co) * cin_s + ci] = (c < nci) ? f2bf(tile[c * taps + t]) : (bf16_t)0;
+    }
+}
+__global__ __launch_bounds__(256) void grad_export_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                          int taps, int rows_total, int ld, int row_off, int col_off, int cout, int cin) {
+    __shared__ float tile[64 * 27];
+    const int co = blockIdx.y, ci0 = blockIdx.x * 64, tid = threadIdx.x;
+    int nci = cin - ci0; if (nci > 64) nci = 64;
+    for (int i = tid; i < taps * 64; i += 256) {
+        const int t = i >> 6, c = i & 63;
+        if (c < nci) tile[c * taps + t] = src[((size_t)t * rows_total + row_off + co) * ld + col_off + ci0 + c];
+    }
+    __syncthreads();
+    float* d = dst + ((size_t)co * cin + ci0) * taps;
+    for (int i = tid; i < nci * taps; i += 256) d[i] = tile[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Optimizer tail on flat fp32 buffers: global gradient norm and Adam with the clip
+// factor folded in.  Both HBM-bound, 16-byte accesses.  The norm is a two-stage deterministic reduction.
+__global__ __launch_bounds__(256) void sq_norm_part_kernel(const float* __restrict__ g, long n, float* __restrict__ part) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    const long nv = n / 4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4*>(g)[i];
+        acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n - nv * 4)) { const float v = g[nv * 4 + threadIdx.x]; acc += v * v; }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(256) void sq_norm_fold_kernel(const float* __restrict__ part, int nparts, float* __restrict__ out) {
+    __shared__ double red[256];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) acc += (double)part[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) *out = (float)red[0];
+}
+struct AdamCoef { float lr, b1, b2, eps, bc1, bc2_sqrt, max_norm; };
+__global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, long n, AdamCoef k, const float* __restrict__ sq_norm) {
+    float clip = 1.f;
+    if (sq_norm && k.max_norm > 0.f) { const float c = k.max_norm / (sqrtf(*sq_norm) + 1e-6f); clip = c < 1.f ? c : 1.f; }
+    const float step = k.lr / k.bc1;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float gi = g[i] * clip;
+        const float mi = k.b1 * m[i] + (1.f - k.b1) * gi;
+        const float vi = k.b2 * v[i] + (1.f - k.b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        p[i] -= step * mi / (sqrtf(vi) / k.bc2_sqrt + k.eps);      // torch.optim.Adam: denom = sqrt(v)/sqrt(bc2) + eps
+    }
 }

@@ -9,7 +9,10 @@ config_train_32g.json:8,41) and then uses only through the nn.Module surface (SU
 library, so there is one source of truth for them; parameters are ordinary fp32 nn.Parameters and are
 re-packed into the library's bf16 weight arena whenever they change.
 
-Inference only in this round: forward runs the hand-written HIP plan and returns tensors without grad_fn.
+``DiffusionModelUNet`` is differentiable w.r.t. its parameters: under ``torch.enable_grad()`` with parameters that
+require grad, forward runs the training plan (same kernels, activations kept) and ``loss.backward()`` runs the
+hand-written backward plan (3d_ldm/train_diffusion.py:197-216).  ``AutoencoderKL`` is inference only (the diffusion
+trainer uses it under ``no_grad``: 3d_ldm/train_diffusion.py:104,180).
 """
 from __future__ import annotations
 
@@ -105,10 +108,31 @@ class _LdmModule(nn.Module):
         self._dirty = True
         return super().train(mode)
 
+    def _param_list(self):
+        """Parameters in the library's order (the order of the flat gradient buffer)."""
+        pl = getattr(self, "_plist", None)
+        if pl is None:
+            L = _lib.lib()
+            d = dict(self.named_parameters())
+            pl = [d[L.ldm_model_param_name(self._h, i).decode()] for i in range(L.ldm_model_num_params(self._h))]
+            self._plist = pl
+        return pl
+
     def _sync_weights(self):
         if not (self._dirty or self.training):
             return
         L = _lib.lib()
+        pl = self._param_list()
+        if pl and all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in pl):
+            # device-resident master weights (training): one call re-packs everything on the GPU
+            sig = tuple((p._version, p.data_ptr()) for p in pl)
+            if self._dirty or sig != getattr(self, "_dev_sig", None):
+                arr = (C.c_void_p * len(pl))(*[p.data_ptr() for p in pl])
+                with torch.cuda.device(pl[0].device):
+                    _lib.check(L.ldm_model_load_params_device(self._h, arr, len(pl), _lib.current_stream()))
+                self._dev_sig = sig
+            self._dirty = False
+            return
         for name, p in self.named_parameters():
             v = p._version
             if self._uploaded_versions.get(name) == (v, p.data_ptr()):
@@ -117,6 +141,30 @@ class _LdmModule(nn.Module):
             _lib.check(L.ldm_model_load_param(self._h, name.encode(), host.data_ptr(), host.numel()))
             self._uploaded_versions[name] = (v, p.data_ptr())
         self._dirty = False
+
+    # -- flat parameter / gradient storage (training) ---------------------------------------------------------
+    def flatten_parameters(self) -> torch.Tensor:
+        """Re-home every parameter as a view of ONE flat fp32 tensor on its current device, in the library's
+        parameter order (= the layout of the flat gradient buffer), and pre-assign ``.grad`` views of a second flat
+        tensor.  Backward then writes gradients in place (no per-parameter copies), the data-parallel all-reduce is a
+        single collective over ``flat_grads`` and the optimizer is one fused kernel over both buffers
+        (``ldm3d.optim.FlatAdam``).  In this mode every backward OVERWRITES the gradients (no accumulation)."""
+        pl = self._param_list()
+        dev = pl[0].device
+        L = _lib.lib()
+        total = int(L.ldm_model_param_numel_total(self._h))
+        flat = torch.empty(total, dtype=torch.float32, device=dev)
+        grads = torch.zeros(total, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for i, p in enumerate(pl):
+                off = int(L.ldm_model_param_offset(self._h, i))
+                v = flat[off:off + p.numel()].view(p.shape)
+                v.copy_(p.detach().to(device=dev, dtype=torch.float32))
+                p.data = v
+                p.grad = grads[off:off + p.numel()].view(p.shape)
+        self.flat_params, self.flat_grads = flat, grads
+        self._dirty = True
+        return flat
 
     def _workspace(self, key: tuple, nbytes: int, device) -> torch.Tensor:
         ws = self._ws.get(key)
@@ -138,6 +186,21 @@ class _LdmModule(nn.Module):
                 self._h = C.c_void_p()
         except Exception:
             pass
+
+
+class _UNetTrainFn(torch.autograd.Function):
+    """eps_hat = UNet(x_t, t; params) with the hand-written backward plan behind ``loss.backward()``."""
+
+    @staticmethod
+    def forward(ctx, module, x, timesteps, cond, *params):
+        ctx.module = module
+        out, ctx.token = module._train_forward(x, timesteps, cond)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        grads = ctx.module._train_backward(ctx.token, grad_out)
+        return (None, None, None, None) + tuple(grads)
 
 
 class DiffusionModelUNet(_LdmModule):
@@ -192,11 +255,14 @@ class DiffusionModelUNet(_LdmModule):
         if context is not None or class_labels is not None or down_block_additional_residuals is not None \
                 or mid_block_additional_residual is not None:
             raise NotImplementedError("context / class_labels / ControlNet residuals are not on the reference's path")
-        if torch.is_grad_enabled() and x.requires_grad:
-            raise NotImplementedError("backward through the HIP UNet is not implemented yet (inference only)")
+        if torch.is_grad_enabled() and (x.requires_grad or (cond is not None and cond.requires_grad)):
+            raise NotImplementedError("gradients w.r.t. the UNet input are not implemented (the reference's trainer "
+                                      "never asks for them: the noisy latent is built under no_grad)")
         self._need_cuda(x, "DiffusionModelUNet.forward")
         if x.dim() != 5:
             raise ValueError(f"expected [B, C, D, H, W], got {tuple(x.shape)}")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self._param_list()):
+            return _UNetTrainFn.apply(self, x, timesteps, cond, *self._param_list())
         B, cx, D, H, W = x.shape
         x = x.detach().to(torch.float32).contiguous()
         cc = 0
@@ -217,6 +283,70 @@ class DiffusionModelUNet(_LdmModule):
             _lib.check(L.ldm_unet_forward(self._h, x.data_ptr(), cx, _lib.ptr(cond), cc, t.data_ptr(), out.data_ptr(),
                                           B, D, H, W, ws.data_ptr(), ws.numel(), _lib.current_stream()))
         return out
+
+
+    # -- training plan ------------------------------------------------------------------------------------------
+    def _prep(self, x, timesteps, cond):
+        B, cx, D, H, W = x.shape
+        x = x.detach().to(torch.float32).contiguous()
+        cc = 0
+        if cond is not None:
+            cond = cond.detach().to(device=x.device, dtype=torch.float32).contiguous()
+            cc = cond.shape[1]
+        t = timesteps.detach().to(device=x.device, dtype=torch.float32).reshape(-1).contiguous()
+        if t.numel() != B:
+            raise ValueError(f"timesteps must have {B} entries, got {t.numel()}")
+        return x, cx, cond, cc, t
+
+    def _train_forward(self, x, timesteps, cond):
+        if not all(p.is_cuda for p in self._param_list()):
+            raise _lib.LdmError("training needs the parameters on the GPU: call .to('cuda') first")
+        x, cx, cond, cc, t = self._prep(x, timesteps, cond)
+        B, _, D, H, W = x.shape
+        self._sync_weights()
+        L = _lib.lib()
+        nbytes = L.ldm_unet_train_workspace_bytes(self._h, B, D, H, W)
+        if nbytes == 0:
+            raise _lib.LdmError((L.ldm_last_error() or b"workspace query failed").decode())
+        ws = self._workspace(("train", B, D, H, W), nbytes, x.device)
+        out = torch.empty((B, self.out_channels, D, H, W), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(L.ldm_unet_train_forward(self._h, x.data_ptr(), cx, _lib.ptr(cond), cc, t.data_ptr(), out.data_ptr(),
+                                                B, D, H, W, ws.data_ptr(), ws.numel(), _lib.current_stream()))
+        self._train_serial = getattr(self, "_train_serial", 0) + 1
+        return out, (self._train_serial, B, D, H, W)
+
+    def _train_backward(self, token, grad_out):
+        serial, B, D, H, W = token
+        if serial != getattr(self, "_train_serial", 0):
+            raise _lib.LdmError("backward of a stale forward: the training workspace holds one forward at a time "
+                                "(call backward before the next grad-enabled forward of the same module)")
+        L = _lib.lib()
+        pl = self._param_list()
+        g = grad_out.detach().to(torch.float32).contiguous()
+        flat_mode = getattr(self, "flat_grads", None) is not None
+        total = int(L.ldm_model_param_numel_total(self._h))
+        flat = self.flat_grads if flat_mode else torch.empty(total, dtype=torch.float32, device=g.device)
+        ws = self._ws[("train", B, D, H, W)]
+        with torch.cuda.device(g.device):
+            _lib.check(L.ldm_unet_train_backward(self._h, g.data_ptr(), flat.data_ptr(), B, D, H, W, ws.data_ptr(), ws.numel(),
+                                                 _lib.current_stream()))
+        self._train_serial += 1                        # the workspace has been consumed
+        offs = self._offsets()
+        if flat_mode:                                  # .grad aliases flat_grads (flatten_parameters): nothing to hand to autograd
+            for i, p in enumerate(pl):
+                if p.grad is None or p.grad.data_ptr() != flat.data_ptr() + 4 * offs[i]:
+                    p.grad = flat[offs[i]:offs[i] + p.numel()].view(p.shape)
+            return [None] * len(pl)
+        return [flat[offs[i]:offs[i] + p.numel()].view(p.shape) if p.requires_grad else None for i, p in enumerate(pl)]
+
+    def _offsets(self):
+        o = getattr(self, "_offs", None)
+        if o is None:
+            L = _lib.lib()
+            o = [int(L.ldm_model_param_offset(self._h, i)) for i in range(L.ldm_model_num_params(self._h))]
+            self._offs = o
+        return o
 
 
 class AutoencoderKL(_LdmModule):

@@ -1,0 +1,66 @@
+"""Optimizer tail of the diffusion trainer on flat buffers.
+
+The reference does (3d_ldm/train_diffusion.py:155-156, 214-223)::
+
+    optimizer = torch.optim.Adam(params=unet.parameters(), lr=args.diffusion_train["lr"])
+    lr_scheduler = torch.optim.lr_scheduler.MultiStepLR(optimizer, milestones=[100, 1000], gamma=0.1)
+    loss.backward(); torch.nn.utils.clip_grad_norm_(unet.parameters(), 1.0); optimizer.step()
+
+``FlatAdam`` is a ``torch.optim.Optimizer`` (so ``MultiStepLR`` and ``zero_grad`` keep working) whose single parameter
+is the module's flat fp32 buffer (``module.flatten_parameters()``): gradient clipping + Adam are two HIP launches over
+191 M elements instead of ~320 per-tensor kernel groups, and the data-parallel mean is one all-reduce of
+``module.flat_grads``.  Same arithmetic as ``torch.optim.Adam`` defaults (betas (0.9, 0.999), eps 1e-8, no weight decay,
+no amsgrad) and as ``clip_grad_norm_`` (scale = max_norm / (norm + 1e-6), clamped to 1).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+
+class FlatAdam(torch.optim.Optimizer):
+    def __init__(self, module, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, max_grad_norm: float | None = None):
+        if getattr(module, "flat_params", None) is None:
+            module.flatten_parameters()
+        self.module = module
+        flat = module.flat_params
+        if not flat.is_cuda:
+            raise _lib.LdmError("FlatAdam needs the module on the GPU (no CPU fallback)")
+        self._flat = torch.nn.Parameter(flat, requires_grad=False)      # shares storage with module.flat_params
+        super().__init__([self._flat], dict(lr=lr, betas=tuple(betas), eps=eps))
+        self.max_grad_norm = max_grad_norm
+        self.exp_avg = torch.zeros_like(flat)
+        self.exp_avg_sq = torch.zeros_like(flat)
+        self.sq_norm = torch.zeros((1,), dtype=torch.float32, device=flat.device)
+        self.steps = 0
+
+    def zero_grad(self, set_to_none: bool = True):     # gradients are overwritten by every backward: nothing to clear
+        pass
+
+    def grad_norm(self) -> torch.Tensor:
+        """Global L2 norm of the current gradients (device scalar), as clip_grad_norm_ returns it."""
+        L = _lib.lib()
+        g = self.module.flat_grads
+        with torch.cuda.device(g.device):
+            _lib.check(L.ldm_grad_sq_norm(g.data_ptr(), g.numel(), self.sq_norm.data_ptr(), _lib.current_stream()))
+        return self.sq_norm.sqrt()[0]
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if closure is not None:
+            raise NotImplementedError("closures are not used by the reference's trainers")
+        L = _lib.lib()
+        grp = self.param_groups[0]
+        p, g = self.module.flat_params, self.module.flat_grads
+        clip = self.max_grad_norm is not None and self.max_grad_norm > 0
+        self.steps += 1
+        with torch.cuda.device(p.device):
+            if clip:
+                _lib.check(L.ldm_grad_sq_norm(g.data_ptr(), g.numel(), self.sq_norm.data_ptr(), _lib.current_stream()))
+            _lib.check(L.ldm_adam_step(p.data_ptr(), g.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), p.numel(),
+                                       float(grp["lr"]), float(grp["betas"][0]), float(grp["betas"][1]), float(grp["eps"]), self.steps,
+                                       self.sq_norm.data_ptr() if clip else None, float(self.max_grad_norm or 0.0),
+                                       _lib.current_stream()))
+        self.module.mark_weights_dirty()               # the bf16 arena is re-packed before the next forward
+        return None

@@ -95,6 +95,31 @@ int ldm_unet_forward(ldm_model* m, const float* x, int x_channels, const float* 
                      const float* timesteps, float* out, int B, int D, int H, int W,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- one training step of the diffusion UNet (3d_ldm/train_diffusion.py:197-223: inferer(...) -> F.mse_loss ->
+ *      loss.backward() -> clip_grad_norm_(1.0) -> Adam.step()).
+ *      train_forward == forward, but keeps every activation / statistic in `workspace`; train_backward consumes that
+ *      workspace and dLoss/d eps_hat (fp32 [B,out_channels,D,H,W]) and overwrites flat_grads (fp32, one element per
+ *      parameter element: parameter i starts at ldm_model_param_offset(m, i) and has its MONAI tensor layout).
+ *      load_params_device re-packs the fp32 master parameters (HOST array of n DEVICE pointers, library order) into
+ *      the bf16 weight arena after an optimizer step.  The flat layout is what the data-parallel all-reduce
+ *      (3d_ldm/train_diffusion.py:147-149 DDP) runs over: one ldm_comm_allreduce of the whole buffer. ----------------- */
+int64_t ldm_model_param_offset(const ldm_model* m, int i);
+int ldm_model_load_params_device(ldm_model* m, const float* const* device_ptrs, int n, void* stream);
+size_t ldm_unet_train_workspace_bytes(ldm_model* m, int B, int D, int H, int W);
+int ldm_unet_train_forward(ldm_model* m, const float* x, int x_channels, const float* cond, int cond_channels,
+                           const float* timesteps, float* out, int B, int D, int H, int W,
+                           void* workspace, size_t workspace_bytes, void* stream);
+int ldm_unet_train_backward(ldm_model* m, const float* grad_out, float* flat_grads, int B, int D, int H, int W,
+                            void* workspace, size_t workspace_bytes, void* stream);
+/* Optimizer tail on flat fp32 buffers (torch.nn.utils.clip_grad_norm_(params, max_norm) 3d_ldm/train_diffusion.py:216
+ * and torch.optim.Adam(lr) :155, torch defaults betas (0.9, 0.999), eps 1e-8, no weight decay):
+ *   grad_sq_norm: *out (device fp32 scalar) = sum g^2.
+ *   adam_step: g' = g * min(1, max_norm / (sqrt(*sq_norm) + 1e-6)) when sq_norm != NULL and max_norm > 0; then
+ *              m = b1 m + (1-b1) g'; v = b2 v + (1-b2) g'^2; p -= lr * (m / (1-b1^step)) / (sqrt(v / (1-b2^step)) + eps). */
+int ldm_grad_sq_norm(const float* flat_grads, int64_t n, float* out, void* stream);
+int ldm_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                  float beta2, float eps, int step, const float* sq_norm, float max_norm, void* stream);
+
 /* ---- AutoencoderKL.encode / sampling / decode (3d_ldm/train_diffusion.py:104,180,195,249,258,310,324;
  *      3d_ldm/train_autoencoder.py:366,579).  encode: x:[B,Cin,D,H,W] -> z_mu, z_sigma, z = mu + sigma*eps
  *      (each [B,L,D/f,H/f,W/f], any of the three outputs may be NULL; eps NULL means eps = 0).

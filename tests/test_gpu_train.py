@@ -1,0 +1,180 @@
+"""Training step of the diffusion UNet (-m gpu): SURVEY.md section 8a rows a6/a7, 3d_ldm/train_diffusion.py:197-223.
+
+The module shell's ``loss.backward()`` runs the hand-written backward plan through the C ABI
+(ldm_unet_train_forward / ldm_unet_train_backward); the checker is torch autograd through the CPU oracle on the same
+seeded weights, inputs and loss.  Every backward kernel is gated tightly on its own in tests/test_gpu_ops.py; end to
+end the gate is again the bf16 noise floor (see tests/test_gpu_models.py): gradients of a bf16 network computed in two
+summation orders are two draws of the same rounding noise, measured here by differentiating the oracle itself with and
+without bf16 rounding points.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import cfgs
+from util import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_grads(sd, cfg, x, t, target, bf):
+    from oracle import unet as ou
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    out = ou.unet_forward(leaves, cfg, x, t, emulate_bf16=bf)
+    loss = F.mse_loss(out, target)
+    loss.backward()
+    return out.detach(), float(loss.detach()), {k: v.grad for k, v in leaves.items()}
+
+
+def _cat(gd, names):
+    return torch.cat([gd[n].reshape(-1).double().cpu() for n in names])
+
+
+@pytest.mark.parametrize("name,dims,b,cond", [("UNET_TINY", (8, 8, 8), 2, 0), ("UNET_TINY_ALT", (6, 10, 8), 1, 0),
+                                              ("UNET_TINY_COND", (8, 12, 4), 1, 4)])
+def test_unet_parameter_gradients_match_oracle_autograd(cuda, name, dims, b, cond):
+    from ldm3d.networks import DiffusionModelUNet
+    from oracle import unet as ou
+    cfg = getattr(cfgs, name)
+    sd = ou.init_state_dict(ou.unet_param_shapes(cfg), 3, gain=0.5)   # gain 1.0 is chaotic: its own bf16/fp32 gradient floor is 0.4
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn((b, cfg["in_channels"], *dims), generator=g)
+    target = torch.randn((b, cfg["out_channels"], *dims), generator=g)
+    t = torch.tensor([211.0, 640.0][:b])
+    out32, loss32, g32 = _oracle_grads(sd, cfg, x, t, target, False)
+    outbf, lossbf, gbf = _oracle_grads(sd, cfg, x, t, target, True)
+
+    m = DiffusionModelUNet(**cfg)
+    m.load_state_dict(sd)
+    m = m.to(cuda).train()
+    xd = x.to(cuda)
+    if cond:                                      # mode="concat": second tensor concatenated inside the packing kernel
+        out = m(x=xd[:, :-cond].contiguous(), timesteps=t.to(cuda), cond=xd[:, -cond:].contiguous())
+    else:
+        out = m(x=xd, timesteps=t.to(cuda))
+    assert out.requires_grad
+    loss = F.mse_loss(out.float(), target.to(cuda))
+    loss.backward()
+    torch.cuda.synchronize()
+    got = {k: p.grad for k, p in m.named_parameters()}
+    names = list(sd.keys())
+    assert all(got[n] is not None and torch.isfinite(got[n]).all() for n in names)
+    floor = rel_l2(_cat(gbf, names), _cat(g32, names))
+    e32, ebf = rel_l2(_cat(got, names), _cat(g32, names)), rel_l2(_cat(got, names), _cat(gbf, names))
+    a, r = _cat(got, names), _cat(g32, names)
+    cos = float((a @ r) / (a.norm() * r.norm()))
+    worst = max(((rel_l2(got[n], g32[n]), n) for n in names if g32[n].norm() > 1e-3 * r.norm()), default=(0.0, ""))
+    print(f"{name}: loss gpu {float(loss):.5f} / fp32 {loss32:.5f} / bf16 {lossbf:.5f}; grad floor {floor:.2e}, "
+          f"GPU vs fp32 {e32:.2e}, vs bf16-oracle {ebf:.2e}, cosine {cos:.5f}, worst tensor {worst[0]:.2e} ({worst[1]})")
+    assert e32 <= 2.0 * floor + 2e-3, (e32, floor)
+    assert ebf <= 2.5 * floor + 2e-3, (ebf, floor)
+    assert cos >= 1.0 - 2.0 * (2.0 * floor + 2e-3) ** 2
+    # every family of parameters individually (catches a wrong export / layout that is small in the global norm)
+    for fam in ("conv.weight", "conv.bias", "norm", "time_emb", "time_embed", "to_q", "to_k", "to_v", "out_proj", "skip_connection"):
+        sel = [n for n in names if fam in n]
+        if sel and _cat(g32, sel).norm() > 0:
+            fl = rel_l2(_cat(gbf, sel), _cat(g32, sel))
+            e = rel_l2(_cat(got, sel), _cat(g32, sel))
+            assert e <= 2.5 * fl + 5e-3, (fam, e, fl)
+
+
+def test_backward_requires_matching_forward(cuda):
+    from ldm3d import _lib
+    from ldm3d.networks import DiffusionModelUNet
+    m = DiffusionModelUNet(**cfgs.UNET_TINY).to(cuda).train()
+    x = torch.randn((1, 4, 8, 8, 8), device=cuda)
+    t = torch.tensor([5.0], device=cuda)
+    o1 = m(x=x, timesteps=t)
+    o2 = m(x=x, timesteps=t)                       # overwrites the workspace o1's backward needs
+    with pytest.raises(_lib.LdmError):
+        o1.sum().backward()
+    o2.sum().backward()
+    assert all(p.grad is not None for p in m.parameters())
+    with torch.no_grad():                          # inference path is untouched by training state
+        assert not m(x=x, timesteps=t).requires_grad
+
+
+def test_device_repack_equals_host_upload(cuda):
+    """ldm_model_load_params_device (fp32 device tensors -> bf16 arena) must produce the bytes ldm_model_load_param does."""
+    from ldm3d.networks import DiffusionModelUNet
+    from oracle import unet as ou
+    cfg = cfgs.UNET_TINY_COND
+    sd = ou.init_state_dict(ou.unet_param_shapes(cfg), 11)
+    x = torch.randn((1, 8, 8, 8, 8), device=cuda)
+    t = torch.tensor([77.0], device=cuda)
+    a = DiffusionModelUNet(**cfg); a.load_state_dict(sd)
+    with torch.no_grad():
+        a._sync_weights()                          # parameters still on the CPU: host upload path
+        ya = a(x=x, timesteps=t)
+        b = DiffusionModelUNet(**cfg); b.load_state_dict(sd); b.to(cuda)
+        yb = b(x=x, timesteps=t)                   # device re-pack path
+    assert torch.equal(ya, yb)
+
+
+def test_flat_adam_matches_torch_adam_and_clip(cuda):
+    from ldm3d.networks import DiffusionModelUNet
+    from ldm3d.optim import FlatAdam
+    m = DiffusionModelUNet(**cfgs.UNET_TINY).to(cuda).train()
+    with torch.no_grad():
+        for p in m.parameters():
+            p.add_(0.01 * torch.randn_like(p))     # leave the zero-initialised convs
+    ref_p = [p.detach().clone().requires_grad_(True) for p in m._param_list()]
+    topt = torch.optim.Adam(ref_p, lr=1e-3)
+    opt = FlatAdam(m, lr=1e-3, max_grad_norm=1.0)
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[2], gamma=0.1)
+    tsched = torch.optim.lr_scheduler.MultiStepLR(topt, milestones=[2], gamma=0.1)
+    x = torch.randn((1, 4, 8, 8, 8), device=cuda)
+    t = torch.tensor([400.0], device=cuda)
+    for it in range(3):
+        loss = F.mse_loss(m(x=x, timesteps=t), torch.ones_like(x))
+        loss.backward()
+        for rp, p in zip(ref_p, m._param_list()):
+            rp.grad = p.grad.detach().clone()
+        n_ref = torch.nn.utils.clip_grad_norm_(ref_p, 1.0)
+        n_got = opt.grad_norm()
+        assert abs(float(n_got) - float(n_ref)) <= 1e-4 * float(n_ref)
+        opt.step(); topt.step(); sched.step(); tsched.step()
+        torch.cuda.synchronize()
+        for rp, p in zip(ref_p, m._param_list()):
+            assert torch.allclose(p.detach(), rp.detach(), rtol=2e-5, atol=2e-7), it
+    assert opt.param_groups[0]["lr"] == pytest.approx(1e-4)
+
+
+def test_few_steps_reduce_the_loss(cuda):
+    """train_diffusion.py:197-223 in miniature: fixed batch, 12 Adam steps, loss must drop."""
+    from ldm3d.networks import DiffusionModelUNet
+    from ldm3d.optim import FlatAdam
+    torch.manual_seed(0)
+    m = DiffusionModelUNet(**cfgs.UNET_TINY).to(cuda).train()
+    opt = FlatAdam(m, lr=2e-4, max_grad_norm=1.0)
+    g = torch.Generator(device=cuda).manual_seed(1)
+    x = torch.randn((2, 4, 8, 8, 8), device=cuda, generator=g)
+    noise = torch.randn((2, 4, 8, 8, 8), device=cuda, generator=g)
+    t = torch.tensor([100.0, 700.0], device=cuda)
+    losses = []
+    for _ in range(12):
+        loss = F.mse_loss(m(x=x, timesteps=t).float(), noise)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    print("losses:", " ".join(f"{v:.4f}" for v in losses))
+    assert all(torch.isfinite(torch.tensor(losses)))
+    assert losses[-1] < 0.8 * losses[0]
+
+
+def test_full_size_unet_backward_runs_and_is_finite(cuda):
+    """Benchmark UNet (191 M parameters) @ 16^3: one fwd + bwd; all gradients finite, non-zero in every tensor."""
+    from ldm3d.networks import DiffusionModelUNet
+    from oracle import unet as ou
+    cfg = cfgs.UNET_FULL
+    m = DiffusionModelUNet(**cfg)
+    m.load_state_dict(ou.init_state_dict(ou.unet_param_shapes(cfg), 5))
+    m = m.to(cuda).train()
+    m.flatten_parameters()
+    x = torch.randn((1, 4, 16, 16, 16), device=cuda)
+    out = m(x=x, timesteps=torch.tensor([321.0], device=cuda))
+    F.mse_loss(out, torch.randn_like(out)).backward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(m.flat_grads).all()
+    for n, p in m.named_parameters():
+        assert p.grad is not None and float(p.grad.abs().max()) > 0.0, n
