@@ -20,6 +20,7 @@ struct WgradParams {
     int dw_ld, dw_ci_off;             // row length / first column (dual-source convs are two launches into one matrix)
     int N, Din, Hin, Win, Dout, Hout, Wout, ksize, stride, pad, ups;
     int M, co_tiles, ci_tiles;
+    int ksplit; long slab_stride;     // voxel range split over `ksplit` workgroups, each writing its own [taps][Cout][ld] slab
 };
 
 __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradParams p) {
@@ -39,12 +40,16 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradParams p)
     const int wa = wq & 1, wb = wq >> 1;       // wave tile: couts [64 wa, +64) x cins [64 wb, +64)
     int bid = blockIdx.x;
     const int ci_t = bid % p.ci_tiles; bid /= p.ci_tiles;
-    const int co_t = bid % p.co_tiles; const int tap = bid / p.co_tiles;
+    const int co_t = bid % p.co_tiles; bid /= p.co_tiles;
+    const int tap = bid % (p.ksize * p.ksize * p.ksize); const int split = bid / (p.ksize * p.ksize * p.ksize);
     const int kk = p.ksize * p.ksize;
     const int kd = tap / kk, kh = (tap - kd * kk) / p.ksize, kw = tap - kd * kk - kh * p.ksize;
     const int DinU = p.Din << p.ups, HinU = p.Hin << p.ups, WinU = p.Win << p.ups;
     const int HWo = p.Hout * p.Wout, DHWo = p.Dout * HWo;
-    const int nsteps = (p.M + KV - 1) / KV;
+    const int steps_all = (p.M + KV - 1) / KV;
+    const int sps = (steps_all + p.ksplit - 1) / p.ksplit;
+    const int s_begin = split * sps;
+    const int nsteps = (s_begin + sps < steps_all ? s_begin + sps : steps_all) - s_begin;     // may be <= 0 for a trailing split
 
     // ---- loader: each wave copies 2 pieces (4 voxel rows x 256 B) of the dY tile and 2 of the X tile per step.
     // lane -> (row = lane / 16 inside the piece, physical 16-B chunk = lane % 16); 32-byte blocks are XOR-swizzled by
@@ -58,7 +63,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradParams p)
         const int f = (row & 3) + 4 * ((row >> 3) & 1);
         l_row[j] = row;
         l_kb[j] = ((((pch >> 1) ^ f) << 1) | (pch & 1)) * 16;
-        int m = row;                           // step 0
+        int m = s_begin * KV + row;            // first step of this split
         vn[j] = m / DHWo; m -= vn[j] * DHWo; vd[j] = m / HWo; m -= vd[j] * HWo; vh[j] = m / p.Wout; vw[j] = m - vh[j] * p.Wout;
     }
     // 64 voxels ahead, decomposed once (q_w < Wout and q_h < Hout, so those carries wrap at most once; volumes smaller
@@ -73,7 +78,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradParams p)
 #define WG_ISSUE() do {                                                                                       \
         char* st_ = smem + (ld_s % NS) * STAGE;                                                               \
         _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                       \
-            const int m_ = ld_s * KV + l_row[j];                                                              \
+            const int m_ = (s_begin + ld_s) * KV + l_row[j];                                                              \
             /* dY row m (rows beyond M and channels beyond the tensor fall outside the buffer -> zeros) */     \
             const bool okc_ = (dy_cb + (unsigned)l_kb[j]) < (unsigned)p.cdy * 2u;                              \
             const unsigned vo_dy = (m_ < p.M && okc_) ? (unsigned)m_ * (unsigned)(p.cdy * 2) + dy_cb + (unsigned)l_kb[j] : 0xFFFFFFFFu; \
@@ -174,7 +179,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradParams p)
     __syncthreads();
     if (grp == 0) {
         // accumulator: col = lane & 15 -> cin, row = 4 fg + r -> cout
-        const size_t tap_off = (size_t)tap * p.Cout * p.dw_ld + p.dw_ci_off;
+        const size_t tap_off = (size_t)split * p.slab_stride + (size_t)tap * p.Cout * p.dw_ld + p.dw_ci_off;
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll

@@ -209,6 +209,8 @@ struct ldm_model {
 };
 
 // ================================================================================================ builder
+static int wgrad_ksplit(long M, int taps, int cout, int cin);
+
 struct Builder {
     ldm_model* m; Plan* plan; Pool pool;
     size_t partial_off = 0, partial_bytes = 0;       // shared split-K slab scratch (sized at the end)
@@ -466,15 +468,16 @@ struct Builder {
         plan->ops.push_back(o);
         gslot[target.off] = sum;
     }
-    void emit_export(size_t src_off, int taps, int rows_total, int ld, int row_off, int col_off, int cout, int cin, int64_t flat_off) {
+    void emit_export(size_t src_off, int taps, int rows_total, int ld, int row_off, int col_off, int cout, int cin, int64_t flat_off,
+                     int nsplit = 1) {
         Op o{}; o.kind = OP_EXPORT; o.r[0] = ws_ref(src_off); o.r[1] = grad_ref(flat_off);
-        o.i[0] = taps; o.i[1] = rows_total; o.i[2] = ld; o.i[3] = row_off; o.i[4] = col_off; o.i[5] = cout; o.i[6] = cin;
+        o.i[0] = taps; o.i[1] = rows_total; o.i[2] = ld; o.i[3] = row_off; o.i[4] = col_off; o.i[5] = cout; o.i[6] = cin; o.i[7] = nsplit;
         plan->ops.push_back(o);
     }
     void export_conv_weights(const ConvW& w, int ld) {           // staging [taps][w.cout][ld] -> every parameter of the slot
         for (const ParamDesc& d : m->params)
             if ((d.kind == PK_CONV_W) && d.dst_off == w.w_off)
-                emit_export(dw_off, d.k * d.k * d.k, w.cout, ld, d.row_off, 0, d.cout, d.cin, d.flat_off);
+                emit_export(dw_off, d.k * d.k * d.k, w.cout, ld, d.row_off, 0, d.cout, d.cin, d.flat_off, cur_ksplit);
     }
     void export_bias(const ConvW& w) {                           // staging vector [couts] -> bias parameter(s) of the slot
         for (const ParamDesc& d : m->params)
@@ -500,8 +503,10 @@ struct Builder {
         int* i = o.i;
         i[0] = dy.C; i[1] = x.C; i[2] = cout; i[3] = cin; i[4] = ld; i[5] = ci_off; i[6] = x.N; i[7] = x.D; i[8] = x.H; i[9] = x.W;
         i[10] = dy.D; i[11] = dy.H; i[12] = dy.W; i[13] = k; i[14] = stride; i[15] = pad; i[16] = ups; i[17] = (int)dy.rows();
+        i[18] = cur_ksplit; i[19] = cur_rows_total;
         plan->ops.push_back(o);
     }
+    int cur_ksplit = 1, cur_rows_total = 0;           // voxel split / slab rows of the weight gradient being staged
     // dX of one source tensor `src` (channels [ci_off, ci_off + src.C) of the conv input) given dY.
     bool emit_dgrad(const Act& dy, const Act& src, const ConvW& w, int ci_off, int k, int stride, int pad, int ups) {
         if (stride == 2 && !(k == 3 && pad == 1)) { err = "backward of a stride-2 conv needs k = 3, pad = 1"; return false; }
@@ -538,6 +543,7 @@ struct Builder {
         if (a.w1) export_bias(*a.w1);
         if (a.temb_row >= 0) emit_colsum(dout, true, ws_ref(dtemb_off + (size_t)a.temb_row * 4), w.cout, tproj_stride);
         // weights
+        cur_ksplit = wgrad_ksplit(dout.rows(), a.k * a.k * a.k, w.cout, cin_real); cur_rows_total = w.cout;
         if (a.xb.valid) {
             emit_wgrad(dout, a.xa, w.cout, a.xa.C, cin_real, 0, a.k, a.stride, a.pad, a.ups);
             emit_wgrad(dout, a.xb, w.cout, a.xb.C, cin_real, a.xa.C, a.k, a.stride, a.pad, a.ups);
@@ -545,6 +551,7 @@ struct Builder {
         export_conv_weights(w, cin_real);
         if (a.w1) {
             const int c1 = a.g1a.C + (a.g1b.valid ? a.g1b.C : 0);
+            cur_ksplit = wgrad_ksplit(dout.rows(), 1, a.w1->cout, c1); cur_rows_total = a.w1->cout;
             emit_wgrad(dout, a.g1a, a.w1->cout, a.g1a.C, c1, 0, 1, 1, 0, 0);
             if (a.g1b.valid) emit_wgrad(dout, a.g1b, a.w1->cout, a.g1b.C, c1, a.g1a.C, 1, 1, 0, 0);
             export_conv_weights(*a.w1, c1);
@@ -823,8 +830,9 @@ static int unet_build(ldm_model* m, int B, int D, int H, int W, Plan* plan, bool
         for (auto& kv : m->convs) {
             const ConvW& w = kv.second; const size_t taps = (size_t)w.k * w.k * w.k;
             max_wt = std::max(max_wt, taps * rup(w.cin_s, 64) * rup(w.cout, 32) * 2);
-            max_dw = std::max(max_dw, taps * w.cout * w.cin_s * 4);
+            max_dw = std::max(max_dw, taps * rup(w.cout, 128) * rup(w.cin_s, 128) * 4);
         }
+        max_dw += (size_t)(512 + 64) * 65536;           // room for the voxel-split slabs (wgrad_ksplit keeps taps*tiles*ksplit <~ 512 tiles)
         b.wt_off = b.pool.alloc(max_wt); b.dw_off = b.pool.alloc(max_dw);
         b.vec_off = b.pool.alloc((size_t)std::max(4096, rows) * 4);
         b.dtemb_off = b.pool.alloc(((size_t)B * rows + 256) * 4);
@@ -1061,11 +1069,20 @@ static inline int grid_for(long total, int per_block = 256, int cap = 4096) {
     long g = (total + per_block - 1) / per_block; if (g > cap) g = cap; if (g < 1) g = 1; return (int)g;
 }
 
+// voxel-range split of the weight-gradient GEMM: enough workgroups for 2 waves of 256 CUs, at least 16 K steps each
+static int wgrad_ksplit(long M, int taps, int cout, int cin) {
+    const long wgs = (long)taps * ((cout + 127) / 128) * ((cin + 127) / 128);
+    const long steps = (M + 63) / 64;
+    long k = (512 + wgs - 1) / wgs;
+    if (k > steps / 16) k = steps / 16;
+    if (k > 16) k = 16;
+    return (int)(k < 1 ? 1 : k);
+}
 static int launch_wgrad(const WgradParams& p, hipStream_t s) {
     constexpr int LDS = 4 * 2 * 64 * 256;
     static bool attr_set = false;
     if (!attr_set) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr_set = true; }
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(p.co_tiles * p.ci_tiles * p.ksize * p.ksize * p.ksize), dim3(512), LDS, s, p);
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(p.co_tiles * p.ci_tiles * p.ksize * p.ksize * p.ksize * p.ksplit), dim3(512), LDS, s, p);
     return 0;
 }
 
@@ -1158,7 +1175,7 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
             // ------------------------------------------------------------------ backward ops
             case OP_WT: {
                 const int cols = rup(i[1], 32);
-                hipLaunchKernelGGL(weight_flip_transpose_kernel, dim3(grid_for((long)i[0] * i[4] * cols)), dim3(256), 0, s,
+                hipLaunchKernelGGL(weight_flip_transpose_kernel, dim3((cols + 63) / 64, (i[4] + 63) / 64, i[0]), dim3(256), 0, s,
                                    (const bf16_t*)rp(bs, o.r[0]), (bf16_t*)rp(bs, o.r[1]), i[0], i[1], i[2], i[3], i[4], i[5], i[6]);
                 break; }
             case OP_WGRAD: {
@@ -1167,17 +1184,18 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                 p.N = i[6]; p.Din = i[7]; p.Hin = i[8]; p.Win = i[9]; p.Dout = i[10]; p.Hout = i[11]; p.Wout = i[12];
                 p.ksize = i[13]; p.stride = i[14]; p.pad = i[15]; p.ups = i[16]; p.M = i[17];
                 p.co_tiles = (p.Cout + 127) / 128; p.ci_tiles = (p.Cin + 127) / 128;
+                p.ksplit = i[18]; p.slab_stride = (long)i[13] * i[13] * i[13] * i[19] * i[4];
                 if ((long)p.M * p.cdy * 2 >= (1L << 32) || (long)p.N * p.Din * p.Hin * p.Win * p.cx * 2 >= (1L << 32))
                     return fail(LDM_ERR_UNSUPPORTED, "weight gradient: tensor exceeds 4 GiB");
                 LDM_TRY(launch_wgrad(p, s));
                 break; }
             case OP_EXPORT:
                 hipLaunchKernelGGL(grad_export_kernel, dim3((i[6] + 63) / 64, i[5]), dim3(256), 0, s, (const float*)rp(bs, o.r[0]),
-                                   (float*)rp(bs, o.r[1]), i[0], i[1], i[2], i[3], i[4], i[5], i[6]);
+                                   (float*)rp(bs, o.r[1]), i[0], i[1], i[2], i[3], i[4], i[5], i[6], i[7] < 1 ? 1 : i[7],
+                                   (long)i[0] * i[1] * i[2]);
                 break;
             case OP_COLSUM: {
-                const int n = i[3] ? i[4] : i[0] * i[4];
-                hipLaunchKernelGGL(colsum_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const float*)rp(bs, o.r[4]),
+                hipLaunchKernelGGL(colsum_finalize_kernel, dim3((i[4] + 15) / 16, i[3] ? 1 : i[0]), dim3(256), 0, s, (const float*)rp(bs, o.r[4]),
                                    (float*)rp(bs, o.r[0]), i[0], i[1], i[2], i[3], i[4], i[5]);
                 break; }
             case OP_GNB: {
@@ -1186,16 +1204,19 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                 p.gamma = (const float*)rp(bs, o.r[6]); p.groups = i[2]; p.DHW = i[3]; p.N = i[4]; p.silu = i[5]; p.nslab = i[6];
                 p.rows_per_slab = i[7]; p.partial = (float*)rp(bs, o.r[4]); p.gsum = (float*)rp(bs, o.r[7]);
                 p.dgamma_n = (float*)rp(bs, o.r[8]); p.dbeta_n = (float*)rp(bs, o.r[9]);
+                if (i[4] == 1 && bs.p[BASE_IO4]) { p.dgamma_n = (float*)bs.p[BASE_IO4] + i[8]; p.dbeta_n = (float*)bs.p[BASE_IO4] + i[9]; }
                 p.acc_a = (const bf16_t*)rp(bs, o.r[10]); p.acc_b = (const bf16_t*)rp(bs, o.r[11]);
                 p.dxa = (bf16_t*)rp(bs, o.r[12]); p.dxb = (bf16_t*)rp(bs, o.r[13]);
                 const int C = i[0] + i[1];
                 float* flat = (float*)bs.p[BASE_IO4];
                 if (!flat) return fail(LDM_ERR_BAD_ARG, "backward without a gradient buffer");
                 hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(i[6], i[4]), dim3(256), 0, s, p);
-                hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(i[2], i[4]), dim3(64), 0, s, p);
+                hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(i[2], i[4]), dim3(256), 0, s, p);
                 hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid_for((long)i[4] * i[3] * (C / 8), 256, 2048)), dim3(256), 0, s, p);
-                hipLaunchKernelGGL(rowsum_n_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)p.dgamma_n, flat + i[8], i[4], C);
-                hipLaunchKernelGGL(rowsum_n_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)p.dbeta_n, flat + i[9], i[4], C);
+                if (i[4] > 1) {
+                    hipLaunchKernelGGL(rowsum_n_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)p.dgamma_n, flat + i[8], i[4], C);
+                    hipLaunchKernelGGL(rowsum_n_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)p.dbeta_n, flat + i[9], i[4], C);
+                }
                 break; }
             case OP_ATTN_BWD: {
                 AttnBwdParams p{}; p.qkv = (const bf16_t*)rp(bs, o.r[0]); p.o = (const bf16_t*)rp(bs, o.r[1]); p.d_o = (const bf16_t*)rp(bs, o.r[2]);
@@ -1677,15 +1698,16 @@ int ldm_op_group_norm(const void* xa, int ca, const void* xb, int cb, const floa
 int ldm_op_weight_flip_transpose(const void* w, void* wt, int ksize, int cout, int cout_pad, int cin, void* stream) {
     if (!w || !wt || (ksize != 1 && ksize != 3) || cout < 1 || cin < 1 || cout_pad < cout) return fail(LDM_ERR_BAD_ARG, "bad argument");
     const int taps = ksize * ksize * ksize, rows = rup(cin, 64), cols = rup(cout, 32);
-    hipLaunchKernelGGL(weight_flip_transpose_kernel, dim3(grid_for((long)taps * rows * cols)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(weight_flip_transpose_kernel, dim3((cols + 63) / 64, (rows + 63) / 64, taps), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)w, (bf16_t*)wt, taps, cout, cout_pad, cin, rows, 0, cin);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
-/* dW[tap][co][ci] (fp32, [k^3][cout][cin]) of y = conv3d(x, w): dy [M][cdy] and x [rows][cx] are NDHWC bf16. */
+/* dW[tap][co][ci] (fp32, [k^3][cout][cin]) of y = conv3d(x, w): dy [M][cdy] and x [rows][cx] are NDHWC bf16.
+ * ksplit > 1 splits the voxel range: dw then holds ksplit partial matrices [ksplit][k^3][cout][cin] to be summed. */
 int ldm_op_conv3d_wgrad(const void* dy, int cdy, const void* x, int cx, float* dw, int cout, int cin,
-                        int N, int Din, int Hin, int Win, int ksize, int stride, int pad, int ups, void* stream) {
+                        int N, int Din, int Hin, int Win, int ksize, int stride, int pad, int ups, int ksplit, void* stream) {
     if (!dy || !x || !dw) return fail(LDM_ERR_BAD_ARG, "null tensor argument");
     if (cdy % 32 || cx % 32 || cout < 1 || cin < 1 || cout > cdy || cin > cx) return fail(LDM_ERR_BAD_ARG, "bad channel counts");
     if ((ksize != 1 && ksize != 3) || stride < 1 || stride > 2 || ups < 0 || ups > 1) return fail(LDM_ERR_UNSUPPORTED, "ksize 1|3, stride 1|2, ups 0|1");
@@ -1698,6 +1720,8 @@ int ldm_op_conv3d_wgrad(const void* dy, int cdy, const void* x, int cx, float* d
     WgradParams p{}; p.dy = (const bf16_t*)dy; p.cdy = cdy; p.x = (const bf16_t*)x; p.cx = cx; p.dw = dw; p.Cout = cout; p.Cin = cin; p.dw_ld = cin; p.dw_ci_off = 0;
     p.N = N; p.Din = Din; p.Hin = Hin; p.Win = Win; p.Dout = Do; p.Hout = Ho; p.Wout = Wo; p.ksize = ksize; p.stride = stride; p.pad = pad; p.ups = ups;
     p.M = (int)M; p.co_tiles = (cout + 127) / 128; p.ci_tiles = (cin + 127) / 128;
+    if (ksplit < 1 || ksplit > 64) return fail(LDM_ERR_BAD_ARG, "ksplit must be in 1..64");
+    p.ksplit = ksplit; p.slab_stride = (long)ksize * ksize * ksize * cout * cin;
     LDM_TRY(launch_wgrad(p, (hipStream_t)stream));
     HIP_TRY(hipGetLastError());
     return 0;
@@ -1737,7 +1761,7 @@ int ldm_op_group_norm_bwd(const void* dy, const void* xa, int ca, const void* xb
     bp.groups = groups; bp.DHW = DHW; bp.N = N; bp.silu = silu; bp.nslab = nslab; bp.rows_per_slab = rps; bp.partial = partial; bp.gsum = gsum;
     bp.dgamma_n = dgn; bp.dbeta_n = dbn; bp.acc_a = (const bf16_t*)acc_a; bp.acc_b = (const bf16_t*)acc_b; bp.dxa = (bf16_t*)dxa; bp.dxb = (bf16_t*)dxb;
     hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(nslab, N), dim3(256), 0, s, bp);
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(groups, N), dim3(64), 0, s, bp);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(groups, N), dim3(256), 0, s, bp);
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid_for((long)N * DHW * cvec, 256, 2048)), dim3(256), 0, s, bp);
     // parameter gradients: sum the per-sample rows (reuses the column-sum finalize with nslab = 1 layout [N][1][C][2]? no: plain loop)
     hipLaunchKernelGGL(rowsum_n_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)dgn, dgamma, N, C);

@@ -322,17 +322,24 @@ __global__ __launch_bounds__(256) void weight_flip_transpose_kernel(const bf16_t
                                                                     int taps, int cout, int cout_pad, int cin, int cin_pad_rows,
                                                                     int ci_off, int ci_cnt) {
     // w: [taps][cout_pad][cin];  wt: [taps][cin_pad_rows][round32(cout)] holding input channels [ci_off, ci_off + ci_cnt)
-    // (one matrix per source tensor of a channel-concatenated conv input)
+    // (one matrix per source tensor of a channel-concatenated conv input).  64 x 64 tiles through LDS so that both the
+    // reads (ci contiguous) and the writes (co contiguous) are coalesced.  grid = (col tiles, row tiles, taps).
+    __shared__ bf16_t tile[64][66];
     const int cols = (cout + 31) / 32 * 32;
-    const long total = (long)taps * cin_pad_rows * cols;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int co = (int)(i % cols);
-        const long r = i / cols;
-        const int ci = (int)(r % cin_pad_rows);
-        const int tp = (int)(r / cin_pad_rows);
-        bf16_t v = 0;
-        if (co < cout && ci < ci_cnt) v = w[((size_t)(taps - 1 - tp) * cout_pad + co) * cin + ci_off + ci];
-        wt[i] = v;
+    const int tp = blockIdx.z, co0 = blockIdx.x * 64, ci0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const bf16_t* src = w + (size_t)(taps - 1 - tp) * cout_pad * cin;
+#pragma unroll 4
+    for (int r = ty; r < 64; r += 4) {                   // r = cout row of the tile, tx = cin column
+        const int co = co0 + r, ci = ci0 + tx;
+        tile[r][tx] = (co < cout && ci < ci_cnt) ? src[(size_t)co * cin + ci_off + ci] : (bf16_t)0;
+    }
+    __syncthreads();
+    bf16_t* dst = wt + (size_t)tp * cin_pad_rows * cols;
+#pragma unroll 4
+    for (int r = ty; r < 64; r += 4) {                   // r = cin row of the output, tx = cout column
+        const int ci = ci0 + r, co = co0 + tx;
+        if (ci < cin_pad_rows && co < cols) dst[(size_t)ci * cols + co] = tile[tx][r];
     }
 }
 
@@ -419,26 +426,53 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const GnBwdParams p) 
 }
 
 // Pass 2: one block per (sample, group): per-channel totals -> dgamma/dbeta (per sample), group means of gamma*g(.xhat).
-__global__ __launch_bounds__(64) void gn_bwd_finalize_kernel(const GnBwdParams p) {
-    const int n = blockIdx.y, g = blockIdx.x, lane = threadIdx.x;
+// 256 threads = (channel of the group) x (slab lanes) when channels-per-group divides 256, else channel by channel.
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const GnBwdParams p) {
+    __shared__ float r1[256], r2[256];
+    const int n = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
     const int C = p.ca + p.cb, cpg = C / p.groups;
-    double S1 = 0.0, S2 = 0.0;
-    for (int c = g * cpg + lane; c < (g + 1) * cpg; c += 64) {
-        double t1 = 0.0, t2 = 0.0;
-        for (int s = 0; s < p.nslab; ++s) {
-            const float* src = p.partial + (((size_t)n * p.nslab + s) * C + c) * 2;
-            t1 += (double)src[0]; t2 += (double)src[1];
+    float S1 = 0.f, S2 = 0.f;                            // valid on tid 0 after the loop
+    if (cpg <= 256 && 256 % cpg == 0) {
+        const int cl = tid % cpg, sl = tid / cpg, lanes = 256 / cpg, c = g * cpg + cl;
+        float t1 = 0.f, t2 = 0.f;
+        for (int s = sl; s < p.nslab; s += lanes) {
+            const float2 v = *reinterpret_cast<const float2*>(p.partial + (((size_t)n * p.nslab + s) * C + c) * 2);
+            t1 += v.x; t2 += v.y;
         }
-        p.dbeta_n[(size_t)n * C + c] = (float)t1;
-        p.dgamma_n[(size_t)n * C + c] = (float)t2;
-        S1 += (double)p.gamma[c] * t1; S2 += (double)p.gamma[c] * t2;
+        r1[tid] = t1; r2[tid] = t2;
+        __syncthreads();
+        float a1 = 0.f, a2 = 0.f;
+        if (tid < cpg) {
+            for (int k = 0; k < lanes; ++k) { a1 += r1[k * cpg + tid]; a2 += r2[k * cpg + tid]; }
+            p.dbeta_n[(size_t)n * C + c] = a1;
+            p.dgamma_n[(size_t)n * C + c] = a2;
+            a1 *= p.gamma[c]; a2 *= p.gamma[c];
+        }
+        __syncthreads();
+        r1[tid] = a1; r2[tid] = a2;
+        __syncthreads();
+        if (tid == 0) for (int k = 0; k < cpg; ++k) { S1 += r1[k]; S2 += r2[k]; }
+    } else {
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+            float t1 = 0.f, t2 = 0.f;
+            for (int s = tid; s < p.nslab; s += 256) {
+                const float* src = p.partial + (((size_t)n * p.nslab + s) * C + c) * 2;
+                t1 += src[0]; t2 += src[1];
+            }
+            r1[tid] = t1; r2[tid] = t2;
+            __syncthreads();
+            for (int o = 128; o > 0; o >>= 1) { if (tid < o) { r1[tid] += r1[tid + o]; r2[tid] += r2[tid + o]; } __syncthreads(); }
+            if (tid == 0) {
+                p.dbeta_n[(size_t)n * C + c] = r1[0]; p.dgamma_n[(size_t)n * C + c] = r2[0];
+                S1 += p.gamma[c] * r1[0]; S2 += p.gamma[c] * r2[0];
+            }
+            __syncthreads();
+        }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { S1 += __shfl_xor(S1, o, 64); S2 += __shfl_xor(S2, o, 64); }
-    if (lane == 0) {
-        const double cnt = (double)cpg * (double)p.DHW;
-        p.gsum[((size_t)n * p.groups + g) * 2] = (float)(S1 / cnt);
-        p.gsum[((size_t)n * p.groups + g) * 2 + 1] = (float)(S2 / cnt);
+    if (tid == 0) {
+        const float cnt = (float)cpg * (float)p.DHW;
+        p.gsum[((size_t)n * p.groups + g) * 2] = S1 / cnt;
+        p.gsum[((size_t)n * p.groups + g) * 2 + 1] = S2 / cnt;
     }
 }
 
@@ -510,19 +544,22 @@ __global__ __launch_bounds__(256) void mse_grad_pack_kernel(const float* __restr
 //   gradient).  Only the first `count` channels are written.
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partial, float* __restrict__ out,
                                                               int N, int nslab, int C, int accumulate_over_n, int count, int out_stride) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (accumulate_over_n) {
-        if (i >= count) return;
-        double t = 0.0;
-        for (int n = 0; n < N; ++n)
-            for (int s = 0; s < nslab; ++s) t += (double)partial[(((size_t)n * nslab + s) * C + i) * 2];
-        out[i] = (float)t;
-    } else {
-        if (i >= N * count) return;
-        const int n = i / count, c = i - n * count;
-        double t = 0.0;
-        for (int s = 0; s < nslab; ++s) t += (double)partial[(((size_t)n * nslab + s) * C + c) * 2];
-        out[(size_t)n * out_stride + c] = (float)t;
+    // grid = (ceil(count / 16), accumulate_over_n ? 1 : N); block = 16 channels x 16 slab lanes
+    __shared__ float red[256];
+    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    const int n0 = accumulate_over_n ? 0 : blockIdx.y, n1 = accumulate_over_n ? N : blockIdx.y + 1;
+    float t = 0.f;
+    if (c < count)
+        for (int n = n0; n < n1; ++n)
+            for (int s = sl; s < nslab; s += 16) t += partial[(((size_t)n * nslab + s) * C + c) * 2];
+    red[threadIdx.x] = t;
+    __syncthreads();
+    if (sl == 0 && c < count) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a += red[k * 16 + cl];
+        out[accumulate_over_n ? (size_t)c : (size_t)blockIdx.y * out_stride + c] = a;
     }
 }
 
@@ -656,13 +693,20 @@ __global__ __launch_bounds__(256) void param_pack_kernel(const float* __restrict
     }
 }
 __global__ __launch_bounds__(256) void grad_export_kernel(const float* __restrict__ src, float* __restrict__ dst,
-                                                          int taps, int rows_total, int ld, int row_off, int col_off, int cout, int cin) {
+                                                          int taps, int rows_total, int ld, int row_off, int col_off, int cout, int cin,
+                                                          int nsplit, long slab_stride) {
+    // src may hold `nsplit` partial matrices (the weight-gradient kernel splits the voxel range): folded here, in order
     __shared__ float tile[64 * 27];
     const int co = blockIdx.y, ci0 = blockIdx.x * 64, tid = threadIdx.x;
     int nci = cin - ci0; if (nci > 64) nci = 64;
     for (int i = tid; i < taps * 64; i += 256) {
         const int t = i >> 6, c = i & 63;
-        if (c < nci) tile[c * taps + t] = src[((size_t)t * rows_total + row_off + co) * ld + col_off + ci0 + c];
+        if (c < nci) {
+            const float* sp = src + ((size_t)t * rows_total + row_off + co) * ld + col_off + ci0 + c;
+            float v = sp[0];
+            for (int k = 1; k < nsplit; ++k) v += sp[(size_t)k * slab_stride];
+            tile[c * taps + t] = v;
+        }
     }
     __syncthreads();
     float* d = dst + ((size_t)co * cin + ci0) * taps;

@@ -1,0 +1,142 @@
+"""Data-parallel training step of the latent-diffusion UNet.
+
+Reference behaviour being reproduced (3d_ldm/train_diffusion.py):
+  :100-124  scale_factor = 1 / std(AE.encode_stage_2_inputs(first label batch)), averaged over ranks
+  :147-149  DDP wrap: parameters broadcast from rank 0, gradients averaged over ranks during backward
+  :155-156  Adam(lr) + MultiStepLR(milestones=[100, 1000], gamma=0.1), stepped once per epoch (:222-223)
+  :172-223  per batch: noise drawn on the HOST then moved (:182), timesteps = randint on the device (:185-187),
+            image latents (condition) under no_grad (:194-195), inferer(..., mode="concat") (:197-205), MSE (:207),
+            NaN -> skip (:210-212), backward (:214), clip_grad_norm_(1.0) (:217), optimizer step (:219)
+
+MI355X design: one process per GPU; the UNet's gradients live in ONE flat fp32 buffer written in place by the
+hand-written backward plan, so the data-parallel exchange is a single (optionally chunked) all-reduce over RCCL/xGMI
+issued right after backward, and clip + Adam are two fused launches over the flat buffers (``FlatAdam``).  Two
+reference quirks are fixed on purpose: the NaN-skip is agreed across ranks with a MAX
+all-reduce (a single rank skipping ``backward`` dead-locks DDP in the reference), and the label encode that the
+reference runs only to learn the latent shape (:179-181) is not executed (``reference_rng_order=True`` restores it).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+
+class GradSync:
+    """Collectives of the data-parallel trainer over torch.distributed ("nccl" = RCCL on ROCm; "gloo" in CPU tests)."""
+
+    def __init__(self, chunk_elems: int = 1 << 26):
+        self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.world = dist.get_world_size() if self.on else 1
+        self.chunk = int(chunk_elems)                    # 64 Mi elements = 256 MB per collective
+        self._avg = self.on and dist.get_backend() == "nccl"
+
+    def broadcast(self, flat: torch.Tensor, src: int = 0) -> None:
+        """Parameter broadcast at wrap time (what DistributedDataParallel.__init__ does)."""
+        if self.on:
+            dist.broadcast(flat, src=src)
+
+    def mean_(self, flat: torch.Tensor) -> torch.Tensor:
+        """In-place mean over ranks of a flat buffer; chunks are queued asynchronously and waited for together."""
+        if not self.on:
+            return flat
+        works = []
+        for lo in range(0, flat.numel(), self.chunk):
+            part = flat[lo:lo + self.chunk]
+            works.append(dist.all_reduce(part, op=dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM, async_op=True))
+        for w in works:
+            w.wait()
+        if not self._avg:
+            flat.mul_(1.0 / self.world)
+        return flat
+
+    def any(self, flag: torch.Tensor) -> torch.Tensor:
+        """Logical OR over ranks of a 0/1 device scalar (the agreed NaN-skip)."""
+        if self.on:
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        return flag
+
+    def mean_scalar(self, t: torch.Tensor) -> torch.Tensor:
+        if not self.on:
+            return t
+        t = t.clone()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t / self.world
+
+
+@torch.no_grad()
+def compute_scale_factor(autoencoder, labels: torch.Tensor, sync: Optional[GradSync] = None) -> torch.Tensor:
+    """1 / std of the label latents of the first batch, averaged over ranks (train_diffusion.py:100-124)."""
+    z = autoencoder.encode_stage_2_inputs(labels)
+    sf = 1.0 / torch.std(z)
+    return (sync or GradSync()).mean_scalar(sf)
+
+
+class DiffusionTrainer:
+    def __init__(self, unet, autoencoder, inferer, lr: float, max_grad_norm: float = 1.0, milestones=(100, 1000),
+                 gamma: float = 0.1, reference_rng_order: bool = False):
+        from .optim import FlatAdam
+        self.unet, self.autoencoder, self.inferer = unet, autoencoder, inferer
+        self.sync = GradSync()
+        self.optimizer = FlatAdam(unet, lr=lr, max_grad_norm=max_grad_norm)      # flattens the parameters
+        self.sync.broadcast(unet.flat_params, 0)
+        unet.mark_weights_dirty()
+        self.lr_scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optimizer, milestones=list(milestones), gamma=gamma)
+        self.reference_rng_order = reference_rng_order
+        self.factor = getattr(autoencoder, "factor", 4)
+
+    def _draw(self, labels: torch.Tensor):
+        B = labels.shape[0]
+        lat = [s // self.factor for s in labels.shape[2:]]
+        if self.reference_rng_order:
+            with torch.no_grad():
+                lat = list(self.autoencoder.encode_stage_2_inputs(labels).shape[2:])
+        noise = torch.randn((B, self.autoencoder.latent_channels, *lat), dtype=torch.float32).to(labels.device)
+        timesteps = torch.randint(0, self.inferer.scheduler.num_train_timesteps, (B,), device=labels.device).long()
+        return noise, timesteps
+
+    def _predict(self, images, labels, noise, timesteps):
+        with torch.no_grad():
+            image_latents = self.autoencoder.encode_stage_2_inputs(images)
+        return self.inferer(inputs=labels, autoencoder_model=self.autoencoder, diffusion_model=self.unet, noise=noise,
+                            timesteps=timesteps, condition=image_latents, mode="concat")
+
+    def train_step(self, images: torch.Tensor, labels: torch.Tensor, noise: Optional[torch.Tensor] = None,
+                   timesteps: Optional[torch.Tensor] = None):
+        """One optimizer step.  Returns (loss [device scalar], skipped [bool])."""
+        self.unet.train()
+        images, labels = images.float(), labels.float()
+        self.optimizer.zero_grad(set_to_none=True)
+        if noise is None or timesteps is None:
+            n2, t2 = self._draw(labels)
+            noise = n2 if noise is None else noise
+            timesteps = t2 if timesteps is None else timesteps
+        noise_pred = self._predict(images, labels, noise, timesteps)
+        loss = F.mse_loss(noise_pred.float(), noise.float())
+        bad = self.sync.any(torch.isnan(loss.detach()).to(torch.float32))
+        if float(bad) > 0.0:                              # every rank skips together
+            return loss.detach(), True
+        loss.backward()
+        self.sync.mean_(self.unet.flat_grads)
+        self.optimizer.step()
+        return loss.detach(), False
+
+    def end_epoch(self):
+        self.lr_scheduler.step()
+
+    @torch.no_grad()
+    def validate(self, loader, device) -> float:
+        """Mean training-style loss over the loader, NaN batches skipped, averaged over ranks (:231-283)."""
+        self.unet.eval()
+        total, n = torch.zeros((), device=device), 0
+        for batch in loader:
+            images, labels = batch["image"].to(device).float(), batch["label"].to(device).float()
+            noise, timesteps = self._draw(labels)
+            v = F.mse_loss(self._predict(images, labels, noise, timesteps).float(), noise.float())
+            if not bool(torch.isnan(v)):
+                total += v
+                n += 1
+        val = total / n if n else torch.tensor(float("inf"), device=device)
+        return float(self.sync.mean_scalar(val))

@@ -164,9 +164,10 @@ int ldm_op_conv3d(const void* xa, int ca, const void* xb, int cb, const void* w,
  *      data gradient of a conv = ldm_op_conv3d on dY with flipped + transposed weights (ldm_op_weight_flip_transpose),
  *      pad' = k-1-pad; for a stride-2 forward conv pass ups = 2 (zero-insertion upsample: odd tap positions read 0). */
 int ldm_op_weight_flip_transpose(const void* w, void* wt, int ksize, int cout, int cout_pad, int cin, void* stream);
-/*      weight gradient: dw[tap][co][ci] (fp32) = sum_m dy[m][co] * x[src(m, tap)][ci]; deterministic (no atomics). */
+/*      weight gradient: dw[tap][co][ci] (fp32) = sum_m dy[m][co] * x[src(m, tap)][ci]; deterministic (no atomics).
+ *      ksplit > 1 splits the voxel range over workgroups: dw = ksplit partial matrices [ksplit][k^3][cout][cin] to sum. */
 int ldm_op_conv3d_wgrad(const void* dy, int cdy, const void* x, int cx, float* dw, int cout, int cin,
-                        int N, int Din, int Hin, int Win, int ksize, int stride, int pad, int ups, void* stream);
+                        int N, int Din, int Hin, int Win, int ksize, int stride, int pad, int ups, int ksplit, void* stream);
 /*      backward of y = act(GroupNorm(cat(xa, xb))): dxa, dxb (bf16 NDHWC, plus acc_a / acc_b when given), dgamma, dbeta (fp32). */
 size_t ldm_op_group_norm_bwd_scratch_bytes(int N, int C, int DHW, int groups);
 int ldm_op_group_norm_bwd(const void* dy, const void* xa, int ca, const void* xb, int cb, const float* gamma, const float* beta,

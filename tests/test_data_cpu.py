@@ -1,0 +1,48 @@
+"""Paired-volume data path (3d_ldm/utils.py:66-240) - CPU only."""
+import argparse
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from ldm3d import data
+
+
+def test_npz_pair_keys_and_shape_checks(tmp_path):
+    vol = np.arange(2 * 4 * 5 * 6, dtype=np.float32).reshape(2, 4, 5, 6)
+    for key in ("arr0", "arr_0", "whatever"):
+        p = tmp_path / f"{key}.npz"
+        np.savez(p, **{key: vol})
+        low, high = data.load_pair(str(p))
+        assert np.array_equal(low, vol[0]) and np.array_equal(high, vol[1])
+    bad = tmp_path / "bad.npz"
+    np.savez(bad, arr0=vol[0])
+    with pytest.raises(RuntimeError):
+        data.load_pair(str(bad))
+
+
+def test_center_crop_and_percentile_scaling_known_answers():
+    assert data.crop_start((10, 11, 12), (4, 4, 4), None) == [3, 3, 4]
+    assert data.crop_start((3, 11, 12), (4, 4, 4), None) == [0, 3, 4]          # roi clipped to the volume
+    v = np.arange(1001, dtype=np.float32).reshape(1, 7, 11, 13)
+    s = data.scale_percentiles(v)                                               # a_min = 0, a_max = p99.5 = 995
+    assert s.min() == 0.0 and abs(float(s.reshape(-1)[995]) - 1.0) < 1e-6
+    assert float(s.max()) > 1.0                                                 # no clipping (MONAI default clip=False)
+    assert np.all(data.scale_percentiles(np.full((2, 2, 2), 3.0, np.float32)) == 0.0)
+
+
+def test_loader_split_crop_and_pairing(tmp_path):
+    files = data.write_synthetic_pairs(str(tmp_path / "d"), 5, (12, 10, 8), seed=1)
+    assert len(files) == 5
+    args = argparse.Namespace(npz_dir=str(tmp_path / "d"), seed=0, val_fraction=0.2)
+    tr, va = data.split_files(args)
+    assert len(tr) == 4 and len(va) == 1 and not set(tr) & set(va)
+    tl, vl = data.prepare_dataloader(args, 2, (8, 8, 8))
+    b = next(iter(tl))
+    assert b["image"].shape == (2, 1, 8, 8, 8) and b["label"].shape == (2, 1, 8, 8, 8) and b["image"].dtype == torch.float32
+    assert float(b["label"].min()) == 0.0
+    ds = data.PairVolumes(tr, (8, 8, 8), randcrop=True, seed=3)
+    assert torch.equal(ds[1]["label"], ds[1]["label"])                          # deterministic per (seed, index)
+    with pytest.raises(ValueError):
+        data.split_files(argparse.Namespace(npz_dir=str(tmp_path / "none")))

@@ -232,7 +232,7 @@ def test_conv_dgrad(cuda, built_lib, cin, cout, dims, k, stride, pad):
     assert err <= TOL_SAME_ROUNDING, err
 
 
-def _wgrad_case(cuda, lib, cin, cout, dims, k, stride, pad, n=1, ups=0, seed=0):
+def _wgrad_case(cuda, lib, cin, cout, dims, k, stride, pad, n=1, ups=0, seed=0, ksplit=1):
     from ldm3d import _lib
     g = torch.Generator().manual_seed(seed)
     x = bf16_round(torch.randn((n, cin, *dims), generator=g))
@@ -243,12 +243,12 @@ def _wgrad_case(cuda, lib, cin, cout, dims, k, stride, pad, n=1, ups=0, seed=0):
     (ref,) = torch.autograd.grad(y, w, dy)                                  # [cout][cin][k][k][k]
     ref = ref.reshape(cout, cin, k ** 3).permute(2, 0, 1).contiguous()       # -> [taps][cout][cin]
     xd, dyd = to_ndhwc_bf16(x).to(cuda), to_ndhwc_bf16(dy).to(cuda)
-    dw = torch.full((k ** 3, cout, cin), float("nan"), dtype=torch.float32, device=cuda)
+    dw = torch.full((ksplit, k ** 3, cout, cin), float("nan"), dtype=torch.float32, device=cuda)
     _lib.check(lib.ldm_op_conv3d_wgrad(dyd.data_ptr(), dyd.shape[-1], xd.data_ptr(), xd.shape[-1], dw.data_ptr(), cout, cin,
-                                       n, *dims, k, stride, pad, ups, torch.cuda.current_stream().cuda_stream))
+                                       n, *dims, k, stride, pad, ups, ksplit, torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
     assert torch.isfinite(dw).all()
-    return rel_l2(dw.cpu(), ref)
+    return rel_l2(dw.sum(0).cpu(), ref)
 
 
 @pytest.mark.parametrize("cin,cout,dims,k,stride,pad,n,ups", [
@@ -258,6 +258,14 @@ def _wgrad_case(cuda, lib, cin, cout, dims, k, stride, pad, n=1, ups=0, seed=0):
 def test_conv_wgrad(cuda, built_lib, cin, cout, dims, k, stride, pad, n, ups):
     """fp32 output, fp32 accumulation over voxels: only summation order separates it from autograd."""
     err = _wgrad_case(cuda, built_lib, cin, cout, dims, k, stride, pad, n, ups)
+    assert err <= 2e-5, err
+
+
+@pytest.mark.parametrize("dims,n,ksplit", [((12, 12, 12), 1, 3), ((6, 6, 6), 1, 4), ((2, 2, 2), 2, 1), ((5, 3, 2), 1, 2), ((24, 24, 24), 1, 5)])
+def test_conv_wgrad_voxel_split_and_tiny_volumes(cuda, built_lib, dims, n, ksplit):
+    """Voxel range split over workgroups (partial matrices summed by the caller), including splits that end up empty
+    and volumes smaller than one 64-voxel K step."""
+    err = _wgrad_case(cuda, built_lib, 64, 96, dims, 3, 1, 1, n, 0, ksplit=ksplit)
     assert err <= 2e-5, err
 
 

@@ -1,0 +1,149 @@
+#!/usr/bin/env python3
+"""train_diffusion.py - same command line, JSON schema, checkpoint names and per-step order as the reference's
+3d_ldm/train_diffusion.py (:24-38 flags, :58-64 config merge, :90-124 autoencoder + scale factor, :127-156 UNet /
+scheduler / inferer / Adam / MultiStepLR, :166-305 epoch loop with validation and rank-0 checkpoints), on the
+MI355X-native path.
+
+    python train_diffusion.py -e config/environment.json -c config/config_train_16g.json -g 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 train_diffusion.py ... -g 8
+
+Opt-in extras (never on by default): --random-init (no autoencoder checkpoint: smoke / benchmark runs),
+--synthetic N (write N synthetic NPZ pairs into npz_dir first), --max-steps K (stop after K optimizer steps),
+--reference-rng-order (also run the label encode the reference uses only to learn the latent shape).
+Scalars go to <tfevent_path>/diffusion/scalars.jsonl (tensorboard is not a dependency here)."""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    parser = argparse.ArgumentParser(description="Latent diffusion model training (MI355X-native)")
+    parser.add_argument("-e", "--environment-file", default="./config/environment.json")
+    parser.add_argument("-c", "--config-file", default="./config/config_train_32g.json")
+    parser.add_argument("-g", "--gpus", default=1, type=int, help="number of gpus per node")
+    parser.add_argument("--random-init", action="store_true")
+    parser.add_argument("--synthetic", type=int, default=0)
+    parser.add_argument("--max-steps", type=int, default=0)
+    parser.add_argument("--reference-rng-order", action="store_true")
+    args = parser.parse_args()
+
+    import torch
+    from ldm3d import parallel
+    from ldm3d.config import define_instance
+    from ldm3d.data import prepare_dataloader, write_synthetic_pairs
+    from ldm3d.inferer import LatentDiffusionInferer
+    from ldm3d.schedulers import DDPMScheduler
+    from ldm3d.trainer import DiffusionTrainer, GradSync, compute_scale_factor
+
+    ddp = args.gpus > 1
+    rank = int(os.environ.get("LOCAL_RANK", "0")) if ddp else 0
+    world = int(os.environ.get("WORLD_SIZE", "1")) if ddp else 1
+    if ddp:
+        parallel.setup_ddp(int(os.environ.get("RANK", rank)), world)
+    device = torch.device("cuda", rank)
+    torch.cuda.set_device(device)
+    torch.set_num_threads(4)
+
+    for path in (args.environment_file, args.config_file):
+        for k, v in json.load(open(path)).items():
+            setattr(args, k, v)
+    torch.manual_seed(42)                               # set_determinism(42), train_diffusion.py:66
+
+    tcfg = args.diffusion_train
+    if args.synthetic and rank == 0:
+        write_synthetic_pairs(args.npz_dir, args.synthetic, tcfg["patch_size"], seed=int(getattr(args, "seed", 0)))
+    if ddp:
+        torch.distributed.barrier()
+    train_loader, val_loader = prepare_dataloader(args, tcfg["batch_size"], tcfg["patch_size"], randcrop=False, rank=rank,
+                                                  world_size=world)
+    log = None
+    if rank == 0:
+        tb = os.path.join(getattr(args, "tfevent_path", os.path.join(args.model_dir, "tfevent")), "diffusion")
+        Path(tb).mkdir(parents=True, exist_ok=True)
+        Path(args.model_dir).mkdir(parents=True, exist_ok=True)
+        log = open(os.path.join(tb, "scalars.jsonl"), "a")
+
+    def scalar(tag, value, step):
+        if log:
+            log.write(json.dumps({"tag": tag, "value": float(value), "step": int(step), "time": time.time()}) + "\n")
+            log.flush()
+
+    autoencoder = define_instance(args, "autoencoder_def")
+    if not args.random_init:
+        autoencoder.load_state_dict(torch.load(os.path.join(args.model_dir, "autoencoder.pt"), map_location="cpu", weights_only=True))
+    else:
+        with torch.no_grad():
+            for p in autoencoder.parameters():
+                if p.dim() > 1 and float(p.abs().max()) == 0.0:
+                    p.normal_(0.0, 0.02)
+    autoencoder = autoencoder.to(device).eval()
+
+    first = next(iter(train_loader))
+    scale_factor = compute_scale_factor(autoencoder, first["label"].to(device).float(), GradSync())
+    print(f"Rank {rank}: scale_factor -> {float(scale_factor):.6f}")
+
+    unet = define_instance(args, "diffusion_def")
+    best_path = os.path.join(args.model_dir, "diffusion_unet.pt")
+    last_path = os.path.join(args.model_dir, "diffusion_unet_last.pt")
+    if getattr(args, "resume_ckpt", False) and os.path.exists(best_path):
+        unet.load_state_dict(torch.load(best_path, map_location="cpu", weights_only=True))
+        print(f"Rank {rank}: loaded {best_path}")
+    elif args.random_init:
+        with torch.no_grad():
+            for p in unet.parameters():
+                if p.dim() > 1 and float(p.abs().max()) == 0.0:
+                    p.normal_(0.0, 0.02)
+    unet = unet.to(device)
+    ns = args.NoiseScheduler
+    scheduler = DDPMScheduler(num_train_timesteps=ns["num_train_timesteps"], schedule="scaled_linear_beta",
+                              beta_start=ns["beta_start"], beta_end=ns["beta_end"])
+    inferer = LatentDiffusionInferer(scheduler, scale_factor=float(scale_factor))
+    trainer = DiffusionTrainer(unet, autoencoder, inferer, lr=tcfg["lr"], reference_rng_order=args.reference_rng_order)
+
+    total_step, best_val, done = 0, float("inf"), False
+    for epoch in range(tcfg["max_epochs"]):
+        if ddp:
+            train_loader.sampler.set_epoch(epoch)
+            val_loader.sampler.set_epoch(epoch)
+        t0, n_steps = time.perf_counter(), 0
+        for step, batch in enumerate(train_loader):
+            loss, skipped = trainer.train_step(batch["image"].to(device), batch["label"].to(device))
+            if skipped:
+                print(f"NaN loss detected at epoch {epoch}, step {step}: skipped on every rank")
+                continue
+            total_step += 1
+            n_steps += 1
+            scalar("train_diffusion_loss_iter", loss, total_step)
+            if args.max_steps and total_step >= args.max_steps:
+                done = True
+                break
+        trainer.end_epoch()
+        torch.cuda.synchronize()
+        if rank == 0:
+            print(f"Epoch {epoch}: {n_steps} steps in {time.perf_counter() - t0:.2f} s, lr {trainer.optimizer.param_groups[0]['lr']:.3g}")
+        if epoch % tcfg["val_interval"] == 0 or done:
+            val = trainer.validate(val_loader, device)
+            if rank == 0:
+                scalar("val_diffusion_loss", val, epoch)
+                print(f"Epoch {epoch} val_diffusion_loss: {val}")
+                torch.save(unet.state_dict(), last_path)
+                if val < best_val:
+                    best_val = val
+                    torch.save(unet.state_dict(), best_path)
+                    print("Got best val noise pred loss. Saved", best_path)
+        if done:
+            break
+    if log:
+        log.close()
+    if ddp:
+        parallel.cleanup_ddp()
+
+
+if __name__ == "__main__":
+    main()
