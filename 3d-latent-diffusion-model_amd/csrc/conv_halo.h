@@ -1,0 +1,381 @@
+// 3x3x3 stride-1 "same" convolution with W-HALO REUSE of the voxel operand (gfx950, bf16 MFMA 16x16x32).
+//
+// Same job, data layout, MFMA roles, epilogue and numerics as conv_igemm_kernel<2,2,64> (conv_igemm.h; the reference's
+// call sites are the nn.Conv3d modules MONAI builds for 3d_ldm/train_diffusion.py:197-205 / 3d_ldm/inference.py:94-99),
+// for the case that carries 95 % of the UNet's FLOPs: k = 3, stride 1, pad 1, one source tensor, Cin % 64 == 0.
+//
+// Why a second kernel: conv_igemm copies one voxel tile AND one weight tile per K step (32 KiB / 2.1 MFLOP) and is bound
+// by the per-CU global->LDS ingest rate (measured ~71 GB/s/CU), not by the matrix pipe.  The three
+// kw taps of one (kd, kh) pair read the SAME voxel rows shifted by one voxel along W, because consecutive tile rows are
+// consecutive voxels in NDHWC memory.  So the voxel tile is copied ONCE per (kd, kh, Cin chunk) and the three kw steps
+// read it from LDS at row offsets 0 / +1 / +2; a lane zeroes its fragment where the shifted voxel would cross the W
+// border (w == 0 for kw = 0, w == W-1 for kw = 2: two precomputed bit masks, 16 v_cndmask per masked step).  Bytes
+// copied per K step drop from 32 KiB to 21.3 KiB (voxels 16 KiB / 3 + weights 16 KiB).
+//
+// Tile geometry: the LDS voxel tile has 128 rows = output rows -1 .. 126 of the tile, so a workgroup produces 126
+// output voxels (rows 126/127 of the MFMA tile are computed on junk and never stored: 1.6 % waste) and no separate
+// halo copy is needed.  Tiles never straddle samples (tile index -> (sample, tile in sample)).
+// Rings: weights 6 x 16 KiB, voxels 3 x 16 KiB, (pair, row) -> voxel table 4.5 KiB = 148.5 KiB of the 160 KiB LDS.
+// The step issued in K step S is S + 6, whose kw equals S's kw: the instruction mix of every step is static.
+#pragma once
+#include "conv_igemm.h"
+
+// ABL: compile-time ablations for timing experiments (LDM_CONV_DBG through the operator-level API only; results are wrong):
+//      4 = no global->LDS copies, 8 = no MFMAs, 16 = no LDS fragment reads, 32 = copies issued but all out of range.
+template <int NSB, int ABL = 0>
+__global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int BM = 128, TM = 126, BN = 128, BK = 64, RB = 128;
+    constexpr int BT = BN * RB, AT = BM * RB;                  // bytes per weight / voxel tile
+    constexpr int NSA = 3;
+    constexpr int AOFF = NSB * BT;                             // voxel ring behind the weight ring
+    constexpr int TOFF = AOFF + NSA * AT;                      // (pair, row) -> voxel table
+    static_assert(NSB == 6, "the static step schedule assumes a 6-deep weight ring (a multiple of the 3 kw steps)");
+    static_assert(TOFF + 9 * BM * 4 <= 160 * 1024, "LDS budget");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wq = wave & 3;
+    const int wm = wq & 1, wn = wq >> 1;
+
+    const int nwg = gridDim.x;
+    int lid = xcd_remap(blockIdx.x, nwg);
+    const int mtile = lid % p.mtiles; lid /= p.mtiles;
+    const int ntile = lid % p.ntiles;
+    const int split = lid / p.ntiles;
+    const int n0 = ntile * BN;
+    const int DHW = p.Dout * p.Hout * p.Wout, HW = p.Hout * p.Wout;
+    const int smp = mtile / p.halo_mtps, tin = mtile - smp * p.halo_mtps;
+    const int l0 = tin * TM;                                   // first output voxel of the tile inside its sample
+    const int m_base = smp * DHW + l0;
+    const int nch = p.nchunk0;
+    const int Q = 9 * nch;                                     // macro steps: (kd, kh) x Cin chunk
+    const int q_begin = split * p.q_per_split;
+    int q_end = q_begin + p.q_per_split; if (q_end > Q) q_end = Q;
+    const int nsteps = 3 * (q_end - q_begin);                  // K steps of this workgroup, relative index 0 .. nsteps-1
+    const unsigned cin2 = (unsigned)p.c0a * 2u;
+    const int dbgflag = p.dbg;
+
+    // ---- (pair, LDS row) -> source voxel; LDS row j holds the voxel under tap (kd, kh, kw = 1) of output l0 - 1 + j
+    int* const tab = reinterpret_cast<int*>(smem + TOFF);
+    for (int e = tid; e < 9 * BM; e += 512) {
+        const int pr = e >> 7, j = e & 127;
+        const int l = l0 - 1 + j;
+        int v = -1;
+        if (l >= 0 && l < DHW) {
+            const int od = l / HW, r = l - od * HW, oh = r / p.Wout, ow = r - oh * p.Wout;
+            const int id = od + pr / 3 - 1, ih = oh + pr % 3 - 1;
+            if ((unsigned)id < (unsigned)p.Din && (unsigned)ih < (unsigned)p.Hin) v = smp * DHW + (id * p.Hin + ih) * p.Win + ow;
+        }
+        tab[e] = v;
+    }
+
+    // ---- loader lanes: every wave copies 2 pieces (8 rows x 128 B) of a voxel tile and 2 of a weight tile
+    const int prow = lane >> 3, pchunk = lane & 7;
+    int a_row[2]; unsigned a_kb[2], a_vo[2], b_vo[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = (wave * 2 + j) * 8 + prow;
+        a_row[j] = row;
+        a_kb[j] = (unsigned)((pchunk ^ ((row >> 1) & 7)) * 16);
+        const int R = row;                                     // same piece geometry for the weight tile
+        const int q = R >> 6, nt = (R >> 4) & 3, i = R & 15;
+        const int co = n0 + 64 * q + 16 * (i >> 2) + 4 * nt + (i & 3);      // see conv_igemm.h: lane ends up with 16 consecutive couts
+        b_vo[j] = (ABL & 32) ? 0xFFFFFFFFu : (unsigned)co * cin2 + a_kb[j];      // ABL 32: every copy out of range (zero fill, no memory traffic)
+    }
+    const unsigned wtap = (unsigned)p.CoutPad * cin2;          // bytes between two taps of the weight tensor
+    __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.x0a, 0, (int)((unsigned)(p.N * DHW) * cin2), 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.w0, 0, (int)(27u * wtap), 0x00020000);
+
+    // issue-stream state (scalar): next step to copy = macro (i_pair, i_chunk), kw i_kw; i_s = its relative index
+    int i_pair = q_begin / nch, i_chunk = q_begin - i_pair * nch, i_s = 0;
+    unsigned i_aslot = 0;                                      // byte offset of the voxel ring slot of the macro being issued
+#define HL_LOAD_TAB() do {                                                                          \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                             \
+            const int v_ = tab[i_pair * BM + a_row[j]];                                             \
+            a_vo[j] = (v_ >= 0 && !(ABL & 32)) ? (unsigned)v_ * cin2 + a_kb[j] : 0xFFFFFFFFu;       \
+        }                                                                                           \
+    } while (0)
+    // copies of one step; KW is the step's kw (static).  Slot of the weight tile = relative step % NSB (static: BSLOT).
+#define HL_ISSUE(KW, BSLOT) do {                                                                    \
+        {                                                                                           \
+            const unsigned sb_ = (unsigned)(i_pair * 3 + (KW)) * wtap + (unsigned)i_chunk * (BK * 2);                      \
+            if (!(ABL & 4)) _Pragma("unroll") for (int j = 0; j < 2; ++j)                           \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr_t)(smem + (BSLOT) * BT + (wave * 2 + j) * 1024), 16, b_vo[j], sb_, 0, 0); \
+            if ((KW) == 0 && !(ABL & 4)) {                                                          \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                       \
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr_t)(smem + AOFF + i_aslot + (wave * 2 + j) * 1024), 16, a_vo[j], \
+                                                             (unsigned)i_chunk * (BK * 2), 0, 0);  \
+            }                                                                                       \
+            ++i_s;                                                                                  \
+        }                                                                                           \
+    } while (0)
+    // issue stream moves on to the next macro step: next Cin chunk, or next (kd, kh) pair (table read + multiply-add per
+    // copied row).  Runs in front of the waits of a kw == 0 step, outside the hot block.
+#define HL_ADVANCE() do {                                                                           \
+        i_aslot = (i_aslot == 2 * AT) ? 0u : i_aslot + AT;                                          \
+        if (++i_chunk == nch) { i_chunk = 0; ++i_pair; if (i_pair < 9) HL_LOAD_TAB(); }             \
+    } while (0)
+
+    // ---- fragment addressing
+    const int fr = lane & 15, fg = lane >> 4;
+    const int ra0 = wm * 64 + fr, rb0 = wn * 64 + fr;
+    const int cfrag = grp * 4 + fg;
+    const int b_rd0 = rb0 * RB + ((cfrag ^ ((rb0 >> 1) & 7)) << 4);
+    int a_rdk[3];                                              // voxel rows shifted by kw: LDS row = tile row + kw
+#pragma unroll
+    for (int k = 0; k < 3; ++k) a_rdk[k] = AOFF + (ra0 + k) * RB + ((cfrag ^ (((ra0 + k) >> 1) & 7)) << 4);
+    // W-border masks of this lane's 4 voxel rows (one per 16-row tile t): bit t = w == 0, bit 4 + t = w == W - 1
+    unsigned wmask = 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int l = l0 + wm * 64 + t * 16 + fr;
+        const int ow = l % p.Wout;
+        wmask |= (ow == 0 ? 1u : 0u) << t;
+        wmask |= (ow == p.Wout - 1 ? 1u : 0u) << (4 + t);
+    }
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 wfA[4], afA[4], wfB[4], afB[4];
+    unsigned c_aslot = 0;                                      // voxel ring slot (byte offset) of the macro step being read NEXT
+
+#define HL_READ(WF, AF, BSLOT, KW) do {                                                             \
+        if (!(ABL & 16)) {                                                                          \
+            const char* sb_ = smem + (BSLOT) * BT + b_rd0;                                          \
+            const char* sa_ = smem + c_aslot + a_rdk[KW];                                           \
+            _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                         \
+                WF[t] = *reinterpret_cast<const bf16x8*>(sb_ + t * 16 * RB);                        \
+                AF[t] = *reinterpret_cast<const bf16x8*>(sa_ + t * 16 * RB);                        \
+            }                                                                                       \
+        }                                                                                           \
+    } while (0)
+#define HL_MASK(AF, KW) do {                                                                        \
+        if ((KW) != 1) {                                                                            \
+            _Pragma("unroll") for (int t = 0; t < 4; ++t)                                           \
+                if ((wmask >> (((KW) == 0 ? 0 : 4) + t)) & 1u) AF[t] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0}; \
+        }                                                                                           \
+    } while (0)
+#define HL_MFMA(WF, AF) do {                                                                        \
+        if (!(ABL & 8)) _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                            \
+            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                        \
+                acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[nt], AF[mt], acc[nt][mt], 0, 0, 0); \
+    } while (0)
+    // One K step at static position J (relative step % 6, kw = J % 3).  VM = copies that may stay in flight while the
+    // data of step S+1 must have landed: steps S+2 .. S+5 -> 2 weight copies each + 2 voxel copies per kw == 0 step.
+    // ISSUE: 1 = steady state (step S+6 exists), 0 = tail (nothing left to issue: drain).
+#define HL_STEP(J, WC, AC, WN, AN) do {                                                             \
+        constexpr int kw_ = (J) % 3, kn_ = ((J) + 1) % 3;                                           \
+        constexpr int vm_ = 8 + 2 * ((((J) + 2) % 3 == 0) + (((J) + 3) % 3 == 0) + (((J) + 4) % 3 == 0) + (((J) + 5) % 3 == 0)); \
+        constexpr int nc_ = (kw_ == 0) ? 4 : 2;                /* copies issued by this step */     \
+        if (kw_ == 0) HL_ADVANCE();                                                                 \
+        if (kn_ == 0) c_aslot = (c_aslot == 2 * AT) ? 0u : c_aslot + AT;                            \
+        /* hard boundary: s_barrier alone does not stop register-only MFMAs from drifting into the neighbouring step  \
+           (instruction selection orders them freely inside a basic block), so every step gets its own block: an       \
+           opaque never-taken branch, as the diagnostic stamps do in conv_igemm_kernel */                               \
+        if (dbgflag & 2048) asm volatile("s_nop 0");                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                    /* fragments of step S have arrived */ \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(vm_) : "memory");                                  \
+        __builtin_amdgcn_s_barrier();                                                               \
+        asm volatile("" ::: "memory");                                                              \
+        HL_MASK(AC, kw_);                                                                           \
+        HL_ISSUE(kw_, (J));                                    /* step S+6 refills the weight slot of step S */ \
+        HL_READ(WN, AN, ((J) + 1) % NSB, kn_);                                                      \
+        HL_MFMA(WC, AC);                                                                            \
+        /* one scheduling region: every copy / LDS read rides in the shadow of an MFMA (border masks float freely) */ \
+        _Pragma("unroll") for (int i_ = 0; i_ < nc_; ++i_) {                                        \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                      \
+            __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);                                      \
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                      \
+        }                                                                                           \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                          \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                      \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                      \
+        }                                                                                           \
+        __builtin_amdgcn_sched_group_barrier(0x008, 16 - nc_ - 8, 0);                               \
+    } while (0)
+
+    // diagnostic (dbg & 512, operator-level API): shader-clock and 100 MHz stamps around the K loop -> effective clock
+#define HL_STAMP(I) do { if ((dbgflag & 512) && tid == 0) {                                         \
+        p.stamps[(size_t)blockIdx.x * 8 + 2 * (I)] = __builtin_amdgcn_s_memrealtime();             \
+        p.stamps[(size_t)blockIdx.x * 8 + 2 * (I) + 1] = __builtin_amdgcn_s_memtime(); } } while (0)
+    // ---- prologue
+    __syncthreads();                                           // table complete
+    HL_STAMP(0);
+    HL_LOAD_TAB();
+    if (nsteps >= 6) {
+        HL_ISSUE(0, 0); HL_ISSUE(1, 1); HL_ISSUE(2, 2); HL_ADVANCE(); HL_ISSUE(0, 3); HL_ISSUE(1, 4); HL_ISSUE(2, 5);
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // step 0 landed; steps 1..5 = 5 x 2 + 2 (one voxel tile) in flight
+    } else {                                                   // a single macro step in this K range
+        HL_ISSUE(0, 0); HL_ISSUE(1, 1); HL_ISSUE(2, 2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    HL_READ(wfA, afA, 0, 0);
+
+    int s = 0;
+    for (; s + 12 <= nsteps; s += 6) {                         // steady state: every step of the block issues step s+6+j
+        HL_STEP(0, wfA, afA, wfB, afB);
+        HL_STEP(1, wfB, afB, wfA, afA);
+        HL_STEP(2, wfA, afA, wfB, afB);
+        HL_STEP(3, wfB, afB, wfA, afA);
+        HL_STEP(4, wfA, afA, wfB, afB);
+        HL_STEP(5, wfB, afB, wfA, afA);
+    }
+    // tail: 3, 6 or 9 steps left (nsteps is a multiple of 3 and s of 6); copies for relative steps >= i_s still to issue
+    for (; s < nsteps; s += 6) {
+#define HL_TAIL_STEP(J, WC, AC, WN, AN) do {                                                        \
+        constexpr int kw_ = (J) % 3, kn_ = ((J) + 1) % 3;                                           \
+        constexpr int vm_ = 8 + 2 * ((((J) + 2) % 3 == 0) + (((J) + 3) % 3 == 0) + (((J) + 4) % 3 == 0) + (((J) + 5) % 3 == 0)); \
+        if (kw_ == 0 && i_s < nsteps) HL_ADVANCE();                                                 \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                                         \
+        HL_MASK(AC, kw_);                                                                           \
+        if (s + (J) + 6 <= nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(vm_) : "memory");       \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                       \
+        __builtin_amdgcn_s_barrier();                                                               \
+        asm volatile("" ::: "memory");                                                              \
+        if (i_s < nsteps) HL_ISSUE(kw_, (J));                                                       \
+        if (s + (J) + 1 < nsteps) {                                                                 \
+            if (kn_ == 0) c_aslot = (c_aslot == 2 * AT) ? 0u : c_aslot + AT;                        \
+            HL_READ(WN, AN, ((J) + 1) % NSB, kn_);                                                  \
+        }                                                                                           \
+        HL_MFMA(WC, AC);                                                                            \
+    } while (0)
+        HL_TAIL_STEP(0, wfA, afA, wfB, afB);
+        HL_TAIL_STEP(1, wfB, afB, wfA, afA);
+        HL_TAIL_STEP(2, wfA, afA, wfB, afB);
+        if (s + 3 >= nsteps) break;
+        HL_TAIL_STEP(3, wfB, afB, wfA, afA);
+        HL_TAIL_STEP(4, wfA, afA, wfB, afB);
+        HL_TAIL_STEP(5, wfB, afB, wfA, afA);
+#undef HL_TAIL_STEP
+    }
+#undef HL_STEP
+#undef HL_MFMA
+#undef HL_MASK
+#undef HL_READ
+#undef HL_ISSUE
+#undef HL_ADVANCE
+#undef HL_LOAD_TAB
+
+    HL_STAMP(1);
+#undef HL_STAMP
+    // ---- intra-workgroup K reduction (the two wave groups took the two 32-deep halves of every K step)
+    const int mt_base = 2 * grp;
+    {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        float* xch = reinterpret_cast<float*>(smem);
+        const int dst = 1 - grp;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int ml = 0; ml < 2; ++ml)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    xch[(((dst * 4 + wq) * 32) + (nt * 2 + ml) * 4 + r) * 64 + lane] = (grp == 0) ? acc[nt][2 + ml][r] : acc[nt][ml][r];
+        __syncthreads();
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int ml = 0; ml < 2; ++ml)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = xch[(((grp * 4 + wq) * 32) + (nt * 2 + ml) * 4 + r) * 64 + lane];
+                    if (grp == 0) acc[nt][ml][r] += v; else acc[nt][2 + ml][r] += v;
+                }
+    }
+
+    // ---- epilogue (conv_igemm.h's, with the 126-row tile mapping).  After the exchange this wave owns the 32-row block
+    //      rows [64 wm + 32 grp, +32) of the tile = 16-row tiles mt_base + {0, 1}; GroupNorm partials go to slab row
+    //      (tile, block) = mtile * 4 + 2 wm + grp  (bitwise reproducible: no atomics).
+    const int cbase = n0 + wn * 64 + 16 * fg;
+    const bool do_stats = (p.stats != nullptr) && (p.splitk == 1) && (p.out != nullptr);
+    float ssum[16], ssq[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { ssum[q] = 0.f; ssq[q] = 0.f; }
+#pragma unroll
+    for (int ml = 0; ml < 2; ++ml) {
+        const int r_t = wm * 64 + (mt_base + ml) * 16 + fr;                // row inside the tile
+        if (r_t >= TM || l0 + r_t >= DHW) continue;
+        const int m = m_base + r_t;
+        float v[16];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[nt * 4 + r] = (grp == 0) ? acc[nt][ml][r] : acc[nt][2 + ml][r];
+        if (p.splitk > 1) {
+            float* dst = p.partial + ((size_t)split * p.M + m) * p.CoutPad + cbase;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4*>(dst + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+            continue;
+        }
+        if (p.bias) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v[q] += p.bias[cbase + q];
+        }
+        if (p.temb) {
+            const float* te = p.temb + (size_t)smp * p.temb_stride + cbase;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v[q] += te[q];
+        }
+        if (p.out_f32) {
+            const int sp = l0 + r_t;
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                if (cbase + q < p.CoutReal) p.out_f32[((size_t)smp * p.CoutReal + cbase + q) * DHW + sp] = v[q];
+            continue;
+        }
+        if (cbase >= p.CoutS) continue;
+        if (p.residual) {
+            const u32x4* rp = reinterpret_cast<const u32x4*>(p.residual + (size_t)m * p.CoutS + cbase);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const u32x4 rv = rp[h];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v[h * 8 + 2 * q] += __uint_as_float(rv[q] << 16);
+                    v[h * 8 + 2 * q + 1] += __uint_as_float(rv[q] & 0xffff0000u);
+                }
+            }
+        }
+        u32x4* op = reinterpret_cast<u32x4*>(p.out + (size_t)m * p.CoutS + cbase);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            u32x4 o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                o[q] = pack2bf(v[h * 8 + 2 * q], v[h * 8 + 2 * q + 1]);
+                const float lo = __uint_as_float(o[q] << 16), hi = __uint_as_float(o[q] & 0xffff0000u);
+                ssum[h * 8 + 2 * q] += lo; ssq[h * 8 + 2 * q] += lo * lo;
+                ssum[h * 8 + 2 * q + 1] += hi; ssq[h * 8 + 2 * q + 1] += hi * hi;
+            }
+            op[h] = o;
+        }
+    }
+    if (do_stats) {
+#define HL_ROW_ADD(X, CTRL) X += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(X), CTRL, 0xf, 0xf, true))
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            HL_ROW_ADD(ssum[q], 0x128); HL_ROW_ADD(ssum[q], 0x124); HL_ROW_ADD(ssum[q], 0x122); HL_ROW_ADD(ssum[q], 0x121);
+            HL_ROW_ADD(ssq[q], 0x128); HL_ROW_ADD(ssq[q], 0x124); HL_ROW_ADD(ssq[q], 0x122); HL_ROW_ADD(ssq[q], 0x121);
+        }
+#undef HL_ROW_ADD
+        const int blk = mtile * 4 + wm * 2 + grp;                          // empty blocks (tile tail) write zeros
+        if (fr == 0 && cbase < p.CoutS) {
+            float* dst = p.stats + ((size_t)blk * p.CoutS + cbase) * 2;
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                *reinterpret_cast<float4*>(dst + 4 * q) = make_float4(ssum[2 * q], ssq[2 * q], ssum[2 * q + 1], ssq[2 * q + 1]);
+        }
+    }
+#endif  // __HIP_DEVICE_COMPILE__
+}

@@ -41,6 +41,7 @@ struct ConvParams {
     int steps0, steps1;               // K steps per group (taps * nchunk0, nchunk1)
     int splitk, steps_per_split;
     int mtiles, ntiles;
+    int halo_mtps, q_per_split;       // conv3_halo_kernel only: 126-row tiles per sample, (kd,kh,chunk) macro steps per K split
     // epilogue (splitk == 1) ------------------------------------------------------------
     const float* bias;                // [CoutPad] or null
     const float* bias2;               // [CoutPad] or null (bias of the fused 1x1 skip)

@@ -23,6 +23,7 @@
 #include "../../include/ldm3d.h"
 #include "attention.h"
 #include "conv_igemm.h"
+#include "conv_halo.h"
 #include "conv_wgrad.h"
 #include "norm_elem.h"
 
@@ -59,7 +60,8 @@ static inline Ref io_ref(int i) { Ref r; r.base = BASE_IO0 + i; r.off = 0; retur
 
 struct Act {                                         // NDHWC bf16 activation living in the workspace
     size_t off = 0; int C = 0; int N = 0, D = 0, H = 0, W = 0; bool valid = false;
-    size_t stats_off = 0; bool has_stats = false;   // GroupNorm partials [ceil(rows/32)][C][2] written by the producer
+    size_t stats_off = 0; bool has_stats = false;   // GroupNorm partials [blocks][C][2] written by the producer
+    int stats_nrb = 0;                               // blocks per sample (0: one per 32 rows of the whole tensor)
     size_t bytes() const { return (size_t)N * D * H * W * C * 2; }
     long rows() const { return (long)N * D * H * W; }
 };
@@ -69,7 +71,7 @@ enum OpKind { OP_PACK, OP_CONV, OP_FINALIZE, OP_GN_STATS, OP_GN_FINALIZE, OP_GN_
               // backward (training plans only)
               OP_WT, OP_WGRAD, OP_EXPORT, OP_COLSUM, OP_GNB, OP_ATTN_BWD, OP_ADD, OP_SUMPOOL, OP_LIN_DX, OP_LIN_DW };
 
-struct ConvCfg { int wgm, wgn, bk, splitk; };
+struct ConvCfg { int wgm, wgn, bk, splitk; int halo = 0, mtps = 0, qps = 0; };   // halo: conv3_halo_kernel (126-row tiles)
 
 struct Op {
     OpKind kind;
@@ -252,9 +254,13 @@ struct Builder {
     };
     std::vector<Tape> tape;
 
-    static ConvCfg choose_cfg(long M, int cout_pad, int steps, int bk) {
+    static bool halo_enabled() { const char* e = getenv("LDM_CONV_HALO"); return e ? atoi(e) != 0 : true; }
+    // halo_n > 0: the conv is eligible for conv3_halo_kernel (3^3, stride 1, pad 1, single source, BK 64); halo_n = N
+    // and halo_dhw = voxels per sample (its 126-row tiles never straddle samples).
+    static ConvCfg choose_cfg(long M, int cout_pad, int steps, int bk, int halo_n = 0, long halo_dhw = 0) {
         ConvCfg best{2, 2, bk, 1}; double best_t = 1e30;
         const int rb = bk * 2;
+        static const int splits[] = {1, 2, 3, 4, 6, 8, 9, 12, 16, 18, 24, 27, 32, 48, 64};
         for (int wgn = 1; wgn <= 4; wgn *= 2) {
             const int bn = 64 * wgn, bm = 64 * (4 / wgn);
             if (cout_pad % bn) continue;
@@ -262,7 +268,6 @@ struct Builder {
             const double c_mfma = (double)bm * bn * bk * 2.0 / 4096.0;           // cycles at the per-CU MFMA peak
             const double c_load = (double)(bm + bn) * rb / 28.0;                 // ~28 B/clk/CU global->LDS
             const double c_step = std::max(c_mfma, c_load) + 60.0;
-            static const int splits[] = {1, 2, 3, 4, 6, 8, 9, 12, 16, 18, 24, 27, 32, 48, 64};
             for (int sk : splits) {
                 if (sk > 1 && steps / sk < 6) break;
                 const long nwg = tiles * sk;
@@ -271,6 +276,22 @@ struct Builder {
                 double t = rounds * (sps * c_step + 2500.0);
                 if (sk > 1) t += 6000.0 + (double)M * cout_pad * 4.0 * sk * 2.0 / 2500.0;   // slab write+read, ~2.5 KB/clk chip
                 if (t < best_t) { best_t = t; best = ConvCfg{4 / wgn, wgn, bk, sk}; }
+            }
+        }
+        if (halo_n > 0 && bk == 64 && cout_pad % 128 == 0 && halo_enabled()) {
+            const int mtps = (int)((halo_dhw + 125) / 126), Q = steps / 3;       // steps = 27 * nchunk
+            const long tiles = (long)halo_n * mtps * (cout_pad / 128);
+            const double c_mfma = 128.0 * 128.0 * 64.0 * 2.0 / 4096.0;
+            const double c_load = (128.0 / 3.0 + 128.0) * 128.0 / 28.0;          // the voxel tile is copied once per 3 steps
+            const double c_step = std::max(c_mfma, c_load) + 30.0;
+            for (int sk : splits) {
+                if (sk > 1 && Q / sk < 3) break;
+                const int qps = (Q + sk - 1) / sk, skr = (Q + qps - 1) / qps;    // every split non-empty
+                const long nwg = tiles * skr;
+                const double rounds = ceil((double)nwg / 256.0);
+                double t = rounds * (3.0 * qps * c_step + 2500.0);
+                if (skr > 1) t += 6000.0 + (double)M * cout_pad * 4.0 * skr * 2.0 / 2500.0;
+                if (t < best_t) { best_t = t; best = ConvCfg{2, 2, 64, skr}; best.halo = 1; best.mtps = mtps; best.qps = qps; }
             }
         }
         return best;
@@ -294,15 +315,20 @@ struct Builder {
         const int taps = a.k * a.k * a.k;
         const int nchunk0 = cin0 / bk, nchunk1 = cin1 / bk;
         const int steps0 = taps * nchunk0, steps1 = nchunk1;
-        ConvCfg cc = choose_cfg(M, w.cout_pad, steps0 + steps1, bk);
+        const bool halo_ok = a.k == 3 && a.stride == 1 && a.pad == 1 && a.ups == 0 && !a.exact && !a.xb.valid && !a.w1 &&
+                             a.xa.D == a.Do && a.xa.H == a.Ho && a.xa.W == a.Wo;
+        ConvCfg cc = choose_cfg(M, w.cout_pad, steps0 + steps1, bk, halo_ok ? N : 0, (long)a.Do * a.Ho * a.Wo);
         const int bm = 64 * cc.wgm, bn = 64 * cc.wgn;
         const int couts = a.f32_out ? 0 : rup(w.cout, 32);
         Act out;
         if (!a.f32_out) {
             out = new_act(N, a.Do, a.Ho, a.Wo, couts);
             if (a.want_stats) {
-                out.stats_off = pool.alloc((size_t)((M + 31) / 32) * couts * 2 * 4);
+                const bool tile_blocks = cc.halo && cc.splitk == 1;               // partials per (126-row tile, 32-row block)
+                const size_t nrb = tile_blocks ? (size_t)N * cc.mtps * 4 : (size_t)((M + 31) / 32);
+                out.stats_off = pool.alloc(nrb * couts * 2 * 4);
                 out.has_stats = true;
+                out.stats_nrb = tile_blocks ? cc.mtps * 4 : 0;
             }
         }
         Op op{}; op.kind = OP_CONV; op.cc = cc;
@@ -321,7 +347,7 @@ struct Builder {
         i[11] = a.k; i[12] = a.stride; i[13] = a.pad; i[14] = a.ups | (a.exact << 1); i[15] = (int)M;
         i[16] = a.f32_out ? rup(w.cout, 32) : couts; i[17] = w.cout_pad; i[18] = a.cout_real ? a.cout_real : w.cout;
         i[19] = nchunk0; i[20] = nchunk1; i[21] = a.temb_stride; i[22] = a.f32_out ? 1 : 0;
-        i[23] = (int)((M + bm - 1) / bm);
+        i[23] = cc.halo ? N * cc.mtps : (int)((M + bm - 1) / bm);
         if (M >= (1L << 31)) { err = "conv " + tag + ": M too large"; return Act(); }
         if (cc.splitk > 1) {
             partial_bytes = std::max(partial_bytes, (size_t)cc.splitk * M * w.cout_pad * 4);
@@ -350,13 +376,15 @@ struct Builder {
             if (train) { o_.r[5] = ws_ref(ab_off); if (o_.kind != OP_GN_APPLY) o_.r[6] = ws_ref(mr_off); }
             else gnab_fixups.push_back(plan->ops.size());
         };
-        const bool fused = xa.has_stats && (!xb.valid || xb.has_stats) && (N == 1 || DHW % 32 == 0);
+        auto blocks_ok = [&](const Act& t) { return t.has_stats && (t.stats_nrb > 0 || N == 1 || DHW % 32 == 0); };
+        auto blocks_of = [&](const Act& t) { return t.stats_nrb > 0 ? t.stats_nrb : (N == 1 ? (DHW + 31) / 32 : DHW / 32); };
+        const bool fused = blocks_ok(xa) && (!xb.valid || blocks_ok(xb));
         if (fused) {                                   // partials came with the tensors: one small reduce
             Op f{}; f.kind = OP_GN_PREP;
             f.r[0] = ws_ref(xa.stats_off); f.r[1] = xb.valid ? ws_ref(xb.stats_off) : Ref();
             f.r[2] = w_ref(g.g_off); f.r[3] = w_ref(g.b_off);
-            f.i[0] = xa.C; f.i[1] = xb.valid ? xb.C : 0; f.i[2] = (N == 1) ? (DHW + 31) / 32 : DHW / 32; f.i[3] = groups;
-            f.i[4] = DHW; f.i[5] = N; f.f[0] = eps;
+            f.i[0] = xa.C; f.i[1] = xb.valid ? xb.C : 0; f.i[2] = blocks_of(xa); f.i[3] = groups;
+            f.i[4] = DHW; f.i[5] = N; f.i[6] = xb.valid ? blocks_of(xb) : 0; f.f[0] = eps;
             ab_ref(f); plan->ops.push_back(f);
         } else {
             const int cvec = C / 8;
@@ -1034,7 +1062,7 @@ static int launch_conv_t(const ConvParams& p, hipStream_t s) {
 
 // ---- optional HIP-event instrumentation of one conv tile configuration (bench.py's roofline leg) ----------
 struct ProfState {
-    bool on = false; int wgm = 0, wgn = 0, bk = 0;
+    bool on = false; int wgm = 0, wgn = 0, bk = 0, halo = 0;
     std::vector<hipEvent_t> ev; size_t used = 0;          // pairs (start, stop)
     std::vector<double> flops;                            // algorithmic FLOPs of each instrumented launch
     double flops_all = 0.0; long launches_all = 0;        // every conv launch while profiling is on
@@ -1051,14 +1079,34 @@ static int launch_conv_impl(const ConvParams& p, const ConvCfg& cc, hipStream_t 
 static int launch_conv(const ConvParams& p, const ConvCfg& cc, hipStream_t s) {
     if (!g_prof.on) return launch_conv_impl(p, cc, s);
     g_prof.flops_all += conv_algorithmic_flops(p); g_prof.launches_all++;
-    const bool hit = cc.wgm == g_prof.wgm && cc.wgn == g_prof.wgn && cc.bk == g_prof.bk && g_prof.used + 2 <= g_prof.ev.size();
+    const bool hit = cc.wgm == g_prof.wgm && cc.wgn == g_prof.wgn && cc.bk == g_prof.bk && cc.halo == g_prof.halo &&
+                     g_prof.used + 2 <= g_prof.ev.size();
     if (hit) HIP_TRY(hipEventRecord(g_prof.ev[g_prof.used], s));
     LDM_TRY(launch_conv_impl(p, cc, s));
     if (hit) { HIP_TRY(hipEventRecord(g_prof.ev[g_prof.used + 1], s)); g_prof.used += 2; g_prof.flops.push_back(conv_algorithmic_flops(p)); }
     return 0;
 }
 
+static int launch_conv_halo(const ConvParams& p, hipStream_t s) {
+    constexpr int LDS = 6 * 16384 + 3 * 16384 + 9 * 128 * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_halo_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_set = true;
+    }
+    if (p.dbg & (4 | 8 | 16 | 32)) {                       // timing ablations (operator-level API + LDM_CONV_DBG only)
+#define ABL_CASE(A) if ((p.dbg & 60) == A) { \
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_halo_kernel<6, A>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); \
+            hipLaunchKernelGGL((conv3_halo_kernel<6, A>), dim3(p.mtiles * p.ntiles * p.splitk), dim3(512), LDS, s, p); return 0; }
+        ABL_CASE(4) ABL_CASE(8) ABL_CASE(16) ABL_CASE(12) ABL_CASE(20) ABL_CASE(24) ABL_CASE(32) ABL_CASE(40)
+#undef ABL_CASE
+    }
+    hipLaunchKernelGGL((conv3_halo_kernel<6>), dim3(p.mtiles * p.ntiles * p.splitk), dim3(512), LDS, s, p);
+    return 0;
+}
+
 static int launch_conv_impl(const ConvParams& p, const ConvCfg& cc, hipStream_t s) {
+    if (cc.halo) return launch_conv_halo(p, s);
 #define CASE(M_, N_, K_) if (cc.wgm == M_ && cc.wgn == N_ && cc.bk == K_) return launch_conv_t<M_, N_, K_>(p, s);
     CASE(2, 2, 64) CASE(4, 1, 64) CASE(1, 4, 64) CASE(2, 2, 32) CASE(4, 1, 32) CASE(1, 4, 32)
 #undef CASE
@@ -1113,6 +1161,8 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                 p.steps0 = i[11] * i[11] * i[11] * i[19]; p.steps1 = i[20];
                 p.splitk = o.cc.splitk; p.steps_per_split = (p.steps0 + p.steps1 + p.splitk - 1) / p.splitk;
                 p.mtiles = i[23]; p.ntiles = p.CoutPad / (64 * o.cc.wgn);
+                p.halo_mtps = o.cc.mtps; p.q_per_split = o.cc.qps;
+                if (o.cc.halo) p.steps_per_split = 3 * o.cc.qps;
                 p.bias = (const float*)rp(bs, o.r[6]); p.bias2 = (const float*)rp(bs, o.r[7]);
                 p.temb = (const float*)rp(bs, o.r[8]); p.temb_stride = i[21];
                 p.residual = (const bf16_t*)rp(bs, o.r[9]);
@@ -1142,7 +1192,7 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                 break; }
             case OP_GN_PREP: {
                 GnPrepParams p{}; p.sa = (const float*)rp(bs, o.r[0]); p.sb = (const float*)rp(bs, o.r[1]); p.ca = i[0]; p.cb = i[1];
-                p.nrb_per_sample = i[2]; p.groups = i[3]; p.DHW = i[4]; p.eps = o.f[0];
+                p.nrb_a = i[2]; p.nrb_b = i[6]; p.groups = i[3]; p.DHW = i[4]; p.eps = o.f[0];
                 p.gamma = (const float*)rp(bs, o.r[2]); p.beta = (const float*)rp(bs, o.r[3]); p.ab = (float*)rp(bs, o.r[5]); p.mr = (float*)rp(bs, o.r[6]);
                 hipLaunchKernelGGL(gn_prep_kernel, dim3(i[3], i[5]), dim3(256), 0, s, p);
                 break; }
@@ -1557,7 +1607,7 @@ int ldm_profile_start(int wgm, int wgn, int bk, int max_launches) {
     g_prof = ProfState();
     g_prof.ev.resize((size_t)max_launches * 2);
     for (auto& e : g_prof.ev) HIP_TRY(hipEventCreate(&e));
-    g_prof.wgm = wgm; g_prof.wgn = wgn; g_prof.bk = bk; g_prof.on = true;
+    g_prof.wgm = wgm; g_prof.wgn = wgn; g_prof.bk = bk & 0xff; g_prof.halo = (bk >> 8) & 1; g_prof.on = true;   // bk | 256 selects conv3_halo_kernel
     return 0;
 }
 /* out[0] = instrumented launches, out[1] = their total ms, out[2] = their total algorithmic FLOPs,
@@ -1582,7 +1632,7 @@ int ldm_model_plan_conv_cfgs(ldm_model* m, const char* kind, int B, int D, int H
     std::shared_ptr<Plan> p; LDM_TRY(get_plan(m, kind, B, D, H, W, &p));
     int n = 0;
     for (const Op& o : p->ops) if (o.kind == OP_CONV) {
-        if (cfgs && n < max_convs) { cfgs[4 * n] = o.cc.wgm; cfgs[4 * n + 1] = o.cc.wgn; cfgs[4 * n + 2] = o.cc.bk; cfgs[4 * n + 3] = o.cc.splitk; }
+        if (cfgs && n < max_convs) { cfgs[4 * n] = o.cc.wgm; cfgs[4 * n + 1] = o.cc.wgn; cfgs[4 * n + 2] = o.cc.bk | (o.cc.halo << 8); cfgs[4 * n + 3] = o.cc.splitk; }
         ++n;
     }
     return n;
@@ -1632,12 +1682,24 @@ int ldm_op_conv3d(const void* xa, int ca, const void* xb, int cb, const void* w,
     p.ksize = ksize; p.stride = stride; p.pad = pad; p.ups = ups; p.exact = exact; p.M = (int)M;
     p.CoutS = rup(cout, 32); p.CoutPad = cout_pad; p.CoutReal = cout;
     p.nchunk0 = cin0 / bk; p.nchunk1 = cin1 / bk; p.steps0 = taps * p.nchunk0; p.steps1 = p.nchunk1;
-    ConvCfg cc = Builder::choose_cfg(M, cout_pad, p.steps0 + p.steps1, bk);
-    if (wgn) { if ((wgn != 1 && wgn != 2 && wgn != 4) || cout_pad % (64 * wgn)) return fail(LDM_ERR_BAD_ARG, "bad wgn"); cc.wgn = wgn; cc.wgm = 4 / wgn; }
+    const bool halo_ok = ksize == 3 && stride == 1 && pad == 1 && ups == 0 && !exact && cb == 0 && cin1 == 0 && bk == 64 &&
+                         cout_pad % 128 == 0 && Builder::halo_enabled();
+    ConvCfg cc = Builder::choose_cfg(M, cout_pad, p.steps0 + p.steps1, bk, halo_ok ? N : 0, (long)Do * Ho * Wo);
+    if (wgn) {                                       // forced tile shape: wgn = 2 keeps the halo kernel where it applies
+        if ((wgn != 1 && wgn != 2 && wgn != 4) || cout_pad % (64 * wgn)) return fail(LDM_ERR_BAD_ARG, "bad wgn");
+        cc.wgn = wgn; cc.wgm = 4 / wgn; cc.halo = (wgn == 2 && halo_ok) ? 1 : 0;
+    }
     if (splitk) cc.splitk = splitk;
     if (cc.splitk < 1 || cc.splitk > p.steps0 + p.steps1) return fail(LDM_ERR_BAD_ARG, "bad splitk");
-    p.splitk = cc.splitk; p.steps_per_split = (p.steps0 + p.steps1 + cc.splitk - 1) / cc.splitk;
-    p.mtiles = (int)((M + 64 * cc.wgm - 1) / (64 * cc.wgm)); p.ntiles = cout_pad / (64 * cc.wgn);
+    if (cc.halo) {                                   // K splits of whole (kd, kh, chunk) macro steps, none empty
+        const int Q = 9 * p.nchunk0;
+        if (cc.splitk > Q) cc.splitk = Q;
+        cc.qps = (Q + cc.splitk - 1) / cc.splitk; cc.splitk = (Q + cc.qps - 1) / cc.qps;
+        cc.mtps = (int)(((long)Do * Ho * Wo + 125) / 126);
+    }
+    p.splitk = cc.splitk; p.steps_per_split = cc.halo ? 3 * cc.qps : (p.steps0 + p.steps1 + cc.splitk - 1) / cc.splitk;
+    p.halo_mtps = cc.mtps; p.q_per_split = cc.qps;
+    p.mtiles = cc.halo ? N * cc.mtps : (int)((M + 64 * cc.wgm - 1) / (64 * cc.wgm)); p.ntiles = cout_pad / (64 * cc.wgn);
     p.bias = bias; p.bias2 = bias2; p.temb = temb; p.temb_stride = temb_stride; p.residual = (const bf16_t*)residual;
     p.out = out_f32 ? nullptr : (bf16_t*)out_bf16; p.out_f32 = out_f32;
     if (cc.splitk > 1) {

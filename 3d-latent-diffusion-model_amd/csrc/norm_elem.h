@@ -123,7 +123,8 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const GnFinalizeParams 
 // epilogues): slab [rowblock][C][2] per source tensor.  grid = (groups, N), 256 threads.
 struct GnPrepParams {
     const float* sa; const float* sb; int ca, cb;      // slabs of the two concatenated sources (sb may be null)
-    int nrb_per_sample; int groups; int DHW; float eps;
+    int nrb_a, nrb_b;                                  // statistics blocks per sample of each source's slab
+    int groups; int DHW; float eps;
     const float* gamma; const float* beta; float* ab;
     float* mr;                                     // optional [N][groups][2] mean, rstd (saved for the backward pass)
 };
@@ -133,14 +134,21 @@ __global__ __launch_bounds__(256) void gn_prep_kernel(const GnPrepParams p) {
     const int n = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
     const int C = p.ca + p.cb;
     const int cpg = C / p.groups;
-    const int items = p.nrb_per_sample * cpg;
+    const int c_lo = g * cpg, c_hi = c_lo + cpg;
     double s = 0.0, q = 0.0;
-    for (int i = tid; i < items; i += 256) {
-        const int rbl = i / cpg, c = g * cpg + (i - rbl * cpg);
-        const int rb = n * p.nrb_per_sample + rbl;
-        const float* src = (c < p.ca) ? p.sa + ((size_t)rb * p.ca + c) * 2 : p.sb + ((size_t)rb * p.cb + (c - p.ca)) * 2;
-        const float2 v = *reinterpret_cast<const float2*>(src);
-        s += (double)v.x; q += (double)v.y;
+    {   // channels of the group that live in source a, then those in source b (a group may straddle the concat boundary)
+        const int a_hi = c_hi < p.ca ? c_hi : p.ca, na = a_hi > c_lo ? a_hi - c_lo : 0;
+        for (int i = tid; i < p.nrb_a * na; i += 256) {
+            const int rbl = i / na, c = c_lo + (i - rbl * na);
+            const float2 v = *reinterpret_cast<const float2*>(p.sa + ((size_t)(n * p.nrb_a + rbl) * p.ca + c) * 2);
+            s += (double)v.x; q += (double)v.y;
+        }
+        const int b_lo = c_lo > p.ca ? c_lo : p.ca, nb = c_hi > b_lo ? c_hi - b_lo : 0;
+        for (int i = tid; i < p.nrb_b * nb; i += 256) {
+            const int rbl = i / nb, c = b_lo + (i - rbl * nb) - p.ca;
+            const float2 v = *reinterpret_cast<const float2*>(p.sb + ((size_t)(n * p.nrb_b + rbl) * p.cb + c) * 2);
+            s += (double)v.x; q += (double)v.y;
+        }
     }
     rs[tid] = s; rq[tid] = q;
     __syncthreads();

@@ -147,6 +147,24 @@ def test_conv_big_level0_shape(cuda, built_lib):
     assert err <= tol, err
 
 
+@pytest.mark.parametrize("cin,cout,dims,n,splitk", [
+    (256, 256, (6, 6, 6), 1, 1), (256, 256, (6, 6, 6), 1, 4), (64, 128, (5, 3, 7), 3, 1), (128, 96, (4, 9, 2), 2, 3),
+    (64, 128, (1, 1, 5), 1, 1), (512, 128, (6, 6, 6), 1, 9), (64, 256, (12, 12, 12), 1, 1), (128, 128, (2, 2, 130), 1, 2),
+    (64, 128, (3, 3, 1), 2, 1)])
+def test_conv3_halo_kernel_shapes(cuda, built_lib, cin, cout, dims, n, splitk):
+    """conv3_halo_kernel (wgn = 2 on an eligible conv): W-border masks for narrow / wide lines, tiles that end inside a
+    sample, several samples, K splits of whole (kd, kh, chunk) macro steps including single-macro-step ranges."""
+    err, tol = _conv_case(cuda, built_lib, cin=(cin, 0), cout=cout, dims=dims, n=n, wgn=2, splitk=splitk, seed=cin + dims[2])
+    assert err <= tol, err
+
+
+@pytest.mark.parametrize("f32_out", [False, True])
+def test_conv3_halo_kernel_epilogues(cuda, built_lib, f32_out):
+    err, tol = _conv_case(cuda, built_lib, cin=(128, 0), cout=128 if not f32_out else 100, dims=(6, 5, 7), n=2, wgn=2,
+                          temb=not f32_out, residual=not f32_out, f32_out=f32_out)
+    assert err <= tol, err
+
+
 @pytest.mark.parametrize("c,groups,dual,silu", [(64, 32, 0, 1), (256, 32, 0, 1), (768, 32, 512, 1), (96, 8, 32, 0), (1024, 32, 512, 1)])
 def test_group_norm_silu(cuda, built_lib, c, groups, dual, silu):
     from ldm3d import _lib
