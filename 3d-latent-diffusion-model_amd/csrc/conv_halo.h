@@ -21,7 +21,7 @@
 #include "conv_igemm.h"
 
 // ABL: compile-time ablations for timing experiments (LDM_CONV_DBG through the operator-level API only; results are wrong):
-//      4 = no global->LDS copies, 8 = no MFMAs, 16 = no LDS fragment reads, 32 = copies issued but all out of range.
+//      4 = no global->LDS copies, 8 = no MFMAs, 16 = no LDS fragment reads, 32 = copies issued but all out of range, 64 = no per-step barrier.
 template <int NSB, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
         __builtin_amdgcn_sched_barrier(0);                                                          \
         __builtin_amdgcn_s_waitcnt(0xC07F);                    /* fragments of step S have arrived */ \
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(vm_) : "memory");                                  \
-        __builtin_amdgcn_s_barrier();                                                               \
+        if (!(ABL & 64)) __builtin_amdgcn_s_barrier();                                              \
         asm volatile("" ::: "memory");                                                              \
         HL_MASK(AC, kw_);                                                                           \
         HL_ISSUE(kw_, (J));                                    /* step S+6 refills the weight slot of step S */ \
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
         HL_MASK(AC, kw_);                                                                           \
         if (s + (J) + 6 <= nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(vm_) : "memory");       \
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                       \
-        __builtin_amdgcn_s_barrier();                                                               \
+        if (!(ABL & 64)) __builtin_amdgcn_s_barrier();                                              \
         asm volatile("" ::: "memory");                                                              \
         if (i_s < nsteps) HL_ISSUE(kw_, (J));                                                       \
         if (s + (J) + 1 < nsteps) {                                                                 \

@@ -1094,11 +1094,11 @@ static int launch_conv_halo(const ConvParams& p, hipStream_t s) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_halo_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr_set = true;
     }
-    if (p.dbg & (4 | 8 | 16 | 32)) {                       // timing ablations (operator-level API + LDM_CONV_DBG only)
-#define ABL_CASE(A) if ((p.dbg & 60) == A) { \
+    if (p.dbg & (4 | 8 | 16 | 32 | 64)) {                  // timing ablations (operator-level API + LDM_CONV_DBG only)
+#define ABL_CASE(A) if ((p.dbg & 124) == A) { \
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_halo_kernel<6, A>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); \
             hipLaunchKernelGGL((conv3_halo_kernel<6, A>), dim3(p.mtiles * p.ntiles * p.splitk), dim3(512), LDS, s, p); return 0; }
-        ABL_CASE(4) ABL_CASE(8) ABL_CASE(16) ABL_CASE(12) ABL_CASE(20) ABL_CASE(24) ABL_CASE(32) ABL_CASE(40)
+        ABL_CASE(4) ABL_CASE(8) ABL_CASE(16) ABL_CASE(12) ABL_CASE(20) ABL_CASE(24) ABL_CASE(32) ABL_CASE(40) ABL_CASE(84) ABL_CASE(68) ABL_CASE(64)
 #undef ABL_CASE
     }
     hipLaunchKernelGGL((conv3_halo_kernel<6>), dim3(p.mtiles * p.ntiles * p.splitk), dim3(512), LDS, s, p);

@@ -13,8 +13,8 @@ step: inference.py has no distributed code) -> weak scaling, no data-path collec
 timing barrier and the MAX over ranks.
 
 Also reported on the same JSON line:
-  roofline     - the dominant kernel (implicit-GEMM conv, 128x128x64 tile) timed live with HIP events on the launch
-                 stream over the timed region: algorithmic FLOPs / measured kernel time vs the dense bf16 MFMA peak.
+  roofline     - the dominant kernel (conv3_halo_kernel: implicit-GEMM 3x3x3 conv, 126x128 tile, K 64 per step) timed live
+                 with HIP events on the launch stream: algorithmic FLOPs / measured kernel time vs the dense bf16 MFMA peak.
   cpu_baseline - the CPU oracle (fp32 torch ops, all host cores) timed on a bounded sample of the same workload.
 """
 import argparse
@@ -30,7 +30,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0         # /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
 UNET_STEP_GFLOP = 889.1                      # SURVEY.md section 8d / BASELINE.md section 3 (2*MAC, real channel counts)
-DOMINANT_TILE = (2, 2, 64)                   # conv_igemm_kernel<2,2,64>: 128 voxels x 128 couts x K 64
+DOMINANT_TILE = (2, 2, 64 | 256)             # conv3_halo_kernel (bk | 256 selects it): 126 voxels x 128 couts x K 64 per step
 
 
 def make_unet(dev, seed=0):
@@ -204,7 +204,7 @@ def main():
         out["roofline"] = {
             "bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": pmc_traffic(),
-            "kernel": "conv_igemm_kernel<2,2,64> (implicit-GEMM conv3d, 128x128x64 tile, bf16 MFMA 16x16x32)",
+            "kernel": "conv3_halo_kernel<6> (implicit-GEMM 3x3x3 stride-1 conv3d, 126x128 tile, W-halo reuse, bf16 MFMA 16x16x32)",
             "launches": int(prof[0]), "avg_launch_us": prof[1] * 1e3 / prof[0],
             "algorithmic_gflop_per_launch": prof[2] / prof[0] / 1e9,
             "share_of_conv_flops": prof[2] / prof[4] if prof[4] else None,

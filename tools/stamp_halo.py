@@ -10,7 +10,7 @@ dev = torch.device("cuda:0"); L = _lib.lib()
 x = torch.randn((1, D, H, W, cin), device=dev).to(torch.bfloat16)
 w = (torch.randn((27, cout, cin), device=dev) / (27 * cin) ** 0.5).to(torch.bfloat16)
 b = torch.zeros((cout,), device=dev); out = torch.empty((1, D, H, W, cout), dtype=torch.bfloat16, device=dev)
-for abl in (0, 4, 8, 20, 24, 32):
+for abl in [int(a) for a in os.environ.get('ABLS', '0,4,8,20,24,32').split(',')]:
     os.environ["LDM_CONV_DBG"] = str(512 + abl)
     scratch = torch.zeros((4 << 20,), dtype=torch.uint8, device=dev)
     for _ in range(5):

@@ -40,7 +40,7 @@ for f in glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
         k = short(r["Kernel_Name"])
         pmc[k][r["Counter_Name"]] += float(r["Counter_Value"])
         ndisp[k][r["Counter_Name"]] += 1
-dom = "conv_igemm_kernel<2, 2, 64, 4, 2>"
+dom = next((k for k in pmc if k.startswith("conv3_halo_kernel")), "conv_igemm_kernel<2, 2, 64, 4, 2>")
 per = {c: pmc[dom][c] / max(1, ndisp[dom][c]) for c in pmc[dom]}
 out["conv_pmc_per_launch"] = per
 if "FETCH_SIZE" in per and "WRITE_SIZE" in per:
