@@ -294,8 +294,8 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
     }
 
     // ---- epilogue (conv_igemm.h's, with the 126-row tile mapping).  After the exchange this wave owns the 32-row block
-    //      rows [64 wm + 32 grp, +32) of the tile = 16-row tiles mt_base + {0, 1}; GroupNorm partials go to slab row
-    //      (tile, block) = mtile * 4 + 2 wm + grp  (bitwise reproducible: no atomics).
+    //      rows [64 wm + 32 grp, +32) of the tile = 16-row tiles mt_base + {0, 1}; GroupNorm partials of the whole tile go to slab
+    //      row `mtile` (bitwise reproducible: no atomics).
     const int cbase = n0 + wn * 64 + 16 * fg;
     const bool do_stats = (p.stats != nullptr) && (p.splitk == 1) && (p.out != nullptr);
     float ssum[16], ssq[16];
@@ -369,12 +369,20 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
             HL_ROW_ADD(ssq[q], 0x128); HL_ROW_ADD(ssq[q], 0x124); HL_ROW_ADD(ssq[q], 0x122); HL_ROW_ADD(ssq[q], 0x121);
         }
 #undef HL_ROW_ADD
-        const int blk = mtile * 4 + wm * 2 + grp;                          // empty blocks (tile tail) write zeros
-        if (fr == 0 && cbase < p.CoutS) {
-            float* dst = p.stats + ((size_t)blk * p.CoutS + cbase) * 2;
+        // fold the tile's four 32-row blocks through LDS (behind the 64 KiB exchange area) -> ONE slab row per tile
+        float* red = reinterpret_cast<float*>(smem + 65536);               // [4][128 couts][2]
+        __syncthreads();
+        if (fr == 0) {
+            float* d = red + (((wm * 2 + grp) * 128) + wn * 64 + 16 * fg) * 2;
 #pragma unroll
-            for (int q = 0; q < 8; ++q)
-                *reinterpret_cast<float4*>(dst + 4 * q) = make_float4(ssum[2 * q], ssq[2 * q], ssum[2 * q + 1], ssq[2 * q + 1]);
+            for (int q = 0; q < 16; ++q) { d[2 * q] = ssum[q]; d[2 * q + 1] = ssq[q]; }
+        }
+        __syncthreads();
+        if (tid < 128 && n0 + tid < p.CoutS) {
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) { s0 += red[(b * 128 + tid) * 2]; s1 += red[(b * 128 + tid) * 2 + 1]; }
+            *reinterpret_cast<float2*>(p.stats + ((size_t)mtile * p.CoutS + n0 + tid) * 2) = make_float2(s0, s1);
         }
     }
 #endif  // __HIP_DEVICE_COMPILE__

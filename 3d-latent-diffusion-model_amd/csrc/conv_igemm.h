@@ -50,7 +50,7 @@ struct ConvParams {
     bf16_t* out;                      // [M][CoutS] bf16 NDHWC            (mode 0)
     float* out_f32;                   // [N][CoutReal][Dout*Hout*Wout]    (mode 1)
     float* partial;                   // [splitk][M][CoutPad] fp32 slabs  (splitk > 1)
-    float* stats;                     // GroupNorm partials of the OUTPUT: [ceil(M/32)][CoutS][2] (sum, sum sq) or null
+    float* stats;                     // GroupNorm partials of the OUTPUT: [mtile][CoutS][2] (sum, sum sq over the tile's rows) or null
     unsigned long long* stamps;       // diagnostic (dbg & 512): per-workgroup s_memrealtime stamps [nwg][8]
     int dbg;                          // timing experiments only (LDM_CONV_DBG): 1 = all voxel rows from the zero page, 2 = all weight rows = row 0
 };
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_igemm_kernel(const ConvParam
     static_assert(PA >= 1 && PB >= 1, "tile too small for this many waves");
     static_assert(KS == NG, "each wave group computes exactly one 32-deep k-substep per K step");
     static_assert((PF - 1) * LPS <= 63 && PF * LPS <= 63, "vmcnt is a 6-bit counter");
-    static_assert(NG == 1 || NS * STAGE >= 65536, "the accumulator exchange needs 64 KiB of LDS");
+    static_assert(NG == 1 || NS * STAGE >= 65536 + 4 * BN * 8, "the accumulator exchange needs 64 KiB of LDS (+ the GroupNorm fold)");
     static_assert(NS * STAGE + 28 * BM * 4 <= 160 * 1024, "ring + tap table must fit the 160 KiB LDS");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -493,11 +493,11 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_igemm_kernel(const ConvParam
     // the (bf16-rounded) output over each 32-row block, written to a slab (no atomics -> bitwise reproducible).
     const int cbase = n0 + wn * 64 + 16 * fg;          // this lane's 16 consecutive couts
     const bool do_stats = (p.stats != nullptr) && (p.splitk == 1) && (p.out != nullptr);
+    float ssum[16], ssq[16];                           // GroupNorm partials of this wave's rows (whole tile after the LDS fold)
 #pragma unroll
-    for (int pr = 0; pr < MTN / 2; ++pr) {             // pairs of 16-row tiles = 32-row statistics blocks
-        float ssum[16], ssq[16];
+    for (int q = 0; q < 16; ++q) { ssum[q] = 0.f; ssq[q] = 0.f; }
 #pragma unroll
-        for (int q = 0; q < 16; ++q) { ssum[q] = 0.f; ssq[q] = 0.f; }
+    for (int pr = 0; pr < MTN / 2; ++pr) {             // pairs of 16-row tiles
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
             const int ml = pr * 2 + hh;
@@ -566,22 +566,32 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_igemm_kernel(const ConvParam
                 op[h] = o;
             }
         }
-        if (do_stats) {
-            // sum over the 16 voxel lanes of each DPP row (lanes sharing fg): rotate-and-add within the row
+    }
+    if (do_stats) {
+        // sum over the 16 voxel lanes of each DPP row (lanes sharing fg): rotate-and-add within the row
 #define LDM_ROW_ADD(X, CTRL) X += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(X), CTRL, 0xf, 0xf, true))
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                LDM_ROW_ADD(ssum[q], 0x128); LDM_ROW_ADD(ssum[q], 0x124); LDM_ROW_ADD(ssum[q], 0x122); LDM_ROW_ADD(ssum[q], 0x121);
-                LDM_ROW_ADD(ssq[q], 0x128); LDM_ROW_ADD(ssq[q], 0x124); LDM_ROW_ADD(ssq[q], 0x122); LDM_ROW_ADD(ssq[q], 0x121);
-            }
+        for (int q = 0; q < 16; ++q) {
+            LDM_ROW_ADD(ssum[q], 0x128); LDM_ROW_ADD(ssum[q], 0x124); LDM_ROW_ADD(ssum[q], 0x122); LDM_ROW_ADD(ssum[q], 0x121);
+            LDM_ROW_ADD(ssq[q], 0x128); LDM_ROW_ADD(ssq[q], 0x124); LDM_ROW_ADD(ssq[q], 0x122); LDM_ROW_ADD(ssq[q], 0x121);
+        }
 #undef LDM_ROW_ADD
-            const int rb = (m0 + wm * 64 + (mt_base + pr * 2) * 16) >> 5;          // 32-row block index
-            if (fr == 0 && cbase < p.CoutS && rb * 32 < p.M) {
-                float* dst = p.stats + ((size_t)rb * p.CoutS + cbase) * 2;
+        // fold the row blocks of the tile (WGM wave rows x NG wave groups) through LDS -> ONE slab row per tile
+        constexpr int NRB = WGM * NG;
+        float* red = reinterpret_cast<float*>(smem + ((NG == 2) ? 65536 : 0));         // [NRB][BN][2]
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();                                   // the ring (and its last fragment reads) is dead in every wave
+        if (fr == 0) {
+            float* d = red + (((wm * NG + grp) * BN) + wn * 64 + 16 * fg) * 2;
 #pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    *reinterpret_cast<float4*>(dst + 4 * q) = make_float4(ssum[2 * q], ssq[2 * q], ssum[2 * q + 1], ssq[2 * q + 1]);
-            }
+            for (int q = 0; q < 16; ++q) { d[2 * q] = ssum[q]; d[2 * q + 1] = ssq[q]; }
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < p.CoutS) {
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int b = 0; b < NRB; ++b) { s0 += red[(b * BN + tid) * 2]; s1 += red[(b * BN + tid) * 2 + 1]; }
+            *reinterpret_cast<float2*>(p.stats + ((size_t)mtile * p.CoutS + n0 + tid) * 2) = make_float2(s0, s1);
         }
     }
     LDM_STAMP(5);

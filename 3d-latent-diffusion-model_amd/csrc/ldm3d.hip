@@ -67,7 +67,7 @@ struct Act {                                         // NDHWC bf16 activation li
 };
 
 enum OpKind { OP_PACK, OP_CONV, OP_FINALIZE, OP_GN_STATS, OP_GN_FINALIZE, OP_GN_PREP, OP_GN_APPLY, OP_ATTN, OP_SINUSOID,
-              OP_GEMV, OP_VAE_HEADS,
+              OP_GEMV, OP_VAE_HEADS, OP_GN_FUSED,
               // backward (training plans only)
               OP_WT, OP_WGRAD, OP_EXPORT, OP_COLSUM, OP_GNB, OP_ATTN_BWD, OP_ADD, OP_SUMPOOL, OP_LIN_DX, OP_LIN_DW };
 
@@ -324,11 +324,16 @@ struct Builder {
         if (!a.f32_out) {
             out = new_act(N, a.Do, a.Ho, a.Wo, couts);
             if (a.want_stats) {
-                const bool tile_blocks = cc.halo && cc.splitk == 1;               // partials per (126-row tile, 32-row block)
-                const size_t nrb = tile_blocks ? (size_t)N * cc.mtps * 4 : (size_t)((M + 31) / 32);
-                out.stats_off = pool.alloc(nrb * couts * 2 * 4);
-                out.has_stats = true;
-                out.stats_nrb = tile_blocks ? cc.mtps * 4 : 0;
+                // GroupNorm partial slabs: one row per conv tile (split-K: one per 32 output rows, written by the finalize)
+                const long dhwo = (long)a.Do * a.Ho * a.Wo;
+                if (cc.splitk > 1) {
+                    out.stats_off = pool.alloc((size_t)((M + 31) / 32) * couts * 2 * 4); out.has_stats = true; out.stats_nrb = 0;
+                } else if (cc.halo) {
+                    out.stats_off = pool.alloc((size_t)N * cc.mtps * couts * 2 * 4); out.has_stats = true; out.stats_nrb = cc.mtps;
+                } else if (N == 1 || dhwo % bm == 0) {                               // tiles must not straddle samples
+                    out.stats_off = pool.alloc((size_t)((M + bm - 1) / bm) * couts * 2 * 4); out.has_stats = true;
+                    out.stats_nrb = (int)(N == 1 ? (M + bm - 1) / bm : dhwo / bm);
+                }
             }
         }
         Op op{}; op.kind = OP_CONV; op.cc = cc;
@@ -379,6 +384,26 @@ struct Builder {
         auto blocks_ok = [&](const Act& t) { return t.has_stats && (t.stats_nrb > 0 || N == 1 || DHW % 32 == 0); };
         auto blocks_of = [&](const Act& t) { return t.stats_nrb > 0 ? t.stats_nrb : (N == 1 ? (DHW + 31) / 32 : DHW / 32); };
         const bool fused = blocks_ok(xa) && (!xb.valid || blocks_ok(xb));
+        const int nrb_tot = fused ? blocks_of(xa) + (xb.valid ? blocks_of(xb) : 0) : 0;
+        if (fused && C / groups <= 64 && nrb_tot <= 256) {   // few slab rows: ONE launch folds them per block and applies
+            Act out = new_act(N, xa.D, xa.H, xa.W, C);
+            const int slices = (C + 63) / 64;
+            int chunks = std::max(1, std::min(512 / (slices * N), (DHW + 31) / 32));
+            int rpb = rup((DHW + chunks - 1) / chunks, 32);
+            chunks = (DHW + rpb - 1) / rpb;
+            Op f{}; f.kind = OP_GN_FUSED;
+            f.r[0] = ws_ref(xa.off); f.r[1] = xb.valid ? ws_ref(xb.off) : Ref(); f.r[2] = w_ref(g.g_off); f.r[3] = w_ref(g.b_off);
+            f.r[7] = ws_ref(xa.stats_off); f.r[8] = xb.valid ? ws_ref(xb.stats_off) : Ref(); f.r[9] = ws_ref(out.off);
+            if (train) { f.r[5] = ws_ref(ab_off); f.r[6] = ws_ref(mr_off); }
+            f.i[0] = xa.C; f.i[1] = xb.valid ? xb.C : 0; f.i[2] = blocks_of(xa); f.i[3] = xb.valid ? blocks_of(xb) : 0;
+            f.i[4] = groups; f.i[5] = DHW; f.i[6] = N; f.i[7] = silu ? 1 : 0; f.i[8] = rpb; f.i[9] = chunks; f.f[0] = eps;
+            plan->ops.push_back(f);
+            if (recording) {
+                Tape t; t.kind = 1; t.g = &g; t.xa = xa; t.xb = xb; t.out = out; t.ab_off = ab_off; t.mr_off = mr_off;
+                t.groups = groups; t.silu = silu; tape.push_back(t);
+            }
+            return out;
+        }
         if (fused) {                                   // partials came with the tensors: one small reduce
             Op f{}; f.kind = OP_GN_PREP;
             f.r[0] = ws_ref(xa.stats_off); f.r[1] = xb.valid ? ws_ref(xb.stats_off) : Ref();
@@ -1195,6 +1220,14 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                 p.nrb_a = i[2]; p.nrb_b = i[6]; p.groups = i[3]; p.DHW = i[4]; p.eps = o.f[0];
                 p.gamma = (const float*)rp(bs, o.r[2]); p.beta = (const float*)rp(bs, o.r[3]); p.ab = (float*)rp(bs, o.r[5]); p.mr = (float*)rp(bs, o.r[6]);
                 hipLaunchKernelGGL(gn_prep_kernel, dim3(i[3], i[5]), dim3(256), 0, s, p);
+                break; }
+            case OP_GN_FUSED: {
+                GnFusedParams p{}; p.xa = (const bf16_t*)rp(bs, o.r[0]); p.xb = (const bf16_t*)rp(bs, o.r[1]); p.ca = i[0]; p.cb = i[1];
+                p.sa = (const float*)rp(bs, o.r[7]); p.sb = (const float*)rp(bs, o.r[8]); p.nrb_a = i[2]; p.nrb_b = i[3];
+                p.groups = i[4]; p.DHW = i[5]; p.N = i[6]; p.silu = i[7]; p.rows_per_block = i[8]; p.eps = o.f[0];
+                p.gamma = (const float*)rp(bs, o.r[2]); p.beta = (const float*)rp(bs, o.r[3]); p.out = (bf16_t*)rp(bs, o.r[9]);
+                p.ab = (float*)rp(bs, o.r[5]); p.mr = (float*)rp(bs, o.r[6]);
+                hipLaunchKernelGGL(gn_fused_apply_kernel, dim3(i[9], (i[0] + i[1] + 63) / 64, i[6]), dim3(256), 0, s, p);
                 break; }
             case OP_GN_APPLY: {
                 GnApplyParams p{}; p.xa = (const bf16_t*)rp(bs, o.r[0]); p.xb = (const bf16_t*)rp(bs, o.r[1]); p.ca = i[0]; p.cb = i[1];

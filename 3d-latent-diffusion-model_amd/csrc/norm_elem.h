@@ -202,6 +202,98 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnApplyParams p) {
     }
 }
 
+// One-launch GroupNorm(+SiLU) for tensors whose producers left few slab rows (one per conv tile): every block first
+// folds the slabs of the channels it needs (its 64-channel slice widened to whole groups), derives mean / rstd of those
+// groups, then normalises its rows.  Replaces gn_prep + gn_apply (two launch floors) wherever slab rows <= 256 per
+// sample; the redundant slab reads stay in L2.  grid = (row chunks, ceil(C / 64), N), 256 threads.
+struct GnFusedParams {
+    const bf16_t* xa; const bf16_t* xb; int ca, cb;
+    const float* sa; const float* sb; int nrb_a, nrb_b;      // slabs [N * nrb][c][2] of the two sources
+    int groups, DHW, N, silu, rows_per_block; float eps;
+    const float* gamma; const float* beta; bf16_t* out;
+    float* ab; float* mr;                              // optional (training): [N][C][2] scale/shift, [N][G][2] mean/rstd
+};
+
+__global__ __launch_bounds__(256) void gn_fused_apply_kernel(const GnFusedParams p) {
+    __shared__ float part[4][192][2];
+    __shared__ double csum[192][2];
+    __shared__ float gstat[64][2];
+    const int tid = threadIdx.x, n = blockIdx.z;
+    const int C = p.ca + p.cb, cpg = C / p.groups;     // host guarantees cpg <= 64
+    const int c0 = blockIdx.y * 64;
+    int c1 = c0 + 64; if (c1 > C) c1 = C;
+    const int g_lo = c0 / cpg, g_hi = (c1 + cpg - 1) / cpg;
+    const int cov_lo = g_lo * cpg, ncov = g_hi * cpg - cov_lo;           // <= 64 + 2 * 63
+    // ---- fold the slabs: thread = (channel of the cover, one of 4 slab lanes)
+    {
+        const int bl = tid >> 6;
+        for (int cc = tid & 63; cc < ncov; cc += 64) {
+            const int c = cov_lo + cc;
+            const bool second = c >= p.ca;
+            const float* sl = second ? p.sb : p.sa;
+            const int cs = second ? p.cb : p.ca, cl = second ? c - p.ca : c, nrb = second ? p.nrb_b : p.nrb_a;
+            float s0 = 0.f, s1 = 0.f;
+            for (int b = bl; b < nrb; b += 4) {
+                const float2 v = *reinterpret_cast<const float2*>(sl + ((size_t)(n * nrb + b) * cs + cl) * 2);
+                s0 += v.x; s1 += v.y;
+            }
+            part[bl][cc][0] = s0; part[bl][cc][1] = s1;
+        }
+    }
+    __syncthreads();
+    if (tid < ncov) {
+        csum[tid][0] = (double)part[0][tid][0] + (double)part[1][tid][0] + (double)part[2][tid][0] + (double)part[3][tid][0];
+        csum[tid][1] = (double)part[0][tid][1] + (double)part[1][tid][1] + (double)part[2][tid][1] + (double)part[3][tid][1];
+    }
+    __syncthreads();
+    if (tid < g_hi - g_lo) {
+        double s = 0.0, q = 0.0;
+        for (int k = 0; k < cpg; ++k) { s += csum[tid * cpg + k][0]; q += csum[tid * cpg + k][1]; }
+        const double cnt = (double)cpg * (double)p.DHW;
+        const double mean = s / cnt;
+        double var = q / cnt - mean * mean; if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+        gstat[tid][0] = (float)mean; gstat[tid][1] = rstd;
+        if (p.mr && blockIdx.x == 0) {
+            p.mr[((size_t)n * p.groups + g_lo + tid) * 2] = (float)mean; p.mr[((size_t)n * p.groups + g_lo + tid) * 2 + 1] = rstd;
+        }
+    }
+    __syncthreads();
+    // ---- apply: thread = (8-channel vector of the slice, row lane)
+    const int vec = tid & 7, rl = tid >> 3;
+    const int c = c0 + vec * 8;
+    if (c >= C) return;
+    float a[8], b[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int g = (c + k) / cpg - g_lo;
+        a[k] = p.gamma[c + k] * gstat[g][1];
+        b[k] = p.beta[c + k] - gstat[g][0] * a[k];
+    }
+    if (p.ab && blockIdx.x == 0 && rl == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { p.ab[((size_t)n * C + c + k) * 2] = a[k]; p.ab[((size_t)n * C + c + k) * 2 + 1] = b[k]; }
+    }
+    const bool second = c >= p.ca;
+    const bf16_t* src = second ? p.xb : p.xa;
+    const int cs = second ? p.cb : p.ca, cl = second ? c - p.ca : c;
+    const int r0 = blockIdx.x * p.rows_per_block;
+    int r1 = r0 + p.rows_per_block; if (r1 > p.DHW) r1 = p.DHW;
+    for (int r = r0 + rl; r < r1; r += 32) {
+        const size_t row = (size_t)n * p.DHW + r;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(src + row * cs + cl);
+        u32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float lo = __uint_as_float(v[k] << 16) * a[2 * k] + b[2 * k];
+            float hi = __uint_as_float(v[k] & 0xffff0000u) * a[2 * k + 1] + b[2 * k + 1];
+            if (p.silu) { lo = silu_f(lo); hi = silu_f(hi); }
+            o[k] = pack2bf(lo, hi);
+        }
+        *reinterpret_cast<u32x4*>(p.out + row * C + c) = o;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // fp32 NCDHW (x | cond channel-concatenated) -> bf16 NDHWC with zero channel padding to Cs.  Once per forward.
 __global__ __launch_bounds__(256) void pack2_ncdhw_kernel(const float* __restrict__ x, int cx, const float* __restrict__ cond,
