@@ -622,8 +622,26 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const FinalizePara
         float v[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[q] = 0.f;
-        for (int s = 0; s < p.splitk; ++s) {
-            const float4* src = reinterpret_cast<const float4*>(p.partial + ((size_t)s * p.M + m) * p.CoutPad + c);
+        // slabs are summed in order 0, 1, 2, ... (bitwise reproducible); four slabs' loads are in flight at a time so the
+        // sum is not one L2 round trip per slab
+        const size_t slab = (size_t)p.M * p.CoutPad;
+        const float* src0 = p.partial + (size_t)m * p.CoutPad + c;
+        int s = 0;
+        for (; s + 4 <= p.splitk; s += 4) {
+            float4 a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4* src = reinterpret_cast<const float4*>(src0 + (size_t)(s + u) * slab);
+                a[u] = src[0]; b[u] = src[1];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                v[0] += a[u].x; v[1] += a[u].y; v[2] += a[u].z; v[3] += a[u].w;
+                v[4] += b[u].x; v[5] += b[u].y; v[6] += b[u].z; v[7] += b[u].w;
+            }
+        }
+        for (; s < p.splitk; ++s) {
+            const float4* src = reinterpret_cast<const float4*>(src0 + (size_t)s * slab);
             const float4 a = src[0], b = src[1];
             v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
             v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
