@@ -47,6 +47,7 @@ SIGNATURES = {
                                    _P, C.c_size_t, _P]),
     "ldm_model_param_offset": (C.c_int64, [_P, C.c_int]),
     "ldm_model_load_params_device": (C.c_int, [_P, C.POINTER(_P), C.c_int, _P]),
+    "ldm_model_load_params_flat": (C.c_int, [_P, _P, _P]),
     "ldm_unet_train_workspace_bytes": (C.c_size_t, [_P, C.c_int, C.c_int, C.c_int, C.c_int]),
     "ldm_unet_train_forward": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int,
                                          _P, C.c_size_t, _P]),

@@ -69,7 +69,7 @@ struct Act {                                         // NDHWC bf16 activation li
 enum OpKind { OP_PACK, OP_CONV, OP_FINALIZE, OP_GN_STATS, OP_GN_FINALIZE, OP_GN_PREP, OP_GN_APPLY, OP_ATTN, OP_SINUSOID,
               OP_GEMV, OP_VAE_HEADS, OP_GN_FUSED,
               // backward (training plans only)
-              OP_WT, OP_WGRAD, OP_EXPORT, OP_COLSUM, OP_GNB, OP_ATTN_BWD, OP_ADD, OP_SUMPOOL, OP_LIN_DX, OP_LIN_DW };
+              OP_WT, OP_WT_BATCH, OP_WGRAD, OP_EXPORT, OP_EXPORT_BATCH, OP_COLSUM, OP_GNB, OP_ATTN_BWD, OP_ADD, OP_SUMPOOL, OP_LIN_DX, OP_LIN_DW };
 
 struct ConvCfg { int wgm, wgn, bk, splitk; int halo = 0, mtps = 0, qps = 0; };   // halo: conv3_halo_kernel (126-row tiles)
 
@@ -115,11 +115,26 @@ struct Pool {                                        // plan-time workspace allo
     }
 };
 
+// Descriptor table of a batched kernel: device copy of the descriptors + (descriptor, local block) per launched block.
+struct DevTable {
+    void* descs = nullptr; int2* map = nullptr; int nblocks = 0;
+    ~DevTable() { if (descs) (void)hipFree(descs); if (map) (void)hipFree(map); }
+    template <class D> int upload(const std::vector<D>& d, const std::vector<int2>& m) {
+        if (d.empty()) return 0;
+        if (hipMalloc(&descs, d.size() * sizeof(D)) != hipSuccess || hipMalloc((void**)&map, m.size() * sizeof(int2)) != hipSuccess) return -1;
+        if (hipMemcpy(descs, d.data(), d.size() * sizeof(D), hipMemcpyHostToDevice) != hipSuccess) return -1;
+        if (hipMemcpy(map, m.data(), m.size() * sizeof(int2), hipMemcpyHostToDevice) != hipSuccess) return -1;
+        nblocks = (int)m.size();
+        return 0;
+    }
+};
+
 struct Plan {
     std::vector<Op> ops;
     size_t ws_bytes = 0;
     size_t bwd_begin = 0;                            // training plans: ops [0, bwd_begin) = forward, the rest = backward
     bool train = false;
+    DevTable wt_tab, exp_tab;                        // training plans: all weight transposes / all gradient exports in one launch each
 };
 
 // ================================================================================================ parameters
@@ -146,6 +161,7 @@ struct ldm_model {
     int loaded_count = 0;
     std::map<std::string, ConvW> convs; std::map<std::string, GnW> gns; std::map<std::string, LinW> lins;
     std::map<std::string, std::shared_ptr<Plan>> plans;
+    DevTable pack_tab;                               // one-launch re-pack of a flat fp32 parameter buffer
     // UNet: stacked time_emb_proj GEMV
     size_t tproj_w_off = 0, tproj_b_off = 0; int tproj_rows = 0; std::map<std::string, int> tproj_row;
 
@@ -507,7 +523,9 @@ struct Builder {
     // fresh buffer; plain pass-through contributions (identity skips) alias the producer's buffer.
     // Parameter gradients go to one flat fp32 buffer (BASE_IO4) in parameter order, MONAI tensor layouts.
     std::map<size_t, Act> gslot;
-    size_t wt_off = 0, dw_off = 0, vec_off = 0, dtemb_off = 0;
+    size_t dw_off = 0, vec_off = 0, dtemb_off = 0;     // staging of the conv being differentiated (fresh per conv: exports run at the end)
+    std::vector<ExportDesc> exp_descs; std::vector<int2> exp_map;
+    std::vector<WtDesc> wt_descs; std::vector<int2> wt_map;
     size_t sin_off = 0, e1_off = 0, e2_off = 0;      // saved time-embedding MLP activations
     static Ref grad_ref(int64_t elem_off) { Ref r; r.base = BASE_IO4; r.off = (size_t)elem_off * 4; return r; }
 
@@ -523,9 +541,11 @@ struct Builder {
     }
     void emit_export(size_t src_off, int taps, int rows_total, int ld, int row_off, int col_off, int cout, int cin, int64_t flat_off,
                      int nsplit = 1) {
-        Op o{}; o.kind = OP_EXPORT; o.r[0] = ws_ref(src_off); o.r[1] = grad_ref(flat_off);
-        o.i[0] = taps; o.i[1] = rows_total; o.i[2] = ld; o.i[3] = row_off; o.i[4] = col_off; o.i[5] = cout; o.i[6] = cin; o.i[7] = nsplit;
-        plan->ops.push_back(o);
+        ExportDesc e{}; e.src_off = (long)src_off; e.dst_off = (long)flat_off; e.slab_stride = (long)taps * rows_total * ld;
+        e.taps = taps; e.rows_total = rows_total; e.ld = ld; e.row_off = row_off; e.col_off = col_off; e.cout = cout; e.cin = cin; e.nsplit = nsplit;
+        const int nb = ((cin + 63) / 64) * cout;
+        for (int b = 0; b < nb; ++b) exp_map.push_back(make_int2((int)exp_descs.size(), b));
+        exp_descs.push_back(e);
     }
     void export_conv_weights(const ConvW& w, int ld) {           // staging [taps][w.cout][ld] -> every parameter of the slot
         for (const ParamDesc& d : m->params)
@@ -564,9 +584,15 @@ struct Builder {
     bool emit_dgrad(const Act& dy, const Act& src, const ConvW& w, int ci_off, int k, int stride, int pad, int ups) {
         if (stride == 2 && !(k == 3 && pad == 1)) { err = "backward of a stride-2 conv needs k = 3, pad = 1"; return false; }
         const int taps = k * k * k;
-        Op t{}; t.kind = OP_WT; t.r[0] = w_ref(w.w_off); t.r[1] = ws_ref(wt_off);
-        t.i[0] = taps; t.i[1] = w.cout; t.i[2] = w.cout_pad; t.i[3] = w.cin_s; t.i[4] = rup(src.C, 64); t.i[5] = ci_off; t.i[6] = src.C;
-        plan->ops.push_back(t);
+        const int rows = rup(src.C, 64), cols = rup(w.cout, 32);
+        const size_t wt_off = pool.alloc((size_t)taps * rows * cols * 2);
+        {   // transposed once per backward by the batched kernel at the head of the backward plan
+            WtDesc e{}; e.src_off = (long)w.w_off; e.dst_off = (long)wt_off; e.taps = taps; e.cout = w.cout; e.cout_pad = w.cout_pad;
+            e.cin = w.cin_s; e.rows = rows; e.ci_off = ci_off; e.ci_cnt = src.C; e.col_tiles = (cols + 63) / 64; e.row_tiles = rows / 64;
+            const int nb = e.col_tiles * e.row_tiles * taps;
+            for (int b = 0; b < nb; ++b) wt_map.push_back(make_int2((int)wt_descs.size(), b));
+            wt_descs.push_back(e);
+        }
         ConvW syn; syn.has = true; syn.k = k; syn.cout = src.C; syn.cout_pad = rup(src.C, 64); syn.cin_s = dy.C;
         ConvArgs d; d.xa = dy; d.w = &syn; d.w_over = ws_ref(wt_off); d.no_bias = true; d.k = k; d.stride = 1; d.pad = k - 1 - pad;
         if (stride == 2) { d.ups = 1; d.exact = 1; }
@@ -591,12 +617,14 @@ struct Builder {
         if (!cin_real) { err = "backward: conv slot without parameters"; return false; }
         if (dout.C != rup(w.cout, 32)) { err = "backward: gradient channel mismatch"; return false; }
         // bias (both biases of a conv with a fused 1x1 skip see the same column sums) and the time-embedding rows
+        vec_off = pool.alloc((size_t)dout.C * 4);
         emit_colsum(dout, false, ws_ref(vec_off), dout.C, 0);
         export_bias(w);
         if (a.w1) export_bias(*a.w1);
         if (a.temb_row >= 0) emit_colsum(dout, true, ws_ref(dtemb_off + (size_t)a.temb_row * 4), w.cout, tproj_stride);
         // weights
         cur_ksplit = wgrad_ksplit(dout.rows(), a.k * a.k * a.k, w.cout, cin_real); cur_rows_total = w.cout;
+        dw_off = pool.alloc((size_t)cur_ksplit * a.k * a.k * a.k * w.cout * cin_real * 4);
         if (a.xb.valid) {
             emit_wgrad(dout, a.xa, w.cout, a.xa.C, cin_real, 0, a.k, a.stride, a.pad, a.ups);
             emit_wgrad(dout, a.xb, w.cout, a.xb.C, cin_real, a.xa.C, a.k, a.stride, a.pad, a.ups);
@@ -605,6 +633,7 @@ struct Builder {
         if (a.w1) {
             const int c1 = a.g1a.C + (a.g1b.valid ? a.g1b.C : 0);
             cur_ksplit = wgrad_ksplit(dout.rows(), 1, a.w1->cout, c1); cur_rows_total = a.w1->cout;
+            dw_off = pool.alloc((size_t)cur_ksplit * a.w1->cout * c1 * 4);
             emit_wgrad(dout, a.g1a, a.w1->cout, a.g1a.C, c1, 0, 1, 1, 0, 0);
             if (a.g1b.valid) emit_wgrad(dout, a.g1b, a.w1->cout, a.g1b.C, c1, a.g1a.C, 1, 1, 0, 0);
             export_conv_weights(*a.w1, c1);
@@ -879,16 +908,8 @@ static int unet_build(ldm_model* m, int B, int D, int H, int W, Plan* plan, bool
         plan->train = true; plan->bwd_begin = plan->ops.size();
         b.recording = false;
         const int rows = m->tproj_rows;
-        size_t max_wt = 0, max_dw = (size_t)rows * temb * 4;
-        for (auto& kv : m->convs) {
-            const ConvW& w = kv.second; const size_t taps = (size_t)w.k * w.k * w.k;
-            max_wt = std::max(max_wt, taps * rup(w.cin_s, 64) * rup(w.cout, 32) * 2);
-            max_dw = std::max(max_dw, taps * rup(w.cout, 128) * rup(w.cin_s, 128) * 4);
-        }
-        max_dw += (size_t)(512 + 64) * 65536;           // room for the voxel-split slabs (wgrad_ksplit keeps taps*tiles*ksplit <~ 512 tiles)
-        b.wt_off = b.pool.alloc(max_wt); b.dw_off = b.pool.alloc(max_dw);
-        b.vec_off = b.pool.alloc((size_t)std::max(4096, rows) * 4);
         b.dtemb_off = b.pool.alloc(((size_t)B * rows + 256) * 4);
+        { Op o{}; o.kind = OP_WT_BATCH; plan->ops.push_back(o); }          // every flipped / transposed weight matrix, one launch
         const int cos_ = rup(c.out_channels, 32);
         Act dout = b.new_act(B, D, H, W, cos_);
         { Op o{}; o.kind = OP_PACK; o.r[0] = io_ref(0); o.r[1] = Ref(); o.r[2] = ws_ref(dout.off);
@@ -896,6 +917,7 @@ static int unet_build(ldm_model* m, int B, int D, int H, int W, Plan* plan, bool
         if (!b.backward_all(dout)) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
         // stacked projections  temb_all = Wt silu(e2) + bt
         const Ref dtemb = ws_ref(b.dtemb_off);
+        b.dw_off = b.pool.alloc((size_t)rows * temb * 4); b.vec_off = b.pool.alloc((size_t)rows * 4);
         b.emit_lin_dw(dtemb, ws_ref(e2_off), ws_ref(b.dw_off), ws_ref(b.vec_off), B, temb, rows, rows, temb, 1);
         for (const ParamDesc& d : m->params) {
             if (d.kind == PK_LINEAR_W && d.dst_off >= m->tproj_w_off && d.dst_off < m->tproj_w_off + (size_t)rows * temb * 2)
@@ -913,6 +935,9 @@ static int unet_build(ldm_model* m, int B, int D, int H, int W, Plan* plan, bool
         b.emit_lin_dw(ws_ref(de1), ws_ref(sin_off), Builder::grad_ref(P("time_embed.0.weight")), Builder::grad_ref(P("time_embed.0.bias")),
                       B, ch[0], temb, temb, ch[0], 0);
         if (!b.err.empty()) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
+        { Op o{}; o.kind = OP_EXPORT_BATCH; plan->ops.push_back(o); }      // every staged parameter gradient -> flat buffer, one launch
+        if (plan->wt_tab.upload(b.wt_descs, b.wt_map) || plan->exp_tab.upload(b.exp_descs, b.exp_map))
+            return fail(LDM_ERR_HIP, "descriptor table upload failed");
     }
     b.finish();
     return 0;
@@ -1261,6 +1286,18 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                 hipLaunchKernelGGL(weight_flip_transpose_kernel, dim3((cols + 63) / 64, (i[4] + 63) / 64, i[0]), dim3(256), 0, s,
                                    (const bf16_t*)rp(bs, o.r[0]), (bf16_t*)rp(bs, o.r[1]), i[0], i[1], i[2], i[3], i[4], i[5], i[6]);
                 break; }
+            case OP_WT_BATCH:
+                if (plan.wt_tab.nblocks)
+                    hipLaunchKernelGGL(weight_flip_transpose_batched_kernel, dim3(plan.wt_tab.nblocks), dim3(256), 0, s,
+                                       (const WtDesc*)plan.wt_tab.descs, (const int2*)plan.wt_tab.map, (const char*)bs.p[BASE_W], bs.p[BASE_WS]);
+                break;
+            case OP_EXPORT_BATCH:
+                if (!bs.p[BASE_IO4]) return fail(LDM_ERR_BAD_ARG, "backward without a gradient buffer");
+                if (plan.exp_tab.nblocks)
+                    hipLaunchKernelGGL(grad_export_batched_kernel, dim3(plan.exp_tab.nblocks), dim3(256), 0, s,
+                                       (const ExportDesc*)plan.exp_tab.descs, (const int2*)plan.exp_tab.map, (const char*)bs.p[BASE_WS],
+                                       (float*)bs.p[BASE_IO4]);
+                break;
             case OP_WGRAD: {
                 WgradParams p{}; p.dy = (const bf16_t*)rp(bs, o.r[0]); p.cdy = i[0]; p.x = (const bf16_t*)rp(bs, o.r[1]); p.cx = i[1];
                 p.dw = (float*)rp(bs, o.r[2]); p.Cout = i[2]; p.Cin = i[3]; p.dw_ld = i[4]; p.dw_ci_off = i[5];
@@ -1502,6 +1539,31 @@ int ldm_model_load_params_device(ldm_model* m, const float* const* ptrs, int n, 
         if (!d.loaded) { d.loaded = true; m->loaded_count++; }
     }
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+/* The same from ONE flat fp32 device buffer holding every parameter at ldm_model_param_offset(i) (the layout of the flat
+ * gradient buffer): a single descriptor-driven launch. */
+int ldm_model_load_params_flat(ldm_model* m, const float* flat, void* stream) {
+    if (!m || !flat) return fail(LDM_ERR_BAD_ARG, "null argument");
+    LDM_TRY(ensure_arena(m));
+    if (!m->pack_tab.nblocks) {
+        std::vector<PackDesc> descs; std::vector<int2> map;
+        for (const ParamDesc& d : m->params) {
+            PackDesc e{}; e.src_off = (long)d.flat_off; e.dst_off = (long)d.dst_off;
+            int nb;
+            if (d.kind == PK_VEC_F32) { e.kind = 1; e.cout = d.cout; nb = (d.cout + 1023) / 1024; }
+            else if (d.kind == PK_LINEAR_W) { e.kind = 0; e.taps = 1; e.cout = d.cout; e.cin = d.cin; e.cin_s = d.cin; e.cout_pad = d.cout; e.row_off = 0; nb = ((d.cin + 63) / 64) * d.cout; }
+            else { e.kind = 0; e.taps = d.k * d.k * d.k; e.cout = d.cout; e.cin = d.cin; e.cin_s = d.cin_s; e.cout_pad = d.cout_pad; e.row_off = d.row_off; nb = ((d.cin_s + 63) / 64) * d.cout; }
+            for (int b = 0; b < nb; ++b) map.push_back(make_int2((int)descs.size(), b));
+            descs.push_back(e);
+        }
+        if (m->pack_tab.upload(descs, map)) return fail(LDM_ERR_HIP, "descriptor table upload failed");
+    }
+    hipLaunchKernelGGL(param_pack_batched_kernel, dim3(m->pack_tab.nblocks), dim3(256), 0, (hipStream_t)stream,
+                       (const PackDesc*)m->pack_tab.descs, (const int2*)m->pack_tab.map, flat, m->arena);
+    HIP_TRY(hipGetLastError());
+    for (ParamDesc& d : m->params) if (!d.loaded) { d.loaded = true; m->loaded_count++; }
     return 0;
 }
 

@@ -853,3 +853,84 @@ __global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ p, c
         p[i] -= step * mi / (sqrtf(vi) / k.bc2_sqrt + k.eps);      // torch.optim.Adam: denom = sqrt(v)/sqrt(bc2) + eps
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// Descriptor-driven (batched) forms of the three per-parameter kernels of a training step: ONE launch each instead of
+// ~100-300 launches at their launch floor.  blockmap[b] = (descriptor index, block index inside that descriptor).
+struct PackDesc { long src_off; long dst_off; int taps, cout, cin, cin_s, cout_pad, row_off, kind, pad_; };   // kind 0 matrix, 1 fp32 vector
+__global__ __launch_bounds__(256) void param_pack_batched_kernel(const PackDesc* __restrict__ descs, const int2* __restrict__ blockmap,
+                                                                 const float* __restrict__ flat, char* __restrict__ arena) {
+    __shared__ float tile[64 * 27];
+    const int2 bm = blockmap[blockIdx.x];
+    const PackDesc e = descs[bm.x];
+    const int tid = threadIdx.x;
+    const float* src = flat + e.src_off;
+    if (e.kind == 1) {                                   // fp32 vector: 1024 elements per block
+        float* dst = reinterpret_cast<float*>(arena + e.dst_off);
+        for (int i = bm.y * 1024 + tid; i < e.cout && i < (bm.y + 1) * 1024; i += 256) dst[i] = src[i];
+        return;
+    }
+    bf16_t* dst = reinterpret_cast<bf16_t*>(arena + e.dst_off);
+    const int nchunk = (e.cin_s + 63) / 64;
+    const int co = bm.y / nchunk, ci0 = (bm.y - co * nchunk) * 64;
+    int nci = e.cin - ci0; if (nci > 64) nci = 64; if (nci < 0) nci = 0;
+    const float* sp = src + ((size_t)co * e.cin + ci0) * e.taps;
+    for (int i = tid; i < nci * e.taps; i += 256) tile[i] = sp[i];
+    __syncthreads();
+    for (int i = tid; i < e.taps * 64; i += 256) {
+        const int t = i >> 6, c = i & 63, ci = ci0 + c;
+        if (ci < e.cin_s) dst[((size_t)t * e.cout_pad + e.row_off + co) * e.cin_s + ci] = (c < nci) ? f2bf(tile[c * e.taps + t]) : (bf16_t)0;
+    }
+}
+
+struct ExportDesc { long src_off; long dst_off; long slab_stride; int taps, rows_total, ld, row_off, col_off, cout, cin, nsplit; };
+__global__ __launch_bounds__(256) void grad_export_batched_kernel(const ExportDesc* __restrict__ descs, const int2* __restrict__ blockmap,
+                                                                  const char* __restrict__ ws, float* __restrict__ flat) {
+    __shared__ float tile[64 * 27];
+    const int2 bm = blockmap[blockIdx.x];
+    const ExportDesc e = descs[bm.x];
+    const int tid = threadIdx.x;
+    const float* src = reinterpret_cast<const float*>(ws + e.src_off);
+    const int nchunk = (e.cin + 63) / 64;
+    const int co = bm.y / nchunk, ci0 = (bm.y - co * nchunk) * 64;
+    int nci = e.cin - ci0; if (nci > 64) nci = 64;
+    for (int i = tid; i < e.taps * 64; i += 256) {
+        const int t = i >> 6, c = i & 63;
+        if (c < nci) {
+            const float* sp = src + ((size_t)t * e.rows_total + e.row_off + co) * e.ld + e.col_off + ci0 + c;
+            float v = sp[0];
+            for (int k = 1; k < e.nsplit; ++k) v += sp[(size_t)k * e.slab_stride];
+            tile[c * e.taps + t] = v;
+        }
+    }
+    __syncthreads();
+    float* d = flat + e.dst_off + ((size_t)co * e.cin + ci0) * e.taps;
+    for (int i = tid; i < nci * e.taps; i += 256) d[i] = tile[i];
+}
+
+struct WtDesc { long src_off; long dst_off; int taps, cout, cout_pad, cin, rows, ci_off, ci_cnt, col_tiles, row_tiles, pad_; };
+__global__ __launch_bounds__(256) void weight_flip_transpose_batched_kernel(const WtDesc* __restrict__ descs, const int2* __restrict__ blockmap,
+                                                                            const char* __restrict__ arena, char* __restrict__ ws) {
+    __shared__ bf16_t tile[64][66];
+    const int2 bm = blockmap[blockIdx.x];
+    const WtDesc e = descs[bm.x];
+    const int cols = (e.cout + 31) / 32 * 32;
+    int b = bm.y;
+    const int ct = b % e.col_tiles; b /= e.col_tiles;
+    const int rt = b % e.row_tiles; const int tp = b / e.row_tiles;
+    const int co0 = ct * 64, ci0 = rt * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const bf16_t* src = reinterpret_cast<const bf16_t*>(arena + e.src_off) + (size_t)(e.taps - 1 - tp) * e.cout_pad * e.cin;
+#pragma unroll 4
+    for (int r = ty; r < 64; r += 4) {
+        const int co = co0 + r, ci = ci0 + tx;
+        tile[r][tx] = (co < e.cout && ci < e.ci_cnt) ? src[(size_t)co * e.cin + e.ci_off + ci] : (bf16_t)0;
+    }
+    __syncthreads();
+    bf16_t* dst = reinterpret_cast<bf16_t*>(ws + e.dst_off) + (size_t)tp * e.rows * cols;
+#pragma unroll 4
+    for (int r = ty; r < 64; r += 4) {
+        const int ci = ci0 + r, co = co0 + tx;
+        if (ci < e.rows && co < cols) dst[(size_t)ci * cols + co] = tile[tx][r];
+    }
+}

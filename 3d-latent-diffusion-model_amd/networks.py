@@ -127,9 +127,13 @@ class _LdmModule(nn.Module):
             # device-resident master weights (training): one call re-packs everything on the GPU
             sig = tuple((p._version, p.data_ptr()) for p in pl)
             if self._dirty or sig != getattr(self, "_dev_sig", None):
-                arr = (C.c_void_p * len(pl))(*[p.data_ptr() for p in pl])
+                flat = getattr(self, "flat_params", None)
                 with torch.cuda.device(pl[0].device):
-                    _lib.check(L.ldm_model_load_params_device(self._h, arr, len(pl), _lib.current_stream()))
+                    if flat is not None and self._is_flat(pl, flat):
+                        _lib.check(L.ldm_model_load_params_flat(self._h, flat.data_ptr(), _lib.current_stream()))
+                    else:
+                        arr = (C.c_void_p * len(pl))(*[p.data_ptr() for p in pl])
+                        _lib.check(L.ldm_model_load_params_device(self._h, arr, len(pl), _lib.current_stream()))
                 self._dev_sig = sig
             self._dirty = False
             return
@@ -141,6 +145,16 @@ class _LdmModule(nn.Module):
             _lib.check(L.ldm_model_load_param(self._h, name.encode(), host.data_ptr(), host.numel()))
             self._uploaded_versions[name] = (v, p.data_ptr())
         self._dirty = False
+
+    def _is_flat(self, pl, flat) -> bool:
+        """Every parameter still is the view of ``flat`` that flatten_parameters made (a .to() or an optimizer that
+        re-binds .data breaks it; the per-tensor path then takes over)."""
+        offs = getattr(self, "_offs", None)
+        if offs is None:
+            L = _lib.lib()
+            offs = self._offs = [int(L.ldm_model_param_offset(self._h, i)) for i in range(len(pl))]
+        base = flat.data_ptr()
+        return flat.is_cuda and all(p.data_ptr() == base + 4 * offs[i] for i, p in enumerate(pl))
 
     # -- flat parameter / gradient storage (training) ---------------------------------------------------------
     def flatten_parameters(self) -> torch.Tensor:

@@ -105,6 +105,7 @@ int ldm_unet_forward(ldm_model* m, const float* x, int x_channels, const float* 
  *      (3d_ldm/train_diffusion.py:147-149 DDP) runs over: one ldm_comm_allreduce of the whole buffer. ----------------- */
 int64_t ldm_model_param_offset(const ldm_model* m, int i);
 int ldm_model_load_params_device(ldm_model* m, const float* const* device_ptrs, int n, void* stream);
+int ldm_model_load_params_flat(ldm_model* m, const float* flat_device, void* stream);   /* all parameters in ONE buffer at their ldm_model_param_offset */
 size_t ldm_unet_train_workspace_bytes(ldm_model* m, int B, int D, int H, int W);
 int ldm_unet_train_forward(ldm_model* m, const float* x, int x_channels, const float* cond, int cond_channels,
                            const float* timesteps, float* out, int B, int D, int H, int W,
