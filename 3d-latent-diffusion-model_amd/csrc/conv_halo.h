@@ -79,11 +79,15 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
     for (int j = 0; j < 2; ++j) {
         const int row = (wave * 2 + j) * 8 + prow;
         a_row[j] = row;
-        a_kb[j] = (unsigned)((pchunk ^ ((row >> 1) & 7)) * 16);
+        // 16-byte chunk swizzle keyed by (row & 7): the low swizzle bit equals the row parity, so the 16 rows a
+        // ds_read_b128 lane group touches hit 16 different bank quads for ANY row shift (the kw-shifted reads below);
+        // the (row >> 1) key of conv_igemm.h is conflict free only for unshifted tiles (2-way conflicts at kw = 1, 2).
+        a_kb[j] = (unsigned)((pchunk ^ (row & 7)) * 16);
+        const unsigned b_kb = (unsigned)((pchunk ^ ((row >> 1) & 7)) * 16);
         const int R = row;                                     // same piece geometry for the weight tile
         const int q = R >> 6, nt = (R >> 4) & 3, i = R & 15;
         const int co = n0 + 64 * q + 16 * (i >> 2) + 4 * nt + (i & 3);      // see conv_igemm.h: lane ends up with 16 consecutive couts
-        b_vo[j] = (ABL & 32) ? 0xFFFFFFFFu : (unsigned)co * cin2 + a_kb[j];      // ABL 32: every copy out of range (zero fill, no memory traffic)
+        b_vo[j] = (ABL & 32) ? 0xFFFFFFFFu : (unsigned)co * cin2 + b_kb;      // ABL 32: every copy out of range (zero fill, no memory traffic)
     }
     const unsigned wtap = (unsigned)p.CoutPad * cin2;          // bytes between two taps of the weight tensor
     __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.x0a, 0, (int)((unsigned)(p.N * DHW) * cin2), 0x00020000);
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
     const int b_rd0 = rb0 * RB + ((cfrag ^ ((rb0 >> 1) & 7)) << 4);
     int a_rdk[3];                                              // voxel rows shifted by kw: LDS row = tile row + kw
 #pragma unroll
-    for (int k = 0; k < 3; ++k) a_rdk[k] = AOFF + (ra0 + k) * RB + ((cfrag ^ (((ra0 + k) >> 1) & 7)) << 4);
+    for (int k = 0; k < 3; ++k) a_rdk[k] = AOFF + (ra0 + k) * RB + ((cfrag ^ ((ra0 + k) & 7)) << 4);
     // W-border masks of this lane's 4 voxel rows (one per 16-row tile t): bit t = w == 0, bit 4 + t = w == W - 1
     unsigned wmask = 0;
 #pragma unroll
