@@ -69,7 +69,7 @@ struct Act {                                         // NDHWC bf16 activation li
 enum OpKind { OP_PACK, OP_CONV, OP_FINALIZE, OP_GN_STATS, OP_GN_FINALIZE, OP_GN_PREP, OP_GN_APPLY, OP_ATTN, OP_SINUSOID,
               OP_GEMV, OP_VAE_HEADS, OP_GN_FUSED,
               // backward (training plans only)
-              OP_WT, OP_WT_BATCH, OP_WGRAD, OP_EXPORT, OP_EXPORT_BATCH, OP_COLSUM, OP_GNB, OP_ATTN_BWD, OP_ADD, OP_SUMPOOL, OP_LIN_DX, OP_LIN_DW };
+              OP_WT, OP_WT_BATCH, OP_WGRAD, OP_EXPORT, OP_EXPORT_BATCH, OP_COLSUM, OP_GNB, OP_ATTN_BWD, OP_ADD, OP_SUMPOOL, OP_LIN_DX, OP_LIN_DW, OP_VAE_HEADS_BWD };
 
 struct ConvCfg { int wgm, wgn, bk, splitk; int halo = 0, mtps = 0, qps = 0; };   // halo: conv3_halo_kernel (126-row tiles)
 
@@ -261,6 +261,7 @@ struct Builder {
         // backward-pass uses of the same kernel (data gradients)
         Ref w_over; bool no_bias = false; int exact = 0;   // weights from the workspace; zero-insertion upsample
         int temb_row = -1;                            // first row of this ResBlock in the stacked time projection
+        int f32_tag = 0;                              // which externally supplied gradient an fp32-output conv receives (0 final, 1 VAE heads)
     };
     struct Tape {                                    // one differentiable forward op, recorded in training plans
         int kind = 0;                                 // 0 conv, 1 GroupNorm(+SiLU), 2 attention
@@ -582,7 +583,7 @@ struct Builder {
     int cur_ksplit = 1, cur_rows_total = 0;           // voxel split / slab rows of the weight gradient being staged
     // dX of one source tensor `src` (channels [ci_off, ci_off + src.C) of the conv input) given dY.
     bool emit_dgrad(const Act& dy, const Act& src, const ConvW& w, int ci_off, int k, int stride, int pad, int ups) {
-        if (stride == 2 && !(k == 3 && pad == 1)) { err = "backward of a stride-2 conv needs k = 3, pad = 1"; return false; }
+        if (stride == 2 && !(k == 3 && (pad == 1 || pad == 0))) { err = "backward of a stride-2 conv needs k = 3, pad 0 | 1"; return false; }
         const int taps = k * k * k;
         const int rows = rup(src.C, 64), cols = rup(w.cout, 32);
         const size_t wt_off = pool.alloc((size_t)taps * rows * cols * 2);
@@ -709,6 +710,20 @@ struct Builder {
         o.i[0] = B; o.i[1] = I; o.i[2] = O; o.i[3] = dy_stride; o.i[4] = x_stride; o.i[5] = silu; o.i[6] = nz;
         plan->ops.push_back(o);
     }
+    // AutoencoderKL: gradient of the fused heads conv from dz (decoder side) and the KL-term gradients (I/O 1, 2)
+    Act dout_heads, vae_zin; size_t vae_ml_off = 0, vae_z_off = 0; int vae_L = 0;
+    bool emit_heads_bwd() {
+        Act dz = take_grad(vae_zin);
+        if (!dz.valid) { err = "backward: latent without a gradient"; return false; }
+        const int cs = rup(2 * vae_L, 32);
+        dout_heads = new_act(dz.N, dz.D, dz.H, dz.W, cs);
+        Op o{}; o.kind = OP_VAE_HEADS_BWD;
+        o.r[0] = ws_ref(dz.off); o.r[1] = ws_ref(vae_ml_off); o.r[2] = ws_ref(vae_z_off); o.r[3] = io_ref(1); o.r[6] = io_ref(2);
+        o.r[7] = ws_ref(dout_heads.off);
+        o.i[0] = dz.N; o.i[1] = vae_L; o.i[2] = cs; o.i[3] = dz.D * dz.H * dz.W; o.i[4] = dz.C;
+        plan->ops.push_back(o);
+        return true;
+    }
     // Walk the tape backwards.  `dout_final` = the packed gradient of the network output (the last conv writes fp32
     // NCDHW straight to the caller, so its gradient arrives through the I/O table).
     bool backward_all(const Act& dout_final) {
@@ -716,7 +731,8 @@ struct Builder {
             const Tape& t = tape[k];
             bool ok = true;
             if (t.kind == 0) {
-                Act dout = t.c.f32_out ? dout_final : take_grad(t.out);
+                if (t.c.f32_out && t.c.f32_tag == 1 && !emit_heads_bwd()) return false;
+                Act dout = t.c.f32_out ? (t.c.f32_tag == 1 ? dout_heads : dout_final) : take_grad(t.out);
                 if (!dout.valid) { err = "backward: conv output without a gradient"; return false; }
                 ok = backward_conv(t, dout);
             } else if (t.kind == 1) ok = backward_gn(t);
@@ -1088,6 +1104,53 @@ static int vae_build_decode(ldm_model* m, int B, int d, int h_, int w, Plan* pla
     return 0;
 }
 
+// AutoencoderKL.forward with the tape + backward (stage-1 trainer, 3d_ldm/train_autoencoder.py:366-451):
+//   forward  I/O: 0 = x, 1 = eps, 2 = z_mu, 3 = z_sigma, 5 = reconstruction
+//   backward I/O: 0 = d recon, 1 = d z_mu (or null), 2 = d z_sigma (or null), 4 = flat parameter gradients
+static int vae_build_train(ldm_model* m, int B, int D, int H, int W, Plan* plan) {
+    const ldm_vae_cfg& c = m->vcfg;
+    Builder b; b.m = m; b.plan = plan; b.train = true; b.recording = true;
+    const int cs = rup(c.in_channels, 32), L = c.latent_channels, ls = rup(L, 32);
+    Act xin = b.new_act(B, D, H, W, cs);
+    { Op o{}; o.kind = OP_PACK; o.r[0] = io_ref(0); o.r[1] = Ref(); o.r[2] = ws_ref(xin.off);
+      o.i[0] = B; o.i[1] = c.in_channels; o.i[2] = cs; o.i[3] = D * H * W; o.i[4] = 1; plan->ops.push_back(o); }
+    const size_t t0 = b.tape.size();
+    Act h;
+    LDM_TRY(vae_run_layout(b, "encoder", ae_encoder_layout(c), xin, c.norm_num_groups, c.norm_eps, false, 0, &h));
+    if (b.tape.size() > t0) b.tape[t0].leaf_input = true;                 // no gradient w.r.t. the image
+    const int dhw = h.D * h.H * h.W;
+    const size_t ml_off = b.pool.alloc((size_t)B * 2 * L * dhw * 4), z_off = b.pool.alloc((size_t)B * L * dhw * 4);
+    { Builder::ConvArgs a; a.xa = h; a.w = &m->convs.at("quant_heads"); a.k = 1; a.pad = 0; a.Do = h.D; a.Ho = h.H; a.Wo = h.W;
+      a.f32_out = true; a.out_ref = ws_ref(ml_off); a.cout_real = 2 * L; a.f32_tag = 1;
+      b.conv(a, "quant_heads"); }
+    if (!b.err.empty()) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
+    { Op o{}; o.kind = OP_VAE_HEADS; o.r[0] = ws_ref(ml_off); o.r[1] = io_ref(1); o.r[2] = io_ref(2); o.r[3] = io_ref(3); o.r[4] = ws_ref(z_off);
+      o.i[0] = B; o.i[1] = L; o.i[2] = dhw; plan->ops.push_back(o); }
+    Act zin = b.new_act(B, h.D, h.H, h.W, ls);
+    { Op o{}; o.kind = OP_PACK; o.r[0] = ws_ref(z_off); o.r[1] = Ref(); o.r[2] = ws_ref(zin.off);
+      o.i[0] = B; o.i[1] = L; o.i[2] = ls; o.i[3] = dhw; o.i[4] = 1; plan->ops.push_back(o); }
+    Builder::ConvArgs pq; pq.xa = zin; pq.w = &m->convs.at("post_quant_conv"); pq.k = 1; pq.pad = 0; pq.Do = h.D; pq.Ho = h.H; pq.Wo = h.W;
+    Act z2 = b.conv(pq, "post_quant_conv");
+    if (!z2.valid) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
+    Act out;
+    LDM_TRY(vae_run_layout(b, "decoder", ae_decoder_layout(c), z2, c.norm_num_groups, c.norm_eps, true, 5, &out));
+    // ---- backward
+    plan->train = true; plan->bwd_begin = plan->ops.size();
+    b.recording = false;
+    b.vae_zin = zin; b.vae_ml_off = ml_off; b.vae_z_off = z_off; b.vae_L = L;
+    { Op o{}; o.kind = OP_WT_BATCH; plan->ops.push_back(o); }
+    const int cos_ = rup(c.out_channels, 32);
+    Act dout = b.new_act(B, D, H, W, cos_);
+    { Op o{}; o.kind = OP_PACK; o.r[0] = io_ref(0); o.r[1] = Ref(); o.r[2] = ws_ref(dout.off);
+      o.i[0] = B; o.i[1] = c.out_channels; o.i[2] = cos_; o.i[3] = D * H * W; o.i[4] = 1; plan->ops.push_back(o); }
+    if (!b.backward_all(dout)) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
+    { Op o{}; o.kind = OP_EXPORT_BATCH; plan->ops.push_back(o); }
+    if (plan->wt_tab.upload(b.wt_descs, b.wt_map) || plan->exp_tab.upload(b.exp_descs, b.exp_map))
+        return fail(LDM_ERR_HIP, "descriptor table upload failed");
+    b.finish();
+    return 0;
+}
+
 // ================================================================================================ launch
 struct Bases { char* p[BASE_COUNT]; };
 static inline char* rp(const Bases& b, const Ref& r) { return r.base == BASE_NULL ? nullptr : (b.p[r.base] ? b.p[r.base] + r.off : nullptr); }
@@ -1194,6 +1257,7 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                 // two fp32 NCDHW sources (x | cond) -> one zero-padded NDHWC bf16 tensor
                 const long total = (long)i[0] * i[3] * i[2];
                 int cx = rt[0], cc = rt[1];
+                if (i[4]) { cx = i[1]; cc = 0; }         // internal pack (fixed channel count, single source)
                 if (cx + cc != i[1]) return fail(LDM_ERR_BAD_ARG, "x_channels + cond_channels = %d, model expects %d", cx + cc, i[1]);
                 hipLaunchKernelGGL(pack2_ncdhw_kernel, dim3(grid_for(total)), dim3(256), 0, s, (const float*)rp(bs, o.r[0]), cx,
                                    (const float*)rp(bs, o.r[1]), cc, (bf16_t*)rp(bs, o.r[2]), i[0], i[2], i[3]);
@@ -1360,6 +1424,12 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                 hipLaunchKernelGGL(linear_bwd_dx_fold_kernel, dim3((i[1] + 255) / 256, i[0]), dim3(256), 0, s, (const float*)rp(bs, o.r[4]),
                                    (const float*)rp(bs, o.r[2]), (float*)rp(bs, o.r[3]), i[1], i[6], i[4], i[0], i[5]);
                 break; }
+            case OP_VAE_HEADS_BWD: {
+                const long total = (long)i[0] * i[3] * i[2];
+                hipLaunchKernelGGL(vae_heads_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)rp(bs, o.r[0]), i[4],
+                                   (const float*)rp(bs, o.r[1]), (const float*)rp(bs, o.r[2]), (const float*)rp(bs, o.r[3]),
+                                   (const float*)rp(bs, o.r[6]), (bf16_t*)rp(bs, o.r[7]), i[0], i[1], i[2], i[3]);
+                break; }
             case OP_LIN_DW:         // i: B, I, O, dy_stride, x_stride, silu
                 hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3(grid_for((long)i[2] * i[1], 256, 1 << 24)), dim3(256), 0, s,
                                    (const float*)rp(bs, o.r[0]), (const float*)rp(bs, o.r[1]), (float*)rp(bs, o.r[2]), (float*)rp(bs, o.r[3]),
@@ -1475,6 +1545,7 @@ static int get_plan(ldm_model* m, const char* kind, int B, int D, int H, int W, 
     if (it != m->plans.end()) { *out = it->second; return 0; }
     std::shared_ptr<Plan> p(new Plan());
     if (m->type == 0) LDM_TRY(unet_build(m, B, D, H, W, p.get(), kind[0] == 't'));
+    else if (kind[0] == 't') LDM_TRY(vae_build_train(m, B, D, H, W, p.get()));
     else if (kind[0] == 'e') LDM_TRY(vae_build_encode(m, B, D, H, W, p.get()));
     else LDM_TRY(vae_build_decode(m, B, D, H, W, p.get()));
     m->plans[key] = p; *out = p;
@@ -1600,6 +1671,38 @@ int ldm_unet_train_backward(ldm_model* m, const float* grad_out, float* flat_gra
     Bases bs{}; bs.p[BASE_WS] = (char*)workspace; bs.p[BASE_W] = m->arena;
     bs.p[BASE_IO0] = (char*)grad_out; bs.p[BASE_IO4] = (char*)flat_grads;
     const int rt[2] = {m->ucfg.out_channels, 0};
+    return run_plan(*p, bs, rt, (hipStream_t)stream, p->bwd_begin, p->ops.size());
+}
+
+size_t ldm_vae_train_workspace_bytes(ldm_model* m, int B, int D, int H, int W) {
+    if (!m || m->type != 1) { fail(LDM_ERR_BAD_ARG, "not an AutoencoderKL handle"); return 0; }
+    std::shared_ptr<Plan> p; if (get_plan(m, "train", B, D, H, W, &p)) return 0;
+    return p->ws_bytes;
+}
+/* AutoencoderKL.forward(x) -> (reconstruction, z_mu, z_sigma) with z = z_mu + z_sigma * eps, keeping the tape in `workspace`. */
+int ldm_vae_train_forward(ldm_model* m, const float* x, const float* eps, float* recon, float* z_mu, float* z_sigma,
+                          int B, int D, int H, int W, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!m || m->type != 1) return fail(LDM_ERR_BAD_ARG, "not an AutoencoderKL handle");
+    if (!x || !eps || !recon || !z_mu || !z_sigma) return fail(LDM_ERR_BAD_ARG, "null tensor argument");
+    const int f = 1 << (m->vcfg.num_levels - 1);
+    if (D % f || H % f || W % f) return fail(LDM_ERR_UNSUPPORTED, "image size must be a multiple of %d", f);
+    std::shared_ptr<Plan> p; LDM_TRY(get_plan(m, "train", B, D, H, W, &p));
+    LDM_TRY(check_ready(m, workspace, workspace_bytes, *p));
+    Bases bs{}; bs.p[BASE_WS] = (char*)workspace; bs.p[BASE_W] = m->arena;
+    bs.p[BASE_IO0] = (char*)x; bs.p[BASE_IO1] = (char*)eps; bs.p[BASE_IO2] = (char*)z_mu; bs.p[BASE_IO3] = (char*)z_sigma; bs.p[BASE_IO5] = (char*)recon;
+    const int rt[2] = {m->vcfg.in_channels, 0};
+    return run_plan(*p, bs, rt, (hipStream_t)stream, 0, p->bwd_begin);
+}
+/* d_recon: [B,Cout,D,H,W]; d_mu / d_sigma: [B,L,d,h,w] or NULL (the KL term's gradients); flat_grads as for the UNet. */
+int ldm_vae_train_backward(ldm_model* m, const float* d_recon, const float* d_mu, const float* d_sigma, float* flat_grads,
+                           int B, int D, int H, int W, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!m || m->type != 1) return fail(LDM_ERR_BAD_ARG, "not an AutoencoderKL handle");
+    if (!d_recon || !flat_grads) return fail(LDM_ERR_BAD_ARG, "null tensor argument");
+    std::shared_ptr<Plan> p; LDM_TRY(get_plan(m, "train", B, D, H, W, &p));
+    LDM_TRY(check_ready(m, workspace, workspace_bytes, *p));
+    Bases bs{}; bs.p[BASE_WS] = (char*)workspace; bs.p[BASE_W] = m->arena;
+    bs.p[BASE_IO0] = (char*)d_recon; bs.p[BASE_IO1] = (char*)d_mu; bs.p[BASE_IO2] = (char*)d_sigma; bs.p[BASE_IO4] = (char*)flat_grads;
+    const int rt[2] = {m->vcfg.out_channels, 0};
     return run_plan(*p, bs, rt, (hipStream_t)stream, p->bwd_begin, p->ops.size());
 }
 

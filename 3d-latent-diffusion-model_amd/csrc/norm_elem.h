@@ -934,3 +934,38 @@ __global__ __launch_bounds__(256) void weight_flip_transpose_batched_kernel(cons
         if (ci < e.rows && co < cols) dst[(size_t)ci * cols + co] = tile[tx][r];
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// Backward of the AutoencoderKL heads + sampling (training: train_autoencoder.py:366-451):
+//   mu, lv = heads;  sigma = exp(0.5 clamp(lv, -30, 20));  z = mu + sigma * eps.
+// Given dz (bf16 NDHWC [M][Ls], from the decoder), g_mu / g_sigma (fp32 NCDHW, from the KL term; may be null):
+//   d_mu = dz + g_mu;   d_lv = (dz * (z - mu) + g_sigma * sigma) * 0.5  inside the clamp, 0 outside.
+// Output: gradient of the fused 1x1 heads conv, bf16 NDHWC [M][Cs] with channels (d_mu | d_lv | 0 padding).
+__global__ __launch_bounds__(256) void vae_heads_bwd_kernel(const bf16_t* __restrict__ dz, int Ls, const float* __restrict__ ml,
+                                                            const float* __restrict__ z, const float* __restrict__ g_mu,
+                                                            const float* __restrict__ g_sigma, bf16_t* __restrict__ dy,
+                                                            int N, int L, int Cs, int DHW) {
+    const long total = (long)N * DHW * Cs;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cs);
+        const long row = i / Cs;
+        const int n = (int)(row / DHW);
+        const int sp = (int)(row - (long)n * DHW);
+        float g = 0.f;
+        if (c < 2 * L) {
+            const int l = c < L ? c : c - L;
+            const float gz = bf2f(dz[row * Ls + l]);
+            const size_t j = ((size_t)n * L + l) * DHW + sp;
+            if (c < L) g = gz + (g_mu ? g_mu[j] : 0.f);
+            else {
+                const float mu = ml[((size_t)n * 2 * L + l) * DHW + sp];
+                const float lv = ml[((size_t)n * 2 * L + L + l) * DHW + sp];
+                if (lv > -30.f && lv < 20.f) {
+                    const float sg = expf(0.5f * lv);
+                    g = 0.5f * (gz * (z[j] - mu) + (g_sigma ? g_sigma[j] * sg : 0.f));
+                }
+            }
+        }
+        dy[i] = f2bf(g);
+    }
+}

@@ -11,8 +11,9 @@ re-packed into the library's bf16 weight arena whenever they change.
 
 ``DiffusionModelUNet`` is differentiable w.r.t. its parameters: under ``torch.enable_grad()`` with parameters that
 require grad, forward runs the training plan (same kernels, activations kept) and ``loss.backward()`` runs the
-hand-written backward plan (3d_ldm/train_diffusion.py:197-216).  ``AutoencoderKL`` is inference only (the diffusion
-trainer uses it under ``no_grad``: 3d_ldm/train_diffusion.py:104,180).
+hand-written backward plan (3d_ldm/train_diffusion.py:197-216); likewise ``AutoencoderKL.forward`` (stage-1 trainer,
+3d_ldm/train_autoencoder.py:366-451).  ``encode`` / ``decode`` alone are inference entry points (the diffusion trainer
+uses them under ``no_grad``: 3d_ldm/train_diffusion.py:104,180).
 """
 from __future__ import annotations
 
@@ -363,6 +364,21 @@ class DiffusionModelUNet(_LdmModule):
         return o
 
 
+class _VaeTrainFn(torch.autograd.Function):
+    """(reconstruction, z_mu, z_sigma) = AutoencoderKL(images; params) with the hand-written backward plan."""
+
+    @staticmethod
+    def forward(ctx, module, x, eps, *params):
+        ctx.module = module
+        recon, z_mu, z_sigma, ctx.token = module._train_forward(x, eps)
+        return recon, z_mu, z_sigma
+
+    @staticmethod
+    def backward(ctx, g_recon, g_mu, g_sigma):
+        grads = ctx.module._train_backward(ctx.token, g_recon, g_mu, g_sigma)
+        return (None, None, None) + tuple(grads)
+
+
 class AutoencoderKL(_LdmModule):
     """MI355X-native AutoencoderKL (kwargs of ``autoencoder_def``, 3d_ldm/config/config_train_16g.json:7-28)."""
 
@@ -458,10 +474,72 @@ class AutoencoderKL(_LdmModule):
     def reconstruct(self, x: torch.Tensor) -> torch.Tensor:
         return self.decode(self.encode(x)[0])
 
-    def forward(self, x: torch.Tensor):
-        """-> (reconstruction, z_mu, z_sigma)  (3d_ldm/train_autoencoder.py:366)."""
+    def forward(self, x: torch.Tensor, eps: Optional[torch.Tensor] = None):
+        """-> (reconstruction, z_mu, z_sigma)  (3d_ldm/train_autoencoder.py:366).  Differentiable w.r.t. the parameters
+        (``loss_g.backward()`` of the stage-1 trainer); ``eps`` (extension) passes the sampling draw explicitly."""
         B, _, D, H, W = x.shape
         f = self.factor
-        eps = torch.randn((B, self.latent_channels, D // f, H // f, W // f), dtype=torch.float32, device=x.device)
+        if eps is None:
+            eps = torch.randn((B, self.latent_channels, D // f, H // f, W // f), dtype=torch.float32, device=x.device)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self._param_list()):
+            if x.requires_grad:
+                raise NotImplementedError("gradients w.r.t. the AutoencoderKL input are not implemented")
+            self._need_cuda(x, "AutoencoderKL.forward")
+            return _VaeTrainFn.apply(self, x, eps, *self._param_list())
         z_mu, z_sigma, z = self._encode(x, eps, True)
         return self.decode(z), z_mu, z_sigma
+
+    # -- training plan ------------------------------------------------------------------------------------------
+    def _train_forward(self, x, eps):
+        if not all(p.is_cuda for p in self._param_list()):
+            raise _lib.LdmError("training needs the parameters on the GPU: call .to('cuda') first")
+        B, _, D, H, W = x.shape
+        x = x.detach().to(torch.float32).contiguous()
+        eps = eps.detach().to(device=x.device, dtype=torch.float32).contiguous()
+        self._sync_weights()
+        L = _lib.lib()
+        nbytes = L.ldm_vae_train_workspace_bytes(self._h, B, D, H, W)
+        if nbytes == 0:
+            raise _lib.LdmError((L.ldm_last_error() or b"workspace query failed").decode())
+        ws = self._workspace(("train", B, D, H, W), nbytes, x.device)
+        f = self.factor
+        recon = torch.empty((B, self.out_channels, D, H, W), dtype=torch.float32, device=x.device)
+        z_mu = torch.empty((B, self.latent_channels, D // f, H // f, W // f), dtype=torch.float32, device=x.device)
+        z_sigma = torch.empty_like(z_mu)
+        with torch.cuda.device(x.device):
+            _lib.check(L.ldm_vae_train_forward(self._h, x.data_ptr(), eps.data_ptr(), recon.data_ptr(), z_mu.data_ptr(), z_sigma.data_ptr(),
+                                               B, D, H, W, ws.data_ptr(), ws.numel(), _lib.current_stream()))
+        self._train_serial = getattr(self, "_train_serial", 0) + 1
+        return recon, z_mu, z_sigma, (self._train_serial, B, D, H, W)
+
+    def _train_backward(self, token, g_recon, g_mu, g_sigma):
+        serial, B, D, H, W = token
+        if serial != getattr(self, "_train_serial", 0):
+            raise _lib.LdmError("backward of a stale forward: the training workspace holds one forward at a time")
+        L = _lib.lib()
+        pl = self._param_list()
+        dev = pl[0].device
+
+        def prep(g):
+            return None if g is None else g.detach().to(torch.float32).contiguous()
+        g_recon, g_mu, g_sigma = prep(g_recon), prep(g_mu), prep(g_sigma)
+        if g_recon is None:
+            f = self.factor
+            g_recon = torch.zeros((B, self.out_channels, D, H, W), dtype=torch.float32, device=dev)
+        flat_mode = getattr(self, "flat_grads", None) is not None
+        total = int(L.ldm_model_param_numel_total(self._h))
+        flat = self.flat_grads if flat_mode else torch.empty(total, dtype=torch.float32, device=dev)
+        ws = self._ws[("train", B, D, H, W)]
+        with torch.cuda.device(dev):
+            _lib.check(L.ldm_vae_train_backward(self._h, g_recon.data_ptr(), _lib.ptr(g_mu), _lib.ptr(g_sigma), flat.data_ptr(),
+                                                B, D, H, W, ws.data_ptr(), ws.numel(), _lib.current_stream()))
+        self._train_serial += 1
+        if getattr(self, "_offs", None) is None:
+            self._offs = [int(L.ldm_model_param_offset(self._h, i)) for i in range(len(pl))]
+        offs = self._offs
+        if flat_mode:
+            for i, p in enumerate(pl):
+                if p.grad is None or p.grad.data_ptr() != flat.data_ptr() + 4 * offs[i]:
+                    p.grad = flat[offs[i]:offs[i] + p.numel()].view(p.shape)
+            return [None] * len(pl)
+        return [flat[offs[i]:offs[i] + p.numel()].view(p.shape) if p.requires_grad else None for i, p in enumerate(pl)]

@@ -112,6 +112,14 @@ int ldm_unet_train_forward(ldm_model* m, const float* x, int x_channels, const f
                            void* workspace, size_t workspace_bytes, void* stream);
 int ldm_unet_train_backward(ldm_model* m, const float* grad_out, float* flat_grads, int B, int D, int H, int W,
                             void* workspace, size_t workspace_bytes, void* stream);
+/* AutoencoderKL.forward(images) -> (reconstruction, z_mu, z_sigma) with its backward (stage-1 trainer,
+ * 3d_ldm/train_autoencoder.py:366-451: recons + KL losses -> loss_g.backward()).  eps: [B,L,d,h,w] N(0,1) draws of the
+ * sampling step; d_mu / d_sigma: gradients of the KL term w.r.t. z_mu / z_sigma (NULL = 0); flat_grads as above. */
+size_t ldm_vae_train_workspace_bytes(ldm_model* m, int B, int D, int H, int W);
+int ldm_vae_train_forward(ldm_model* m, const float* x, const float* eps, float* recon, float* z_mu, float* z_sigma,
+                          int B, int D, int H, int W, void* workspace, size_t workspace_bytes, void* stream);
+int ldm_vae_train_backward(ldm_model* m, const float* d_recon, const float* d_mu, const float* d_sigma, float* flat_grads,
+                           int B, int D, int H, int W, void* workspace, size_t workspace_bytes, void* stream);
 /* Optimizer tail on flat fp32 buffers (torch.nn.utils.clip_grad_norm_(params, max_norm) 3d_ldm/train_diffusion.py:216
  * and torch.optim.Adam(lr) :155, torch defaults betas (0.9, 0.999), eps 1e-8, no weight decay):
  *   grad_sq_norm: *out (device fp32 scalar) = sum g^2.
