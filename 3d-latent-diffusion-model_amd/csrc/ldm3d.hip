@@ -1718,9 +1718,9 @@ int ldm_grad_sq_norm(const float* flat_grads, int64_t n, float* out, void* strea
     return 0;
 }
 int ldm_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
-                  float beta2, float eps, int step, const float* sq_norm, float max_norm, void* stream) {
+                  float beta2, float eps, float weight_decay, int step, const float* sq_norm, float max_norm, void* stream) {
     if (!params || !grads || !exp_avg || !exp_avg_sq || n < 0 || step < 1) return fail(LDM_ERR_BAD_ARG, "bad argument");
-    AdamCoef k{lr, beta1, beta2, eps, 1.0f - powf(beta1, (float)step), sqrtf(1.0f - powf(beta2, (float)step)), max_norm};
+    AdamCoef k{lr, beta1, beta2, eps, 1.0f - powf(beta1, (float)step), sqrtf(1.0f - powf(beta2, (float)step)), max_norm, lr * weight_decay};
     hipLaunchKernelGGL(adam_step_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq,
                        (long)n, k, sq_norm);
     HIP_TRY(hipGetLastError());

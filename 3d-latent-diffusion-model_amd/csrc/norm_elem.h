@@ -839,7 +839,7 @@ __global__ __launch_bounds__(256) void sq_norm_fold_kernel(const float* __restri
     for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
     if (threadIdx.x == 0) *out = (float)red[0];
 }
-struct AdamCoef { float lr, b1, b2, eps, bc1, bc2_sqrt, max_norm; };
+struct AdamCoef { float lr, b1, b2, eps, bc1, bc2_sqrt, max_norm, decay; };   // decay = lr * weight_decay (AdamW, decoupled)
 __global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                         float* __restrict__ v, long n, AdamCoef k, const float* __restrict__ sq_norm) {
     float clip = 1.f;
@@ -850,7 +850,8 @@ __global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ p, c
         const float mi = k.b1 * m[i] + (1.f - k.b1) * gi;
         const float vi = k.b2 * v[i] + (1.f - k.b2) * gi * gi;
         m[i] = mi; v[i] = vi;
-        p[i] -= step * mi / (sqrtf(vi) / k.bc2_sqrt + k.eps);      // torch.optim.Adam: denom = sqrt(v)/sqrt(bc2) + eps
+        const float pi = p[i] * (1.f - k.decay);                   // torch.optim.AdamW: param.mul_(1 - lr * weight_decay) first
+        p[i] = pi - step * mi / (sqrtf(vi) / k.bc2_sqrt + k.eps);  // torch.optim.Adam: denom = sqrt(v)/sqrt(bc2) + eps
     }
 }
 

@@ -9,8 +9,10 @@ The reference does (3d_ldm/train_diffusion.py:155-156, 214-223)::
 ``FlatAdam`` is a ``torch.optim.Optimizer`` (so ``MultiStepLR`` and ``zero_grad`` keep working) whose single parameter
 is the module's flat fp32 buffer (``module.flatten_parameters()``): gradient clipping + Adam are two HIP launches over
 191 M elements instead of ~320 per-tensor kernel groups, and the data-parallel mean is one all-reduce of
-``module.flat_grads``.  Same arithmetic as ``torch.optim.Adam`` defaults (betas (0.9, 0.999), eps 1e-8, no weight decay,
-no amsgrad) and as ``clip_grad_norm_`` (scale = max_norm / (norm + 1e-6), clamped to 1).
+``module.flat_grads``.  Same arithmetic as ``torch.optim.Adam`` (defaults betas (0.9, 0.999), eps 1e-8, no amsgrad) and,
+with ``weight_decay > 0``, as the decoupled ``torch.optim.AdamW`` of the stage-1 trainer
+(3d_ldm/train_autoencoder.py:274-279: betas (0.5, 0.9), weight_decay 1e-5), and as ``clip_grad_norm_`` (scale = max_norm /
+(norm + 1e-6), clamped to 1).
 """
 from __future__ import annotations
 
@@ -20,7 +22,8 @@ from . import _lib
 
 
 class FlatAdam(torch.optim.Optimizer):
-    def __init__(self, module, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, max_grad_norm: float | None = None):
+    def __init__(self, module, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, max_grad_norm: float | None = None,
+                 weight_decay: float = 0.0):
         if getattr(module, "flat_params", None) is None:
             module.flatten_parameters()
         self.module = module
@@ -28,7 +31,7 @@ class FlatAdam(torch.optim.Optimizer):
         if not flat.is_cuda:
             raise _lib.LdmError("FlatAdam needs the module on the GPU (no CPU fallback)")
         self._flat = torch.nn.Parameter(flat, requires_grad=False)      # shares storage with module.flat_params
-        super().__init__([self._flat], dict(lr=lr, betas=tuple(betas), eps=eps))
+        super().__init__([self._flat], dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
         self.max_grad_norm = max_grad_norm
         self.exp_avg = torch.zeros_like(flat)
         self.exp_avg_sq = torch.zeros_like(flat)
@@ -59,7 +62,8 @@ class FlatAdam(torch.optim.Optimizer):
             if clip:
                 _lib.check(L.ldm_grad_sq_norm(g.data_ptr(), g.numel(), self.sq_norm.data_ptr(), _lib.current_stream()))
             _lib.check(L.ldm_adam_step(p.data_ptr(), g.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), p.numel(),
-                                       float(grp["lr"]), float(grp["betas"][0]), float(grp["betas"][1]), float(grp["eps"]), self.steps,
+                                       float(grp["lr"]), float(grp["betas"][0]), float(grp["betas"][1]), float(grp["eps"]),
+                                       float(grp.get("weight_decay", 0.0)), self.steps,
                                        self.sq_norm.data_ptr() if clip else None, float(self.max_grad_norm or 0.0),
                                        _lib.current_stream()))
         self.module.mark_weights_dirty()               # the bf16 arena is re-packed before the next forward

@@ -140,3 +140,82 @@ class DiffusionTrainer:
                 n += 1
         val = total / n if n else torch.tensor(float("inf"), device=device)
         return float(self.sync.mean_scalar(val))
+
+
+# ------------------------------------------------------------------------------------------------ stage 1: AutoencoderKL
+def kl_loss(z_mu: torch.Tensor, z_sigma: torch.Tensor) -> torch.Tensor:
+    """The reference's KL term (3d_ldm/utils.py:249-262): 0.5 * sum(mu^2 + s^2 - log(s^2 + eps) - 1) over all but the batch
+    dimension with s = clamp(sigma, min=1e-8), divided by the batch size, clamped to [0, 1000]."""
+    eps = 1e-8
+    s = torch.clamp(z_sigma, min=eps)
+    kl = 0.5 * torch.sum(z_mu.pow(2) + s.pow(2) - torch.log(s.pow(2) + eps) - 1, dim=list(range(1, z_sigma.dim())))
+    return torch.clamp(kl / kl.shape[0], 0.0, 1000.0)
+
+
+class AutoencoderTrainer:
+    """Generator step of the stage-1 trainer (3d_ldm/train_autoencoder.py:352-451) on the HIP forward/backward plans:
+    clamp the images to [0, 1] (:362), ``reconstruction, z_mu, z_sigma = autoencoder(images)`` (:366), reconstruction L1 / L2
+    (:226-233,374), KL (:375,386) * kl_weight, NaN-skip agreed over ranks, ``loss_g.backward()``, ``clip_grad_norm_(0.5)`` and
+    AdamW(betas (0.5, 0.9), weight_decay 1e-5) (:274-279,440-451), lr scaled by sqrt(world) * 0.5 under DDP (:246-259).
+
+    Not on this path (stated where it matters): the perceptual term needs a downloaded SqueezeNet
+    (no network here: its weight must be 0, otherwise construction fails loudly) and the PatchDiscriminator /
+    adversarial term that the reference switches on after 5 warm-up epochs is not implemented: training stays in the
+    reference's warm-up regime and says so once."""
+
+    def __init__(self, autoencoder, lr: float, kl_weight: float, recon_loss: str = "l1", perceptual_weight: float = 0.0,
+                 max_grad_norm: float = 0.5, weight_decay: float = 1e-5, warm_up_epochs: int = 5):
+        from .optim import FlatAdam
+        if perceptual_weight:
+            raise NotImplementedError("perceptual loss (pretrained SqueezeNet, train_autoencoder.py:236) is not available offline: "
+                                      "set autoencoder_train.perceptual_weight to 0")
+        self.autoencoder = autoencoder
+        self.sync = GradSync()
+        world = self.sync.world
+        lr = lr * (world ** 0.5 * 0.5 if world > 1 else 1.0)
+        self.optimizer = FlatAdam(autoencoder, lr=lr, betas=(0.5, 0.9), eps=1e-8, weight_decay=weight_decay, max_grad_norm=max_grad_norm)
+        self.sync.broadcast(autoencoder.flat_params, 0)
+        autoencoder.mark_weights_dirty()
+        self.kl_weight, self.l2 = kl_weight, recon_loss == "l2"
+        self.warm_up_epochs, self._warned = warm_up_epochs, False
+
+    def intensity_loss(self, a, b):
+        return F.mse_loss(a, b) if self.l2 else F.l1_loss(a, b)
+
+    def train_step(self, images: torch.Tensor, epoch: int = 0, eps: Optional[torch.Tensor] = None):
+        """-> (dict of detached scalar losses, skipped)."""
+        if epoch > self.warm_up_epochs and not self._warned:
+            print("note: the adversarial term (PatchDiscriminator, train_autoencoder.py:407-424,454-494) is not implemented on "
+                  "this path; continuing with reconstruction + KL only")
+            self._warned = True
+        self.autoencoder.train()
+        images = torch.clamp(images.float(), 0.0, 1.0)
+        bad_in = self.sync.any((~torch.isfinite(images)).any().to(torch.float32))
+        if float(bad_in) > 0.0:
+            return {}, True
+        reconstruction, z_mu, z_sigma = self.autoencoder(images, eps=eps)
+        recons = self.intensity_loss(reconstruction, images)
+        kl = kl_loss(z_mu, z_sigma).mean()
+        loss_g = recons + self.kl_weight * kl
+        bad = self.sync.any((~torch.isfinite(loss_g.detach())).to(torch.float32))
+        if float(bad) > 0.0:
+            return {}, True
+        loss_g.backward()
+        self.sync.mean_(self.autoencoder.flat_grads)
+        self.optimizer.step()
+        return {"recons": recons.detach(), "kl": kl.detach(), "loss_g": loss_g.detach()}, False
+
+    @torch.no_grad()
+    def validate(self, loader, device) -> float:
+        """Mean clamped-reconstruction loss (:565-611), averaged over ranks."""
+        self.autoencoder.eval()
+        total, n = torch.zeros((), device=device), 0
+        for batch in loader:
+            images = torch.clamp(batch["image"].to(device).float(), 0.0, 1.0)
+            reconstruction, _, _ = self.autoencoder(images)
+            v = self.intensity_loss(torch.clamp(reconstruction, 0.0, 1.0), images)
+            if bool(torch.isfinite(v)):
+                total += v
+                n += 1
+        val = total / n if n else torch.tensor(float("inf"), device=device)
+        return float(self.sync.mean_scalar(val))

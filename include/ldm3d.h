@@ -124,10 +124,11 @@ int ldm_vae_train_backward(ldm_model* m, const float* d_recon, const float* d_mu
  * and torch.optim.Adam(lr) :155, torch defaults betas (0.9, 0.999), eps 1e-8, no weight decay):
  *   grad_sq_norm: *out (device fp32 scalar) = sum g^2.
  *   adam_step: g' = g * min(1, max_norm / (sqrt(*sq_norm) + 1e-6)) when sq_norm != NULL and max_norm > 0; then
- *              m = b1 m + (1-b1) g'; v = b2 v + (1-b2) g'^2; p -= lr * (m / (1-b1^step)) / (sqrt(v / (1-b2^step)) + eps). */
+ *              m = b1 m + (1-b1) g'; v = b2 v + (1-b2) g'^2; p = p (1 - lr wd) - lr * (m / (1-b1^step)) / (sqrt(v / (1-b2^step)) + eps)
+ *              (wd = 0: torch.optim.Adam of train_diffusion.py:155; wd > 0: the decoupled AdamW of train_autoencoder.py:274-279). */
 int ldm_grad_sq_norm(const float* flat_grads, int64_t n, float* out, void* stream);
 int ldm_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
-                  float beta2, float eps, int step, const float* sq_norm, float max_norm, void* stream);
+                  float beta2, float eps, float weight_decay, int step, const float* sq_norm, float max_norm, void* stream);
 
 /* ---- AutoencoderKL.encode / sampling / decode (3d_ldm/train_diffusion.py:104,180,195,249,258,310,324;
  *      3d_ldm/train_autoencoder.py:366,579).  encode: x:[B,Cin,D,H,W] -> z_mu, z_sigma, z = mu + sigma*eps

@@ -46,3 +46,12 @@ def test_loader_split_crop_and_pairing(tmp_path):
     assert torch.equal(ds[1]["label"], ds[1]["label"])                          # deterministic per (seed, index)
     with pytest.raises(ValueError):
         data.split_files(argparse.Namespace(npz_dir=str(tmp_path / "none")))
+
+
+def test_trainer_kl_loss_matches_oracle_and_closed_form():
+    from ldm3d.trainer import kl_loss
+    from oracle import autoencoder as oa
+    g = torch.Generator().manual_seed(0)
+    mu, sigma = torch.randn((2, 3, 4, 4, 4), generator=g), torch.rand((2, 3, 4, 4, 4), generator=g) + 0.1
+    assert torch.allclose(kl_loss(mu, sigma), oa.kl_loss(mu, sigma))
+    assert float(kl_loss(torch.zeros(1, 1, 2, 2, 2), torch.ones(1, 1, 2, 2, 2)).abs().max()) < 1e-6      # KL(N(0,1) || N(0,1)) = 0

@@ -246,3 +246,25 @@ def test_autoencoder_full_size_backward_runs(cuda):
     torch.cuda.synchronize()
     for n, p in m.named_parameters():
         assert p.grad is not None and torch.isfinite(p.grad).all() and float(p.grad.abs().max()) > 0.0, n
+
+
+def test_flat_adam_weight_decay_matches_torch_adamw(cuda):
+    """AdamW(betas=(0.5, 0.9), weight_decay=1e-5) + clip 0.5 of train_autoencoder.py:274-279,440-451 on the flat buffers."""
+    from ldm3d.networks import AutoencoderKL
+    from ldm3d.optim import FlatAdam
+    torch.manual_seed(3)
+    m = AutoencoderKL(**cfgs.VAE_TINY).to(cuda).train()
+    ref_p = [p.detach().clone().requires_grad_(True) for p in m._param_list()]
+    topt = torch.optim.AdamW(ref_p, lr=1e-3, betas=(0.5, 0.9), weight_decay=1e-2, eps=1e-8)
+    opt = FlatAdam(m, lr=1e-3, betas=(0.5, 0.9), weight_decay=1e-2, max_grad_norm=0.5)
+    x = torch.rand((1, 2, 16, 16, 16), device=cuda)
+    for it in range(2):
+        recon, mu, sigma = m(x)
+        (F.l1_loss(recon, x) + 1e-4 * (mu ** 2).mean()).backward()
+        for rp, p in zip(ref_p, m._param_list()):
+            rp.grad = p.grad.detach().clone()
+        torch.nn.utils.clip_grad_norm_(ref_p, 0.5)
+        opt.step(); topt.step()
+        torch.cuda.synchronize()
+        for rp, p in zip(ref_p, m._param_list()):
+            assert torch.allclose(p.detach(), rp.detach(), rtol=2e-5, atol=2e-7), it
