@@ -7,6 +7,9 @@ unet_full_24.pt : benchmark UNet (tests/cfgs.py UNET_FULL) on the headline shape
                   torch.Generator on CPU), only eps_hat is stored (bf16-emulating and pure fp32 oracle), as fp16-safe
                   fp32 tensors (2 x 221 KB).
 sched_tables.pt : DDPM/DDIM known values of the (T=1000, scaled_linear_beta, 0.0015->0.0195) schedule.
+train_step_tiny.pt : one training step of tests/cfgs.py UNET_TINY (train_diffusion.py:197-219 in miniature): seeds, the MSE
+                  loss, per-parameter gradient norms and projections on seeded +-1 directions (fp32 and bf16-emulating
+                  oracle, torch autograd), and the parameter checksum after one Adam step with clip 1.0.
 """
 import os
 import sys
@@ -20,6 +23,45 @@ sys.path.insert(0, os.path.dirname(HERE))
 import cfgs  # noqa: E402
 from oracle import unet as ou  # noqa: E402
 from oracle.schedulers import OracleDDPM  # noqa: E402
+
+
+def train_case():
+    """Seeded (weights, x, t, target) of the golden training step; shared with tests/test_gpu_train.py."""
+    cfg = cfgs.UNET_TINY
+    sd = ou.init_state_dict(ou.unet_param_shapes(cfg), 21, gain=0.5)
+    g = torch.Generator().manual_seed(22)
+    x = torch.randn((2, 4, 8, 8, 8), generator=g)
+    target = torch.randn((2, 4, 8, 8, 8), generator=g)
+    t = torch.tensor([123.0, 877.0])
+    return cfg, sd, x, t, target
+
+
+def directions(sd, k=4, seed=23):
+    g = torch.Generator().manual_seed(seed)
+    return {n: (torch.randint(0, 2, (k, v.numel()), generator=g).float() * 2 - 1) for n, v in sd.items()}
+
+
+def train_golden():
+    import torch.nn.functional as F
+    cfg, sd, x, t, target = train_case()
+    dirs = directions(sd)
+    out = dict(torch_version=torch.__version__)
+    for tag, bf in (("fp32", False), ("bf16", True)):
+        leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        loss = F.mse_loss(ou.unet_forward(leaves, cfg, x, t, emulate_bf16=bf), target)
+        loss.backward()
+        out[f"loss_{tag}"] = float(loss.detach())
+        out[f"grad_norm_{tag}"] = {k: float(v.grad.norm()) for k, v in leaves.items()}
+        out[f"grad_proj_{tag}"] = {k: (dirs[k] @ v.grad.reshape(-1)).tolist() for k, v in leaves.items()}
+        if not bf:                                   # one Adam step (lr 1e-3, clip 1.0) on the fp32 gradients
+            params = [v for v in leaves.values()]
+            opt = torch.optim.Adam(params, lr=1e-3)
+            out["total_grad_norm_fp32"] = float(torch.nn.utils.clip_grad_norm_(params, 1.0))
+            opt.step()
+            out["param_sum_after_adam_fp32"] = float(sum(v.detach().double().sum() for v in params))
+            out["param_abs_sum_after_adam_fp32"] = float(sum(v.detach().double().abs().sum() for v in params))
+    torch.save(out, os.path.join(HERE, "train_step_tiny.pt"))
+    print("train golden: loss fp32 %.6f bf16 %.6f, |g| %.4f" % (out["loss_fp32"], out["loss_bf16"], out["total_grad_norm_fp32"]))
 
 
 def main():
@@ -37,6 +79,7 @@ def main():
           f"{float((e_bf - e_32).norm() / e_32.norm()):.3e}")
     torch.save(dict(weight_seed=wseed, input_seed=iseed, t=t, eps_bf16_oracle=e_bf, eps_fp32_oracle=e_32,
                     torch_version=torch.__version__), os.path.join(HERE, "unet_full_24.pt"))
+    train_golden()
     s = OracleDDPM(**cfgs.SCHED)
     torch.save(dict(betas=s.betas, alphas_cumprod=s.alphas_cumprod), os.path.join(HERE, "sched_tables.pt"))
 

@@ -268,3 +268,49 @@ def test_flat_adam_weight_decay_matches_torch_adamw(cuda):
         torch.cuda.synchronize()
         for rp, p in zip(ref_p, m._param_list()):
             assert torch.allclose(p.detach(), rp.detach(), rtol=2e-5, atol=2e-7), it
+
+
+def test_training_step_matches_committed_golden(cuda):
+    """tests/golden/train_step_tiny.pt (CPU oracle + torch autograd, generated by tests/golden/make_golden.py): loss,
+    per-parameter gradient norms / seeded projections, and the parameter checksum after one clipped Adam step."""
+    import os
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import make_golden as mg
+    from ldm3d.networks import DiffusionModelUNet
+    from ldm3d.optim import FlatAdam
+    gold = torch.load(os.path.join(here, "golden", "train_step_tiny.pt"), weights_only=False)
+    cfg, sd, x, t, target = mg.train_case()
+    dirs = mg.directions(sd)
+    m = DiffusionModelUNet(**cfg)
+    m.load_state_dict(sd)
+    m = m.to(cuda).train()
+    opt = FlatAdam(m, lr=1e-3, max_grad_norm=1.0)
+    loss = F.mse_loss(m(x=x.to(cuda), timesteps=t.to(cuda)).float(), target.to(cuda))
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss) - gold["loss_fp32"]) <= 2e-3 * gold["loss_fp32"]
+    names = list(sd.keys())
+    got = {k: p.grad.detach().cpu() for k, p in m.named_parameters()}
+    gp = torch.tensor([v for n in names for v in (dirs[n] @ got[n].reshape(-1)).tolist()]).double()
+    r32 = torch.tensor([v for n in names for v in gold["grad_proj_fp32"][n]]).double()
+    rbf = torch.tensor([v for n in names for v in gold["grad_proj_bf16"][n]]).double()
+    floor = float((rbf - r32).norm() / r32.norm())
+    e32 = float((gp - r32).norm() / r32.norm())
+    gn = torch.tensor([float(got[n].norm()) for n in names]).double()
+    rn = torch.tensor([gold["grad_norm_fp32"][n] for n in names]).double()
+    en = float((gn - rn).norm() / rn.norm())
+    print(f"golden train step: loss {float(loss):.6f} vs {gold['loss_fp32']:.6f}; projection rel-L2 {e32:.2e} (bf16 floor {floor:.2e}); "
+          f"per-tensor norm rel-L2 {en:.2e}")
+    assert e32 <= 2.0 * floor + 5e-3, (e32, floor)
+    assert en <= 2e-2
+    total = float(opt.grad_norm())
+    assert abs(total - gold["total_grad_norm_fp32"]) <= 2e-2 * gold["total_grad_norm_fp32"]
+    opt.step()
+    torch.cuda.synchronize()
+    s = float(m.flat_params.double().sum())
+    sa = float(m.flat_params.double().abs().sum())
+    # Adam's first step moves every element by ~lr * sign(g): the checksum pins the layout / export of every gradient
+    assert abs(sa - gold["param_abs_sum_after_adam_fp32"]) <= 1e-4 * gold["param_abs_sum_after_adam_fp32"]
+    assert abs(s - gold["param_sum_after_adam_fp32"]) <= 0.02 * m.flat_params.numel() * 1e-3 + 1e-3 * abs(gold["param_sum_after_adam_fp32"])
