@@ -364,3 +364,12 @@ def test_attention_backward(cuda, built_lib, b, n, c):
     for name, sl in (("dq", slice(0, c)), ("dk", slice(c, 2 * c)), ("dv", slice(2 * c, 3 * c))):
         e = rel_l2(got[..., sl], ref[..., sl])
         assert e <= 1.5e-2, (name, e)
+
+
+@pytest.mark.parametrize("cin,cout,dims,n,ksplit", [(64, 96, (6, 6, 6), 1, 1), (128, 256, (5, 7, 6), 2, 2), (256, 128, (12, 12, 12), 1, 4),
+                                                    (64, 64, (2, 3, 1), 1, 1), (96, 160, (4, 4, 30), 1, 3)])
+def test_conv_wgrad_kw_triplet_kernel(cuda, built_lib, monkeypatch, cin, cout, dims, n, ksplit):
+    """conv_wgrad3_kernel (opt-in, LDM_WGRAD3=1): three kw taps per workgroup over zero-padded line positions."""
+    monkeypatch.setenv("LDM_WGRAD3", "1")
+    err = _wgrad_case(cuda, built_lib, cin, cout, dims, 3, 1, 1, n, 0, ksplit=ksplit, seed=cin)
+    assert err <= 2e-5, err
