@@ -23,6 +23,7 @@ struct WgradParams {
     int ksplit; long slab_stride;     // voxel range split over `ksplit` workgroups, each writing its own [taps][Cout][ld] slab
 };
 
+template <int ABL1 = 0>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int KV = 64;                     // voxels per K step
@@ -82,14 +83,14 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradParams p)
             /* dY row m (rows beyond M and channels beyond the tensor fall outside the buffer -> zeros) */     \
             const bool okc_ = (dy_cb + (unsigned)l_kb[j]) < (unsigned)p.cdy * 2u;                              \
             const unsigned vo_dy = (m_ < p.M && okc_) ? (unsigned)m_ * (unsigned)(p.cdy * 2) + dy_cb + (unsigned)l_kb[j] : 0xFFFFFFFFu; \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, (lds_ptr_t)(st_ + (wave * 2 + j) * 1024), 16, vo_dy, 0, 0, 0); \
+            if (!(ABL1 & 4)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, (lds_ptr_t)(st_ + (wave * 2 + j) * 1024), 16, vo_dy, 0, 0, 0); \
             /* X row src(m, tap) */                                                                            \
             const int id = vd[j] * p.stride + kd - p.pad, ih = vh[j] * p.stride + kh - p.pad, iw = vw[j] * p.stride + kw - p.pad; \
             const bool ok_ = (m_ < p.M) & ((unsigned)id < (unsigned)DinU) & ((unsigned)ih < (unsigned)HinU) & ((unsigned)iw < (unsigned)WinU) & \
                              ((x_cb + (unsigned)l_kb[j]) < (unsigned)p.cx * 2u);                               \
             const int src_ = ((vn[j] * p.Din + (id >> p.ups)) * p.Hin + (ih >> p.ups)) * p.Win + (iw >> p.ups); \
             const unsigned vo_x = ok_ ? (unsigned)src_ * (unsigned)(p.cx * 2) + x_cb + (unsigned)l_kb[j] : 0xFFFFFFFFu; \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(st_ + KV * TR + (wave * 2 + j) * 1024), 16, vo_x, 0, 0, 0); \
+            if (!(ABL1 & 4)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(st_ + KV * TR + (wave * 2 + j) * 1024), 16, vo_x, 0, 0, 0); \
             /* advance this row by 64 output voxels */                                                         \
             vw[j] += q_w; if (vw[j] >= p.Wout) { vw[j] -= p.Wout; ++vh[j]; }                                   \
             vh[j] += q_h; if (vh[j] >= p.Hout) { vh[j] -= p.Hout; ++vd[j]; }                                   \
@@ -119,6 +120,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradParams p)
         for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
     bf16x8 afA[4], bfA[4], afB[4], bfB[4];
 #define WG_READ(AF, BF, SLOT) do {                                                                  \
+        if (ABL1 & 16) break;                                                                       \
         const char* sb_ = smem + (SLOT) * STAGE;                                                    \
         _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                             \
             const s16x4 al_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(sb_ + a_lo[t])); \
@@ -130,6 +132,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradParams p)
         }                                                                                           \
     } while (0)
 #define WG_MFMA(AF, BF) do {                                                                        \
+        if (ABL1 & 8) break;                                                                        \
         _Pragma("unroll") for (int a = 0; a < 4; ++a)                                               \
             _Pragma("unroll") for (int b = 0; b < 4; ++b)                                           \
                 acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[a], BF[b], acc[a][b], 0, 0, 0); \

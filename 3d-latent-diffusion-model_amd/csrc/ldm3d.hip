@@ -1274,8 +1274,14 @@ static int launch_wgrad3(const Wgrad3Params& p, hipStream_t s) {
 static int launch_wgrad(const WgradParams& p, hipStream_t s) {
     constexpr int LDS = 4 * 2 * 64 * 256;
     static bool attr_set = false;
-    if (!attr_set) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr_set = true; }
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(p.co_tiles * p.ci_tiles * p.ksize * p.ksize * p.ksize * p.ksplit), dim3(512), LDS, s, p);
+    if (!attr_set) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr_set = true; }
+    { const char* e = getenv("LDM_CONV_DBG"); const int dbg = e ? atoi(e) : 0;      // timing ablations (results are wrong)
+#define W1_ABL(A) if (dbg == A) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<A>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); \
+          hipLaunchKernelGGL(conv_wgrad_kernel<A>, dim3(p.co_tiles * p.ci_tiles * p.ksize * p.ksize * p.ksize * p.ksplit), dim3(512), LDS, s, p); return 0; }
+      W1_ABL(4) W1_ABL(8) W1_ABL(16) W1_ABL(12) W1_ABL(20) W1_ABL(24)
+#undef W1_ABL
+    }
+    hipLaunchKernelGGL(conv_wgrad_kernel<0>, dim3(p.co_tiles * p.ci_tiles * p.ksize * p.ksize * p.ksize * p.ksplit), dim3(512), LDS, s, p);
     return 0;
 }
 
