@@ -12,6 +12,23 @@
 #pragma once
 #include "common.h"
 
+// ds_read_b64_tr_b16 through inline asm.  Through the builtin, hipcc (ROCm 7.2) orders every such read behind ALL pending
+// LDS-DMA copies with a full `s_waitcnt vmcnt(0)` (it cannot tell which ring slot the read touches), which drains the
+// prefetch ring on every K step: the weight-gradient kernels then run one un-overlapped copy round trip per step.  The
+// asm form is invisible to that logic; the kernels already order reads and copies by hand (counted vmcnt + barrier), and
+// wait for the fragments with an explicit lgkmcnt(0) behind a sched_barrier before the MFMAs use them.
+typedef __attribute__((ext_vector_type(4))) short wg_s16x4;
+__device__ __forceinline__ wg_s16x4 ds_read_tr16_b64_raw(const char* lds_ptr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    wg_s16x4 v;
+    const unsigned a = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)lds_ptr;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(a));
+    return v;
+#else
+    return wg_s16x4{};
+#endif
+}
+
 struct WgradParams {
     const bf16_t* dy; int cdy;        // [M][cdy]   output-gradient, NDHWC bf16 (cdy = stored channels of the conv output)
     const bf16_t* x; int cx;          // [rows_in][cx] conv input (single source)
@@ -20,6 +37,7 @@ struct WgradParams {
     int dw_ld, dw_ci_off;             // row length / first column (dual-source convs are two launches into one matrix)
     int N, Din, Hin, Win, Dout, Hout, Wout, ksize, stride, pad, ups;
     int M, co_tiles, ci_tiles;
+    int dbg;                          // 2048 never set: feeds the opaque per-step branch
     int ksplit; long slab_stride;     // voxel range split over `ksplit` workgroups, each writing its own [taps][Cout][ld] slab
 };
 
@@ -52,49 +70,73 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradParams p)
     const int s_begin = split * sps;
     const int nsteps = (s_begin + sps < steps_all ? s_begin + sps : steps_all) - s_begin;     // may be <= 0 for a trailing split
 
-    // ---- loader: each wave copies 2 pieces (4 voxel rows x 256 B) of the dY tile and 2 of the X tile per step.
-    // lane -> (row = lane / 16 inside the piece, physical 16-B chunk = lane % 16); 32-byte blocks are XOR-swizzled by
-    // f(row) = (row & 3) + 4 * ((row >> 3) & 1) so the transposed reads below are bank-conflict free.
-    const int prow = lane >> 4, pch = lane & 15;
-    int l_row[2], l_kb[2];                     // voxel row inside the step, logical channel byte this lane fetches
-    int vw[2], vh[2], vd[2], vn[2];            // output coordinates of that row at the current step (updated incrementally)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int row = (wave * 2 + j) * 4 + prow;
-        const int f = (row & 3) + 4 * ((row >> 3) & 1);
-        l_row[j] = row;
-        l_kb[j] = ((((pch >> 1) ^ f) << 1) | (pch & 1)) * 16;
-        int m = s_begin * KV + row;            // first step of this split
-        vn[j] = m / DHWo; m -= vn[j] * DHWo; vd[j] = m / HWo; m -= vd[j] * HWo; vh[j] = m / p.Wout; vw[j] = m - vh[j] * p.Wout;
+    // ---- source-offset table (double buffered, behind the ring): thread r < 128 owns row slot r of a ring stage (64 dY rows
+    //      then 64 X rows), keeps the output coordinates of the voxel that slot holds at the step being prepared, advances
+    //      them by 64 voxels per step and publishes the row's byte offset (0xFFFFFFFF: beyond M / tap in the zero padding ->
+    //      the copy writes zeros).  The copy path of every lane is then a table read + add per piece, loop free, so the whole
+    //      K step is one basic block in which copies and fragment reads ride between the MFMAs.  Three table buffers: a fast
+    //      wave may publish for step k + 1 while a slow one still reads the table of step k - 1.
+    unsigned* const tab = reinterpret_cast<unsigned*>(smem + NS * STAGE);
+    const bool owner = tid < 2 * KV, own_x = tid >= KV;
+    const int own_row = own_x ? tid - KV : tid;
+    int vw = 0, vh = 0, vd = 0, vn = 0, vm = s_begin * KV + own_row;
+    if (owner) {
+        int m = vm;
+        vn = m / DHWo; m -= vn * DHWo; vd = m / HWo; m -= vd * HWo; vh = m / p.Wout; vw = m - vh * p.Wout;
     }
     // 64 voxels ahead, decomposed once (q_w < Wout and q_h < Hout, so those carries wrap at most once; volumes smaller
     // than 64 voxels make q_d >= Dout, hence the loop on the depth carry)
     const int q_d = KV / HWo, q_h = (KV - q_d * HWo) / p.Wout, q_w = KV - q_d * HWo - q_h * p.Wout;
+#define WG_PUBLISH(PAR) do {                                                                                  \
+        if (owner) {                                                                                          \
+            unsigned off_ = 0xFFFFFFFFu;                                                                      \
+            if (!own_x) { if (vm < p.M) off_ = (unsigned)vm * (unsigned)(p.cdy * 2); }                        \
+            else {                                                                                            \
+                const int id = vd * p.stride + kd - p.pad, ih = vh * p.stride + kh - p.pad, iw = vw * p.stride + kw - p.pad; \
+                const bool ok_ = (vm < p.M) & ((unsigned)id < (unsigned)DinU) & ((unsigned)ih < (unsigned)HinU) & ((unsigned)iw < (unsigned)WinU); \
+                const int src_ = ((vn * p.Din + (id >> p.ups)) * p.Hin + (ih >> p.ups)) * p.Win + (iw >> p.ups); \
+                if (ok_) off_ = (unsigned)src_ * (unsigned)(p.cx * 2);                                        \
+            }                                                                                                 \
+            tab[(PAR) * 2 * KV + tid] = off_;                                                                 \
+            vm += KV;                                                                                         \
+            vw += q_w; if (vw >= p.Wout) { vw -= p.Wout; ++vh; }                                              \
+            vh += q_h; if (vh >= p.Hout) { vh -= p.Hout; ++vd; }                                              \
+            vd += q_d; while (vd >= p.Dout) { vd -= p.Dout; ++vn; }                                           \
+        }                                                                                                     \
+    } while (0)
+
+    // ---- loader lanes: each wave copies 2 pieces (4 voxel rows x 256 B) of the dY tile and 2 of the X tile per step.
+    // lane -> (row = lane / 16 inside the piece, physical 16-B chunk = lane % 16); 32-byte blocks are XOR-swizzled by
+    // f(row) = (row & 3) + 4 * ((row >> 3) & 1) so the transposed reads below are bank-conflict free.
+    const int prow = lane >> 4, pch = lane & 15;
+    int l_row[2]; unsigned l_ady[2], l_ax[2];     // voxel row inside the step, channel byte added to the row offset (or OOB)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = (wave * 2 + j) * 4 + prow;
+        const int f = (row & 3) + 4 * ((row >> 3) & 1);
+        const unsigned kb = (unsigned)(((((pch >> 1) ^ f) << 1) | (pch & 1)) * 16);
+        l_row[j] = row;
+        l_ady[j] = ((unsigned)co_t * 256u + kb < (unsigned)p.cdy * 2u) ? (unsigned)co_t * 256u + kb : 0xFFFFFFFFu;
+        l_ax[j] = ((unsigned)ci_t * 256u + kb < (unsigned)p.cx * 2u) ? (unsigned)ci_t * 256u + kb : 0xFFFFFFFFu;
+    }
     __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (int)((unsigned)p.M * (unsigned)p.cdy * 2u), 0x00020000);
     __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
         (void*)p.x, 0, (int)((unsigned)(p.N * p.Din * p.Hin * p.Win) * (unsigned)p.cx * 2u), 0x00020000);
-    const unsigned dy_cb = (unsigned)co_t * 256u, x_cb = (unsigned)ci_t * 256u;   // byte offset of the channel tile
     int ld_s = 0;
 
-#define WG_ISSUE() do {                                                                                       \
+    // table reads of one step's four copies (issued ahead of the waits), then the copies themselves
+#define WG_TAB(T, PAR) do {                                                                                   \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                       \
+            T[2 * j] = tab[(PAR) * 2 * KV + l_row[j]]; T[2 * j + 1] = tab[(PAR) * 2 * KV + KV + l_row[j]];    \
+        }                                                                                                     \
+    } while (0)
+#define WG_COPIES(T) do {                                                                                     \
         char* st_ = smem + (ld_s % NS) * STAGE;                                                               \
         _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                       \
-            const int m_ = (s_begin + ld_s) * KV + l_row[j];                                                              \
-            /* dY row m (rows beyond M and channels beyond the tensor fall outside the buffer -> zeros) */     \
-            const bool okc_ = (dy_cb + (unsigned)l_kb[j]) < (unsigned)p.cdy * 2u;                              \
-            const unsigned vo_dy = (m_ < p.M && okc_) ? (unsigned)m_ * (unsigned)(p.cdy * 2) + dy_cb + (unsigned)l_kb[j] : 0xFFFFFFFFu; \
+            const unsigned vo_dy = ((T[2 * j] == 0xFFFFFFFFu) | (l_ady[j] == 0xFFFFFFFFu)) ? 0xFFFFFFFFu : T[2 * j] + l_ady[j]; \
+            const unsigned vo_x = ((T[2 * j + 1] == 0xFFFFFFFFu) | (l_ax[j] == 0xFFFFFFFFu)) ? 0xFFFFFFFFu : T[2 * j + 1] + l_ax[j]; \
             if (!(ABL1 & 4)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, (lds_ptr_t)(st_ + (wave * 2 + j) * 1024), 16, vo_dy, 0, 0, 0); \
-            /* X row src(m, tap) */                                                                            \
-            const int id = vd[j] * p.stride + kd - p.pad, ih = vh[j] * p.stride + kh - p.pad, iw = vw[j] * p.stride + kw - p.pad; \
-            const bool ok_ = (m_ < p.M) & ((unsigned)id < (unsigned)DinU) & ((unsigned)ih < (unsigned)HinU) & ((unsigned)iw < (unsigned)WinU) & \
-                             ((x_cb + (unsigned)l_kb[j]) < (unsigned)p.cx * 2u);                               \
-            const int src_ = ((vn[j] * p.Din + (id >> p.ups)) * p.Hin + (ih >> p.ups)) * p.Win + (iw >> p.ups); \
-            const unsigned vo_x = ok_ ? (unsigned)src_ * (unsigned)(p.cx * 2) + x_cb + (unsigned)l_kb[j] : 0xFFFFFFFFu; \
             if (!(ABL1 & 4)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(st_ + KV * TR + (wave * 2 + j) * 1024), 16, vo_x, 0, 0, 0); \
-            /* advance this row by 64 output voxels */                                                         \
-            vw[j] += q_w; if (vw[j] >= p.Wout) { vw[j] -= p.Wout; ++vh[j]; }                                   \
-            vh[j] += q_h; if (vh[j] >= p.Hout) { vh[j] -= p.Hout; ++vd[j]; }                                   \
-            vd[j] += q_d; while (vd[j] >= p.Dout) { vd[j] -= p.Dout; ++vn[j]; }                                   \
         }                                                                                                     \
         ++ld_s;                                                                                               \
     } while (0)
@@ -123,10 +165,10 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradParams p)
         if (ABL1 & 16) break;                                                                       \
         const char* sb_ = smem + (SLOT) * STAGE;                                                    \
         _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                             \
-            const s16x4 al_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(sb_ + a_lo[t])); \
-            const s16x4 ah_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(sb_ + a_hi[t])); \
-            const s16x4 bl_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(sb_ + b_lo[t])); \
-            const s16x4 bh_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(sb_ + b_hi[t])); \
+            const s16x4 al_ = ds_read_tr16_b64_raw(sb_ + a_lo[t]); \
+            const s16x4 ah_ = ds_read_tr16_b64_raw(sb_ + a_hi[t]); \
+            const s16x4 bl_ = ds_read_tr16_b64_raw(sb_ + b_lo[t]); \
+            const s16x4 bh_ = ds_read_tr16_b64_raw(sb_ + b_hi[t]); \
             AF[t] = (bf16x8){al_[0], al_[1], al_[2], al_[3], ah_[0], ah_[1], ah_[2], ah_[3]};       \
             BF[t] = (bf16x8){bl_[0], bl_[1], bl_[2], bl_[3], bh_[0], bh_[1], bh_[2], bh_[3]};       \
         }                                                                                           \
@@ -137,35 +179,83 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradParams p)
             _Pragma("unroll") for (int b = 0; b < 4; ++b)                                           \
                 acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[a], BF[b], acc[a][b], 0, 0, 0); \
     } while (0)
+    // table protocol: publish #k (offsets of step k) goes to buffer k % 3; the copies of step k (in step k - NS, behind that
+    // step's barrier) read it; publish #k happens at the top of step k - NS - 1 and overwrites #k-3, read two barriers earlier.
+    // Steady-state step: owners publish (branchy, in front of the waits), then ONE basic block: table reads, waits,
+    // barrier, 4 copies + 16 transposed fragment reads interleaved with the 16 MFMAs of the step.
+#define WG_FAST(S, AC, BC, AN, BN) do {                                                             \
+        if (dbgf & 2048) asm volatile("s_nop 0");              /* opaque branch: one basic block per step */ \
+        WG_PUBLISH(((S) + NS + 1) % 3);                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+        unsigned t_[4];                                                                             \
+        WG_TAB(t_, ((S) + NS) % 3);                            /* published one barrier ago: readable ahead of the waits */ \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                    /* fragments of step S, table values, own table write retired */ \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF - 1) * LPS) : "memory");                       \
+        __builtin_amdgcn_s_barrier();                                                               \
+        asm volatile("" ::: "memory");                                                              \
+        __builtin_amdgcn_sched_barrier(0);                     /* nothing (MFMAs on asm-read fragments) moves above the waits */ \
+        WG_COPIES(t_);                                                                              \
+        WG_READ(AN, BN, ((S) + 1) % NS);                                                            \
+        WG_MFMA(AC, BC);                                                                            \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                          \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                      \
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                      \
+        }                                                                                           \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                          \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                      \
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                      \
+        }                                                                                           \
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                          \
+    } while (0)
 #define WG_HALF(S, AC, BC, AN, BN) do {                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
         __builtin_amdgcn_s_waitcnt(0xC07F);                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
         if ((S) + 1 < nsteps) {                                                                     \
             if ((S) + PF < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF - 1) * LPS) : "memory"); \
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                   \
             __builtin_amdgcn_s_barrier();                                                           \
             asm volatile("" ::: "memory");                                                          \
-            if (ld_s < nsteps) WG_ISSUE();                                                          \
+            if (ld_s < nsteps) { unsigned t_[4]; WG_TAB(t_, ((S) + NS) % 3); WG_COPIES(t_); }       \
             WG_READ(AN, BN, ((S) + 1) % NS);                                                        \
+            WG_PUBLISH(((S) + NS + 1) % 3);                                                         \
         }                                                                                           \
         WG_MFMA(AC, BC);                                                                            \
     } while (0)
 
+    const int dbgf = p.dbg;
+    WG_PUBLISH(0);
+    __syncthreads();
 #pragma unroll
-    for (int i = 0; i < NS; ++i) if (i < nsteps) WG_ISSUE();
+    for (int i = 0; i < NS; ++i) {
+        if (i < nsteps) { unsigned t_[4]; WG_TAB(t_, i % 3); WG_COPIES(t_); }
+        __syncthreads();                                       // table #i read by every wave
+        WG_PUBLISH((i + 1) % 3);                               // #1 .. #NS
+        __syncthreads();
+    }
     if (nsteps > PF) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PF * LPS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     WG_READ(afA, bfA, 0);
-    for (int s = 0; s < nsteps; s += 2) {
+    int s = 0;
+    // steady state: step s + NS exists (copies issued every step), two steps per iteration for the static fragment sets
+    for (; s + NS + 2 <= nsteps; s += 2) {
+        WG_FAST(s, afA, bfA, afB, bfB);
+        WG_FAST(s + 1, afB, bfB, afA, bfA);
+    }
+    for (; s < nsteps; s += 2) {
         WG_HALF(s, afA, bfA, afB, bfB);
         if (s + 1 >= nsteps) break;
         WG_HALF(s + 1, afB, bfB, afA, bfA);
     }
+#undef WG_FAST
 #undef WG_HALF
 #undef WG_MFMA
 #undef WG_READ
-#undef WG_ISSUE
+#undef WG_COPIES
+#undef WG_TAB
+#undef WG_PUBLISH
 
     // ---- reduce the two wave groups through LDS (group 1 -> group 0), then group 0 stores ------------------------
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -338,8 +428,8 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad3_kernel(const Wgrad3Params 
         const int a_lo = (BASE) + r_lo * TR + tp8, a_hi = a_lo + 4 * TR;                            \
         _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                             \
             const int c_ = (COLBLK) * 4 + t;                                                        \
-            const s16x4 l_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)((SB) + a_lo + ((c_ ^ f_lo) << 5))); \
-            const s16x4 h_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)((SB) + a_hi + ((c_ ^ f_hi) << 5))); \
+            const s16x4 l_ = ds_read_tr16_b64_raw((SB) + a_lo + ((c_ ^ f_lo) << 5)); \
+            const s16x4 h_ = ds_read_tr16_b64_raw((SB) + a_hi + ((c_ ^ f_hi) << 5)); \
             F[t] = (bf16x8){l_[0], l_[1], l_[2], l_[3], h_[0], h_[1], h_[2], h_[3]};                \
         }                                                                                           \
     } while (0)
@@ -373,23 +463,33 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad3_kernel(const Wgrad3Params 
         int row0 = 8 * fg + tq, tp8 = tp * 8;
         asm volatile("" : "+v"(row0), "+v"(tp8));              // opaque: no hoisting of the derived addresses out of the loop
         bf16x8 af0[4], af1[4], b0[4], b1[4];
+        // fragment reads are inline asm (see ds_read_tr16_b64_raw): every use is ordered by hand: W3_WAIT retires all reads
+        // issued so far and pins the following MFMAs behind it; each MFMA group runs while the next group's reads are in flight
+#define W3_WAIT() do { __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } while (0)
         W3_LOAD(af0, sb, 0, wa, 0);
         W3_LOAD(b0, sb, KV * TR, wb, 0);
         // the slot of step s - 1 is free (all waves passed the barrier): refill it with step s + NS - 1
         if (s >= 1 && ld_s < nsteps) W3_ISSUE((s + NS - 1) & 1);
+        W3_WAIT();
         W3_LOAD(b1, sb, KV * TR, wb, 1);
         W3_MFMA(0, af0, b0);
+        W3_WAIT();
         W3_LOAD(b0, sb, KV * TR, wb, 2);
         W3_MFMA(1, af0, b1);
+        W3_WAIT();
         W3_LOAD(af1, sb, 0, wa, 32);
         W3_LOAD(b1, sb, KV * TR, wb, 32);
         W3_MFMA(2, af0, b0);
         W3_PUBLISH((s + NS) & 1);                              // offsets of step s + NS, read at step s + 1
+        W3_WAIT();
         W3_LOAD(b0, sb, KV * TR, wb, 33);
         W3_MFMA(0, af1, b1);
+        W3_WAIT();
         W3_LOAD(b1, sb, KV * TR, wb, 34);
         W3_MFMA(1, af1, b0);
+        W3_WAIT();
         W3_MFMA(2, af1, b1);
+#undef W3_WAIT
     }
 #undef W3_MFMA
 #undef W3_LOAD

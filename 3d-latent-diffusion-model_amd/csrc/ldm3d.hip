@@ -1240,7 +1240,9 @@ static inline int grid_for(long total, int per_block = 256, int cap = 4096) {
 static int wgrad_ksplit(long M, int taps, int cout, int cin) {
     const long wgs = (long)taps * ((cout + 127) / 128) * ((cin + 127) / 128);
     const long steps = (M + 63) / 64;
-    long k = (512 + wgs - 1) / wgs;
+    const char* e = getenv("LDM_WGRAD_WGS");                 // tuning knob: workgroups aimed at (default: one round of 256 CUs)
+    const long target = e ? atol(e) : 256;
+    long k = (target + wgs / 2) / wgs;                       // nearest count of whole rounds
     if (k > steps / 16) k = steps / 16;
     if (k > 16) k = 16;
     return (int)(k < 1 ? 1 : k);
@@ -1272,7 +1274,7 @@ static int launch_wgrad3(const Wgrad3Params& p, hipStream_t s) {
     return 0;
 }
 static int launch_wgrad(const WgradParams& p, hipStream_t s) {
-    constexpr int LDS = 4 * 2 * 64 * 256;
+    constexpr int LDS = 4 * 2 * 64 * 256 + 3 * 128 * 4;        // ring + triple-buffered source-offset table
     static bool attr_set = false;
     if (!attr_set) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr_set = true; }
     { const char* e = getenv("LDM_CONV_DBG"); const int dbg = e ? atoi(e) : 0;      // timing ablations (results are wrong)
