@@ -51,7 +51,6 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradParams p)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     typedef __attribute__((ext_vector_type(4))) short s16x4;
-    typedef __attribute__((address_space(3))) s16x4* lds_s16x4_t;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -325,7 +324,6 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad3_kernel(const Wgrad3Params 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     typedef __attribute__((ext_vector_type(4))) short s16x4;
-    typedef __attribute__((address_space(3))) s16x4* lds_s16x4_t;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

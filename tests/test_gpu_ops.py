@@ -373,3 +373,13 @@ def test_conv_wgrad_kw_triplet_kernel(cuda, built_lib, monkeypatch, cin, cout, d
     monkeypatch.setenv("LDM_WGRAD3", "1")
     err = _wgrad_case(cuda, built_lib, cin, cout, dims, 3, 1, 1, n, 0, ksplit=ksplit, seed=cin)
     assert err <= 2e-5, err
+
+
+def test_conv3_halo_vs_general_kernel(cuda, built_lib, monkeypatch):
+    """Both kernels for the same conv (LDM_CONV_HALO toggles the planner's choice): each within tolerance of torch and of
+    each other (they differ only in fp32 summation order over K)."""
+    kw = dict(cin=(128, 0), cout=128, dims=(7, 6, 9), n=2, wgn=2, temb=True, residual=True, seed=5)
+    e_halo, tol = _conv_case(cuda, built_lib, **kw)
+    monkeypatch.setenv("LDM_CONV_HALO", "0")
+    e_gen, _ = _conv_case(cuda, built_lib, **kw)
+    assert e_halo <= tol and e_gen <= tol, (e_halo, e_gen)
