@@ -198,6 +198,11 @@ def main():
                    "weights": "random init, seeded", "launch": "eager (one C-ABI call per forward, ~215 kernel launches)"},
         "steps_per_s_per_gpu": args.steps / dt,
         "unet_step_tflops": UNET_STEP_GFLOP / ms_per_step,
+        # SURVEY.md section 8d asks for the three fractions side by side (per GPU): whole step vs the dense bf16 MFMA peak,
+        # vs the vector-fp32 peak north_star's wording implies (157 TFLOP/s), and algorithmic bytes (0.992 GB/step) vs HBM
+        "whole_step_fractions": {"mfma_bf16_dense": UNET_STEP_GFLOP / ms_per_step / MFMA_BF16_DENSE_PEAK_TFLOPS,
+                                 "vector_fp32_157TF": UNET_STEP_GFLOP / ms_per_step / 157.0,
+                                 "hbm_8TBps": 0.992 / (ms_per_step * 1e-3) / 8000.0},
     }
     if profile and prof[0] > 0:
         achieved = prof[2] / (prof[1] * 1e-3) / 1e12
