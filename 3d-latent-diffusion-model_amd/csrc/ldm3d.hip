@@ -407,7 +407,7 @@ struct Builder {
         if (fused && C / groups <= 64 && nrb_tot <= 256) {   // few slab rows: ONE launch folds them per block and applies
             Act out = new_act(N, xa.D, xa.H, xa.W, C);
             const int slices = (C + 63) / 64;
-            int chunks = std::max(1, std::min(512 / (slices * N), (DHW + 31) / 32));
+            int chunks = std::max(1, std::min(256 / (slices * N), (DHW + 31) / 32));   // one round of the 256 CUs: the slab fold is per block
             int rpb = rup((DHW + chunks - 1) / chunks, 32);
             chunks = (DHW + rpb - 1) / rpb;
             Op f{}; f.kind = OP_GN_FUSED;

@@ -232,12 +232,21 @@ __global__ __launch_bounds__(256) void gn_fused_apply_kernel(const GnFusedParams
             const bool second = c >= p.ca;
             const float* sl = second ? p.sb : p.sa;
             const int cs = second ? p.cb : p.ca, cl = second ? c - p.ca : c, nrb = second ? p.nrb_b : p.nrb_a;
-            float s0 = 0.f, s1 = 0.f;
-            for (int b = bl; b < nrb; b += 4) {
-                const float2 v = *reinterpret_cast<const float2*>(sl + ((size_t)(n * nrb + b) * cs + cl) * 2);
+            float s0 = 0.f, s1 = 0.f, u0 = 0.f, u1 = 0.f, w0 = 0.f, w1 = 0.f, x0 = 0.f, x1 = 0.f;
+            const float* base = sl + ((size_t)n * nrb * cs + cl) * 2;
+            int b = bl;
+            for (; b + 12 < nrb; b += 16) {                 // four slab rows in flight per thread (fixed order: reproducible)
+                const float2 v0 = *reinterpret_cast<const float2*>(base + (size_t)b * cs * 2);
+                const float2 v1 = *reinterpret_cast<const float2*>(base + (size_t)(b + 4) * cs * 2);
+                const float2 v2 = *reinterpret_cast<const float2*>(base + (size_t)(b + 8) * cs * 2);
+                const float2 v3 = *reinterpret_cast<const float2*>(base + (size_t)(b + 12) * cs * 2);
+                s0 += v0.x; s1 += v0.y; u0 += v1.x; u1 += v1.y; w0 += v2.x; w1 += v2.y; x0 += v3.x; x1 += v3.y;
+            }
+            for (; b < nrb; b += 4) {
+                const float2 v = *reinterpret_cast<const float2*>(base + (size_t)b * cs * 2);
                 s0 += v.x; s1 += v.y;
             }
-            part[bl][cc][0] = s0; part[bl][cc][1] = s1;
+            part[bl][cc][0] = (s0 + u0) + (w0 + x0); part[bl][cc][1] = (s1 + u1) + (w1 + x1);
         }
     }
     __syncthreads();
