@@ -164,3 +164,24 @@ def test_golden_vector_is_reproducible_from_its_seeds():
     tabs = torch.load(os.path.join(os.path.dirname(__file__), "golden", "sched_tables.pt"), weights_only=False)
     s = OracleDDPM(**cfgs.SCHED)
     assert torch.equal(tabs["betas"], s.betas) and torch.equal(tabs["alphas_cumprod"], s.alphas_cumprod)
+
+
+def test_training_golden_is_reproducible_from_its_seeds():
+    """tests/golden/train_step_tiny.pt (loss, gradient norms) regenerates from the seeds in make_golden.train_case()."""
+    import os
+    import sys
+    import torch.nn.functional as F
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import make_golden as mg
+    from oracle import unet as ou
+    gold = torch.load(os.path.join(here, "golden", "train_step_tiny.pt"), weights_only=False)
+    cfg, sd, x, t, target = mg.train_case()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    loss = F.mse_loss(ou.unet_forward(leaves, cfg, x, t), target)
+    loss.backward()
+    assert abs(float(loss) - gold["loss_fp32"]) <= 1e-5 * gold["loss_fp32"]
+    total = torch.sqrt(sum((v.grad.double() ** 2).sum() for v in leaves.values()))
+    assert abs(float(total) - gold["total_grad_norm_fp32"]) <= 1e-4 * gold["total_grad_norm_fp32"]
+    name = "middle_block.resnet_1.conv1.conv.weight"
+    assert abs(float(leaves[name].grad.norm()) - gold["grad_norm_fp32"][name]) <= 1e-4 * gold["grad_norm_fp32"][name]
