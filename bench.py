@@ -119,6 +119,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="launch every kernel from the host instead of replaying the HIP graph")
     args = ap.parse_args()
 
     import torch
@@ -139,6 +140,8 @@ def main():
     from ldm3d.schedulers import DDPMScheduler
     L = _lib.lib()
     unet = make_unet(dev, seed=rank)
+    if not args.eager:
+        unet.enable_graph_replay(True)       # same kernels; one hipGraphLaunch per forward keeps the host far off the critical path
     sch = DDPMScheduler(**cfgs.SCHED)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     x = torch.randn((1, 4, 24, 24, 24), device=dev, generator=gen)
@@ -170,6 +173,7 @@ def main():
         profile = (not args.no_roofline) and rank == 0
         prof = (C.c_double * 5)()
         if profile:
+            unet.enable_graph_replay(False)     # HIP events around individual launches need eager launches
             _lib.check(L.ldm_profile_start(*DOMINANT_TILE, 64 * args.steps + 64))
             for i in range(args.steps):
                 x = step(args.warmup + args.steps + i, x)
@@ -195,7 +199,10 @@ def main():
         "config": {"workload": "DiffusionModelUNet (channels 256/256/512, attn at 12^3 and 6^3, 191.18 M params) fwd + DDPM "
                                "step on 1x4x24^3, 1000-step schedule scaled_linear_beta 0.0015-0.0195 (BASELINE configs[2])",
                    "per_gpu_batch": 1, "parallelism": f"replicas x{world} (independent chains, no collective)",
-                   "weights": "random init, seeded", "launch": "eager (one C-ABI call per forward, ~215 kernel launches)"},
+                   "weights": "random init, seeded",
+                   "launch": ("eager (one C-ABI call per forward, ~215 kernel launches)" if args.eager else
+                              "HIP graph replay of the forward plan (one C-ABI call = one hipGraphLaunch of ~215 kernels; "
+                              "scheduler step eager)")},
         "steps_per_s_per_gpu": args.steps / dt,
         "unet_step_tflops": UNET_STEP_GFLOP / ms_per_step,
         # SURVEY.md section 8d asks for the three fractions side by side (per GPU): whole step vs the dense bf16 MFMA peak,

@@ -130,6 +130,11 @@ int ldm_grad_sq_norm(const float* flat_grads, int64_t n, float* out, void* strea
 int ldm_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int step, const float* sq_norm, float max_norm, void* stream);
 
+/* HIP-graph replay of the UNet forward plan (the sampling loop of 3d_ldm/inference.py:88-99 calls the UNet 1000 times per
+ * volume with the same shapes): with on != 0, ldm_unet_forward records its launches into a hipGraph the second time it sees
+ * a (x, cond, timesteps, out, workspace, stream) pointer set and replays it afterwards.  Results are identical. */
+int ldm_model_set_graph_mode(ldm_model* m, int on);
+
 /* ---- AutoencoderKL.encode / sampling / decode (3d_ldm/train_diffusion.py:104,180,195,249,258,310,324;
  *      3d_ldm/train_autoencoder.py:366,579).  encode: x:[B,Cin,D,H,W] -> z_mu, z_sigma, z = mu + sigma*eps
  *      (each [B,L,D/f,H/f,W/f], any of the three outputs may be NULL; eps NULL means eps = 0).

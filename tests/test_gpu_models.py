@@ -285,3 +285,23 @@ def test_inferer_call_concat_mode(cuda):
               timesteps=ts.to(cuda), condition=cond.to(cuda), mode="concat", vae_eps=veps.to(cuda)).cpu()
     args = (usd, ucfg, vsd, vcfg, OracleDDPM(**cfgs.SCHED), 1.3, img, noise, ts.float(), veps, cond, "concat")
     floor_gate(got, oi.inferer_call(*args, emulate_bf16=True), oi.inferer_call(*args, emulate_bf16=False), "inferer __call__ concat")
+
+
+def test_unet_graph_replay_is_bit_identical_to_eager(cuda):
+    """ldm_model_set_graph_mode: the forward plan replayed as a HIP graph (second and later calls on the same buffers)
+    gives exactly the eager result, also after the weights and the inputs change."""
+    m, sd = _unet_pair(cfgs.UNET_TINY, 5, cuda)
+    g = torch.Generator().manual_seed(6)
+    xs = [torch.randn((2, 4, 8, 8, 8), generator=g).to(cuda) for _ in range(4)]
+    t = torch.tensor([10.0, 700.0], device=cuda)
+    with torch.no_grad():
+        eager = [m(x=x, timesteps=t).clone() for x in xs]
+        m.enable_graph_replay(True)
+        replay = [m(x=x, timesteps=t).clone() for x in xs]         # call 1 eager, call 2 captures, calls 3-4 replay
+        for a, b in zip(eager, replay):
+            assert torch.equal(a, b)
+        for p in m.parameters():
+            p.mul_(1.01)
+        r2 = m(x=xs[0], timesteps=t).clone()
+        m.enable_graph_replay(False)
+        assert torch.equal(r2, m(x=xs[0], timesteps=t))
