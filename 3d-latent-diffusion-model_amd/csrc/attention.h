@@ -21,12 +21,17 @@ struct AttnParams {
     float* lse;                       // optional [B][heads][N]: log-sum-exp of the scaled scores (saved for the backward pass)
 };
 
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
+// S > 1: the workgroup carries S groups of 4 waves; group g walks the key tiles g, g+S, g+2S, ... with its own LDS double
+// buffer and the groups' (max, sum, O) partials are merged through LDS at the end (in-workgroup split of the key range):
+// at N = 1728 the grid is only 27 x heads workgroups, so the extra waves are what hides the load -> LDS -> MFMA latency chain.
+template <int S>
+__global__ __launch_bounds__(256 * S) void attn_fwd_kernel(const AttnParams p) {
     constexpr int D = 64, KT = 64;
     constexpr int TILE = KT * 128 + KT * 128;         // one K image + one V image (both row-major [key][d], swizzled)
-    __shared__ __attribute__((aligned(16))) char smem[2 * TILE];   // double buffered
+    extern __shared__ __attribute__((aligned(16))) char smem_all[];   // S x double buffer (S * 32 KiB)
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6, grp = threadIdx.x >> 8;
+    char* smem = smem_all + grp * 2 * TILE;
     const int fr = lane & 15, fg = lane >> 4;
     const int b = blockIdx.z, head = blockIdx.y;
     const int q0 = blockIdx.x * 64 + wave * 16;
@@ -48,8 +53,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     for (int i = 0; i < 4; ++i) ot[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float mrun = -INFINITY, lrun = 0.f;               // running max / per-lane partial row sum
 
-    // staging split (issue early / write late): the global loads of tile t+1 are issued before the MFMAs of tile t and
-    // written to the other LDS image after them, so their latency hides under the compute; one barrier per tile.
+    // staging split (issue early / write late): the global loads of the group's next tile are issued before the MFMAs of
+    // the current one and written to the other LDS image after them, so their latency hides under the compute; one barrier
+    // per tile.  The prefetch is unconditional (rows clamped) so that no wait for it is needed before the tile's own MFMAs.
     u32x4 kreg[2], vreg[2];
     auto stage_load = [&](int k0) {
 #pragma unroll
@@ -75,15 +81,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     };
 
     const int ntile = (p.N + KT - 1) / KT;
-    stage_load(0);
+    const int nrounds = (ntile + S - 1) / S;          // every group runs the same number of rounds (barriers are workgroup-wide)
+    stage_load(grp * KT);
+    asm volatile("" :: "v"(qf[0]), "v"(qf[1]));       // Q has landed before the loop: no load wait is left inside it
     stage_write(smem, smem + KT * 128);
     __syncthreads();
-    for (int t = 0; t < ntile; ++t) {
+    for (int it = 0; it < nrounds; ++it) {
+        const int t = it * S + grp;
         const int k0 = t * KT;
-        const char* ks = smem + (t & 1) * TILE;       // K tile  [64 keys][64 d] bf16, 16-B chunks XOR-swizzled
+        const char* ks = smem + (it & 1) * TILE;      // K tile  [64 keys][64 d] bf16, 16-B chunks XOR-swizzled
         const char* vs = ks + KT * 128;               // V tile  [64 keys][64 d] bf16, read transposed (ds_read_b64_tr_b16)
-        if (t + 1 < ntile) stage_load(k0 + KT);
-
+        stage_load(k0 + S * KT);
+        if (t < ntile) {                              // wave-uniform
         // ---- S^T = K Q^T : st[j][r] = S[q = fr][key = k0 + 16 j + 4 fg + r] ------------------------
         f32x4 st[4];
 #pragma unroll
@@ -154,16 +163,44 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
                 ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[h], ot[dt], 0, 0, 0);
             }
         }
-        // ---- late write of tile t+1 into the other image (its last readers finished before the previous barrier) ----
-        if (t + 1 < ntile) {
-            char* nk = smem + ((t + 1) & 1) * TILE;
+        }
+        // ---- late write of the next tile into the other image (its last readers finished before the previous barrier) ----
+        {
+            char* nk = smem + ((it + 1) & 1) * TILE;
             stage_write(nk, nk + KT * 128);
         }
         __syncthreads();
     }
-    // ---- normalise and store ------------------------------------------------------------------------
+    // ---- merge the S groups' partials (all staging images are dead after the last barrier) ----------------------
     lrun += __shfl_xor(lrun, 16, 64);
     lrun += __shfl_xor(lrun, 32, 64);
+    if constexpr (S > 1) {
+        // per (group, wave): O^T partial [4 dt][64 lanes] f32x4 = 4 KiB, then m and l per query (16 floats each)
+        float* xo = reinterpret_cast<float*>(smem_all) + (size_t)(grp * 4 + wave) * (1024 + 32);
+        if (grp > 0) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(xo + (dt * 64 + lane) * 4) = ot[dt];
+            if (fg == 0) { xo[1024 + fr] = mrun; xo[1040 + fr] = lrun; }
+        }
+        __syncthreads();
+        if (grp > 0) return;
+#pragma unroll
+        for (int g = 1; g < S; ++g) {                  // fixed order: reproducible
+            const float* xg = reinterpret_cast<const float*>(smem_all) + (size_t)(g * 4 + wave) * (1024 + 32);
+            const float mg = xg[1024 + fr], lg = xg[1040 + fr];
+            const float mnew = fmaxf(mrun, mg);        // group 0 always owns tile 0: finite
+            const float a0 = __expf(mrun - mnew), a1 = __expf(mg - mnew);      // mg = -inf (group without a tile) -> 0
+            lrun = lrun * a0 + lg * a1;
+            mrun = mnew;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const f32x4 og = *reinterpret_cast<const f32x4*>(xg + (dt * 64 + lane) * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ot[dt][r] = ot[dt][r] * a0 + og[r] * a1;
+            }
+        }
+    }
+    // ---- normalise and store ------------------------------------------------------------------------
     const float inv = 1.0f / lrun;
     const int qr = q0 + fr;
     if (p.lse && qr < p.N && fg == 0) p.lse[((size_t)b * p.heads + head) * p.N + qr] = mrun + __logf(lrun);
@@ -177,6 +214,23 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
             *reinterpret_cast<u32x2*>(orow + dt * 16 + 4 * fg) = o;
         }
     }
+}
+
+// S = 4 wave groups once a (batch, head) has at least 4 key tiles, else the plain 4-wave kernel
+static inline hipError_t launch_attn_fwd(const AttnParams& p, hipStream_t s) {
+    const dim3 grid((p.N + 63) / 64, p.heads, p.B);
+    if (p.N > 3 * 64) {
+        static bool once = false;
+        if (!once) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
+            if (e != hipSuccess) return e;
+            once = true;
+        }
+        hipLaunchKernelGGL(attn_fwd_kernel<4>, grid, dim3(1024), 4 * 32768, s, p);
+    } else {
+        hipLaunchKernelGGL(attn_fwd_kernel<1>, grid, dim3(256), 32768, s, p);
+    }
+    return hipGetLastError();
 }
 
 

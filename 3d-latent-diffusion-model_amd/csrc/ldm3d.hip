@@ -1295,9 +1295,33 @@ static int launch_wgrad(const WgradParams& p, hipStream_t s) {
 
 static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_t s, size_t begin = 0, size_t end = (size_t)-1) {
     if (end > plan.ops.size()) end = plan.ops.size();
+    // LDM_PLAN_TRACE=<file>: measurement aid (tools/plan_trace.py) -- a HIP event before every op, one CSV row per op appended
+    static const char* trace_path = getenv("LDM_PLAN_TRACE");
+    std::vector<hipEvent_t> tev;
+    if (trace_path) { tev.resize(end - begin + 1); for (auto& e : tev) HIP_TRY(hipEventCreate(&e)); }
+    struct TraceDone {
+        const Plan& plan; size_t begin, end; std::vector<hipEvent_t>& ev; hipStream_t s; const char* path;
+        ~TraceDone() {
+            if (ev.empty()) return;
+            (void)hipEventRecord(ev.back(), s); (void)hipEventSynchronize(ev.back());
+            FILE* f = fopen(path, "a");
+            for (size_t oi = begin; oi < end && f; ++oi) {
+                const Op& o = plan.ops[oi]; float ms = 0.f; (void)hipEventElapsedTime(&ms, ev[oi - begin], ev[oi - begin + 1]);
+                fprintf(f, "%zu,%zu,%d,%.3f", plan.ops.size(), oi, (int)o.kind, ms * 1e3f);
+                if (o.kind == OP_CONV || o.kind == OP_FINALIZE)
+                    fprintf(f, ",M=%d k=%d s=%d ups=%d cin=%d+%d(x%d) cin1=%d couts=%d cfg=%dx%dx%d splitk=%d halo=%d mtps=%d qps=%d", o.i[15], o.i[11], o.i[12],
+                            o.i[14], o.i[0], o.i[1], o.i[19], o.i[2] + o.i[3], o.i[16], o.cc.wgm, o.cc.wgn, o.cc.bk, o.cc.splitk, o.cc.halo, o.cc.mtps, o.cc.qps);
+                else fprintf(f, ",i=%d %d %d %d %d %d", o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.i[5]);
+                fprintf(f, "\n");
+            }
+            if (f) fclose(f);
+            for (auto e : ev) (void)hipEventDestroy(e);
+        }
+    } trace_done{plan, begin, end, tev, s, trace_path};
     for (size_t oi = begin; oi < end; ++oi) {
         const Op& o = plan.ops[oi];
         const int* i = o.i;
+        if (trace_path) HIP_TRY(hipEventRecord(tev[oi - begin], s));
         switch (o.kind) {
             case OP_PACK: {
                 // two fp32 NCDHW sources (x | cond) -> one zero-padded NDHWC bf16 tensor
@@ -1373,7 +1397,7 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
             case OP_ATTN: {
                 AttnParams p{}; p.qkv = (const bf16_t*)rp(bs, o.r[0]); p.out = (bf16_t*)rp(bs, o.r[1]);
                 p.B = i[0]; p.N = i[1]; p.C = i[2]; p.heads = i[3]; p.scale = o.f[0]; p.lse = (float*)rp(bs, o.r[2]);
-                hipLaunchKernelGGL(attn_fwd_kernel, dim3((i[1] + 63) / 64, i[3], i[0]), dim3(256), 0, s, p);
+                HIP_TRY(launch_attn_fwd(p, s));
                 break; }
             case OP_SINUSOID:
                 hipLaunchKernelGGL(temb_sinusoid_kernel, dim3(grid_for((long)i[0] * i[1])), dim3(256), 0, s,
@@ -2133,7 +2157,7 @@ int ldm_op_group_norm_bwd(const void* dy, const void* xa, int ca, const void* xb
 int ldm_op_attention(const void* qkv, void* out, int B, int N, int C, void* stream) {
     if (!qkv || !out || B < 1 || N < 1 || C < 64 || C % 64) return fail(LDM_ERR_BAD_ARG, "bad argument (head_dim is 64, C % 64 == 0)");
     AttnParams p{}; p.qkv = (const bf16_t*)qkv; p.out = (bf16_t*)out; p.B = B; p.N = N; p.C = C; p.heads = C / 64; p.scale = 0.125f; p.lse = nullptr;
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3((N + 63) / 64, C / 64, B), dim3(256), 0, (hipStream_t)stream, p);
+    HIP_TRY(launch_attn_fwd(p, (hipStream_t)stream));
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -2142,7 +2166,7 @@ int ldm_op_attention(const void* qkv, void* out, int B, int N, int C, void* stre
 int ldm_op_attention_train(const void* qkv, void* out, float* lse, int B, int N, int C, void* stream) {
     if (!qkv || !out || !lse || B < 1 || N < 1 || C < 64 || C % 64) return fail(LDM_ERR_BAD_ARG, "bad argument");
     AttnParams p{}; p.qkv = (const bf16_t*)qkv; p.out = (bf16_t*)out; p.B = B; p.N = N; p.C = C; p.heads = C / 64; p.scale = 0.125f; p.lse = lse;
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3((N + 63) / 64, C / 64, B), dim3(256), 0, (hipStream_t)stream, p);
+    HIP_TRY(launch_attn_fwd(p, (hipStream_t)stream));
     HIP_TRY(hipGetLastError());
     return 0;
 }
