@@ -42,6 +42,11 @@ struct ConvParams {
     int splitk, steps_per_split;
     int mtiles, ntiles;
     int halo_mtps, q_per_split;       // conv3_halo_kernel only: 126-row tiles per sample, (kd,kh,chunk) macro steps per K split
+    // phase mode (nearest x2 upsample + 3^3 conv, pad 1, as eight 2^3 convolutions on the LOW-resolution grid, one per output
+    // parity (pd, ph, pw): 8 taps instead of 27.  ksize = 2, w0 = [parity][tap][CoutPad][cin] with the 3^3 taps that land on
+    // the same source voxel pre-summed (phase_weights_kernel).  Tiles are [sample][parity][mtiles_pp] over the source voxels;
+    // M, partial slabs, stats and the output rows stay in output order.
+    int phase_mode, mtiles_pp;
     // epilogue (splitk == 1) ------------------------------------------------------------
     const float* bias;                // [CoutPad] or null
     const float* bias2;               // [CoutPad] or null (bias of the fused 1x1 skip)
@@ -104,7 +109,17 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_igemm_kernel(const ConvParam
     const int mtile = lid % p.mtiles; lid /= p.mtiles;
     const int ntile = lid % p.ntiles;
     const int split = lid / p.ntiles;
-    const int m0 = mtile * BM, n0 = ntile * BN;
+    int m0 = mtile * BM; const int n0 = ntile * BN;
+    int Mloc = p.M;                                    // rows addressed by m0 + row
+    int ph_n = 0, ph_d = 0, ph_h = 0, ph_w = 0;        // phase mode: sample and output parity of this tile
+    const bf16_t* w0p = p.w0;
+    if (p.phase_mode) {
+        const int t8 = mtile / p.mtiles_pp, phase = t8 & 7;
+        m0 = (mtile - t8 * p.mtiles_pp) * BM; ph_n = t8 >> 3;
+        ph_d = phase >> 2; ph_h = (phase >> 1) & 1; ph_w = phase & 1;
+        Mloc = p.Din * p.Hin * p.Win;
+        w0p += (size_t)phase * 8 * p.CoutPad * (p.c0a + p.c0b);
+    }
     const int steps_total = p.steps0 + p.steps1;
     const int s_begin = split * p.steps_per_split;
     int s_end = s_begin + p.steps_per_split; if (s_end > steps_total) s_end = steps_total;
@@ -134,14 +149,25 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_igemm_kernel(const ConvParam
         const int taps = p.ksize * p.ksize * p.ksize;
         if (row < BM) {
             int n = 0, od = 0, oh = 0, ow = 0;
-            if (m < p.M) { n = m / DHWo; int r = m - n * DHWo; od = r / HWo; r -= od * HWo; oh = r / p.Wout; ow = r - oh * p.Wout; }
+            if (p.phase_mode) {
+                n = ph_n;
+                if (m < Mloc) { od = m / (p.Hin * p.Win); int r = m - od * p.Hin * p.Win; oh = r / p.Win; ow = r - oh * p.Win; }
+            } else if (m < p.M) { n = m / DHWo; int r = m - n * DHWo; od = r / HWo; r -= od * HWo; oh = r / p.Wout; ow = r - oh * p.Wout; }
             const int nb = n * p.Din * p.Hin * p.Win;
             if (part == 0) tapv[taps * BM + row] = -1;             // sentinel row read by the one-tap-ahead prefetch
+            if (p.phase_mode) {
+                for (int tap = part; tap < 8; tap += TPR) {        // source voxel = low + tap bit - 1 + parity, per dimension
+                    const int id = od + (tap >> 2) - 1 + ph_d, ih = oh + ((tap >> 1) & 1) - 1 + ph_h, iw = ow + (tap & 1) - 1 + ph_w;
+                    const bool ok = (m < Mloc) & ((unsigned)id < (unsigned)p.Din) & ((unsigned)ih < (unsigned)p.Hin) &
+                                    ((unsigned)iw < (unsigned)p.Win) & !(dbg & 1);
+                    tapv[tap * BM + row] = ok ? nb + (id * p.Hin + ih) * p.Win + iw : -1;
+                }
+            } else
             for (int tap = part; tap < taps; tap += TPR) {
                 int kd = 0, kh = 0, kw = 0;
                 if (p.ksize == 3) { kd = tap / 9; kh = (tap - kd * 9) / 3; kw = tap - kd * 9 - kh * 3; }
                 const int id = od * p.stride + kd - p.pad, ih = oh * p.stride + kh - p.pad, iw = ow * p.stride + kw - p.pad;
-                const bool ok = (m < p.M) & ((unsigned)id < (unsigned)DinU) & ((unsigned)ih < (unsigned)HinU) &
+                const bool ok = (m < Mloc) & ((unsigned)id < (unsigned)DinU) & ((unsigned)ih < (unsigned)HinU) &
                                 ((unsigned)iw < (unsigned)WinU) & !(dbg & 1) & !(p.exact & (id | ih | iw) & 1);
                 tapv[tap * BM + row] = ok ? nb + ((id >> p.ups) * p.Hin + (ih >> p.ups)) * p.Win + (iw >> p.ups) : -1;
             }
@@ -154,7 +180,7 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_igemm_kernel(const ConvParam
         const int swz = (row >> SWZ_SHIFT) & (CPR - 1);
         a_kb[j] = (pchunk ^ swz) * 16;                 // byte offset of this lane's logical chunk inside the BK chunk
         a_row[j] = row;
-        a_m[j] = (m0 + row < p.M && !(dbg & 1)) ? m0 + row : -1;
+        a_m[j] = (m0 + row < Mloc && !(dbg & 1)) ? m0 + row : -1;
     }
     int b_row[PB], b_kb[PB];
 #pragma unroll
@@ -201,7 +227,7 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_igemm_kernel(const ConvParam
         rs_a0 = __builtin_amdgcn_make_buffer_rsrc((void*)(sg_grp ? p.x1a : p.x0a), 0, (int)(rows_ * (unsigned)g_ca * 2u), 0x00020000); \
         rs_a1 = __builtin_amdgcn_make_buffer_rsrc((void*)(sg_grp ? p.x1b : p.x0b), 0, (int)(rows_ * (unsigned)g_cb * 2u), 0x00020000); \
         g_wtap = (unsigned)p.CoutPad * (unsigned)cin_ * 2u;                                                   \
-        rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)(sg_grp ? p.w1 : p.w0), 0,                            \
+        rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)(sg_grp ? p.w1 : w0p), 0,                            \
                                                  (int)((unsigned)(sg_grp ? 1 : p.ksize * p.ksize * p.ksize) * g_wtap), 0x00020000); \
         _Pragma("unroll") for (int j = 0; j < PB; ++j)                                                        \
             b_vo[j] = (unsigned)b_row[j] * (unsigned)(cin_ * 2) + (unsigned)b_kb[j];                          \
@@ -501,8 +527,14 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_igemm_kernel(const ConvParam
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
             const int ml = pr * 2 + hh;
-            const int m = m0 + wm * 64 + (mt_base + ml) * 16 + fr;
-            if (m >= p.M) continue;
+            int m = m0 + wm * 64 + (mt_base + ml) * 16 + fr;
+            if (m >= Mloc) continue;
+            int n_ph = 0;
+            if (p.phase_mode) {                        // source voxel of this tile's parity -> output row
+                const int dl = m / (p.Hin * p.Win); int r2 = m - dl * p.Hin * p.Win; const int hl = r2 / p.Win, wl = r2 - hl * p.Win;
+                m = ((ph_n * p.Dout + 2 * dl + ph_d) * p.Hout + 2 * hl + ph_h) * p.Wout + 2 * wl + ph_w;
+                n_ph = ph_n;
+            }
             float v[16];
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
@@ -518,7 +550,7 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_igemm_kernel(const ConvParam
                     *reinterpret_cast<float4*>(dst + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
                 continue;
             }
-            const int n = m / DHWo;
+            const int n = p.phase_mode ? n_ph : m / DHWo;
             if (p.bias) {
 #pragma unroll
                 for (int q = 0; q < 16; ++q) v[q] += p.bias[cbase + q];

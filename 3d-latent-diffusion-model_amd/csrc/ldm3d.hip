@@ -147,7 +147,8 @@ struct ParamDesc {
     bool loaded = false;
 };
 
-struct ConvW { size_t w_off = 0; size_t b_off = 0; int cout = 0, cout_pad = 0, cin_s = 0, k = 1; bool has = false; };
+struct ConvW { size_t w_off = 0; size_t b_off = 0; int cout = 0, cout_pad = 0, cin_s = 0, k = 1; bool has = false;
+               size_t wp_off = 0; };                 // upsample convs: the derived phase weights [8][8][cout_pad][cin_s] (0 = none)
 struct GnW { size_t g_off = 0, b_off = 0; int C = 0; };
 struct LinW { size_t w_off = 0, b_off = 0; int in = 0, out = 0; };
 
@@ -172,6 +173,10 @@ struct ldm_model {
     size_t tproj_w_off = 0, tproj_b_off = 0; int tproj_rows = 0; std::map<std::string, int> tproj_row;
 
     size_t arena_alloc(size_t bytes) { size_t o = arena_bytes; arena_bytes += rup_sz(bytes, 256); return o; }
+    // weights derived from the packed ones (phase weights of the upsample convs): rebuilt on the stream of the next inference
+    // call after any parameter upload
+    struct PhaseW { size_t w_off, wp_off; int cout_pad, cin_s; };
+    std::vector<PhaseW> phase_ws; bool derived_dirty = true;
     int64_t flat_total = 0;
     void add_param(const ParamDesc& d) {
         pindex[d.name] = (int)params.size(); params.push_back(d);
@@ -199,8 +204,12 @@ struct ldm_model {
         c.b_off = arena_alloc((size_t)c.cout_pad * 4);
         return c;
     }
-    void reg_conv(const std::string& name, int cin, int cin_s, int cout, int k) {
+    void reg_conv(const std::string& name, int cin, int cin_s, int cout, int k, bool phase = false) {
         ConvW c = new_conv_slot(cin_s, cout, k);
+        if (phase && k == 3) {
+            c.wp_off = arena_alloc((size_t)64 * c.cout_pad * cin_s * 2);
+            phase_ws.push_back(PhaseW{c.w_off, c.wp_off, c.cout_pad, cin_s});
+        }
         reg_conv_into(name, c, cin, cout, k, 0, false);
         convs[name] = c;
     }
@@ -280,6 +289,7 @@ struct Builder {
     std::vector<Tape> tape;
 
     static bool halo_enabled() { const char* e = getenv("LDM_CONV_HALO"); return e ? atoi(e) != 0 : true; }
+    static bool phase_enabled() { const char* e = getenv("LDM_CONV_PHASE"); return e ? atoi(e) != 0 : true; }
     // halo_n > 0: the conv is eligible for conv3_halo_kernel (3^3, stride 1, pad 1, single source, BK 64); halo_n = N
     // and halo_dhw = voxels per sample (its 126-row tiles never straddle samples).
     static ConvCfg choose_cfg(long M, int cout_pad, int steps, int bk, int halo_n = 0, long halo_dhw = 0) {
@@ -337,7 +347,11 @@ struct Builder {
         }
         const int N = a.xa.N;
         const long M = (long)N * a.Do * a.Ho * a.Wo;
-        const int taps = a.k * a.k * a.k;
+        // inference plans run (nearest x2 upsample -> 3^3 conv) as eight 2^3 convs on the source grid (conv_igemm.h, phase mode)
+        const bool phase = a.ups == 1 && !a.exact && a.k == 3 && a.stride == 1 && a.pad == 1 && !train && !a.xb.valid && !a.w1 &&
+                           a.w_over.base == BASE_NULL && w.wp_off != 0 && phase_enabled() &&
+                           a.Do == 2 * a.xa.D && a.Ho == 2 * a.xa.H && a.Wo == 2 * a.xa.W;
+        const int taps = phase ? 8 : a.k * a.k * a.k;
         const int nchunk0 = cin0 / bk, nchunk1 = cin1 / bk;
         const int steps0 = taps * nchunk0, steps1 = nchunk1;
         const bool halo_ok = a.k == 3 && a.stride == 1 && a.pad == 1 && a.ups == 0 && !a.exact && !a.xb.valid && !a.w1 &&
@@ -345,6 +359,7 @@ struct Builder {
         ConvCfg cc = choose_cfg(M, w.cout_pad, steps0 + steps1, bk, halo_ok ? N : 0, (long)a.Do * a.Ho * a.Wo);
         const int bm = 64 * cc.wgm, bn = 64 * cc.wgn;
         const int couts = a.f32_out ? 0 : rup(w.cout, 32);
+        const int mtiles_pp = (int)(((long)a.xa.D * a.xa.H * a.xa.W + bm - 1) / bm);      // phase mode: tiles per (sample, parity)
         Act out;
         if (!a.f32_out) {
             out = new_act(N, a.Do, a.Ho, a.Wo, couts);
@@ -355,6 +370,8 @@ struct Builder {
                     out.stats_off = pool.alloc((size_t)((M + 31) / 32) * couts * 2 * 4); out.has_stats = true; out.stats_nrb = 0;
                 } else if (cc.halo) {
                     out.stats_off = pool.alloc((size_t)N * cc.mtps * couts * 2 * 4); out.has_stats = true; out.stats_nrb = cc.mtps;
+                } else if (phase) {                                                  // tiles are per (sample, parity)
+                    out.stats_off = pool.alloc((size_t)N * 8 * mtiles_pp * couts * 2 * 4); out.has_stats = true; out.stats_nrb = 8 * mtiles_pp;
                 } else if (N == 1 || dhwo % bm == 0) {                               // tiles must not straddle samples
                     out.stats_off = pool.alloc((size_t)((M + bm - 1) / bm) * couts * 2 * 4); out.has_stats = true;
                     out.stats_nrb = (int)(N == 1 ? (M + bm - 1) / bm : dhwo / bm);
@@ -363,7 +380,7 @@ struct Builder {
         }
         Op op{}; op.kind = OP_CONV; op.cc = cc;
         op.r[0] = ws_ref(a.xa.off); op.r[1] = a.xb.valid ? ws_ref(a.xb.off) : Ref();
-        op.r[2] = a.w_over.base != BASE_NULL ? a.w_over : w_ref(w.w_off);
+        op.r[2] = a.w_over.base != BASE_NULL ? a.w_over : w_ref(phase ? w.wp_off : w.w_off);
         op.r[3] = a.w1 ? ws_ref(a.g1a.off) : Ref(); op.r[4] = (a.w1 && a.g1b.valid) ? ws_ref(a.g1b.off) : Ref();
         op.r[5] = a.w1 ? w_ref(a.w1->w_off) : Ref();
         op.r[6] = a.no_bias ? Ref() : w_ref(w.b_off); op.r[7] = a.w1 ? w_ref(a.w1->b_off) : Ref();
@@ -374,10 +391,10 @@ struct Builder {
         int* i = op.i;
         i[0] = a.xa.C; i[1] = a.xb.valid ? a.xb.C : 0; i[2] = a.w1 ? a.g1a.C : 0; i[3] = (a.w1 && a.g1b.valid) ? a.g1b.C : 0;
         i[4] = N; i[5] = a.xa.D; i[6] = a.xa.H; i[7] = a.xa.W; i[8] = a.Do; i[9] = a.Ho; i[10] = a.Wo;
-        i[11] = a.k; i[12] = a.stride; i[13] = a.pad; i[14] = a.ups | (a.exact << 1); i[15] = (int)M;
+        i[11] = phase ? 2 : a.k; i[12] = a.stride; i[13] = a.pad; i[14] = phase ? 4 : (a.ups | (a.exact << 1)); i[15] = (int)M;
         i[16] = a.f32_out ? rup(w.cout, 32) : couts; i[17] = w.cout_pad; i[18] = a.cout_real ? a.cout_real : w.cout;
         i[19] = nchunk0; i[20] = nchunk1; i[21] = a.temb_stride; i[22] = a.f32_out ? 1 : 0;
-        i[23] = cc.halo ? N * cc.mtps : (int)((M + bm - 1) / bm);
+        i[23] = cc.halo ? N * cc.mtps : phase ? N * 8 * mtiles_pp : (int)((M + bm - 1) / bm);
         if (M >= (1L << 31)) { err = "conv " + tag + ": M too large"; return Act(); }
         if (cc.splitk > 1) {
             partial_bytes = std::max(partial_bytes, (size_t)cc.splitk * M * w.cout_pad * 4);
@@ -816,7 +833,7 @@ static int unet_register(ldm_model* m) {
             reg_res(p, rin + skip_c, oc);
             if (c.attention_levels[lvl]) { snprintf(p, sizeof p, "up_blocks.%d.attentions.%d", i, j); m->reg_attn(p, oc); }
         }
-        if (i != L - 1) { char p[96]; snprintf(p, sizeof p, "up_blocks.%d.upsampler.conv", i); m->reg_conv(p, oc, oc, oc, 3); }
+        if (i != L - 1) { char p[96]; snprintf(p, sizeof p, "up_blocks.%d.upsampler.conv", i); m->reg_conv(p, oc, oc, oc, 3, true); }
     }
     m->reg_gn("out.0", ch[0]);
     m->reg_conv("out.2", ch[0], ch[0], c.out_channels, 3);
@@ -1023,7 +1040,7 @@ static int vae_register(ldm_model* m) {
                     break;
                 case 2: return fail(LDM_ERR_UNSUPPORTED, "AutoencoderKL attention blocks (single head, d = C) are not implemented");
                 case 3: m->reg_conv(std::string(p) + ".conv", bl.a, bl.a, bl.a, 3); break;
-                case 4: m->reg_conv(std::string(p) + ".postconv", bl.a, bl.a, bl.a, 3); break;
+                case 4: m->reg_conv(std::string(p) + ".postconv", bl.a, bl.a, bl.a, 3, true); break;
                 case 5: m->reg_gn(p, bl.a); break;
             }
         }
@@ -1340,7 +1357,8 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                 p.w1 = (const bf16_t*)rp(bs, o.r[5]);
                 p.zero_page = (const bf16_t*)bs.p[BASE_W];
                 p.N = i[4]; p.Din = i[5]; p.Hin = i[6]; p.Win = i[7]; p.Dout = i[8]; p.Hout = i[9]; p.Wout = i[10];
-                p.ksize = i[11]; p.stride = i[12]; p.pad = i[13]; p.ups = i[14] & 1; p.exact = i[14] >> 1; p.M = i[15];
+                p.ksize = i[11]; p.stride = i[12]; p.pad = i[13]; p.ups = i[14] & 1; p.exact = (i[14] >> 1) & 1; p.M = i[15];
+                p.phase_mode = (i[14] >> 2) & 1; p.mtiles_pp = p.phase_mode ? i[23] / (8 * i[4]) : 0;
                 p.CoutS = i[16]; p.CoutPad = i[17]; p.CoutReal = i[18]; p.nchunk0 = i[19]; p.nchunk1 = i[20];
                 p.steps0 = i[11] * i[11] * i[11] * i[19]; p.steps1 = i[20];
                 p.splitk = o.cc.splitk; p.steps_per_split = (p.steps0 + p.steps1 + p.splitk - 1) / p.splitk;
@@ -1616,6 +1634,20 @@ int ldm_model_load_param(ldm_model* m, const char* name, const float* src, size_
         }
     }
     if (!d.loaded) { d.loaded = true; m->loaded_count++; }
+    m->derived_dirty = true;
+    return 0;
+}
+
+// phase weights of the upsample convs, rebuilt (stream-ordered) after a parameter upload: called by the inference entries
+static int ensure_derived(ldm_model* m, hipStream_t s) {
+    if (!m->derived_dirty) return 0;
+    for (const auto& pw : m->phase_ws) {
+        const long vecs = (long)pw.cout_pad * pw.cin_s / 8;
+        hipLaunchKernelGGL(phase_weights_kernel, dim3((unsigned)((vecs + 255) / 256), 64), dim3(256), 0, s,
+                           (const bf16_t*)(m->arena + pw.w_off), (bf16_t*)(m->arena + pw.wp_off), pw.cout_pad, pw.cin_s);
+    }
+    HIP_TRY(hipGetLastError());
+    m->derived_dirty = false;
     return 0;
 }
 
@@ -1661,6 +1693,7 @@ int ldm_unet_forward(ldm_model* m, const float* x, int x_channels, const float* 
     Bases bs{}; bs.p[BASE_WS] = (char*)workspace; bs.p[BASE_W] = m->arena;
     bs.p[BASE_IO0] = (char*)x; bs.p[BASE_IO1] = (char*)cond; bs.p[BASE_IO2] = (char*)timesteps; bs.p[BASE_IO3] = (char*)out;
     const int rt[2] = {x_channels, cond_channels};
+    LDM_TRY(ensure_derived(m, (hipStream_t)stream));
     if (!m->graph_mode || g_prof.on) return run_plan(*p, bs, rt, (hipStream_t)stream);
     // ---- graph replay: same launches, recorded once per pointer set
     const void* key[6] = {x, cond, timesteps, out, workspace, stream};
@@ -1727,6 +1760,7 @@ int ldm_model_load_params_device(ldm_model* m, const float* const* ptrs, int n, 
         if (!d.loaded) { d.loaded = true; m->loaded_count++; }
     }
     HIP_TRY(hipGetLastError());
+    m->derived_dirty = true;
     return 0;
 }
 
@@ -1752,6 +1786,7 @@ int ldm_model_load_params_flat(ldm_model* m, const float* flat, void* stream) {
                        (const PackDesc*)m->pack_tab.descs, (const int2*)m->pack_tab.map, flat, m->arena);
     HIP_TRY(hipGetLastError());
     for (ParamDesc& d : m->params) if (!d.loaded) { d.loaded = true; m->loaded_count++; }
+    m->derived_dirty = true;
     return 0;
 }
 
@@ -1880,6 +1915,7 @@ int ldm_vae_decode(ldm_model* m, const float* z, float* out, int B, int d, int h
     Bases bs{}; bs.p[BASE_WS] = (char*)workspace; bs.p[BASE_W] = m->arena;
     bs.p[BASE_IO0] = (char*)z; bs.p[BASE_IO1] = (char*)out;
     const int rt[2] = {m->vcfg.latent_channels, 0};
+    LDM_TRY(ensure_derived(m, (hipStream_t)stream));
     return run_plan(*p, bs, rt, (hipStream_t)stream);
 }
 

@@ -215,7 +215,7 @@ struct GnFusedParams {
 };
 
 __global__ __launch_bounds__(256) void gn_fused_apply_kernel(const GnFusedParams p) {
-    __shared__ float part[4][192][2];
+    __shared__ __attribute__((aligned(16))) float part[8][96][4];
     __shared__ double csum[192][2];
     __shared__ float gstat[64][2];
     const int tid = threadIdx.x, n = blockIdx.z;
@@ -224,35 +224,81 @@ __global__ __launch_bounds__(256) void gn_fused_apply_kernel(const GnFusedParams
     int c1 = c0 + 64; if (c1 > C) c1 = C;
     const int g_lo = c0 / cpg, g_hi = (c1 + cpg - 1) / cpg;
     const int cov_lo = g_lo * cpg, ncov = g_hi * cpg - cov_lo;           // <= 64 + 2 * 63
-    // ---- fold the slabs: thread = (channel of the cover, one of 4 slab lanes)
-    {
-        const int bl = tid >> 6;
-        for (int cc = tid & 63; cc < ncov; cc += 64) {
-            const int c = cov_lo + cc;
-            const bool second = c >= p.ca;
-            const float* sl = second ? p.sb : p.sa;
-            const int cs = second ? p.cb : p.ca, cl = second ? c - p.ca : c, nrb = second ? p.nrb_b : p.nrb_a;
-            float s0 = 0.f, s1 = 0.f, u0 = 0.f, u1 = 0.f, w0 = 0.f, w1 = 0.f, x0 = 0.f, x1 = 0.f;
-            const float* base = sl + ((size_t)n * nrb * cs + cl) * 2;
-            int b = bl;
-            for (; b + 12 < nrb; b += 16) {                 // four slab rows in flight per thread (fixed order: reproducible)
-                const float2 v0 = *reinterpret_cast<const float2*>(base + (size_t)b * cs * 2);
-                const float2 v1 = *reinterpret_cast<const float2*>(base + (size_t)(b + 4) * cs * 2);
-                const float2 v2 = *reinterpret_cast<const float2*>(base + (size_t)(b + 8) * cs * 2);
-                const float2 v3 = *reinterpret_cast<const float2*>(base + (size_t)(b + 12) * cs * 2);
-                s0 += v0.x; s1 += v0.y; u0 += v1.x; u1 += v1.y; w0 += v2.x; w1 += v2.y; x0 += v3.x; x1 += v3.y;
-            }
-            for (; b < nrb; b += 4) {
-                const float2 v = *reinterpret_cast<const float2*>(base + (size_t)b * cs * 2);
-                s0 += v.x; s1 += v.y;
-            }
-            part[bl][cc][0] = (s0 + u0) + (w0 + x0); part[bl][cc][1] = (s1 + u1) + (w1 + x1);
+    // ---- the block's first rows are requested before the fold, so that their latency overlaps it
+    //      apply mapping: thread = (8-channel vector of the slice, row lane)
+    constexpr int PF = 8;
+    const int vec = tid & 7, rl = tid >> 3;
+    const int c = c0 + vec * 8;
+    const bool active = c < C;
+    const bool second_x = c >= p.ca;
+    const bf16_t* src = second_x ? p.xb : p.xa;
+    const int xcs = second_x ? p.cb : p.ca, xcl = second_x ? c - p.ca : c;
+    const int r0 = blockIdx.x * p.rows_per_block;
+    int r1 = r0 + p.rows_per_block; if (r1 > p.DHW) r1 = p.DHW;
+    u32x4 v[PF];
+    if (active) {
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            int r = r0 + rl + 32 * k; if (r >= r1) r = r1 - 1;          // clamped: unconditional loads stay in flight together
+            v[k] = *reinterpret_cast<const u32x4*>(src + ((size_t)n * p.DHW + r) * xcs + xcl);
         }
     }
-    __syncthreads();
-    if (tid < ncov) {
-        csum[tid][0] = (double)part[0][tid][0] + (double)part[1][tid][0] + (double)part[2][tid][0] + (double)part[3][tid][0];
-        csum[tid][1] = (double)part[0][tid][1] + (double)part[1][tid][1] + (double)part[2][tid][1] + (double)part[3][tid][1];
+    // ---- fold the slabs (fixed order: reproducible)
+    if (((cpg | p.ca) & 1) == 0) {
+        // thread = (channel pair of the cover, one of 8 slab lanes); 16 slab rows in flight per thread
+        const int bl = tid >> 5;
+        for (int pp = tid & 31; pp < (ncov >> 1); pp += 32) {
+            const int cch = cov_lo + 2 * pp;
+            const bool second = cch >= p.ca;
+            const float* sl = second ? p.sb : p.sa;
+            const int cs = second ? p.cb : p.ca, cl = second ? cch - p.ca : cch, nrb = second ? p.nrb_b : p.nrb_a;
+            const float* base = sl + ((size_t)n * nrb * cs + cl) * 2;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int b0 = bl; b0 < nrb; b0 += 128) {
+                float4 t[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    int bb = b0 + 8 * k; const bool ok = bb < nrb; if (!ok) bb = nrb - 1;
+                    t[k] = *reinterpret_cast<const float4*>(base + (size_t)bb * cs * 2);
+                    if (!ok) t[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int k = 0; k < 16; ++k) { acc.x += t[k].x; acc.y += t[k].y; acc.z += t[k].z; acc.w += t[k].w; }
+            }
+            *reinterpret_cast<float4*>(&part[bl][pp][0]) = acc;
+        }
+        __syncthreads();
+        if (tid < ncov) {
+            const int pp = tid >> 1, o = (tid & 1) * 2;
+            double s = 0.0, q = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { s += (double)part[k][pp][o]; q += (double)part[k][pp][o + 1]; }
+            csum[tid][0] = s; csum[tid][1] = q;
+        }
+    } else {
+        // odd channels per group: thread = (channel of the cover, one of 4 slab lanes)
+        const int bl = tid >> 6;
+        float* part1 = &part[0][0][0];                 // viewed as [4][192][2]
+        for (int cc = tid & 63; cc < ncov; cc += 64) {
+            const int cch = cov_lo + cc;
+            const bool second = cch >= p.ca;
+            const float* sl = second ? p.sb : p.sa;
+            const int cs = second ? p.cb : p.ca, cl = second ? cch - p.ca : cch, nrb = second ? p.nrb_b : p.nrb_a;
+            float s0 = 0.f, s1 = 0.f;
+            const float* base = sl + ((size_t)n * nrb * cs + cl) * 2;
+            for (int bb = bl; bb < nrb; bb += 4) {
+                const float2 t = *reinterpret_cast<const float2*>(base + (size_t)bb * cs * 2);
+                s0 += t.x; s1 += t.y;
+            }
+            part1[(bl * 192 + cc) * 2] = s0; part1[(bl * 192 + cc) * 2 + 1] = s1;
+        }
+        __syncthreads();
+        if (tid < ncov) {
+            double s = 0.0, q = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { s += (double)part1[(k * 192 + tid) * 2]; q += (double)part1[(k * 192 + tid) * 2 + 1]; }
+            csum[tid][0] = s; csum[tid][1] = q;
+        }
     }
     __syncthreads();
     if (tid < g_hi - g_lo) {
@@ -268,10 +314,8 @@ __global__ __launch_bounds__(256) void gn_fused_apply_kernel(const GnFusedParams
         }
     }
     __syncthreads();
-    // ---- apply: thread = (8-channel vector of the slice, row lane)
-    const int vec = tid & 7, rl = tid >> 3;
-    const int c = c0 + vec * 8;
-    if (c >= C) return;
+    // ---- apply
+    if (!active) return;
     float a[8], b[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -283,23 +327,29 @@ __global__ __launch_bounds__(256) void gn_fused_apply_kernel(const GnFusedParams
 #pragma unroll
         for (int k = 0; k < 8; ++k) { p.ab[((size_t)n * C + c + k) * 2] = a[k]; p.ab[((size_t)n * C + c + k) * 2 + 1] = b[k]; }
     }
-    const bool second = c >= p.ca;
-    const bf16_t* src = second ? p.xb : p.xa;
-    const int cs = second ? p.cb : p.ca, cl = second ? c - p.ca : c;
-    const int r0 = blockIdx.x * p.rows_per_block;
-    int r1 = r0 + p.rows_per_block; if (r1 > p.DHW) r1 = p.DHW;
-    for (int r = r0 + rl; r < r1; r += 32) {
-        const size_t row = (size_t)n * p.DHW + r;
-        const u32x4 v = *reinterpret_cast<const u32x4*>(src + row * cs + cl);
-        u32x4 o;
+    for (int rb = r0 + rl; rb < r1; rb += 32 * PF) {
+        if (rb != r0 + rl) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float lo = __uint_as_float(v[k] << 16) * a[2 * k] + b[2 * k];
-            float hi = __uint_as_float(v[k] & 0xffff0000u) * a[2 * k + 1] + b[2 * k + 1];
-            if (p.silu) { lo = silu_f(lo); hi = silu_f(hi); }
-            o[k] = pack2bf(lo, hi);
+            for (int k = 0; k < PF; ++k) {
+                int r = rb + 32 * k; if (r >= r1) r = r1 - 1;
+                v[k] = *reinterpret_cast<const u32x4*>(src + ((size_t)n * p.DHW + r) * xcs + xcl);
+            }
         }
-        *reinterpret_cast<u32x4*>(p.out + row * C + c) = o;
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            const int r = rb + 32 * k;
+            if (r < r1) {
+                u32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float lo = __uint_as_float(v[k][j] << 16) * a[2 * j] + b[2 * j];
+                    float hi = __uint_as_float(v[k][j] & 0xffff0000u) * a[2 * j + 1] + b[2 * j + 1];
+                    if (p.silu) { lo = silu_f(lo); hi = silu_f(hi); }
+                    o[j] = pack2bf(lo, hi);
+                }
+                *reinterpret_cast<u32x4*>(p.out + ((size_t)n * p.DHW + r) * C + c) = o;
+            }
+        }
     }
 }
 
@@ -978,4 +1028,40 @@ __global__ __launch_bounds__(256) void vae_heads_bwd_kernel(const bf16_t* __rest
         }
         dy[i] = f2bf(g);
     }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Phase weights of a (nearest x2 upsample -> 3^3 conv, pad 1): out[parity][tap2][co][ci] = sum of the 3^3 taps that read the
+// same low-resolution voxel.  Per dimension, output o = 2 l + p reads up[o-1], up[o], up[o+1] with up[i] = low[i >> 1]:
+//   p = 0: low[l-1] <- k0,      low[l]   <- k1 + k2        p = 1: low[l] <- k0 + k1,   low[l+1] <- k2
+// (tap bit 0 = the lower of the two source voxels).  Source: the packed bf16 [27][cout_pad][cin_s] matrix; sums in fp32.
+// grid = (blocks over cout_pad * cin_s / 8, 64), 256 threads; thread = 8 consecutive cin of one cout row.
+__global__ __launch_bounds__(256) void phase_weights_kernel(const bf16_t* __restrict__ w3, bf16_t* __restrict__ wp, int cout_pad, int cin_s) {
+    const long vecs = (long)cout_pad * cin_s / 8;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= vecs) return;
+    const int phase = blockIdx.y >> 3, tap = blockIdx.y & 7;
+    const int pb[3] = {phase >> 2, (phase >> 1) & 1, phase & 1}, tb[3] = {tap >> 2, (tap >> 1) & 1, tap & 1};
+    int lo[3], hi[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        if (pb[d] == 0) { lo[d] = tb[d] ? 1 : 0; hi[d] = tb[d] ? 2 : 0; }
+        else            { lo[d] = tb[d] ? 2 : 0; hi[d] = tb[d] ? 2 : 1; }
+    }
+    float acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+    const size_t mat = (size_t)cout_pad * cin_s;
+    for (int kd = lo[0]; kd <= hi[0]; ++kd)
+        for (int kh = lo[1]; kh <= hi[1]; ++kh)
+            for (int kw = lo[2]; kw <= hi[2]; ++kw) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(w3 + (size_t)((kd * 3 + kh) * 3 + kw) * mat + idx * 8);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { acc[2 * q] += __uint_as_float(v[q] << 16); acc[2 * q + 1] += __uint_as_float(v[q] & 0xffff0000u); }
+            }
+    u32x4 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = pack2bf(acc[2 * q], acc[2 * q + 1]);
+    *reinterpret_cast<u32x4*>(wp + (size_t)blockIdx.y * mat + idx * 8) = o;
 }
