@@ -24,17 +24,21 @@ struct AttnParams {
 // S > 1: the workgroup carries S groups of 4 waves; group g walks the key tiles g, g+S, g+2S, ... with its own LDS double
 // buffer and the groups' (max, sum, O) partials are merged through LDS at the end (in-workgroup split of the key range):
 // at N = 1728 the grid is only 27 x heads workgroups, so the extra waves are what hides the load -> LDS -> MFMA latency chain.
-template <int S>
-__global__ __launch_bounds__(256 * S) void attn_fwd_kernel(const AttnParams p) {
+// QW = waves (16 query rows each) per group; DB = double-buffered K/V images (one barrier per tile) or a single image with
+// two barriers per tile (S = 8 groups of 2 waves: 32 query rows per workgroup, twice the workgroups at N = 1728).
+template <int S, int QW, bool DB>
+__global__ __launch_bounds__(64 * QW * S) void attn_fwd_kernel(const AttnParams p) {
     constexpr int D = 64, KT = 64;
     constexpr int TILE = KT * 128 + KT * 128;         // one K image + one V image (both row-major [key][d], swizzled)
-    extern __shared__ __attribute__((aligned(16))) char smem_all[];   // S x double buffer (S * 32 KiB)
+    constexpr int GT = 64 * QW;                       // threads per group
+    constexpr int NIT = 512 / GT;                     // staged (row, chunk) pairs per thread
+    extern __shared__ __attribute__((aligned(16))) char smem_all[];   // S x (double) buffer
 
-    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6, grp = threadIdx.x >> 8;
-    char* smem = smem_all + grp * 2 * TILE;
+    const int tid = threadIdx.x % GT, lane = tid & 63, wave = tid >> 6, grp = threadIdx.x / GT;
+    char* smem = smem_all + grp * (DB ? 2 : 1) * TILE;
     const int fr = lane & 15, fg = lane >> 4;
     const int b = blockIdx.z, head = blockIdx.y;
-    const int q0 = blockIdx.x * 64 + wave * 16;
+    const int q0 = blockIdx.x * (16 * QW) + wave * 16;
     const int ld = 3 * p.C;                           // token stride (elements)
     const bf16_t* base = p.qkv + (size_t)b * p.N * ld;
     const int hoff = head * D;
@@ -56,11 +60,11 @@ __global__ __launch_bounds__(256 * S) void attn_fwd_kernel(const AttnParams p) {
     // staging split (issue early / write late): the global loads of the group's next tile are issued before the MFMAs of
     // the current one and written to the other LDS image after them, so their latency hides under the compute; one barrier
     // per tile.  The prefetch is unconditional (rows clamped) so that no wait for it is needed before the tile's own MFMAs.
-    u32x4 kreg[2], vreg[2];
+    u32x4 kreg[NIT], vreg[NIT];
     auto stage_load = [&](int k0) {
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int idx = tid + it * 256;           // 512 (row, chunk) pairs
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * GT;            // 512 (row, chunk) pairs
             const int row = idx >> 3, ch = idx & 7;
             int kr = k0 + row; if (kr >= p.N) kr = p.N - 1;
             const bf16_t* tok = base + (size_t)kr * ld + hoff + ch * 8;
@@ -70,8 +74,8 @@ __global__ __launch_bounds__(256 * S) void attn_fwd_kernel(const AttnParams p) {
     };
     auto stage_write = [&](char* ks, char* vs) {
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int idx = tid + it * 256;
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * GT;
             const int row = idx >> 3, ch = idx & 7;
             *reinterpret_cast<u32x4*>(ks + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)) = kreg[it];
             // V stays row-major; its 32-byte blocks are XOR-swizzled by (row>>1)&3 so that the transposed reads
@@ -89,7 +93,7 @@ __global__ __launch_bounds__(256 * S) void attn_fwd_kernel(const AttnParams p) {
     for (int it = 0; it < nrounds; ++it) {
         const int t = it * S + grp;
         const int k0 = t * KT;
-        const char* ks = smem + (it & 1) * TILE;      // K tile  [64 keys][64 d] bf16, 16-B chunks XOR-swizzled
+        const char* ks = smem + (DB ? (it & 1) * TILE : 0);   // K tile  [64 keys][64 d] bf16, 16-B chunks XOR-swizzled
         const char* vs = ks + KT * 128;               // V tile  [64 keys][64 d] bf16, read transposed (ds_read_b64_tr_b16)
         stage_load(k0 + S * KT);
         if (t < ntile) {                              // wave-uniform
@@ -165,8 +169,9 @@ __global__ __launch_bounds__(256 * S) void attn_fwd_kernel(const AttnParams p) {
         }
         }
         // ---- late write of the next tile into the other image (its last readers finished before the previous barrier) ----
+        if constexpr (!DB) __syncthreads();            // single image: every reader of this tile is done
         {
-            char* nk = smem + ((it + 1) & 1) * TILE;
+            char* nk = smem + (DB ? ((it + 1) & 1) * TILE : 0);
             stage_write(nk, nk + KT * 128);
         }
         __syncthreads();
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(256 * S) void attn_fwd_kernel(const AttnParams p) {
     lrun += __shfl_xor(lrun, 32, 64);
     if constexpr (S > 1) {
         // per (group, wave): O^T partial [4 dt][64 lanes] f32x4 = 4 KiB, then m and l per query (16 floats each)
-        float* xo = reinterpret_cast<float*>(smem_all) + (size_t)(grp * 4 + wave) * (1024 + 32);
+        float* xo = reinterpret_cast<float*>(smem_all) + (size_t)(grp * QW + wave) * (1024 + 32);
         if (grp > 0) {
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(xo + (dt * 64 + lane) * 4) = ot[dt];
@@ -186,7 +191,7 @@ __global__ __launch_bounds__(256 * S) void attn_fwd_kernel(const AttnParams p) {
         if (grp > 0) return;
 #pragma unroll
         for (int g = 1; g < S; ++g) {                  // fixed order: reproducible
-            const float* xg = reinterpret_cast<const float*>(smem_all) + (size_t)(g * 4 + wave) * (1024 + 32);
+            const float* xg = reinterpret_cast<const float*>(smem_all) + (size_t)(g * QW + wave) * (1024 + 32);
             const float mg = xg[1024 + fr], lg = xg[1040 + fr];
             const float mnew = fmaxf(mrun, mg);        // group 0 always owns tile 0: finite
             const float a0 = __expf(mrun - mnew), a1 = __expf(mg - mnew);      // mg = -inf (group without a tile) -> 0
@@ -216,20 +221,20 @@ __global__ __launch_bounds__(256 * S) void attn_fwd_kernel(const AttnParams p) {
     }
 }
 
-// S = 4 wave groups once a (batch, head) has at least 4 key tiles, else the plain 4-wave kernel
+// 8 groups of 2 waves (32 query rows per workgroup) for long sequences, 4 groups of 4 waves once a (batch, head) has at least
+// 4 key tiles, else the plain 4-wave kernel
 static inline hipError_t launch_attn_fwd(const AttnParams& p, hipStream_t s) {
-    const dim3 grid((p.N + 63) / 64, p.heads, p.B);
-    if (p.N > 3 * 64) {
-        static bool once = false;
-        if (!once) {
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
-            if (e != hipSuccess) return e;
-            once = true;
-        }
-        hipLaunchKernelGGL(attn_fwd_kernel<4>, grid, dim3(1024), 4 * 32768, s, p);
-    } else {
-        hipLaunchKernelGGL(attn_fwd_kernel<1>, grid, dim3(256), 32768, s, p);
+    static bool once = false;
+    if (!once) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<4, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<8, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384);
+        if (e != hipSuccess) return e;
+        once = true;
     }
+    if (p.N >= 1024 && (long)((p.N + 63) / 64) * p.heads * p.B < 128)      // small grid: twice the workgroups beats the extra K/V traffic
+        hipLaunchKernelGGL((attn_fwd_kernel<8, 2, false>), dim3((p.N + 31) / 32, p.heads, p.B), dim3(1024), 8 * 16384, s, p);
+    else if (p.N > 3 * 64) hipLaunchKernelGGL((attn_fwd_kernel<4, 4, true>), dim3((p.N + 63) / 64, p.heads, p.B), dim3(1024), 4 * 32768, s, p);
+    else hipLaunchKernelGGL((attn_fwd_kernel<1, 4, true>), dim3((p.N + 63) / 64, p.heads, p.B), dim3(256), 32768, s, p);
     return hipGetLastError();
 }
 
