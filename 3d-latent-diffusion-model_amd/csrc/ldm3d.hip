@@ -24,6 +24,7 @@
 #include "attention.h"
 #include "conv_igemm.h"
 #include "conv_halo.h"
+#include "gemm_light.h"
 #include "conv_wgrad.h"
 #include "norm_elem.h"
 
@@ -69,7 +70,8 @@ struct Act {                                         // NDHWC bf16 activation li
 enum OpKind { OP_PACK, OP_CONV, OP_FINALIZE, OP_GN_STATS, OP_GN_FINALIZE, OP_GN_PREP, OP_GN_APPLY, OP_ATTN, OP_SINUSOID,
               OP_GEMV, OP_VAE_HEADS, OP_GN_FUSED,
               // backward (training plans only)
-              OP_WT, OP_WT_BATCH, OP_WGRAD, OP_EXPORT, OP_EXPORT_BATCH, OP_COLSUM, OP_GNB, OP_ATTN_BWD, OP_ADD, OP_SUMPOOL, OP_LIN_DX, OP_LIN_DW, OP_VAE_HEADS_BWD };
+              OP_WT, OP_WT_BATCH, OP_WGRAD, OP_EXPORT, OP_EXPORT_BATCH, OP_COLSUM, OP_GNB, OP_ATTN_BWD, OP_ADD, OP_SUMPOOL, OP_LIN_DX, OP_LIN_DW, OP_VAE_HEADS_BWD,
+              OP_GEMM_LIGHT };                     // 1x1 convolution with short K (gemm_light.h)
 
 struct ConvCfg { int wgm, wgn, bk, splitk; int halo = 0, mtps = 0, qps = 0; };   // halo: conv3_halo_kernel (126-row tiles)
 
@@ -289,6 +291,7 @@ struct Builder {
     std::vector<Tape> tape;
 
     static bool halo_enabled() { const char* e = getenv("LDM_CONV_HALO"); return e ? atoi(e) != 0 : true; }
+    static bool light_enabled() { const char* e = getenv("LDM_GEMM_LIGHT"); return e ? atoi(e) != 0 : true; }
     static bool phase_enabled() { const char* e = getenv("LDM_CONV_PHASE"); return e ? atoi(e) != 0 : true; }
     // halo_n > 0: the conv is eligible for conv3_halo_kernel (3^3, stride 1, pad 1, single source, BK 64); halo_n = N
     // and halo_dhw = voxels per sample (its 126-row tiles never straddle samples).
@@ -351,6 +354,25 @@ struct Builder {
         const bool phase = a.ups == 1 && !a.exact && a.k == 3 && a.stride == 1 && a.pad == 1 && !train && !a.xb.valid && !a.w1 &&
                            a.w_over.base == BASE_NULL && w.wp_off != 0 && phase_enabled() &&
                            a.Do == 2 * a.xa.D && a.Ho == 2 * a.xa.H && a.Wo == 2 * a.xa.W;
+        if (gemm_light_ok(a.k, a.stride, a.ups, cin0, !a.xb.valid && !a.w1, !a.f32_out && a.temb.base == BASE_NULL) && light_enabled() &&
+            a.xa.D == a.Do && a.xa.H == a.Ho && a.xa.W == a.Wo && M * (long)cin0 * 2 < (1L << 31)) {
+            const int big = gemm_light_big(M, w.cout_pad), rows = big ? 64 : 32;
+            const int couts_l = rup(w.cout, 32);
+            Act out = new_act(N, a.Do, a.Ho, a.Wo, couts_l);
+            const long dhwo = (long)a.Do * a.Ho * a.Wo;
+            if (a.want_stats && (N == 1 || dhwo % rows == 0)) {
+                out.stats_off = pool.alloc((size_t)((M + rows - 1) / rows) * couts_l * 2 * 4); out.has_stats = true;
+                out.stats_nrb = (int)(N == 1 ? (M + rows - 1) / rows : dhwo / rows);
+            }
+            Op op{}; op.kind = OP_GEMM_LIGHT;
+            op.r[0] = ws_ref(a.xa.off); op.r[2] = a.w_over.base != BASE_NULL ? a.w_over : w_ref(w.w_off);
+            op.r[6] = a.no_bias ? Ref() : w_ref(w.b_off); op.r[9] = a.residual.valid ? ws_ref(a.residual.off) : Ref();
+            op.r[10] = ws_ref(out.off); op.r[12] = out.has_stats ? ws_ref(out.stats_off) : Ref();
+            op.i[0] = (int)M; op.i[1] = cin0; op.i[2] = couts_l; op.i[3] = w.cout_pad; op.i[4] = big;
+            plan->ops.push_back(op);
+            if (recording) { Tape t; t.kind = 0; t.c = a; t.out = out; tape.push_back(t); }
+            return out;
+        }
         const int taps = phase ? 8 : a.k * a.k * a.k;
         const int nchunk0 = cin0 / bk, nchunk1 = cin1 / bk;
         const int steps0 = taps * nchunk0, steps1 = nchunk1;
@@ -1381,6 +1403,12 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                     hipLaunchKernelGGL(splitk_finalize_kernel, dim3((p.M + 31) / 32, (p.CoutS + 63) / 64), dim3(256), 0, s, f);
                 }
                 break; }
+            case OP_GEMM_LIGHT: {       // i: M, K, CoutS, CoutPad, big
+                LightParams p{}; p.x = (const bf16_t*)rp(bs, o.r[0]); p.w = (const bf16_t*)rp(bs, o.r[2]); p.bias = (const float*)rp(bs, o.r[6]);
+                p.residual = (const bf16_t*)rp(bs, o.r[9]); p.out = (bf16_t*)rp(bs, o.r[10]); p.stats = (float*)rp(bs, o.r[12]);
+                p.M = i[0]; p.K = i[1]; p.CoutS = i[2];
+                HIP_TRY(launch_gemm_light(p, i[3], i[4], s));
+                break; }
             case OP_GN_STATS: {
                 GnStatsParams p{}; p.xa = (const bf16_t*)rp(bs, o.r[0]); p.xb = (const bf16_t*)rp(bs, o.r[1]); p.ca = i[0]; p.cb = i[1];
                 p.DHW = i[2]; p.nslab = i[3]; p.rows_per_slab = i[4]; p.partial = (float*)rp(bs, o.r[4]);
@@ -2024,6 +2052,13 @@ int ldm_op_conv3d(const void* xa, int ca, const void* xb, int cb, const void* w,
               Wo = (Wu + pad_total - ksize) / stride + 1;
     const long M = (long)N * Do * Ho * Wo;
     if (M >= (1L << 31) || M < 1) return fail(LDM_ERR_BAD_ARG, "bad output size");
+    if (!wgn && !splitk && out_bf16 && !out_f32 && gemm_light_ok(ksize, stride, ups, cin0, cb == 0 && cin1 == 0, !temb && !bias2) &&
+        Builder::light_enabled() && M * (long)cin0 * 2 < (1L << 31)) {
+        LightParams lp{}; lp.x = (const bf16_t*)xa; lp.w = (const bf16_t*)w; lp.bias = bias; lp.residual = (const bf16_t*)residual;
+        lp.out = (bf16_t*)out_bf16; lp.stats = nullptr; lp.M = (int)M; lp.K = cin0; lp.CoutS = rup(cout, 32);
+        HIP_TRY(launch_gemm_light(lp, cout_pad, gemm_light_big(M, cout_pad), (hipStream_t)stream));
+        return 0;
+    }
     const int taps = ksize * ksize * ksize;
     ConvParams p{};
     p.x0a = (const bf16_t*)xa; p.x0b = (const bf16_t*)xb; p.c0a = ca; p.c0b = cb; p.w0 = (const bf16_t*)w;
