@@ -659,6 +659,19 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const FinalizePara
         const size_t slab = (size_t)p.M * p.CoutPad;
         const float* src0 = p.partial + (size_t)m * p.CoutPad + c;
         int s = 0;
+        for (; s + 8 <= p.splitk; s += 8) {              // eight slabs' loads in flight (the launch is latency bound)
+            float4 a[8], b[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float4* src = reinterpret_cast<const float4*>(src0 + (size_t)(s + u) * slab);
+                a[u] = src[0]; b[u] = src[1];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                v[0] += a[u].x; v[1] += a[u].y; v[2] += a[u].z; v[3] += a[u].w;
+                v[4] += b[u].x; v[5] += b[u].y; v[6] += b[u].z; v[7] += b[u].w;
+            }
+        }
         for (; s + 4 <= p.splitk; s += 4) {
             float4 a[4], b[4];
 #pragma unroll

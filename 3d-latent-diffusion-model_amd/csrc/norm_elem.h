@@ -236,12 +236,15 @@ __global__ __launch_bounds__(256) void gn_fused_apply_kernel(const GnFusedParams
     const int r0 = blockIdx.x * p.rows_per_block;
     int r1 = r0 + p.rows_per_block; if (r1 > p.DHW) r1 = p.DHW;
     u32x4 v[PF];
+    float4 gam[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)}, bet[2] = {gam[0], gam[0]};
     if (active) {
 #pragma unroll
         for (int k = 0; k < PF; ++k) {
             int r = r0 + rl + 32 * k; if (r >= r1) r = r1 - 1;          // clamped: unconditional loads stay in flight together
             v[k] = *reinterpret_cast<const u32x4*>(src + ((size_t)n * p.DHW + r) * xcs + xcl);
         }
+        gam[0] = *reinterpret_cast<const float4*>(p.gamma + c); gam[1] = *reinterpret_cast<const float4*>(p.gamma + c + 4);
+        bet[0] = *reinterpret_cast<const float4*>(p.beta + c); bet[1] = *reinterpret_cast<const float4*>(p.beta + c + 4);
     }
     // ---- fold the slabs (fixed order: reproducible)
     if (((cpg | p.ca) & 1) == 0) {
@@ -317,11 +320,13 @@ __global__ __launch_bounds__(256) void gn_fused_apply_kernel(const GnFusedParams
     // ---- apply
     if (!active) return;
     float a[8], b[8];
+    const float gk[8] = {gam[0].x, gam[0].y, gam[0].z, gam[0].w, gam[1].x, gam[1].y, gam[1].z, gam[1].w};
+    const float bk[8] = {bet[0].x, bet[0].y, bet[0].z, bet[0].w, bet[1].x, bet[1].y, bet[1].z, bet[1].w};
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int g = (c + k) / cpg - g_lo;
-        a[k] = p.gamma[c + k] * gstat[g][1];
-        b[k] = p.beta[c + k] - gstat[g][0] * a[k];
+        a[k] = gk[k] * gstat[g][1];
+        b[k] = bk[k] - gstat[g][0] * a[k];
     }
     if (p.ab && blockIdx.x == 0 && rl == 0) {
 #pragma unroll
