@@ -23,6 +23,17 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
 }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
+// 16-byte store; WT = true: write-through (sc1): the bytes leave the XCD's L2 while the kernel still runs instead of in the
+// write-back at its end (short launches whose consumers run on every XCD anyway).  Experiment knob: LDM_WT_STORES.
+#ifndef LDM_WT_CONV
+#define LDM_WT_CONV 0           // experiment: write-through stores in the conv / GEMM / attention epilogues too
+#endif
+template <bool WT>
+__device__ __forceinline__ void store16(void* ptr, u32x4 v) {
+    if constexpr (WT) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(ptr), "v"(v) : "memory");
+    else *reinterpret_cast<u32x4*>(ptr) = v;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -595,7 +595,7 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_igemm_kernel(const ConvParam
                     ssum[h * 8 + 2 * q] += lo; ssq[h * 8 + 2 * q] += lo * lo;
                     ssum[h * 8 + 2 * q + 1] += hi; ssq[h * 8 + 2 * q + 1] += hi * hi;
                 }
-                op[h] = o;
+                store16<LDM_WT_CONV != 0>(&op[h], o);
             }
         }
     }
@@ -639,6 +639,7 @@ struct FinalizeParams {
     bf16_t* out; float* out_f32; float* stats;
 };
 
+template <bool WT>
 __global__ __launch_bounds__(256) void splitk_finalize_kernel(const FinalizeParams p) {
     // block = 32 rows (blockIdx.x) x 64 channels (blockIdx.y); thread = one row x 8 channels
     __shared__ float red[4][8][16];
@@ -725,7 +726,7 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const FinalizePara
                 const float lo = __uint_as_float(o[q] << 16), hi = __uint_as_float(o[q] & 0xffff0000u);
                 ss[2 * q] = lo; sq[2 * q] = lo * lo; ss[2 * q + 1] = hi; sq[2 * q + 1] = hi * hi;
             }
-            *reinterpret_cast<u32x4*>(p.out + (size_t)m * p.CoutS + c) = o;
+            store16<WT>(p.out + (size_t)m * p.CoutS + c, o);
         }
     }
     if (do_stats) {     // fold the 32 rows: 8 row lanes per wave by shuffles (lane = row*8 + cv), 4 waves through LDS

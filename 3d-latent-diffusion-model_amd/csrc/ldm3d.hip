@@ -1332,6 +1332,8 @@ static int launch_wgrad(const WgradParams& p, hipStream_t s) {
     return 0;
 }
 
+static bool wt_stores() { static const int v = [] { const char* e = getenv("LDM_WT_STORES"); return e ? atoi(e) : 1; }(); return v != 0; }   // GroupNorm / finalize outputs written through (sc1): -24 us per step
+
 static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_t s, size_t begin = 0, size_t end = (size_t)-1) {
     if (end > plan.ops.size()) end = plan.ops.size();
     // LDM_PLAN_TRACE=<file>: measurement aid (tools/plan_trace.py) -- a HIP event before every op, one CSV row per op appended
@@ -1400,7 +1402,8 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                     f.CoutS = p.CoutS; f.CoutReal = p.CoutReal; f.DHWo = p.Dout * p.Hout * p.Wout;
                     f.bias = p.bias; f.bias2 = p.bias2; f.temb = p.temb; f.temb_stride = p.temb_stride; f.residual = p.residual;
                     f.out = p.out; f.out_f32 = p.out_f32; f.stats = p.stats;
-                    hipLaunchKernelGGL(splitk_finalize_kernel, dim3((p.M + 31) / 32, (p.CoutS + 63) / 64), dim3(256), 0, s, f);
+                    if (wt_stores()) hipLaunchKernelGGL(splitk_finalize_kernel<true>, dim3((p.M + 31) / 32, (p.CoutS + 63) / 64), dim3(256), 0, s, f);
+                    else hipLaunchKernelGGL(splitk_finalize_kernel<false>, dim3((p.M + 31) / 32, (p.CoutS + 63) / 64), dim3(256), 0, s, f);
                 }
                 break; }
             case OP_GEMM_LIGHT: {       // i: M, K, CoutS, CoutPad, big
@@ -1432,7 +1435,8 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                 p.groups = i[4]; p.DHW = i[5]; p.N = i[6]; p.silu = i[7]; p.rows_per_block = i[8]; p.eps = o.f[0];
                 p.gamma = (const float*)rp(bs, o.r[2]); p.beta = (const float*)rp(bs, o.r[3]); p.out = (bf16_t*)rp(bs, o.r[9]);
                 p.ab = (float*)rp(bs, o.r[5]); p.mr = (float*)rp(bs, o.r[6]);
-                hipLaunchKernelGGL(gn_fused_apply_kernel, dim3(i[9], (i[0] + i[1] + 63) / 64, i[6]), dim3(256), 0, s, p);
+                if (wt_stores()) hipLaunchKernelGGL(gn_fused_apply_kernel<true>, dim3(i[9], (i[0] + i[1] + 63) / 64, i[6]), dim3(256), 0, s, p);
+                else hipLaunchKernelGGL(gn_fused_apply_kernel<false>, dim3(i[9], (i[0] + i[1] + 63) / 64, i[6]), dim3(256), 0, s, p);
                 break; }
             case OP_GN_APPLY: {
                 GnApplyParams p{}; p.xa = (const bf16_t*)rp(bs, o.r[0]); p.xb = (const bf16_t*)rp(bs, o.r[1]); p.ca = i[0]; p.cb = i[1];
@@ -2103,7 +2107,7 @@ int ldm_op_conv3d(const void* xa, int ca, const void* xb, int cb, const void* w,
         FinalizeParams f{}; f.partial = p.partial; f.splitk = p.splitk; f.M = p.M; f.CoutPad = p.CoutPad; f.CoutS = p.CoutS;
         f.CoutReal = p.CoutReal; f.DHWo = Do * Ho * Wo; f.bias = bias; f.bias2 = bias2; f.temb = temb; f.temb_stride = temb_stride;
         f.residual = p.residual; f.out = p.out; f.out_f32 = p.out_f32; f.stats = nullptr;
-        hipLaunchKernelGGL(splitk_finalize_kernel, dim3((p.M + 31) / 32, (p.CoutS + 63) / 64), dim3(256), 0, (hipStream_t)stream, f);
+        hipLaunchKernelGGL(splitk_finalize_kernel<false>, dim3((p.M + 31) / 32, (p.CoutS + 63) / 64), dim3(256), 0, (hipStream_t)stream, f);
     }
     HIP_TRY(hipGetLastError());
     return 0;

@@ -214,6 +214,7 @@ struct GnFusedParams {
     float* ab; float* mr;                              // optional (training): [N][C][2] scale/shift, [N][G][2] mean/rstd
 };
 
+template <bool WT>
 __global__ __launch_bounds__(256) void gn_fused_apply_kernel(const GnFusedParams p) {
     __shared__ __attribute__((aligned(16))) float part[8][96][4];
     __shared__ double csum[192][2];
@@ -352,7 +353,7 @@ __global__ __launch_bounds__(256) void gn_fused_apply_kernel(const GnFusedParams
                     if (p.silu) { lo = silu_f(lo); hi = silu_f(hi); }
                     o[j] = pack2bf(lo, hi);
                 }
-                *reinterpret_cast<u32x4*>(p.out + ((size_t)n * p.DHW + r) * C + c) = o;
+                store16<WT>(p.out + ((size_t)n * p.DHW + r) * C + c, o);
             }
         }
     }
