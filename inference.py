@@ -6,8 +6,13 @@
 
 Extensions, all opt-in: --steps N switches to an N-step DDIM schedule (the reference always runs the full DDPM chain);
 --random-init skips the checkpoints (synthetic smoke runs); under torchrun with -g > 1 the -n samples are dealt to the
-ranks round-robin (independent chains, no collective: the reference is single process).  Volumes are written as
-NIfTI-1 by this package's own writer (nibabel is not a dependency)."""
+ranks round-robin (independent chains, no collective: the reference is single process); --batch B denoises B volumes
+per chain in one forward (tools/bench_chains.py: 1.6x the latent-steps/s of one-at-a-time at B = 4); --condition FILE
+runs the conditional sampling the trained model is for: the low-count volume of an NPZ pair is
+cropped / percentile-scaled like the training data (3d_ldm/utils.py:94-143), encoded by the autoencoder and concatenated
+to the noisy latent at every step (mode="concat", 3d_ldm/train_diffusion.py:326-333), with the scale factor that
+train_diffusion.py saved (model_dir/scale_factor.json, or --scale-factor).  Volumes are written as NIfTI-1 by this
+package's own writer (nibabel is not a dependency)."""
 import argparse
 import json
 import logging
@@ -30,6 +35,9 @@ def parse_cli():
     ap.add_argument("--steps", type=int, default=0, help="0 = all training timesteps with DDPM (reference behaviour); N = N-step DDIM")
     ap.add_argument("--random-init", action="store_true", help="no checkpoints: random weights")
     ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--batch", type=int, default=1, help="volumes denoised together in one chain")
+    ap.add_argument("--condition", default=None, help="NPZ pair whose low-count volume conditions the sampling (mode='concat')")
+    ap.add_argument("--scale-factor", type=float, default=None, help="latent scale (default: model_dir/scale_factor.json, else 1.0)")
     ns = ap.parse_args()
     for path in (ns.environment_file, ns.config_file):           # both JSON files land on the namespace, config last
         with open(path) as fh:
@@ -66,6 +74,29 @@ def make_scheduler(ns):
     return DDPMScheduler(**kw)
 
 
+def resolve_scale_factor(ns) -> float:
+    if ns.scale_factor is not None:
+        return float(ns.scale_factor)
+    path = os.path.join(getattr(ns, "model_dir", "."), "scale_factor.json")
+    if os.path.exists(path):
+        with open(path) as fh:
+            return float(json.load(fh)["scale_factor"])
+    return 1.0                                                   # the reference's hard-coded value (inference.py:85)
+
+
+def condition_latent(path, patch, autoencoder, scale_factor, device):
+    """Low-count volume of an NPZ pair -> centre crop, 0..99.5 percentile scaling -> scaled image latent [1, C, d, h, w]."""
+    import numpy as np
+    import torch
+    from ldm3d.data import crop, crop_start, load_pair, scale_percentiles
+    image, _ = load_pair(path)
+    f = autoencoder.factor                                       # a volume smaller than the patch is used whole (the loaders clip the
+    roi = [min(int(p), int(d)) // f * f for p, d in zip(patch, image.shape)]      # roi the same way), cut to a multiple of the VAE factor
+    image = scale_percentiles(crop(image, crop_start(image.shape, roi, None), roi))
+    x = torch.from_numpy(np.ascontiguousarray(image))[None, None].to(device)
+    return autoencoder.encode_stage_2_inputs(x) * scale_factor
+
+
 def main():
     ns = parse_cli()
     import torch
@@ -82,19 +113,34 @@ def main():
 
     autoencoder, unet = load_networks(ns, device)
     scheduler = make_scheduler(ns)
-    inferer = LatentDiffusionInferer(scheduler, scale_factor=1.0)
+    inferer = LatentDiffusionInferer(scheduler, scale_factor=resolve_scale_factor(ns))
     out_dir = Path(ns.output_dir)
     out_dir.mkdir(parents=True, exist_ok=True)
-    shape = [1, unet.in_channels] + [int(p) // autoencoder.factor for p in ns.diffusion_train["patch_size"]]
-    for idx in parallel.shard_indices(ns.num, rank, world):
+    patch = [int(p) for p in ns.diffusion_train["patch_size"]]
+    cond = None
+    if ns.condition:
+        with torch.no_grad():
+            cond = condition_latent(ns.condition, patch, autoencoder, inferer.scale_factor, device)
+        if unet.in_channels != 2 * autoencoder.latent_channels:
+            raise SystemExit(f"--condition needs a concat-conditioned UNet (in_channels {2 * autoencoder.latent_channels}), got {unet.in_channels}")
+    elif unet.in_channels != unet.out_channels:
+        raise SystemExit(f"this UNet is concat-conditioned (in_channels {unet.in_channels}, out_channels {unet.out_channels}): pass --condition FILE")
+    lat_ch = autoencoder.latent_channels if cond is not None else unet.in_channels
+    todo = list(parallel.shard_indices(ns.num, rank, world))
+    for lo in range(0, len(todo), max(1, ns.batch)):
+        ids = todo[lo:lo + max(1, ns.batch)]
+        shape = [len(ids), lat_ch] + (list(cond.shape[2:]) if cond is not None else [p // autoencoder.factor for p in patch])
         z = torch.randn(shape, dtype=torch.float32).to(device)    # host draw then move, as the reference does
         t0 = time.perf_counter()
         with torch.no_grad():
-            vol = inferer.sample(input_noise=z, autoencoder_model=autoencoder, diffusion_model=unet, scheduler=scheduler)
+            kw = {} if cond is None else dict(conditioning=cond.expand(len(ids), -1, -1, -1, -1).contiguous(), mode="concat")
+            vol = inferer.sample(input_noise=z, autoencoder_model=autoencoder, diffusion_model=unet, scheduler=scheduler, **kw)
         torch.cuda.synchronize()
-        stem = out_dir / time.strftime(f"synimg_%Y%m%d_%H%M%S_r{rank}_{idx}")
-        written = save_nifti(vol[0, 0].unsqueeze(-1).cpu().numpy(), str(stem))
-        log.info("rank %d: %s %s in %.2f s", rank, written, tuple(vol.shape), time.perf_counter() - t0)
+        for j, idx in enumerate(ids):
+            stem = out_dir / time.strftime(f"synimg_%Y%m%d_%H%M%S_r{rank}_{idx}")
+            written = save_nifti(vol[j, 0].unsqueeze(-1).cpu().numpy(), str(stem))
+            log.info("rank %d: %s %s", rank, written, tuple(vol.shape[1:]))
+        log.info("rank %d: %d volume(s) in %.2f s", rank, len(ids), time.perf_counter() - t0)
     if world > 1:
         parallel.cleanup_ddp()
 

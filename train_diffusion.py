@@ -87,6 +87,11 @@ def main():
     first = next(iter(train_loader))
     scale_factor = compute_scale_factor(autoencoder, first["label"].to(device).float(), GradSync())
     print(f"Rank {rank}: scale_factor -> {float(scale_factor):.6f}")
+    if rank == 0:                                   # kept next to the checkpoints: inference.py reads it back (the reference
+        # hard-codes 1.0 there, inference.py:85)
+        os.makedirs(args.model_dir, exist_ok=True)
+        with open(os.path.join(args.model_dir, "scale_factor.json"), "w") as fh:
+            json.dump({"scale_factor": float(scale_factor)}, fh)
 
     unet = define_instance(args, "diffusion_def")
     best_path = os.path.join(args.model_dir, "diffusion_unet.pt")
