@@ -318,21 +318,33 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdParams p)
 #pragma unroll
     for (int i = 0; i < 4; ++i) dq[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int ntile = (p.N + KT - 1) / KT;
+    // the next tile's rows are loaded into registers (unconditionally, rows clamped) before the current tile's MFMAs and
+    // written to LDS after them: their latency hides under the compute
+    u32x4 kreg[2], vreg[2];
+    auto stage_load = [&](int k0) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int idx = tid + it * 256, row = idx >> 3, ch = idx & 7;
+            int kr = k0 + row; if (kr >= p.N) kr = p.N - 1;
+            const bf16_t* tok = base + (size_t)kr * ld + hoff + ch * 8;
+            kreg[it] = *reinterpret_cast<const u32x4*>(tok + p.C);
+            vreg[it] = *reinterpret_cast<const u32x4*>(tok + 2 * p.C);
+        }
+    };
+    stage_load(0);
+    asm volatile("" :: "v"(qf[0]), "v"(qf[1]), "v"(dof[0]), "v"(dof[1]), "v"(lse), "v"(dlt));   // landed before the loop
     for (int t = 0; t < ntile; ++t) {
         const int k0 = t * KT;
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int idx = tid + it * 256, row = idx >> 3, ch = idx & 7;
-            int kr = k0 + row; if (kr >= p.N) kr = p.N - 1;
-            const bf16_t* tok = base + (size_t)kr * ld + hoff + ch * 8;
-            const u32x4 kv = *reinterpret_cast<const u32x4*>(tok + p.C);
-            const u32x4 vv = *reinterpret_cast<const u32x4*>(tok + 2 * p.C);
-            *reinterpret_cast<u32x4*>(k_row + attn_row_off(row, ch)) = kv;
-            *reinterpret_cast<u32x4*>(k_tr + attn_tr_off(row, ch)) = kv;
-            *reinterpret_cast<u32x4*>(v_row + attn_row_off(row, ch)) = vv;
+            *reinterpret_cast<u32x4*>(k_row + attn_row_off(row, ch)) = kreg[it];
+            *reinterpret_cast<u32x4*>(k_tr + attn_tr_off(row, ch)) = kreg[it];
+            *reinterpret_cast<u32x4*>(v_row + attn_row_off(row, ch)) = vreg[it];
         }
         __syncthreads();
+        stage_load(k0 + KT);
         bf16x8 dsf[2];                                 // dS^T fragments (B operand of the dQ product)
         f32x4 st[4], dp[4];
 #pragma unroll
@@ -403,26 +415,39 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdParams p
 #pragma unroll
     for (int i = 0; i < 4; ++i) { dk[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     const int ntile = (p.N + QT - 1) / QT;
+    // register prefetch of the next query tile (unconditional, rows clamped), as in the dQ kernel
+    u32x4 qreg[2], oreg[2]; float lreg = 0.f, dreg = 0.f;
+    auto stage_load = [&](int q0) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int idx = tid + it * 256, row = idx >> 3, ch = idx & 7;
+            int qr = q0 + row; if (qr >= p.N) qr = p.N - 1;
+            qreg[it] = *reinterpret_cast<const u32x4*>(base + (size_t)qr * ld + hoff + ch * 8);
+            oreg[it] = *reinterpret_cast<const u32x4*>(p.d_o + ((size_t)b * p.N + qr) * p.C + hoff + ch * 8);
+        }
+        {
+            int qr = q0 + (tid & (QT - 1)); const bool ok = qr < p.N; if (!ok) qr = p.N - 1;
+            const float l = p.lse[((size_t)b * p.heads + head) * p.N + qr];
+            lreg = ok ? l : INFINITY;                                                      // exp(s - inf) = 0 masks the row
+            dreg = p.delta[((size_t)b * p.heads + head) * p.N + qr];
+        }
+    };
+    stage_load(0);
+    asm volatile("" :: "v"(kf[0]), "v"(kf[1]), "v"(vf[0]), "v"(vf[1]));                   // landed before the loop
     for (int t = 0; t < ntile; ++t) {
         const int q0 = t * QT;
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int idx = tid + it * 256, row = idx >> 3, ch = idx & 7;
-            int qr = q0 + row; if (qr >= p.N) qr = p.N - 1;
-            const u32x4 qv = *reinterpret_cast<const u32x4*>(base + (size_t)qr * ld + hoff + ch * 8);
-            const u32x4 ov = *reinterpret_cast<const u32x4*>(p.d_o + ((size_t)b * p.N + qr) * p.C + hoff + ch * 8);
-            *reinterpret_cast<u32x4*>(q_row + attn_row_off(row, ch)) = qv;
-            *reinterpret_cast<u32x4*>(q_tr + attn_tr_off(row, ch)) = qv;
-            *reinterpret_cast<u32x4*>(do_row + attn_row_off(row, ch)) = ov;
-            *reinterpret_cast<u32x4*>(do_tr + attn_tr_off(row, ch)) = ov;
+            *reinterpret_cast<u32x4*>(q_row + attn_row_off(row, ch)) = qreg[it];
+            *reinterpret_cast<u32x4*>(q_tr + attn_tr_off(row, ch)) = qreg[it];
+            *reinterpret_cast<u32x4*>(do_row + attn_row_off(row, ch)) = oreg[it];
+            *reinterpret_cast<u32x4*>(do_tr + attn_tr_off(row, ch)) = oreg[it];
         }
-        if (tid < QT) {
-            int qr = q0 + tid; const bool ok = qr < p.N; if (!ok) qr = p.N - 1;
-            s_lse[tid] = ok ? p.lse[((size_t)b * p.heads + head) * p.N + qr] : INFINITY;      // exp(s - inf) = 0 masks the row
-            s_dlt[tid] = p.delta[((size_t)b * p.heads + head) * p.N + qr];
-        }
+        if (tid < QT) { s_lse[tid] = lreg; s_dlt[tid] = dreg; }
         __syncthreads();
+        stage_load(q0 + QT);
         // S[q][key] = Q K^T and dP[q][key] = dO V^T with the key on the lane (col = fr), q = 16 j + 4 fg + r
         f32x4 st[4], dp[4];
 #pragma unroll
