@@ -14,9 +14,9 @@ for spec in sys.argv[1:] or ["256,768,1728", "256,256,1728", "512,1536,216", "51
     b = torch.zeros((cout,), device=dev); out = torch.empty((1, 1, 1, M, cout), dtype=torch.bfloat16, device=dev)
     scratch = torch.zeros((1 << 20,), dtype=torch.uint8, device=dev)
     st_ = torch.cuda.current_stream().cuda_stream
-    def run():
+    def run(wgn=2, splitk=1):       # forced tile = conv_igemm_kernel; (0, 0) = automatic = gemm_light_kernel where it applies
         _lib.check(L.ldm_op_conv3d(x.data_ptr(), cin, None, 0, w.data_ptr(), b.data_ptr(), None, 0, None, 0, None, None, None, 0,
-                                   None, out.data_ptr(), None, 1, 1, 1, M, 1, 1, 0, 0, cout, cout, 2, 1, scratch.data_ptr(), scratch.numel(), st_))
+                                   None, out.data_ptr(), None, 1, 1, 1, M, 1, 1, 0, 0, cout, cout, wgn, splitk, scratch.data_ptr(), scratch.numel(), st_))
     for _ in range(5):
         run()
     torch.cuda.synchronize()
@@ -36,5 +36,12 @@ for spec in sys.argv[1:] or ["256,768,1728", "256,256,1728", "512,1536,216", "51
     for _ in range(50):
         run()
     e1.record(); torch.cuda.synchronize()
-    print(f"  back-to-back launches: {e0.elapsed_time(e1) * 20:.2f} us each")
+    print(f"  back-to-back launches: {e0.elapsed_time(e1) * 20:.2f} us each (conv_igemm_kernel)")
+    for _ in range(5):
+        run(0, 0)
+    e0.record()
+    for _ in range(50):
+        run(0, 0)
+    e1.record(); torch.cuda.synchronize()
+    print(f"  back-to-back launches: {e0.elapsed_time(e1) * 20:.2f} us each (automatic: gemm_light_kernel)")
     os.environ["LDM_CONV_DBG"] = "512"
