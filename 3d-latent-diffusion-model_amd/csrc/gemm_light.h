@@ -10,7 +10,8 @@
 #include "common.h"
 
 struct LightParams {
-    const bf16_t* x; const bf16_t* w;     // [M][K], [CoutPad][K]
+    const bf16_t* x; const bf16_t* w;     // [M][ca] (| xb [M][K - ca], channel-concatenated), [CoutPad][K]
+    const bf16_t* xb; int ca;             // second source or null (ca = K)
     const float* bias;                    // [CoutPad] or null
     const bf16_t* residual;               // [M][CoutS] or null
     bf16_t* out;                          // [M][CoutS]
@@ -28,11 +29,13 @@ __global__ __launch_bounds__(64) void gemm_light_kernel(const LightParams p) {
     const bf16_t* wrow[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) wrow[nt] = p.w + (size_t)(n0 + 4 * NT * (fr >> 2) + 4 * nt + (fr & 3)) * p.K + 8 * fg;
-    const bf16_t* xrow[MT];
+    const bf16_t* xrow[MT]; const bf16_t* xbrow[MT];
+    const int cb2 = p.K - p.ca;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         int m = m0 + 16 * mt + fr; if (m >= p.M) m = p.M - 1;                     // clamped: rows past M are computed and dropped
-        xrow[mt] = p.x + (size_t)m * p.K + 8 * fg;
+        xrow[mt] = p.x + (size_t)m * p.ca + 8 * fg;
+        xbrow[mt] = p.xb ? p.xb + (size_t)m * cb2 + 8 * fg - p.ca : xrow[mt];    // indexed with the global k
     }
     f32x4 acc[NT][MT];
 #pragma unroll
@@ -47,7 +50,8 @@ __global__ __launch_bounds__(64) void gemm_light_kernel(const LightParams p) {
           _Pragma("unroll") for (int s = 0; s < CH; ++s) {                                            \
               const int k_ = (c_ * CH + s) * 32;                                                      \
               _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) WF[s][nt] = *reinterpret_cast<const bf16x8*>(wrow[nt] + k_); \
-              _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) XF[s][mt] = *reinterpret_cast<const bf16x8*>(xrow[mt] + k_); \
+              const bool sec_ = k_ >= p.ca;                           /* wave-uniform: the step lies in the second source */ \
+              _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) XF[s][mt] = *reinterpret_cast<const bf16x8*>((sec_ ? xbrow[mt] : xrow[mt]) + k_); \
           } }                                                                                         \
     } while (0)
 #define GL_MFMA(WF, XF) do {                                                                          \

@@ -82,6 +82,9 @@ struct Op {
     int i[24];
     float f[2];
     ConvCfg cc;
+    // inference plans: lane 1 = the side stream (work off the critical path: time embedding, 1x1 skip GEMMs); sync = before
+    // this op its lane waits for everything issued so far on the other lane
+    int lane = 0; bool sync = false;
 };
 
 struct Pool {                                        // plan-time workspace allocator (first fit + coalescing)
@@ -170,6 +173,7 @@ struct ldm_model {
     int graph_mode = 0;
     struct GraphEntry { const Plan* plan; const void* ptr[6]; int rt[2]; int seen; hipGraphExec_t exec; };
     std::vector<GraphEntry> graphs;
+    hipStream_t side_stream = nullptr; std::vector<hipEvent_t> lane_events;     // side lane of the inference plans (run_plan)
     hipStream_t cap_stream = nullptr;        // capture happens on a private stream (the caller's may be the null stream, which cannot capture)
     // UNet: stacked time_emb_proj GEMV
     size_t tproj_w_off = 0, tproj_b_off = 0; int tproj_rows = 0; std::map<std::string, int> tproj_row;
@@ -280,6 +284,7 @@ struct Builder {
         // backward-pass uses of the same kernel (data gradients)
         Ref w_over; bool no_bias = false; int exact = 0;   // weights from the workspace; zero-insertion upsample
         int temb_row = -1;                            // first row of this ResBlock in the stacked time projection
+        int lane = 0; bool sync = false;              // Op::lane / Op::sync of the emitted (first) op
         int f32_tag = 0;                              // which externally supplied gradient an fp32-output conv receives (0 final, 1 VAE heads)
     };
     struct Tape {                                    // one differentiable forward op, recorded in training plans
@@ -292,6 +297,10 @@ struct Builder {
 
     static bool halo_enabled() { const char* e = getenv("LDM_CONV_HALO"); return e ? atoi(e) != 0 : true; }
     static bool light_enabled() { const char* e = getenv("LDM_GEMM_LIGHT"); return e ? atoi(e) != 0 : true; }
+    bool temb_pending = false;
+    // measured (MI355X, ROCm 7.2): 14 fork / join pairs per step cost more than the overlapped work saves: 2.36 vs 2.17 ms per
+    // step under graph replay, 2.29 ms eager.  Kept as an opt-in experiment (LDM_SIDE_LANE=1).
+    static bool side_lane_enabled() { const char* e = getenv("LDM_SIDE_LANE"); return e ? atoi(e) != 0 : false; }
     static bool phase_enabled() { const char* e = getenv("LDM_CONV_PHASE"); return e ? atoi(e) != 0 : true; }
     // halo_n > 0: the conv is eligible for conv3_halo_kernel (3^3, stride 1, pad 1, single source, BK 64); halo_n = N
     // and halo_dhw = voxels per sample (its 126-row tiles never straddle samples).
@@ -354,7 +363,7 @@ struct Builder {
         const bool phase = a.ups == 1 && !a.exact && a.k == 3 && a.stride == 1 && a.pad == 1 && !train && !a.xb.valid && !a.w1 &&
                            a.w_over.base == BASE_NULL && w.wp_off != 0 && phase_enabled() &&
                            a.Do == 2 * a.xa.D && a.Ho == 2 * a.xa.H && a.Wo == 2 * a.xa.W;
-        if (gemm_light_ok(a.k, a.stride, a.ups, cin0, !a.xb.valid && !a.w1, !a.f32_out && a.temb.base == BASE_NULL) && light_enabled() &&
+        if (gemm_light_ok(a.k, a.stride, a.ups, cin0, !a.w1, !a.f32_out && a.temb.base == BASE_NULL) && light_enabled() &&
             a.xa.D == a.Do && a.xa.H == a.Ho && a.xa.W == a.Wo && M * (long)cin0 * 2 < (1L << 31)) {
             const int big = gemm_light_big(M, w.cout_pad), rows = big ? 64 : 32;
             const int couts_l = rup(w.cout, 32);
@@ -365,8 +374,10 @@ struct Builder {
                 out.stats_nrb = (int)(N == 1 ? (M + rows - 1) / rows : dhwo / rows);
             }
             Op op{}; op.kind = OP_GEMM_LIGHT;
-            op.r[0] = ws_ref(a.xa.off); op.r[2] = a.w_over.base != BASE_NULL ? a.w_over : w_ref(w.w_off);
+            op.r[0] = ws_ref(a.xa.off); op.r[1] = a.xb.valid ? ws_ref(a.xb.off) : Ref();
+            op.r[2] = a.w_over.base != BASE_NULL ? a.w_over : w_ref(w.w_off);
             op.r[6] = a.no_bias ? Ref() : w_ref(w.b_off); op.r[9] = a.residual.valid ? ws_ref(a.residual.off) : Ref();
+            op.i[5] = a.xa.C; op.lane = a.lane; op.sync = a.sync;
             op.r[10] = ws_ref(out.off); op.r[12] = out.has_stats ? ws_ref(out.stats_off) : Ref();
             op.i[0] = (int)M; op.i[1] = cin0; op.i[2] = couts_l; op.i[3] = w.cout_pad; op.i[4] = big;
             plan->ops.push_back(op);
@@ -400,7 +411,7 @@ struct Builder {
                 }
             }
         }
-        Op op{}; op.kind = OP_CONV; op.cc = cc;
+        Op op{}; op.kind = OP_CONV; op.cc = cc; op.lane = a.lane; op.sync = a.sync;
         op.r[0] = ws_ref(a.xa.off); op.r[1] = a.xb.valid ? ws_ref(a.xb.off) : Ref();
         op.r[2] = a.w_over.base != BASE_NULL ? a.w_over : w_ref(phase ? w.wp_off : w.w_off);
         op.r[3] = a.w1 ? ws_ref(a.g1a.off) : Ref(); op.r[4] = (a.w1 && a.g1b.valid) ? ws_ref(a.g1b.off) : Ref();
@@ -425,7 +436,7 @@ struct Builder {
         (void)bn;
         plan->ops.push_back(op);
         if (cc.splitk > 1) {
-            Op f = op; f.kind = OP_FINALIZE;
+            Op f = op; f.kind = OP_FINALIZE; f.sync = false;
             partial_fixups.push_back(plan->ops.size());
             plan->ops.push_back(f);
         }
@@ -517,12 +528,23 @@ struct Builder {
     Act resblock(const std::string& p, const Act& xa, const Act& xb, int cout, int groups, float eps,
                  const std::string& skip_name, bool with_temb) {
         const int cin = xa.C + (xb.valid ? xb.C : 0);
+        // inference: the 1x1 skip projection runs as a light GEMM on the side lane, concurrently with norm1 / conv1 / norm2, and
+        // enters conv2 as its residual: conv2 stays a single-source 3^3 conv (halo kernel) instead of the fused two-group form
+        Act sk;
+        if (cin != cout && !train && side_lane_enabled() && cin % 128 == 0) {
+            ConvArgs cs; cs.xa = xa; cs.xb = xb; cs.w = &m->convs.at(p + skip_name); cs.k = 1; cs.pad = 0;
+            cs.Do = xa.D; cs.Ho = xa.H; cs.Wo = xa.W; cs.want_stats = false; cs.lane = 1; cs.sync = true;
+            sk = conv(cs, p + skip_name);
+            if (!sk.valid) return Act();
+            if (plan->ops.back().kind != OP_GEMM_LIGHT) { err = "resblock: side-lane skip needs the light GEMM"; return Act(); }
+        }
         Act h0 = gn_apply(m->gns.at(p + ".norm1"), xa, xb, groups, eps, true);
         if (!h0.valid) return Act();
         ConvArgs c1; c1.xa = h0; c1.w = &m->convs.at(p + ".conv1"); c1.Do = xa.D; c1.Ho = xa.H; c1.Wo = xa.W;
         if (with_temb) {
             c1.temb = ws_ref(temb_all_off + (size_t)m->tproj_row.at(p) * 4); c1.temb_stride = tproj_stride;
             c1.temb_row = m->tproj_row.at(p);
+            if (temb_pending) { c1.sync = true; temb_pending = false; }      // first consumer joins the side lane
         }
         Act h1 = conv(c1, p + ".conv1");
         free_act(h0);
@@ -531,10 +553,12 @@ struct Builder {
         free_act(h1);
         if (!h2.valid) return Act();
         ConvArgs c2; c2.xa = h2; c2.w = &m->convs.at(p + ".conv2"); c2.Do = xa.D; c2.Ho = xa.H; c2.Wo = xa.W;
-        if (cin != cout) { c2.g1a = xa; c2.g1b = xb; c2.w1 = &m->convs.at(p + skip_name); }
+        if (sk.valid) { c2.residual = sk; c2.sync = true; }
+        else if (cin != cout) { c2.g1a = xa; c2.g1b = xb; c2.w1 = &m->convs.at(p + skip_name); }
         else { if (xb.valid) { err = "resblock: identity skip with concat input"; return Act(); } c2.residual = xa; }
         Act out = conv(c2, p + ".conv2");
         free_act(h2);
+        if (sk.valid) free_act(sk);
         return out;
     }
 
@@ -884,11 +908,15 @@ static int unet_build(ldm_model* m, int B, int D, int H, int W, Plan* plan, bool
     const size_t e2_off = b.pool.alloc((size_t)B * temb * 4);
     b.tproj_stride = m->tproj_rows;
     b.temb_all_off = b.pool.alloc(((size_t)B * m->tproj_rows + 256) * 4);
-    { Op o{}; o.kind = OP_SINUSOID; o.r[0] = io_ref(2); o.r[1] = ws_ref(sin_off); o.i[0] = B; o.i[1] = ch[0]; plan->ops.push_back(o); }
+    // inference: the whole time-embedding chain runs on the side lane, beside pack / conv_in / the first GroupNorm
+    const int tlane = (!train && Builder::side_lane_enabled()) ? 1 : 0;
+    { Op o{}; o.kind = OP_SINUSOID; o.r[0] = io_ref(2); o.r[1] = ws_ref(sin_off); o.i[0] = B; o.i[1] = ch[0]; o.lane = tlane; o.sync = tlane != 0;
+      plan->ops.push_back(o); }
     auto gemv = [&](size_t w_off, size_t b_off, size_t x_off, size_t y_off, int I, int O, int xs, int ys, int silu) {
         Op o{}; o.kind = OP_GEMV; o.r[0] = w_ref(w_off); o.r[1] = w_ref(b_off); o.r[2] = ws_ref(x_off); o.r[3] = ws_ref(y_off);
-        o.i[0] = I; o.i[1] = O; o.i[2] = xs; o.i[3] = ys; o.i[4] = silu; o.i[5] = B; plan->ops.push_back(o);
+        o.i[0] = I; o.i[1] = O; o.i[2] = xs; o.i[3] = ys; o.i[4] = silu; o.i[5] = B; o.lane = tlane; plan->ops.push_back(o);
     };
+    b.temb_pending = tlane != 0;
     const LinW& l0 = m->lins.at("time_embed.0"); const LinW& l2 = m->lins.at("time_embed.2");
     gemv(l0.w_off, l0.b_off, sin_off, e1_off, ch[0], temb, ch[0], temb, 0);
     gemv(l2.w_off, l2.b_off, e1_off, e2_off, temb, temb, temb, temb, 1);
@@ -1334,7 +1362,10 @@ static int launch_wgrad(const WgradParams& p, hipStream_t s) {
 
 static bool wt_stores() { static const int v = [] { const char* e = getenv("LDM_WT_STORES"); return e ? atoi(e) : 1; }(); return v != 0; }   // GroupNorm / finalize outputs written through (sc1): -24 us per step
 
-static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_t s, size_t begin = 0, size_t end = (size_t)-1) {
+struct LaneCtx { hipStream_t side = nullptr; std::vector<hipEvent_t>* events = nullptr; };
+
+static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_t s, size_t begin = 0, size_t end = (size_t)-1,
+                    LaneCtx lanes = LaneCtx()) {
     if (end > plan.ops.size()) end = plan.ops.size();
     // LDM_PLAN_TRACE=<file>: measurement aid (tools/plan_trace.py) -- a HIP event before every op, one CSV row per op appended
     static const char* trace_path = getenv("LDM_PLAN_TRACE");
@@ -1359,10 +1390,32 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
             for (auto e : ev) (void)hipEventDestroy(e);
         }
     } trace_done{plan, begin, end, tev, s, trace_path};
+    // lanes: ops tagged lane 1 go to the side stream; Op::sync makes the op's lane wait (event) for what the other lane has
+    // been given so far.  Without a side stream (training, tracing, profiling) everything runs in plan order on s.
+    const hipStream_t s_main = s;
+    const bool use_side = lanes.side != nullptr && lanes.events != nullptr && !trace_path && !g_prof.on;
+    size_t ev_i = 0; bool side_dirty = false;
+    auto cross = [&](hipStream_t from, hipStream_t to) -> int {
+        if (ev_i >= lanes.events->size()) { hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); lanes.events->push_back(e); }
+        hipEvent_t e = (*lanes.events)[ev_i++];
+        HIP_TRY(hipEventRecord(e, from)); HIP_TRY(hipStreamWaitEvent(to, e, 0));
+        return 0;
+    };
+    struct JoinAtExit {                                 // every return path leaves the side lane joined to s (stream capture needs it)
+        bool& dirty; decltype(cross)& x; hipStream_t side, main;
+        ~JoinAtExit() { if (dirty) (void)x(side, main); }
+    } join_at_exit{side_dirty, cross, lanes.side, s_main};
     for (size_t oi = begin; oi < end; ++oi) {
         const Op& o = plan.ops[oi];
         const int* i = o.i;
-        if (trace_path) HIP_TRY(hipEventRecord(tev[oi - begin], s));
+        if (trace_path) HIP_TRY(hipEventRecord(tev[oi - begin], s_main));
+        const bool on_side = use_side && o.lane == 1;
+        if (use_side && o.sync) {
+            if (on_side) LDM_TRY(cross(s_main, lanes.side));
+            else if (side_dirty) { LDM_TRY(cross(lanes.side, s_main)); side_dirty = false; }
+        }
+        if (on_side) side_dirty = true;
+        const hipStream_t s = on_side ? lanes.side : s_main;
         switch (o.kind) {
             case OP_PACK: {
                 // two fp32 NCDHW sources (x | cond) -> one zero-padded NDHWC bf16 tensor
@@ -1409,7 +1462,7 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
             case OP_GEMM_LIGHT: {       // i: M, K, CoutS, CoutPad, big
                 LightParams p{}; p.x = (const bf16_t*)rp(bs, o.r[0]); p.w = (const bf16_t*)rp(bs, o.r[2]); p.bias = (const float*)rp(bs, o.r[6]);
                 p.residual = (const bf16_t*)rp(bs, o.r[9]); p.out = (bf16_t*)rp(bs, o.r[10]); p.stats = (float*)rp(bs, o.r[12]);
-                p.M = i[0]; p.K = i[1]; p.CoutS = i[2];
+                p.M = i[0]; p.K = i[1]; p.CoutS = i[2]; p.xb = (const bf16_t*)rp(bs, o.r[1]); p.ca = p.xb ? i[5] : i[1];
                 HIP_TRY(launch_gemm_light(p, i[3], i[4], s));
                 break; }
             case OP_GN_STATS: {
@@ -1612,6 +1665,8 @@ void ldm_model_destroy(ldm_model* m) {
     if (!m) return;
     for (auto& g : m->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
     if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
+    if (m->side_stream) (void)hipStreamDestroy(m->side_stream);
+    for (auto e : m->lane_events) (void)hipEventDestroy(e);
     if (m->arena) (void)hipFree(m->arena);
     delete m;
 }
@@ -1726,7 +1781,9 @@ int ldm_unet_forward(ldm_model* m, const float* x, int x_channels, const float* 
     bs.p[BASE_IO0] = (char*)x; bs.p[BASE_IO1] = (char*)cond; bs.p[BASE_IO2] = (char*)timesteps; bs.p[BASE_IO3] = (char*)out;
     const int rt[2] = {x_channels, cond_channels};
     LDM_TRY(ensure_derived(m, (hipStream_t)stream));
-    if (!m->graph_mode || g_prof.on) return run_plan(*p, bs, rt, (hipStream_t)stream);
+    if (!m->side_stream) HIP_TRY(hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking));
+    LaneCtx lanes; lanes.side = m->side_stream; lanes.events = &m->lane_events;
+    if (!m->graph_mode || g_prof.on) return run_plan(*p, bs, rt, (hipStream_t)stream, 0, (size_t)-1, lanes);
     // ---- graph replay: same launches, recorded once per pointer set
     const void* key[6] = {x, cond, timesteps, out, workspace, stream};
     ldm_model::GraphEntry* ge = nullptr;
@@ -1741,11 +1798,11 @@ int ldm_unet_forward(ldm_model* m, const float* x, int x_channels, const float* 
         m->graphs.push_back(g); ge = &m->graphs.back();
     }
     if (ge->exec) { HIP_TRY(hipGraphLaunch(ge->exec, (hipStream_t)stream)); return 0; }
-    if (ge->seen++ == 0) return run_plan(*p, bs, rt, (hipStream_t)stream);       // first sight: eager (also warms one-time set-up)
+    if (ge->seen++ == 0) return run_plan(*p, bs, rt, (hipStream_t)stream, 0, (size_t)-1, lanes);   // first sight: eager (also warms one-time set-up)
     hipGraph_t graph = nullptr;
     if (!m->cap_stream) HIP_TRY(hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeThreadLocal));
-    const int rc = run_plan(*p, bs, rt, m->cap_stream);
+    const int rc = run_plan(*p, bs, rt, m->cap_stream, 0, (size_t)-1, lanes);
     const hipError_t ec = hipStreamEndCapture(m->cap_stream, &graph);
     if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
     if (ec != hipSuccess || !graph) return fail(LDM_ERR_HIP, "stream capture failed: %s", hipGetErrorString(ec));
@@ -2056,10 +2113,11 @@ int ldm_op_conv3d(const void* xa, int ca, const void* xb, int cb, const void* w,
               Wo = (Wu + pad_total - ksize) / stride + 1;
     const long M = (long)N * Do * Ho * Wo;
     if (M >= (1L << 31) || M < 1) return fail(LDM_ERR_BAD_ARG, "bad output size");
-    if (!wgn && !splitk && out_bf16 && !out_f32 && gemm_light_ok(ksize, stride, ups, cin0, cb == 0 && cin1 == 0, !temb && !bias2) &&
+    if (!wgn && !splitk && out_bf16 && !out_f32 && gemm_light_ok(ksize, stride, ups, cin0, cin1 == 0, !temb && !bias2) &&
         Builder::light_enabled() && M * (long)cin0 * 2 < (1L << 31)) {
         LightParams lp{}; lp.x = (const bf16_t*)xa; lp.w = (const bf16_t*)w; lp.bias = bias; lp.residual = (const bf16_t*)residual;
         lp.out = (bf16_t*)out_bf16; lp.stats = nullptr; lp.M = (int)M; lp.K = cin0; lp.CoutS = rup(cout, 32);
+        lp.xb = (const bf16_t*)xb; lp.ca = ca;
         HIP_TRY(launch_gemm_light(lp, cout_pad, gemm_light_big(M, cout_pad), (hipStream_t)stream));
         return 0;
     }
