@@ -168,7 +168,7 @@ struct ldm_model {
     std::map<std::string, ConvW> convs; std::map<std::string, GnW> gns; std::map<std::string, LinW> lins;
     std::map<std::string, std::shared_ptr<Plan>> plans;
     DevTable pack_tab;                               // one-launch re-pack of a flat fp32 parameter buffer
-    // HIP-graph replay of the forward plan (ldm_model_set_graph_mode): one hipGraphLaunch instead of ~215 kernel launches
+    // HIP-graph replay of the forward plan (ldm_model_set_graph_mode): one hipGraphLaunch instead of ~150 kernel launches
     // per step on the host.  A graph is instantiated per (plan, pointer set) the second time that set is seen.
     int graph_mode = 0;
     struct GraphEntry { const Plan* plan; const void* ptr[6]; int rt[2]; int seen; hipGraphExec_t exec; };
@@ -463,7 +463,8 @@ struct Builder {
         if (fused && C / groups <= 64 && nrb_tot <= 256) {   // few slab rows: ONE launch folds them per block and applies
             Act out = new_act(N, xa.D, xa.H, xa.W, C);
             const int slices = (C + 63) / 64;
-            int chunks = std::max(1, std::min(256 / (slices * N), (DHW + 31) / 32));   // one round of the 256 CUs: the slab fold is per block
+            static const int gn_blocks = [] { const char* e = getenv("LDM_GN_BLOCKS"); return e ? atoi(e) : 256; }();   // tuning knob
+            int chunks = std::max(1, std::min(gn_blocks / (slices * N), (DHW + 31) / 32));   // one round of the 256 CUs: the slab fold is per block
             int rpb = rup((DHW + chunks - 1) / chunks, 32);
             chunks = (DHW + rpb - 1) / rpb;
             Op f{}; f.kind = OP_GN_FUSED;
@@ -1814,7 +1815,7 @@ int ldm_unet_forward(ldm_model* m, const float* x, int x_channels, const float* 
 
 /* on != 0: ldm_unet_forward replays a HIP graph of its launch plan whenever it sees the same (x, cond, timesteps, out,
  * workspace, stream) pointers again (callers keep those buffers fixed: the Python shell stages through persistent tensors).
- * Same kernels, same results; only the host cost per step changes (one graph launch instead of ~215 launches). */
+ * Same kernels, same results; only the host cost per step changes (one graph launch instead of ~150 launches). */
 int ldm_model_set_graph_mode(ldm_model* m, int on) {
     if (!m) return fail(LDM_ERR_BAD_ARG, "null model");
     m->graph_mode = on ? 1 : 0;

@@ -321,7 +321,7 @@ class DiffusionModelUNet(_LdmModule):
 
 
     def enable_graph_replay(self, on: bool = True):
-        """Inference: replay the forward plan as ONE HIP graph launch per call instead of ~215 kernel launches (same
+        """Inference: replay the forward plan as ONE HIP graph launch per call instead of ~150 kernel launches (same
         kernels and results; the host cost per step drops from ~1.6 ms to ~0.1 ms, which matters when many ranks share a
         host).  The returned tensor is then a persistent buffer that the next forward overwrites."""
         _lib.check(_lib.lib().ldm_model_set_graph_mode(self._h, 1 if on else 0))

@@ -200,8 +200,8 @@ def main():
                                "step on 1x4x24^3, 1000-step schedule scaled_linear_beta 0.0015-0.0195 (BASELINE configs[2])",
                    "per_gpu_batch": 1, "parallelism": f"replicas x{world} (independent chains, no collective)",
                    "weights": "random init, seeded",
-                   "launch": ("eager (one C-ABI call per forward, ~215 kernel launches)" if args.eager else
-                              "HIP graph replay of the forward plan (one C-ABI call = one hipGraphLaunch of ~215 kernels; "
+                   "launch": ("eager (one C-ABI call per forward, ~150 kernel launches)" if args.eager else
+                              "HIP graph replay of the forward plan (one C-ABI call = one hipGraphLaunch of ~150 kernels; "
                               "scheduler step eager)")},
         "steps_per_s_per_gpu": args.steps / dt,
         "unet_step_tflops": UNET_STEP_GFLOP / ms_per_step,
