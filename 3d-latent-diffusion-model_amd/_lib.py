@@ -85,6 +85,7 @@ SIGNATURES = {
     "ldm_op_attention_train": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "ldm_op_attention_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "ldm_profile_start": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "ldm_profile_detail": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]),
     "ldm_profile_stop": (C.c_int, [C.POINTER(C.c_double)]),
     "ldm_model_plan_conv_cfgs": (C.c_int, [_P, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]),
     "ldm_comm_unique_id": (C.c_int, [C.c_char_p]),

@@ -2051,6 +2051,18 @@ int ldm_profile_start(int wgm, int wgn, int bk, int max_launches) {
     g_prof.wgm = wgm; g_prof.wgn = wgn; g_prof.bk = bk & 0xff; g_prof.halo = (bk >> 8) & 1; g_prof.on = true;   // bk | 256 selects conv3_halo_kernel
     return 0;
 }
+/* Per-launch view of the instrumented launches, to be called BEFORE ldm_profile_stop (which frees the events): fills
+ * flops[k] / ms[k] for k < min(n, max) and returns n (the number of instrumented launches) or a negative status. */
+int ldm_profile_detail(double* flops, double* ms, int max) {
+    if (!flops || !ms || max < 0) return fail(LDM_ERR_BAD_ARG, "null argument");
+    const int n = (int)(g_prof.used / 2);
+    for (int k = 0; k < n && k < max; ++k) {
+        HIP_TRY(hipEventSynchronize(g_prof.ev[2 * k + 1]));
+        float t = 0.f; HIP_TRY(hipEventElapsedTime(&t, g_prof.ev[2 * k], g_prof.ev[2 * k + 1]));
+        flops[k] = g_prof.flops[k]; ms[k] = t;
+    }
+    return n;
+}
 /* out[0] = instrumented launches, out[1] = their total ms, out[2] = their total algorithmic FLOPs,
  * out[3] = all conv launches seen, out[4] = algorithmic FLOPs of all conv launches seen */
 int ldm_profile_stop(double out[5]) {

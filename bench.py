@@ -178,6 +178,14 @@ def main():
             for i in range(args.steps):
                 x = step(args.warmup + args.steps + i, x)
             torch.cuda.synchronize()
+            nmax = 64 * args.steps + 64
+            dfl, dms = (C.c_double * nmax)(), (C.c_double * nmax)()
+            nl = L.ldm_profile_detail(dfl, dms, nmax)
+            by_shape = {}
+            for k in range(max(0, min(nl, nmax))):                # launches of one shape have the same algorithmic FLOP count
+                e = by_shape.setdefault(round(dfl[k]), [0, 0.0])
+                e[0] += 1
+                e[1] += dms[k]
             _lib.check(L.ldm_profile_stop(prof))
     assert torch.isfinite(x).all()
 
@@ -220,6 +228,11 @@ def main():
             "launches": int(prof[0]), "avg_launch_us": prof[1] * 1e3 / prof[0],
             "algorithmic_gflop_per_launch": prof[2] / prof[0] / 1e9,
             "share_of_conv_flops": prof[2] / prof[4] if prof[4] else None,
+            # the same measurement split by launch shape (identified by its algorithmic FLOP count): the 24^3 launches carry the
+            # FLOPs, the split-K 12^3 / 6^3 launches are bound by the per-launch floor
+            "by_shape": [{"gflop_per_launch": fl / 1e9, "launches_per_step": n / args.steps, "avg_launch_us": ms * 1e3 / n,
+                          "tflops": fl * n / (ms * 1e-3) / 1e12, "frac": fl * n / (ms * 1e-3) / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS}
+                         for fl, (n, ms) in sorted(by_shape.items(), reverse=True)],
             "whole_step_frac_of_mfma_peak": UNET_STEP_GFLOP / ms_per_step / MFMA_BF16_DENSE_PEAK_TFLOPS,
             "how": "HIP events on the launch stream around every launch of this kernel, second pass of the same K steps; "
                    "traffic = HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), read side x2 per "

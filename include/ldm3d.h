@@ -206,6 +206,7 @@ int ldm_op_attention_bwd(const void* qkv, const void* o, const void* d_o, const 
  *      out = {instrumented launches, their total ms, their algorithmic FLOPs, all conv launches, all conv FLOPs}.
  *      plan_conv_cfgs lists the {wgm, wgn, bk, splitk} the planner chose per conv of a plan ("unet"|"enc"|"dec"). -- */
 int ldm_profile_start(int wgm, int wgn, int bk, int max_launches);
+int ldm_profile_detail(double* flops, double* ms, int max);   /* per instrumented launch; call before ldm_profile_stop; returns their number */
 int ldm_profile_stop(double out[5]);
 int ldm_model_plan_conv_cfgs(ldm_model* m, const char* kind, int B, int D, int H, int W, int* cfgs, int max_convs);
 
