@@ -305,3 +305,28 @@ def test_unet_graph_replay_is_bit_identical_to_eager(cuda):
         r2 = m(x=xs[0], timesteps=t).clone()
         m.enable_graph_replay(False)
         assert torch.equal(r2, m(x=xs[0], timesteps=t))
+
+
+def test_upsample_phase_convs_match_fused_upsample_form(cuda, monkeypatch):
+    """Inference plans run (nearest x2 upsample -> 3^3 conv) as eight 2^3 phase convolutions with pre-summed weights
+    (DESIGN.md section 3.1c); LDM_CONV_PHASE=0 keeps the 27-tap fused-upsample form.  Both forms sit inside the noise-floor
+    gate of the oracle, for the UNet (one upsampler) and for the VAE decoder (two)."""
+    from oracle import autoencoder as oa
+    from oracle import unet as ou
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn((2, 4, 8, 12, 4), generator=g)
+    t = torch.tensor([37.0, 911.0])
+    z = torch.randn((1, cfgs.VAE_TINY["latent_channels"], 4, 4, 4), generator=g)
+    outs = {}
+    for phase in ("1", "0"):
+        monkeypatch.setenv("LDM_CONV_PHASE", phase)
+        m, sd = _unet_pair(cfgs.UNET_TINY, 1, cuda)          # plans are built per module instance: the knob is read then
+        v, vsd = _vae_pair(cfgs.VAE_TINY, 7, cuda)
+        with torch.no_grad():
+            outs[phase] = (m(x=x.to(cuda), timesteps=t.to(cuda)).cpu(), v.decode_stage_2_outputs(z.to(cuda)).cpu())
+    ref_bf, ref32 = ou.unet_forward(sd, cfgs.UNET_TINY, x, t, emulate_bf16=True), ou.unet_forward(sd, cfgs.UNET_TINY, x, t, emulate_bf16=False)
+    dec_bf, dec32 = oa.decode(vsd, cfgs.VAE_TINY, z, emulate_bf16=True), oa.decode(vsd, cfgs.VAE_TINY, z, emulate_bf16=False)
+    for phase in ("1", "0"):
+        floor_gate(outs[phase][0], ref_bf, ref32, f"UNet, LDM_CONV_PHASE={phase}")
+        floor_gate(outs[phase][1], dec_bf, dec32, f"VAE decode, LDM_CONV_PHASE={phase}")
+    assert not torch.equal(outs["1"][0], outs["0"][0])        # the two forms really are different launch plans

@@ -383,3 +383,21 @@ def test_conv3_halo_vs_general_kernel(cuda, built_lib, monkeypatch):
     monkeypatch.setenv("LDM_CONV_HALO", "0")
     e_gen, _ = _conv_case(cuda, built_lib, **kw)
     assert e_halo <= tol and e_gen <= tol, (e_halo, e_gen)
+
+
+# ---------------------------------------------------------------------------------------------- light GEMM (1x1 convolutions)
+@pytest.mark.parametrize("cin,cout,dims,n,residual", [
+    ((256, 0), 256, (12, 12, 12), 1, True),      # out_proj shape of the 12^3 level (32 x 32 wave tiles)
+    ((512, 0), 1536, (6, 6, 6), 1, False),       # q|k|v of the 6^3 level
+    ((128, 128), 96, (5, 7, 3), 2, True),        # two concatenated sources, ragged M, channel padding (cout 96 -> 128 weight rows)
+    ((256, 0), 512, (16, 16, 16), 1, False),     # 64 x 64 wave tiles (>= 256 tiles)
+    ((128, 0), 64, (4, 4, 4), 1, False),         # a single K chunk
+])
+def test_gemm_light_kernel(cuda, built_lib, monkeypatch, cin, cout, dims, n, residual):
+    """1x1 convolutions with Cin % 128 == 0 run on gemm_light_kernel (fragments straight from global memory); the same
+    case on conv_igemm_kernel (LDM_GEMM_LIGHT=0) must also hold: both within the same-rounding tolerance of torch."""
+    kw = dict(cin=cin, cout=cout, dims=dims, n=n, k=1, pad=0, residual=residual, seed=11)
+    e_light, tol = _conv_case(cuda, built_lib, **kw)
+    monkeypatch.setenv("LDM_GEMM_LIGHT", "0")
+    e_gen, _ = _conv_case(cuda, built_lib, **kw)
+    assert e_light <= tol and e_gen <= tol, (e_light, e_gen)
