@@ -127,11 +127,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    # rehearsal of the multi-rank control flow on a one-GPU box: LDM_BENCH_REHEARSAL=1 puts every rank on cuda:0 and uses gloo
+    # (NCCL/RCCL refuses two ranks on one device); the numbers of such a run mean nothing
+    rehearsal = os.environ.get("LDM_BENCH_REHEARSAL", "0") == "1"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", init_method="env://", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            local_rank = 0
+            dist.init_process_group(backend="gloo", init_method="env://")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", init_method="env://", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
 
