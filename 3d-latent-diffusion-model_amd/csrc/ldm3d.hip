@@ -359,6 +359,12 @@ struct Builder {
         }
         const int N = a.xa.N;
         const long M = (long)N * a.Do * a.Ho * a.Wo;
+        {   // the loaders address each source through a buffer descriptor with 32-bit byte offsets
+            const long rows0 = (long)N * a.xa.D * a.xa.H * a.xa.W;
+            const long big = std::max(std::max(rows0 * a.xa.C, a.xb.valid ? rows0 * a.xb.C : 0L),
+                                      a.w1 ? std::max(M * a.g1a.C, a.g1b.valid ? M * a.g1b.C : 0L) : 0L) * 2;
+            if (big >= (1L << 32)) { err = "conv " + tag + ": a source tensor exceeds 4 GiB (split the batch)"; return Act(); }
+        }
         // inference plans run (nearest x2 upsample -> 3^3 conv) as eight 2^3 convs on the source grid (conv_igemm.h, phase mode)
         const bool phase = a.ups == 1 && !a.exact && a.k == 3 && a.stride == 1 && a.pad == 1 && !train && !a.xb.valid && !a.w1 &&
                            a.w_over.base == BASE_NULL && w.wp_off != 0 && phase_enabled() &&

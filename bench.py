@@ -33,11 +33,14 @@ UNET_STEP_GFLOP = 889.1                      # SURVEY.md section 8d / BASELINE.m
 DOMINANT_TILE = (2, 2, 64 | 256)             # conv3_halo_kernel (bk | 256 selects it): 126 voxels x 128 couts x K 64 per step
 
 
-def make_unet(dev, seed=0):
+def make_unet(dev, seed=0, in_channels=None):
     import torch
     import cfgs
     from ldm3d.networks import DiffusionModelUNet
-    m = DiffusionModelUNet(**cfgs.UNET_FULL)
+    cfg = dict(cfgs.UNET_FULL)
+    if in_channels is not None:               # concat-conditioned variant (tools/bench_configs.py)
+        cfg["in_channels"] = in_channels
+    m = DiffusionModelUNet(**cfg)
     g = torch.Generator().manual_seed(seed)
     with torch.no_grad():                     # random init everywhere (MONAI zero-inits conv2/out: zeros would flatter DVFS)
         for name, p in m.named_parameters():
