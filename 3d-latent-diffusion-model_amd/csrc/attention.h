@@ -55,7 +55,8 @@ __global__ __launch_bounds__(64 * QW * S) void attn_fwd_kernel(const AttnParams 
     f32x4 ot[4];                                      // O^T: ot[dt][r] = O[q = fr][d = dt*16 + 4*fg + r]
 #pragma unroll
     for (int i = 0; i < 4; ++i) ot[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float mrun = -INFINITY, lrun = 0.f;               // running max / per-lane partial row sum
+    float mrun = -INFINITY, lrun = 0.f;               // running max (raw score units) / per-lane partial row sum
+    const float cexp = p.scale * 1.44269504088896340736f;     // scale * log2(e)
 
     // staging split (issue early / write late): the global loads of the group's next tile are issued before the MFMAs of
     // the current one and written to the other LDS image after them, so their latency hides under the compute; one barrier
@@ -110,21 +111,23 @@ __global__ __launch_bounds__(64 * QW * S) void attn_fwd_kernel(const AttnParams 
                 st[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[k2], st[j], 0, 0, 0);
             }
         }
-        // ---- online softmax ----------------------------------------------------------------------
-        float tmax = -INFINITY;
+        // ---- online softmax: the running max is kept in RAW score units (scale > 0 commutes with max) and the scale is folded
+        //      into the exponent: p = exp2(s * c - m * c), c = scale * log2(e) -> one FMA + one v_exp per score.  Only the last
+        //      (partial) tile masks keys beyond N. --------------------------------------------------------------------------
+        if (k0 + KT > p.N) {                           // wave-uniform
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = k0 + 16 * j + 4 * fg + r;
-                const float sv = (key < p.N) ? st[j][r] * p.scale : -INFINITY;
-                st[j][r] = sv;
-                tmax = fmaxf(tmax, sv);
-            }
+                for (int r = 0; r < 4; ++r)
+                    if (k0 + 16 * j + 4 * fg + r >= p.N) st[j][r] = -INFINITY;
+        }
+        float tmax = fmaxf(fmaxf(fmaxf(st[0][0], st[0][1]), fmaxf(st[0][2], st[0][3])), fmaxf(fmaxf(st[1][0], st[1][1]), fmaxf(st[1][2], st[1][3])));
+        tmax = fmaxf(tmax, fmaxf(fmaxf(fmaxf(st[2][0], st[2][1]), fmaxf(st[2][2], st[2][3])), fmaxf(fmaxf(st[3][0], st[3][1]), fmaxf(st[3][2], st[3][3]))));
         tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float mnew = fmaxf(mrun, tmax);          // finite: every tile holds >= 1 valid key
-        const float alpha = __expf(mrun - mnew);
+        const float alpha = __builtin_amdgcn_exp2f((mrun - mnew) * cexp);
+        const float mc = -mnew * cexp;
         mrun = mnew;
         float psum = 0.f;
         bf16x8 pf[2];                                  // P^T fragments: k-slot (fg, e): e<4 -> sub-tile 2h, e>=4 -> 2h+1
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(64 * QW * S) void attn_fwd_kernel(const AttnParams 
             float pv[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float pe = __expf(st[2 * h + (e >> 2)][e & 3] - mnew);
+                const float pe = __builtin_amdgcn_exp2f(fmaf(st[2 * h + (e >> 2)][e & 3], cexp, mc));
                 psum += pe;
                 pv[e] = pe;
             }
@@ -143,10 +146,12 @@ __global__ __launch_bounds__(64 * QW * S) void attn_fwd_kernel(const AttnParams 
             pf[h] = *reinterpret_cast<bf16x8*>(&pk);
         }
         lrun = lrun * alpha + psum;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {      // the max rarely moves after the first tiles: skip the rescale then
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
+            for (int dt = 0; dt < 4; ++dt) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ot[dt][r] *= alpha;
+                for (int r = 0; r < 4; ++r) ot[dt][r] *= alpha;
+            }
         }
         // ---- O^T += V^T P^T : the A operand V^T[d][key] comes from the row-major V image through the hardware
         //      transpose read: lane 4q+p of a 16-lane group addresses row (key) q, columns (d) 4p..4p+3 of a 4 x 16 block
@@ -194,7 +199,7 @@ __global__ __launch_bounds__(64 * QW * S) void attn_fwd_kernel(const AttnParams 
             const float* xg = reinterpret_cast<const float*>(smem_all) + (size_t)(g * QW + wave) * (1024 + 32);
             const float mg = xg[1024 + fr], lg = xg[1040 + fr];
             const float mnew = fmaxf(mrun, mg);        // group 0 always owns tile 0: finite
-            const float a0 = __expf(mrun - mnew), a1 = __expf(mg - mnew);      // mg = -inf (group without a tile) -> 0
+            const float a0 = __builtin_amdgcn_exp2f((mrun - mnew) * cexp), a1 = __builtin_amdgcn_exp2f((mg - mnew) * cexp);   // mg = -inf (group without a tile) -> 0
             lrun = lrun * a0 + lg * a1;
             mrun = mnew;
 #pragma unroll
@@ -208,7 +213,7 @@ __global__ __launch_bounds__(64 * QW * S) void attn_fwd_kernel(const AttnParams 
     // ---- normalise and store ------------------------------------------------------------------------
     const float inv = 1.0f / lrun;
     const int qr = q0 + fr;
-    if (p.lse && qr < p.N && fg == 0) p.lse[((size_t)b * p.heads + head) * p.N + qr] = mrun + __logf(lrun);
+    if (p.lse && qr < p.N && fg == 0) p.lse[((size_t)b * p.heads + head) * p.N + qr] = mrun * p.scale + __logf(lrun);
     if (qr < p.N) {
         bf16_t* orow = p.out + ((size_t)b * p.N + qr) * p.C + hoff;
 #pragma unroll
