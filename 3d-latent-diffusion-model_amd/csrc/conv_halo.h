@@ -22,11 +22,16 @@
 
 // ABL: compile-time ablations for timing experiments (LDM_CONV_DBG through the operator-level API only; results are wrong):
 //      4 = no global->LDS copies, 8 = no MFMAs, 16 = no LDS fragment reads, 32 = copies issued but all out of range, 64 = no per-step barrier.
-template <int NSB, int ABL = 0>
+// TALL: the same kernel on a 254-voxel x 64-cout tile (waves 4 x 1 instead of 2 x 2, every wave still 64 x 64): the layers with
+// Cout = 64 (the AutoencoderKL's 96^3 level) get the halo reuse too, and the copied bytes per K step drop to 8 KiB of weights +
+// 32 / 3 KiB of voxels = 18.7 KiB.
+template <int NSB, int ABL = 0, bool TALL = false>
 __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int BM = 128, TM = 126, BN = 128, BK = 64, RB = 128;
+    constexpr int BM = TALL ? 256 : 128, TM = BM - 2, BN = TALL ? 64 : 128, BK = 64, RB = 128;
     constexpr int BT = BN * RB, AT = BM * RB;                  // bytes per weight / voxel tile
+    constexpr int PA = BM / 64, PB = BN / 64;                  // 1 KiB copy pieces per wave: voxel tile, weight tile
+    constexpr int WGM = TALL ? 4 : 2;                          // wave rows (x 2 K groups = row blocks of the GroupNorm fold)
     constexpr int NSA = 3;
     constexpr int AOFF = NSB * BT;                             // voxel ring behind the weight ring
     constexpr int TOFF = AOFF + NSA * AT;                      // (pair, row) -> voxel table
@@ -38,7 +43,7 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, wq = wave & 3;
-    const int wm = wq & 1, wn = wq >> 1;
+    const int wm = TALL ? wq : (wq & 1), wn = TALL ? 0 : (wq >> 1);
 
     const int nwg = gridDim.x;
     int lid = xcd_remap(blockIdx.x, nwg);
@@ -61,7 +66,7 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
     // ---- (pair, LDS row) -> source voxel; LDS row j holds the voxel under tap (kd, kh, kw = 1) of output l0 - 1 + j
     int* const tab = reinterpret_cast<int*>(smem + TOFF);
     for (int e = tid; e < 9 * BM; e += 512) {
-        const int pr = e >> 7, j = e & 127;
+        const int pr = e / BM, j = e % BM;
         const int l = l0 - 1 + j;
         int v = -1;
         if (l >= 0 && l < DHW) {
@@ -72,19 +77,22 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
         tab[e] = v;
     }
 
-    // ---- loader lanes: every wave copies 2 pieces (8 rows x 128 B) of a voxel tile and 2 of a weight tile
+    // ---- loader lanes: every wave copies PA pieces (8 rows x 128 B) of a voxel tile and PB of a weight tile
     const int prow = lane >> 3, pchunk = lane & 7;
-    int a_row[2]; unsigned a_kb[2], a_vo[2], b_vo[2];
+    int a_row[PA]; unsigned a_kb[PA], a_vo[PA], b_vo[PB];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int row = (wave * 2 + j) * 8 + prow;
+    for (int j = 0; j < PA; ++j) {
+        const int row = (wave * PA + j) * 8 + prow;
         a_row[j] = row;
         // 16-byte chunk swizzle keyed by (row & 7): the low swizzle bit equals the row parity, so the 16 rows a
         // ds_read_b128 lane group touches hit 16 different bank quads for ANY row shift (the kw-shifted reads below);
         // the (row >> 1) key of conv_igemm.h is conflict free only for unshifted tiles (2-way conflicts at kw = 1, 2).
         a_kb[j] = (unsigned)((pchunk ^ (row & 7)) * 16);
-        const unsigned b_kb = (unsigned)((pchunk ^ ((row >> 1) & 7)) * 16);
-        const int R = row;                                     // same piece geometry for the weight tile
+    }
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+        const int R = (wave * PB + j) * 8 + prow;              // row of the weight tile
+        const unsigned b_kb = (unsigned)((pchunk ^ ((R >> 1) & 7)) * 16);
         const int q = R >> 6, nt = (R >> 4) & 3, i = R & 15;
         const int co = n0 + 64 * q + 16 * (i >> 2) + 4 * nt + (i & 3);      // see conv_igemm.h: lane ends up with 16 consecutive couts
         b_vo[j] = (ABL & 32) ? 0xFFFFFFFFu : (unsigned)co * cin2 + b_kb;      // ABL 32: every copy out of range (zero fill, no memory traffic)
@@ -97,7 +105,7 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
     int i_pair = q_begin / nch, i_chunk = q_begin - i_pair * nch, i_s = 0;
     unsigned i_aslot = 0;                                      // byte offset of the voxel ring slot of the macro being issued
 #define HL_LOAD_TAB() do {                                                                          \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                             \
+        _Pragma("unroll") for (int j = 0; j < PA; ++j) {                                            \
             const int v_ = tab[i_pair * BM + a_row[j]];                                             \
             a_vo[j] = (v_ >= 0 && !(ABL & 32)) ? (unsigned)v_ * cin2 + a_kb[j] : 0xFFFFFFFFu;       \
         }                                                                                           \
@@ -106,11 +114,11 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
 #define HL_ISSUE(KW, BSLOT) do {                                                                    \
         {                                                                                           \
             const unsigned sb_ = (unsigned)(i_pair * 3 + (KW)) * wtap + (unsigned)i_chunk * (BK * 2);                      \
-            if (!(ABL & 4)) _Pragma("unroll") for (int j = 0; j < 2; ++j)                           \
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr_t)(smem + (BSLOT) * BT + (wave * 2 + j) * 1024), 16, b_vo[j], sb_, 0, 0); \
+            if (!(ABL & 4)) _Pragma("unroll") for (int j = 0; j < PB; ++j)                          \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr_t)(smem + (BSLOT) * BT + (wave * PB + j) * 1024), 16, b_vo[j], sb_, 0, 0); \
             if ((KW) == 0 && !(ABL & 4)) {                                                          \
-                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                       \
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr_t)(smem + AOFF + i_aslot + (wave * 2 + j) * 1024), 16, a_vo[j], \
+                _Pragma("unroll") for (int j = 0; j < PA; ++j)                                      \
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr_t)(smem + AOFF + i_aslot + (wave * PA + j) * 1024), 16, a_vo[j], \
                                                              (unsigned)i_chunk * (BK * 2), 0, 0);  \
             }                                                                                       \
             ++i_s;                                                                                  \
@@ -175,8 +183,8 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
     // ISSUE: 1 = steady state (step S+6 exists), 0 = tail (nothing left to issue: drain).
 #define HL_STEP(J, WC, AC, WN, AN) do {                                                             \
         constexpr int kw_ = (J) % 3, kn_ = ((J) + 1) % 3;                                           \
-        constexpr int vm_ = 8 + 2 * ((((J) + 2) % 3 == 0) + (((J) + 3) % 3 == 0) + (((J) + 4) % 3 == 0) + (((J) + 5) % 3 == 0)); \
-        constexpr int nc_ = (kw_ == 0) ? 4 : 2;                /* copies issued by this step */     \
+        constexpr int vm_ = 4 * PB + PA * ((((J) + 2) % 3 == 0) + (((J) + 3) % 3 == 0) + (((J) + 4) % 3 == 0) + (((J) + 5) % 3 == 0)); \
+        constexpr int nc_ = (kw_ == 0) ? PB + PA : PB;         /* copies issued by this step */     \
         if (kw_ == 0) HL_ADVANCE();                                                                 \
         if (kn_ == 0) c_aslot = (c_aslot == 2 * AT) ? 0u : c_aslot + AT;                            \
         /* hard boundary: s_barrier alone does not stop register-only MFMAs from drifting into the neighbouring step  \
@@ -215,7 +223,7 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
     HL_LOAD_TAB();
     if (nsteps >= 6) {
         HL_ISSUE(0, 0); HL_ISSUE(1, 1); HL_ISSUE(2, 2); HL_ADVANCE(); HL_ISSUE(0, 3); HL_ISSUE(1, 4); HL_ISSUE(2, 5);
-        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // step 0 landed; steps 1..5 = 5 x 2 + 2 (one voxel tile) in flight
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * PB + PA) : "memory");      // step 0 landed; steps 1..5 = 5 weight tiles + one voxel tile in flight
     } else {                                                   // a single macro step in this K range
         HL_ISSUE(0, 0); HL_ISSUE(1, 1); HL_ISSUE(2, 2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -237,7 +245,7 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
     for (; s < nsteps; s += 6) {
 #define HL_TAIL_STEP(J, WC, AC, WN, AN) do {                                                        \
         constexpr int kw_ = (J) % 3, kn_ = ((J) + 1) % 3;                                           \
-        constexpr int vm_ = 8 + 2 * ((((J) + 2) % 3 == 0) + (((J) + 3) % 3 == 0) + (((J) + 4) % 3 == 0) + (((J) + 5) % 3 == 0)); \
+        constexpr int vm_ = 4 * PB + PA * ((((J) + 2) % 3 == 0) + (((J) + 3) % 3 == 0) + (((J) + 4) % 3 == 0) + (((J) + 5) % 3 == 0)); \
         if (kw_ == 0 && i_s < nsteps) HL_ADVANCE();                                                 \
         __builtin_amdgcn_s_waitcnt(0xC07F);                                                         \
         HL_MASK(AC, kw_);                                                                           \
@@ -373,19 +381,19 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
             HL_ROW_ADD(ssq[q], 0x128); HL_ROW_ADD(ssq[q], 0x124); HL_ROW_ADD(ssq[q], 0x122); HL_ROW_ADD(ssq[q], 0x121);
         }
 #undef HL_ROW_ADD
-        // fold the tile's four 32-row blocks through LDS (behind the 64 KiB exchange area) -> ONE slab row per tile
-        float* red = reinterpret_cast<float*>(smem + 65536);               // [4][128 couts][2]
+        // fold the tile's 32-row blocks through LDS (behind the 64 KiB exchange area) -> ONE slab row per tile
+        float* red = reinterpret_cast<float*>(smem + 65536);               // [2 WGM][BN couts][2]
         __syncthreads();
         if (fr == 0) {
-            float* d = red + (((wm * 2 + grp) * 128) + wn * 64 + 16 * fg) * 2;
+            float* d = red + (((wm * 2 + grp) * BN) + wn * 64 + 16 * fg) * 2;
 #pragma unroll
             for (int q = 0; q < 16; ++q) { d[2 * q] = ssum[q]; d[2 * q + 1] = ssq[q]; }
         }
         __syncthreads();
-        if (tid < 128 && n0 + tid < p.CoutS) {
+        if (tid < BN && n0 + tid < p.CoutS) {
             float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-            for (int b = 0; b < 4; ++b) { s0 += red[(b * 128 + tid) * 2]; s1 += red[(b * 128 + tid) * 2 + 1]; }
+            for (int b = 0; b < 2 * WGM; ++b) { s0 += red[(b * BN + tid) * 2]; s1 += red[(b * BN + tid) * 2 + 1]; }
             *reinterpret_cast<float2*>(p.stats + ((size_t)mtile * p.CoutS + n0 + tid) * 2) = make_float2(s0, s1);
         }
     }

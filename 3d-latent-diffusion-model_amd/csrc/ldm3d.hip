@@ -296,6 +296,8 @@ struct Builder {
     std::vector<Tape> tape;
 
     static bool halo_enabled() { const char* e = getenv("LDM_CONV_HALO"); return e ? atoi(e) != 0 : true; }
+    // LDM_HALO_TALL: 0 = never, 1 = wherever the cost model prefers it, 2 (default) = only for Cout % 128 != 0
+    static int tall_mode() { const char* e = getenv("LDM_HALO_TALL"); return e ? atoi(e) : 2; }
     static bool light_enabled() { const char* e = getenv("LDM_GEMM_LIGHT"); return e ? atoi(e) != 0 : true; }
     bool temb_pending = false;
     // measured (MI355X, ROCm 7.2): 14 fork / join pairs per step cost more than the overlapped work saves: 2.36 vs 2.17 ms per
@@ -339,6 +341,24 @@ struct Builder {
                 double t = rounds * (3.0 * qps * c_step + 2500.0);
                 if (skr > 1) t += 6000.0 + (double)M * cout_pad * 4.0 * skr * 2.0 / 2500.0;
                 if (t < best_t) { best_t = t; best = ConvCfg{2, 2, 64, skr}; best.halo = 1; best.mtps = mtps; best.qps = qps; }
+            }
+        }
+        // the tall halo tile (254 voxels x 64 couts, halo = 2): always for Cout % 128 != 0, else where the model says so
+        if (halo_n > 0 && bk == 64 && cout_pad % 64 == 0 && halo_enabled() && tall_mode() != 0) {
+            const int mtps = (int)((halo_dhw + 253) / 254), Q = steps / 3;
+            const long tiles = (long)halo_n * mtps * (cout_pad / 64);
+            const double c_mfma = 256.0 * 64.0 * 64.0 * 2.0 / 4096.0;
+            const double c_load = (256.0 / 3.0 + 64.0) * 128.0 / 28.0;
+            const double c_step = std::max(c_mfma, c_load) + 30.0;
+            for (int sk : splits) {
+                if (sk > 1 && Q / sk < 3) break;
+                const int qps = (Q + sk - 1) / sk, skr = (Q + qps - 1) / qps;
+                const long nwg = tiles * skr;
+                const double rounds = ceil((double)nwg / 256.0);
+                double t = rounds * (3.0 * qps * c_step + 2500.0);
+                if (skr > 1) t += 6000.0 + (double)M * cout_pad * 4.0 * skr * 2.0 / 2500.0;
+                if (tall_mode() == 2 && cout_pad % 128 == 0) t = 1e31;           // mode 2: only where the 128-cout tile cannot run
+                if (t < best_t) { best_t = t; best = ConvCfg{4, 1, 64, skr}; best.halo = 2; best.mtps = mtps; best.qps = qps; }
             }
         }
         return best;
@@ -1286,12 +1306,18 @@ static int launch_conv(const ConvParams& p, const ConvCfg& cc, hipStream_t s) {
     return 0;
 }
 
-static int launch_conv_halo(const ConvParams& p, hipStream_t s) {
+static int launch_conv_halo(const ConvParams& p, hipStream_t s, bool tall = false) {
     constexpr int LDS = 6 * 16384 + 3 * 16384 + 9 * 128 * 4;
+    constexpr int LDS_TALL = 6 * 8192 + 3 * 32768 + 9 * 256 * 4;
     static bool attr_set = false;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_halo_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_halo_kernel<6, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TALL));
         attr_set = true;
+    }
+    if (tall) {
+        hipLaunchKernelGGL((conv3_halo_kernel<6, 0, true>), dim3(p.mtiles * p.ntiles * p.splitk), dim3(512), LDS_TALL, s, p);
+        return 0;
     }
     if (p.dbg & (4 | 8 | 16 | 32 | 64)) {                  // timing ablations (operator-level API + LDM_CONV_DBG only)
 #define ABL_CASE(A) if ((p.dbg & 124) == A) { \
@@ -1305,7 +1331,7 @@ static int launch_conv_halo(const ConvParams& p, hipStream_t s) {
 }
 
 static int launch_conv_impl(const ConvParams& p, const ConvCfg& cc, hipStream_t s) {
-    if (cc.halo) return launch_conv_halo(p, s);
+    if (cc.halo) return launch_conv_halo(p, s, cc.halo == 2);
 #define CASE(M_, N_, K_) if (cc.wgm == M_ && cc.wgn == N_ && cc.bk == K_) return launch_conv_t<M_, N_, K_>(p, s);
     CASE(2, 2, 64) CASE(4, 1, 64) CASE(1, 4, 64) CASE(2, 2, 32) CASE(4, 1, 32) CASE(1, 4, 32)
 #undef CASE
@@ -2150,11 +2176,11 @@ int ldm_op_conv3d(const void* xa, int ca, const void* xb, int cb, const void* w,
     p.CoutS = rup(cout, 32); p.CoutPad = cout_pad; p.CoutReal = cout;
     p.nchunk0 = cin0 / bk; p.nchunk1 = cin1 / bk; p.steps0 = taps * p.nchunk0; p.steps1 = p.nchunk1;
     const bool halo_ok = ksize == 3 && stride == 1 && pad == 1 && ups == 0 && !exact && cb == 0 && cin1 == 0 && bk == 64 &&
-                         cout_pad % 128 == 0 && Builder::halo_enabled();
+                         Builder::halo_enabled();
     ConvCfg cc = Builder::choose_cfg(M, cout_pad, p.steps0 + p.steps1, bk, halo_ok ? N : 0, (long)Do * Ho * Wo);
     if (wgn) {                                       // forced tile shape: wgn = 2 keeps the halo kernel where it applies
         if ((wgn != 1 && wgn != 2 && wgn != 4) || cout_pad % (64 * wgn)) return fail(LDM_ERR_BAD_ARG, "bad wgn");
-        cc.wgn = wgn; cc.wgm = 4 / wgn; cc.halo = (wgn == 2 && halo_ok) ? 1 : 0;
+        cc.wgn = wgn; cc.wgm = 4 / wgn; cc.halo = (wgn == 2 && halo_ok && cout_pad % 128 == 0) ? 1 : (wgn == 1 && halo_ok && Builder::tall_mode() != 0) ? 2 : 0;
     }
     if (splitk) cc.splitk = splitk;
     if (cc.splitk < 1 || cc.splitk > p.steps0 + p.steps1) return fail(LDM_ERR_BAD_ARG, "bad splitk");
@@ -2162,7 +2188,7 @@ int ldm_op_conv3d(const void* xa, int ca, const void* xb, int cb, const void* w,
         const int Q = 9 * p.nchunk0;
         if (cc.splitk > Q) cc.splitk = Q;
         cc.qps = (Q + cc.splitk - 1) / cc.splitk; cc.splitk = (Q + cc.qps - 1) / cc.qps;
-        cc.mtps = (int)(((long)Do * Ho * Wo + 125) / 126);
+        cc.mtps = (int)(((long)Do * Ho * Wo + (cc.halo == 2 ? 253 : 125)) / (cc.halo == 2 ? 254 : 126));
     }
     p.splitk = cc.splitk; p.steps_per_split = cc.halo ? 3 * cc.qps : (p.steps0 + p.steps1 + cc.splitk - 1) / cc.splitk;
     p.halo_mtps = cc.mtps; p.q_per_split = cc.qps;

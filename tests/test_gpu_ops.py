@@ -401,3 +401,11 @@ def test_gemm_light_kernel(cuda, built_lib, monkeypatch, cin, cout, dims, n, res
     monkeypatch.setenv("LDM_GEMM_LIGHT", "0")
     e_gen, _ = _conv_case(cuda, built_lib, **kw)
     assert e_light <= tol and e_gen <= tol, (e_light, e_gen)
+
+
+@pytest.mark.parametrize("cin,cout,dims,n,splitk", [(64, 64, (9, 7, 10), 1, 1), (128, 64, (6, 6, 6), 2, 3), (64, 32, (13, 5, 8), 1, 1)])
+def test_conv3_tall_halo_tile(cuda, built_lib, cin, cout, dims, n, splitk):
+    """conv3_halo_kernel<6, 0, true>: the 254-voxel x 64-cout tile that carries the Cout = 64 layers of the AutoencoderKL
+    (forced here with wgn = 1; ragged last tiles, several samples, split K, channel padding, all epilogue inputs)."""
+    err, tol = _conv_case(cuda, built_lib, cin=(cin, 0), cout=cout, dims=dims, n=n, wgn=1, splitk=splitk, temb=True, residual=True, seed=13)
+    assert err <= tol, err

@@ -20,6 +20,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--what", default="unet", choices=["unet", "enc", "dec"], help="plan: UNet forward at 24^3, or the VAE encode / decode at 96^3")
     args = ap.parse_args()
     path = os.environ.get("LDM_PLAN_TRACE")
     if not path:
@@ -29,12 +30,26 @@ def main():
     import torch
     import bench
     dev = torch.device("cuda:0")
-    unet = bench.make_unet(dev, seed=0)
-    x = torch.randn((1, 4, 24, 24, 24), device=dev)
-    t = torch.tensor([500.0], device=dev)
+    if args.what == "unet":
+        unet = bench.make_unet(dev, seed=0)
+        x = torch.randn((1, 4, 24, 24, 24), device=dev)
+        t = torch.tensor([500.0], device=dev)
+        run = lambda: unet(x=x, timesteps=t)
+    else:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import cfgs
+        from ldm3d.networks import AutoencoderKL
+        vae = AutoencoderKL(**cfgs.VAE_FULL)
+        with torch.no_grad():
+            for p in vae.parameters():
+                if p.dim() > 1:
+                    p.normal_(0.0, 0.02)
+        vae = vae.to(dev).eval()
+        img, lat = torch.rand((1, 1, 96, 96, 96), device=dev), torch.randn((1, 4, 24, 24, 24), device=dev)
+        run = (lambda: vae.encode(img)) if args.what == "enc" else (lambda: vae.decode(lat))
     with torch.no_grad():
         for _ in range(args.warmup + args.steps):
-            unet(x=x, timesteps=t)
+            run()
     torch.cuda.synchronize()
     rows = [ln.rstrip("\n").split(",", 4) for ln in open(path)]
     nops = int(rows[0][0])
