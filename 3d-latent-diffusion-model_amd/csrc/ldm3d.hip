@@ -358,6 +358,7 @@ struct Builder {
                 double t = rounds * (3.0 * qps * c_step + 2500.0);
                 if (skr > 1) t += 6000.0 + (double)M * cout_pad * 4.0 * skr * 2.0 / 2500.0;
                 if (tall_mode() == 2 && cout_pad % 128 == 0) t = 1e31;           // mode 2: only where the 128-cout tile cannot run
+                if (tall_mode() == 3 && skr == 1 && best.halo == 1 && best.splitk == 1) t = 0.0;   // mode 3 (experiments): wherever the 128-cout tile runs unsplit
                 if (t < best_t) { best_t = t; best = ConvCfg{4, 1, 64, skr}; best.halo = 2; best.mtps = mtps; best.qps = qps; }
             }
         }
