@@ -1725,6 +1725,9 @@ static int ensure_arena(ldm_model* m) {
     if (m->arena) return 0;
     HIP_TRY(hipMalloc((void**)&m->arena, m->arena_bytes));
     HIP_TRY(hipMemset(m->arena, 0, m->arena_bytes));
+    // the memset runs on the null stream and may still be in flight when this returns; the uploads that follow go to the
+    // caller's stream, which need not synchronise with the null stream (non-blocking streams): wait here, once per model
+    HIP_TRY(hipDeviceSynchronize());
     return 0;
 }
 
@@ -2131,6 +2134,7 @@ static int ensure_zero_page() {
     if (g_zero_page) return 0;
     HIP_TRY(hipMalloc((void**)&g_zero_page, 8192));
     HIP_TRY(hipMemset(g_zero_page, 0, 8192));
+    HIP_TRY(hipDeviceSynchronize());                 // see ensure_arena
     return 0;
 }
 
@@ -2411,6 +2415,7 @@ int ldm_comm_init(int rank, int world, const char id[128], ldm_comm** out) {
     RCCL_TRY(g_rccl.CommInitRank(&c->comm, world, u, rank));
     HIP_TRY(hipMalloc((void**)&c->token, 256));
     HIP_TRY(hipMemset(c->token, 0, 256));
+    HIP_TRY(hipDeviceSynchronize());
     *out = c.release();
     return 0;
 }

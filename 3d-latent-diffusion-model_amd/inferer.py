@@ -77,3 +77,42 @@ class LatentDiffusionInferer:
         if save_intermediates:
             return out, [autoencoder_model.decode_stage_2_outputs(x / self.scale_factor) for x in intermediates]
         return out
+
+    @torch.no_grad()
+    def sample_concurrent(self, input_noises: Sequence[torch.Tensor], autoencoder_model, diffusion_models: Sequence,
+                          scheduler=None, conditionings: Optional[Sequence[Optional[torch.Tensor]]] = None,
+                          mode: str = "crossattn") -> List[torch.Tensor]:
+        """K independent reverse-diffusion chains on one GPU, one stream and one module instance per chain, advanced
+        round-robin from this thread so that the launches of different chains overlap (a single B = 1 chain is bound by the
+        per-launch floor: DESIGN.md sections 3.5 / 5c).  Same arithmetic per chain as ``sample``; returns the decoded volumes.
+        Not in the reference (it samples one volume at a time, 3d_ldm/inference.py:88-102)."""
+        if len(diffusion_models) < len(input_noises):
+            raise ValueError("one diffusion model instance per chain is needed (each owns a workspace and a launch graph)")
+        scheduler = scheduler or self.scheduler
+        conds = list(conditionings) if conditionings is not None else [None] * len(input_noises)
+        if any(c is not None for c in conds) and mode != "concat":
+            raise NotImplementedError("cross-attention conditioning is not on the reference's path (mode='concat')")
+        dev = input_noises[0].device
+        main = torch.cuda.current_stream(dev)
+        streams = [torch.cuda.Stream(device=dev) for _ in input_noises]
+        images = list(input_noises)
+        tbufs = []
+        for st, img in zip(streams, images):
+            st.wait_stream(main)
+            tbufs.append(torch.empty((img.shape[0],), dtype=torch.float32, device=dev))
+        for t in scheduler.timesteps.tolist():
+            for k, st in enumerate(streams):
+                with torch.cuda.stream(st):
+                    tbufs[k].fill_(float(t))
+                    if conds[k] is not None:
+                        eps = diffusion_models[k](x=images[k], timesteps=tbufs[k], context=None, cond=conds[k])
+                    else:
+                        eps = diffusion_models[k](x=images[k], timesteps=tbufs[k], context=None)
+                    images[k], _ = scheduler.step(eps, t, images[k])
+        outs = []
+        for k, st in enumerate(streams):                    # the autoencoder (one workspace) decodes the chains one after another
+            main.wait_stream(st)
+            images[k].record_stream(main)
+            latent = images[k] if self.scale_factor == 1.0 else images[k] / self.scale_factor
+            outs.append(autoencoder_model.decode_stage_2_outputs(latent) if autoencoder_model is not None else latent)
+        return outs

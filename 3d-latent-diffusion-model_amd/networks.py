@@ -442,7 +442,12 @@ class AutoencoderKL(_LdmModule):
         self._need_cuda(x, "AutoencoderKL.encode")
         if torch.is_grad_enabled() and x.requires_grad:
             raise NotImplementedError("backward through the HIP AutoencoderKL is not implemented yet (inference only)")
+        if x.dim() != 5 or x.shape[1] != self.in_channels:
+            raise _lib.LdmError(f"AutoencoderKL.encode: expected an image [B, {self.in_channels}, D, H, W], got {tuple(x.shape)}")
         B, _, D, H, W = x.shape
+        if eps is not None and tuple(eps.shape) != (B, self.latent_channels, D // self.factor, H // self.factor, W // self.factor):
+            raise _lib.LdmError(f"AutoencoderKL.encode: eps has shape {tuple(eps.shape)}, expected "
+                                f"{(B, self.latent_channels, D // self.factor, H // self.factor, W // self.factor)}")
         x = x.detach().to(torch.float32).contiguous()
         self._sync_weights()
         L = _lib.lib()
@@ -482,6 +487,8 @@ class AutoencoderKL(_LdmModule):
         self._need_cuda(z, "AutoencoderKL.decode")
         if torch.is_grad_enabled() and z.requires_grad:
             raise NotImplementedError("backward through the HIP AutoencoderKL is not implemented yet (inference only)")
+        if z.dim() != 5 or z.shape[1] != self.latent_channels:     # the C entry takes a raw pointer: a wrong channel count would read past the tensor
+            raise _lib.LdmError(f"AutoencoderKL.decode: expected a latent [B, {self.latent_channels}, d, h, w], got {tuple(z.shape)}")
         B, _, d, h, w = z.shape
         z = z.detach().to(torch.float32).contiguous()
         self._sync_weights()

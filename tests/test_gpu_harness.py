@@ -44,6 +44,8 @@ def test_train_then_conditional_sampling(tmp_path):
     _run("inference.py", env_file, "-n", "3", "--batch", "2", "--steps", "4", "--condition", pair)
     vols = sorted(glob.glob(str(tmp_path / "out" / "*.nii")))
     assert len(vols) == 3
+    _run("inference.py", env_file, "-n", "4", "--batch", "1", "--chains", "2", "--steps", "4", "--condition", pair)   # two concurrent chains
+    assert len(glob.glob(str(tmp_path / "out" / "*.nii"))) == 7
     with open(vols[0], "rb") as fh:                      # NIfTI-1 header: sizeof_hdr 348, dim[1..3] = the decoded volume
         hdr = fh.read(348)
     assert struct.unpack("<i", hdr[:4])[0] == 348

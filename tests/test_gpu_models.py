@@ -330,3 +330,30 @@ def test_upsample_phase_convs_match_fused_upsample_form(cuda, monkeypatch):
         floor_gate(outs[phase][0], ref_bf, ref32, f"UNet, LDM_CONV_PHASE={phase}")
         floor_gate(outs[phase][1], dec_bf, dec32, f"VAE decode, LDM_CONV_PHASE={phase}")
     assert not torch.equal(outs["1"][0], outs["0"][0])        # the two forms really are different launch plans
+
+
+def test_sample_concurrent_equals_sequential_sampling(cuda):
+    """LatentDiffusionInferer.sample_concurrent: two chains advanced round-robin on their own streams (own module instance
+    each, graph replay on) give bit for bit what ``sample`` gives for each noise tensor on its own."""
+    from ldm3d.inferer import LatentDiffusionInferer
+    from ldm3d.schedulers import DDIMScheduler
+    m1, sd = _unet_pair(cfgs.UNET_TINY, 3, cuda)
+    m2, _ = _unet_pair(cfgs.UNET_TINY, 3, cuda)
+    m_ref, _ = _unet_pair(cfgs.UNET_TINY, 3, cuda)
+    v, _ = _vae_pair(cfgs.VAE_TINY, 7, cuda)
+    for m in (m1, m2):
+        m.enable_graph_replay(True)
+    sch = DDIMScheduler(**cfgs.SCHED)
+    sch.set_timesteps(5)
+    inf = LatentDiffusionInferer(sch, scale_factor=0.8)
+    g = torch.Generator().manual_seed(31)
+    zs = [torch.randn((1, 4, 4, 4, 4), generator=g).to(cuda), torch.randn((2, 4, 4, 4, 4), generator=g).to(cuda)]
+    with pytest.raises(Exception, match="expected a latent"):       # 4-channel UNet latents do not fit the 8-channel tiny VAE
+        v.decode_stage_2_outputs(zs[0])
+    v, _ = _vae_pair(dict(cfgs.VAE_TINY, latent_channels=4), 7, cuda)
+    with torch.no_grad():
+        seq = [inf.sample(input_noise=z, autoencoder_model=v, diffusion_model=m_ref, scheduler=sch) for z in zs]
+        con = inf.sample_concurrent(zs, v, [m1, m2], scheduler=sch)
+    torch.cuda.synchronize()
+    for a, b in zip(seq, con):
+        assert a.shape == b.shape and torch.equal(a, b)
