@@ -283,6 +283,8 @@ class DiffusionModelUNet(_LdmModule):
         cc = 0
         if cond is not None:
             cond = cond.detach().to(device=x.device, dtype=torch.float32).contiguous()
+            if cond.dim() != 5 or cond.shape[0] != B or tuple(cond.shape[2:]) != (D, H, W):
+                raise ValueError(f"cond must be [{B}, C, {D}, {H}, {W}], got {tuple(cond.shape)}")
             cc = cond.shape[1]
         t = timesteps.detach().to(device=x.device, dtype=torch.float32).reshape(-1).contiguous()
         if t.numel() != B:
@@ -336,6 +338,8 @@ class DiffusionModelUNet(_LdmModule):
         cc = 0
         if cond is not None:
             cond = cond.detach().to(device=x.device, dtype=torch.float32).contiguous()
+            if cond.dim() != 5 or cond.shape[0] != B or tuple(cond.shape[2:]) != (D, H, W):
+                raise ValueError(f"cond must be [{B}, C, {D}, {H}, {W}], got {tuple(cond.shape)}")
             cc = cond.shape[1]
         t = timesteps.detach().to(device=x.device, dtype=torch.float32).reshape(-1).contiguous()
         if t.numel() != B:
