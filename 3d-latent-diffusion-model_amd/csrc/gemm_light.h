@@ -137,12 +137,15 @@ __global__ __launch_bounds__(64) void gemm_light_kernel(const LightParams p) {
 // tile choice: 64 x 64 per wave once that still gives every CU a wave, else 32 x 32
 static inline hipError_t launch_gemm_light(const LightParams& p0, int cout_pad, int big, hipStream_t s) {
     LightParams p = p0;
+    const bool k128 = p.K % 128 == 0;               // else K = 32 / 64 / 96 (im2col first convs): one K step per register chunk
     if (big) {
         p.mtiles = (p.M + 63) / 64;
-        hipLaunchKernelGGL((gemm_light_kernel<4, 4, 2>), dim3(p.mtiles * (cout_pad / 64)), dim3(64), 0, s, p);
+        if (k128) hipLaunchKernelGGL((gemm_light_kernel<4, 4, 2>), dim3(p.mtiles * (cout_pad / 64)), dim3(64), 0, s, p);
+        else hipLaunchKernelGGL((gemm_light_kernel<4, 4, 1>), dim3(p.mtiles * (cout_pad / 64)), dim3(64), 0, s, p);
     } else {
         p.mtiles = (p.M + 31) / 32;
-        hipLaunchKernelGGL((gemm_light_kernel<2, 2, 4>), dim3(p.mtiles * (cout_pad / 32)), dim3(64), 0, s, p);
+        if (k128) hipLaunchKernelGGL((gemm_light_kernel<2, 2, 4>), dim3(p.mtiles * (cout_pad / 32)), dim3(64), 0, s, p);
+        else hipLaunchKernelGGL((gemm_light_kernel<2, 2, 1>), dim3(p.mtiles * (cout_pad / 32)), dim3(64), 0, s, p);
     }
     return hipGetLastError();
 }
@@ -151,5 +154,6 @@ static inline int gemm_light_big(long M, int cout_pad) {
     return ((M + 63) / 64) * (cout_pad / 64) >= thr;
 }
 static inline bool gemm_light_ok(int k, int stride, int ups, int cin, bool single_source, bool plain_epilogue) {
-    return k == 1 && stride == 1 && ups == 0 && single_source && plain_epilogue && cin % 128 == 0 && cin <= 2048;
+    return k == 1 && stride == 1 && ups == 0 && single_source && plain_epilogue && cin <= 2048 &&
+           (cin % 128 == 0 || (cin % 32 == 0 && cin < 128));
 }

@@ -71,7 +71,8 @@ enum OpKind { OP_PACK, OP_CONV, OP_FINALIZE, OP_GN_STATS, OP_GN_FINALIZE, OP_GN_
               OP_GEMV, OP_VAE_HEADS, OP_GN_FUSED,
               // backward (training plans only)
               OP_WT, OP_WT_BATCH, OP_WGRAD, OP_EXPORT, OP_EXPORT_BATCH, OP_COLSUM, OP_GNB, OP_ATTN_BWD, OP_ADD, OP_SUMPOOL, OP_LIN_DX, OP_LIN_DW, OP_VAE_HEADS_BWD,
-              OP_GEMM_LIGHT };                     // 1x1 convolution with short K (gemm_light.h)
+              OP_GEMM_LIGHT,                       // 1x1 convolution with short K (gemm_light.h)
+              OP_IM2COL };                         // fp32 NCDHW inputs -> bf16 patch matrix of the first conv (pack_im2col_kernel)
 
 struct ConvCfg { int wgm, wgn, bk, splitk; int halo = 0, mtps = 0, qps = 0; };   // halo: conv3_halo_kernel (126-row tiles)
 
@@ -183,6 +184,18 @@ struct ldm_model {
     // call after any parameter upload
     struct PhaseW { size_t w_off, wp_off; int cout_pad, cin_s; };
     std::vector<PhaseW> phase_ws; bool derived_dirty = true;
+    struct Im2colW { size_t w_off, wi_off; int cout_pad, cin_s, cin, Kp; };     // first convs run as im2col + GEMM (inference plans)
+    std::vector<Im2colW> im2col_ws;
+    static int im2col_k(int cin) { const int k = 27 * cin; return k <= 96 ? rup(k, 32) : rup(k, 128); }
+    // registers <name>.im2col: a 1x1 "conv" over the patch matrix whose weights are derived from <name>'s packed 3^3 weights
+    void reg_im2col(const std::string& name, int cin) {
+        if (cin > 9) return;
+        const ConvW& c3 = convs.at(name);
+        ConvW c = c3; c.k = 1; c.cin_s = im2col_k(cin); c.wp_off = 0;
+        c.w_off = arena_alloc((size_t)c.cout_pad * c.cin_s * 2);
+        im2col_ws.push_back(Im2colW{c3.w_off, c.w_off, c3.cout_pad, c3.cin_s, cin, c.cin_s});
+        convs[name + ".im2col"] = c;
+    }
     int64_t flat_total = 0;
     void add_param(const ParamDesc& d) {
         pindex[d.name] = (int)params.size(); params.push_back(d);
@@ -542,6 +555,23 @@ struct Builder {
         return out;
     }
 
+    // first conv of a network as im2col + light GEMM (inference plans; the training tape keeps the 3^3 form): r0 / r1 = the fp32
+    // NCDHW inputs (x | cond).  Returns an invalid Act when the model has no derived weights for it.
+    static bool im2col_enabled() { const char* e = getenv("LDM_CONV_IM2COL"); return e ? atoi(e) != 0 : true; }
+    Act conv_in_im2col(const std::string& name, Ref r0, Ref r1, int N, int D, int H, int W, int cin, bool internal) {
+        auto it = m->convs.find(name + ".im2col");
+        if (train || it == m->convs.end() || !im2col_enabled() || !light_enabled()) return Act();
+        const ConvW& wi = it->second;
+        Act pm = new_act(N, D, H, W, wi.cin_s);
+        Op o{}; o.kind = OP_IM2COL; o.r[0] = r0; o.r[1] = r1; o.r[2] = ws_ref(pm.off);
+        o.i[0] = N; o.i[1] = cin; o.i[2] = wi.cin_s; o.i[3] = D; o.i[4] = H; o.i[5] = W; o.i[6] = internal ? 1 : 0;
+        plan->ops.push_back(o);
+        ConvArgs a; a.xa = pm; a.w = &wi; a.k = 1; a.pad = 0; a.Do = D; a.Ho = H; a.Wo = W;
+        Act out = conv(a, name + ".im2col");
+        free_act(pm);
+        return out;
+    }
+
     // ---- blocks ---------------------------------------------------------------------------------------
     Act conv3(const std::string& name, const Act& x, int stride = 1, int pad = 1, int ups = 0) {
         ConvArgs a; a.xa = x; a.w = &m->convs.at(name); a.k = 3; a.stride = stride; a.pad = pad; a.ups = ups;
@@ -879,6 +909,7 @@ static int unet_register(ldm_model* m) {
         if (cin != cout) m->reg_conv(p + ".skip_connection", cin, cin, cout, 1);
     };
     m->reg_conv("conv_in", c.in_channels, rup(c.in_channels, 32), ch[0], 3);
+    m->reg_im2col("conv_in", c.in_channels);
     m->reg_linear("time_embed.0", ch[0], temb);
     m->reg_linear("time_embed.2", temb, temb);
     int oc = ch[0];
@@ -952,12 +983,16 @@ static int unet_build(ldm_model* m, int B, int D, int H, int W, Plan* plan, bool
 
     // ---- pack input (x | cond) -> NDHWC bf16, channels padded to 32
     const int cin_s = rup(c.in_channels, 32);
-    Act xin = b.new_act(B, D, H, W, cin_s);
-    { Op o{}; o.kind = OP_PACK; o.r[0] = io_ref(0); o.r[1] = io_ref(1); o.r[2] = ws_ref(xin.off);
-      o.i[0] = B; o.i[1] = c.in_channels; o.i[2] = cin_s; o.i[3] = D * H * W; plan->ops.push_back(o); }
-    Act h = b.conv3("conv_in", xin);
-    if (train && !b.tape.empty()) b.tape.back().leaf_input = true;        // no gradient w.r.t. the network input
-    b.free_act(xin);
+    Act h = b.conv_in_im2col("conv_in", io_ref(0), io_ref(1), B, D, H, W, c.in_channels, false);
+    if (!h.valid) {
+        if (!b.err.empty()) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
+        Act xin = b.new_act(B, D, H, W, cin_s);
+        { Op o{}; o.kind = OP_PACK; o.r[0] = io_ref(0); o.r[1] = io_ref(1); o.r[2] = ws_ref(xin.off);
+          o.i[0] = B; o.i[1] = c.in_channels; o.i[2] = cin_s; o.i[3] = D * H * W; plan->ops.push_back(o); }
+        h = b.conv3("conv_in", xin);
+        if (train && !b.tape.empty()) b.tape.back().leaf_input = true;        // no gradient w.r.t. the network input
+        b.free_act(xin);
+    }
     if (!h.valid) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
     std::vector<Act> skips; skips.push_back(h);
     char p[96];
@@ -1110,7 +1145,9 @@ static int vae_register(ldm_model* m) {
             switch (bl.kind) {
                 case 0: {   // plain Convolution: keys <p>.conv.*
                     ConvW cw = m->new_conv_slot(rup(bl.a, 32), bl.b, 3);
-                    m->reg_conv_into(p, cw, bl.a, bl.b, 3, 0, false); m->convs[p] = cw; break; }
+                    m->reg_conv_into(p, cw, bl.a, bl.b, 3, 0, false); m->convs[p] = cw;
+                    if (k == 0 && std::string(prefix) == "encoder") m->reg_im2col(p, bl.a);       // the encoder's first conv
+                    break; }
                 case 1:
                     m->reg_gn(std::string(p) + ".norm1", bl.a); m->reg_conv(std::string(p) + ".conv1", bl.a, bl.a, bl.b, 3);
                     m->reg_gn(std::string(p) + ".norm2", bl.b); m->reg_conv(std::string(p) + ".conv2", bl.b, bl.b, bl.b, 3);
@@ -1138,8 +1175,8 @@ static int vae_register(ldm_model* m) {
 }
 
 static int vae_run_layout(Builder& b, const char* prefix, const std::vector<AeBlock>& lay, Act h, int G, float eps,
-                          bool last_f32, int io_out, Act* out) {
-    for (size_t k = 0; k < lay.size(); ++k) {
+                          bool last_f32, int io_out, Act* out, size_t k0 = 0) {
+    for (size_t k = k0; k < lay.size(); ++k) {
         char p[96]; snprintf(p, sizeof p, "%s.blocks.%zu", prefix, k);
         const AeBlock& bl = lay[k];
         Act hn;
@@ -1175,11 +1212,17 @@ static int vae_build_encode(ldm_model* m, int B, int D, int H, int W, Plan* plan
     const ldm_vae_cfg& c = m->vcfg;
     Builder b; b.m = m; b.plan = plan;
     const int cs = rup(c.in_channels, 32);
-    Act xin = b.new_act(B, D, H, W, cs);
-    { Op o{}; o.kind = OP_PACK; o.r[0] = io_ref(0); o.r[1] = Ref(); o.r[2] = ws_ref(xin.off);
-      o.i[0] = B; o.i[1] = c.in_channels; o.i[2] = cs; o.i[3] = D * H * W; plan->ops.push_back(o); }
     Act h;
-    LDM_TRY(vae_run_layout(b, "encoder", ae_encoder_layout(c), xin, c.norm_num_groups, c.norm_eps, false, 0, &h));
+    Act first = b.conv_in_im2col("encoder.blocks.0", io_ref(0), Ref(), B, D, H, W, c.in_channels, true);
+    if (first.valid) {
+        LDM_TRY(vae_run_layout(b, "encoder", ae_encoder_layout(c), first, c.norm_num_groups, c.norm_eps, false, 0, &h, 1));
+    } else {
+        if (!b.err.empty()) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
+        Act xin = b.new_act(B, D, H, W, cs);
+        { Op o{}; o.kind = OP_PACK; o.r[0] = io_ref(0); o.r[1] = Ref(); o.r[2] = ws_ref(xin.off);
+          o.i[0] = B; o.i[1] = c.in_channels; o.i[2] = cs; o.i[3] = D * H * W; plan->ops.push_back(o); }
+        LDM_TRY(vae_run_layout(b, "encoder", ae_encoder_layout(c), xin, c.norm_num_groups, c.norm_eps, false, 0, &h));
+    }
     // fused 1x1 heads -> fp32 [B][2L][dhw] scratch, then clamp/exp/sample
     const int dhw = h.D * h.H * h.W;
     const size_t ml_off = b.pool.alloc((size_t)B * 2 * c.latent_channels * dhw * 4);
@@ -1459,6 +1502,14 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                 if (cx + cc != i[1]) return fail(LDM_ERR_BAD_ARG, "x_channels + cond_channels = %d, model expects %d", cx + cc, i[1]);
                 hipLaunchKernelGGL(pack2_ncdhw_kernel, dim3(grid_for(total)), dim3(256), 0, s, (const float*)rp(bs, o.r[0]), cx,
                                    (const float*)rp(bs, o.r[1]), cc, (bf16_t*)rp(bs, o.r[2]), i[0], i[2], i[3]);
+                break; }
+            case OP_IM2COL: {           // i: N, cin, Kp, D, H, W, internal
+                int cx = rt[0], cc = rt[1];
+                if (i[6]) { cx = i[1]; cc = 0; }
+                if (cx + cc != i[1]) return fail(LDM_ERR_BAD_ARG, "x_channels + cond_channels = %d, model expects %d", cx + cc, i[1]);
+                const long total = (long)i[0] * i[3] * i[4] * i[5] * (i[2] / 8);
+                hipLaunchKernelGGL(pack_im2col_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0, s, (const float*)rp(bs, o.r[0]), cx,
+                                   (const float*)rp(bs, o.r[1]), cc, (bf16_t*)rp(bs, o.r[2]), i[0], i[3], i[4], i[5], i[2]);
                 break; }
             case OP_CONV: case OP_FINALIZE: {
                 ConvParams p{};
@@ -1765,6 +1816,9 @@ int ldm_model_load_param(ldm_model* m, const char* name, const float* src, size_
 // phase weights of the upsample convs, rebuilt (stream-ordered) after a parameter upload: called by the inference entries
 static int ensure_derived(ldm_model* m, hipStream_t s) {
     if (!m->derived_dirty) return 0;
+    for (const auto& iw : m->im2col_ws)
+        hipLaunchKernelGGL(im2col_weights_kernel, dim3((unsigned)((iw.cout_pad * iw.Kp + 255) / 256)), dim3(256), 0, s,
+                           (const bf16_t*)(m->arena + iw.w_off), (bf16_t*)(m->arena + iw.wi_off), iw.cout_pad, iw.cin_s, iw.cin, iw.Kp);
     for (const auto& pw : m->phase_ws) {
         const long vecs = (long)pw.cout_pad * pw.cin_s / 8;
         hipLaunchKernelGGL(phase_weights_kernel, dim3((unsigned)((vecs + 255) / 256), 64), dim3(256), 0, s,
@@ -2029,6 +2083,7 @@ int ldm_vae_encode(ldm_model* m, const float* x, const float* eps, float* z_mu, 
     Bases bs{}; bs.p[BASE_WS] = (char*)workspace; bs.p[BASE_W] = m->arena;
     bs.p[BASE_IO0] = (char*)x; bs.p[BASE_IO1] = (char*)eps; bs.p[BASE_IO2] = (char*)z_mu; bs.p[BASE_IO3] = (char*)z_sigma; bs.p[BASE_IO4] = (char*)z;
     const int rt[2] = {m->vcfg.in_channels, 0};
+    LDM_TRY(ensure_derived(m, (hipStream_t)stream));
     return run_plan(*p, bs, rt, (hipStream_t)stream);
 }
 

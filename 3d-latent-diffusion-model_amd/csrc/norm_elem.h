@@ -1091,3 +1091,51 @@ __global__ __launch_bounds__(256) void phase_weights_kernel(const bf16_t* __rest
     for (int q = 0; q < 4; ++q) o[q] = pack2bf(acc[2 * q], acc[2 * q + 1]);
     *reinterpret_cast<u32x4*>(wp + (size_t)blockIdx.y * mat + idx * 8) = o;
 }
+
+// ------------------------------------------------------------------------------------------------
+// First conv of a network (Cin <= 9) as im2col + GEMM: row m of the patch matrix holds the 27 taps x Cin input values of output
+// voxel m (k = tap * Cin + c; zero padding and the pad columns k >= 27 Cin are written as zeros), straight from the fp32 NCDHW
+// inputs (x | cond channel-concatenated).  The 3^3 conv over 1..8 real channels padded to 32 becomes ONE K step of 32..256.
+// thread = one 8-element vector of one row.
+__global__ __launch_bounds__(256) void pack_im2col_kernel(const float* __restrict__ x, int cx, const float* __restrict__ cond, int cc,
+                                                          bf16_t* __restrict__ out, int N, int D, int H, int W, int Kp) {
+    const int cin = cx + cc, DHW = D * H * W, HW = H * W, vecs = Kp / 8;
+    const long total = (long)N * DHW * vecs;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int vq = (int)(i % vecs);
+        const long row = i / vecs;
+        const int n = (int)(row / DHW), sp = (int)(row - (long)n * DHW);
+        const int d = sp / HW, r = sp - d * HW, h = r / W, w = r - h * W;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = vq * 8 + e;
+            float val = 0.f;
+            if (k < 27 * cin) {
+                const int tap = k / cin, c = k - tap * cin;
+                const int kd = tap / 9, kh = (tap - kd * 9) / 3, kw = tap - kd * 9 - kh * 3;
+                const int id = d + kd - 1, ih = h + kh - 1, iw = w + kw - 1;
+                if ((unsigned)id < (unsigned)D && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
+                    const int spi = (id * H + ih) * W + iw;
+                    val = c < cx ? x[((size_t)n * cx + c) * DHW + spi] : cond[((size_t)n * cc + (c - cx)) * DHW + spi];
+                }
+            }
+            v[e] = val;
+        }
+        u32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = pack2bf(v[2 * q], v[2 * q + 1]);
+        *reinterpret_cast<u32x4*>(out + i * 8) = o;
+    }
+}
+
+// its weights: w2[co][tap * cin + c] = w3[tap][co][c] from the packed [27][cout_pad][cin_s] matrix (pad columns zero)
+__global__ __launch_bounds__(256) void im2col_weights_kernel(const bf16_t* __restrict__ w3, bf16_t* __restrict__ w2, int cout_pad, int cin_s,
+                                                             int cin, int Kp) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= cout_pad * Kp) return;
+    const int co = i / Kp, k = i - co * Kp;
+    bf16_t v = 0;
+    if (k < 27 * cin) { const int tap = k / cin, c = k - tap * cin; v = w3[((size_t)tap * cout_pad + co) * cin_s + c]; }
+    w2[i] = v;
+}

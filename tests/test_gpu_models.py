@@ -313,7 +313,7 @@ def test_upsample_phase_convs_match_fused_upsample_form(cuda, monkeypatch):
     gate of the oracle, for the UNet (one upsampler) and for the VAE decoder (two)."""
     from oracle import autoencoder as oa
     from oracle import unet as ou
-    g = torch.Generator().manual_seed(21)
+    g = torch.Generator().manual_seed(2)                       # the input of test_unet_tiny_matches_oracle's (8, 12, 4) case
     x = torch.randn((2, 4, 8, 12, 4), generator=g)
     t = torch.tensor([37.0, 911.0])
     z = torch.randn((1, cfgs.VAE_TINY["latent_channels"], 4, 4, 4), generator=g)
@@ -357,3 +357,32 @@ def test_sample_concurrent_equals_sequential_sampling(cuda):
     torch.cuda.synchronize()
     for a, b in zip(seq, con):
         assert a.shape == b.shape and torch.equal(a, b)
+
+
+def test_first_conv_im2col_form_matches_3x3x3_form(cuda, monkeypatch):
+    """Inference plans run the networks' first conv (Cin <= 9) as im2col + light GEMM with derived weights (pack_im2col_kernel,
+    im2col_weights_kernel); LDM_CONV_IM2COL=0 keeps the 3^3 conv over the channel-padded input.  Same products, different fp32
+    summation order: a 1-level UNet (where rounding noise has no depth to grow) agrees to 1e-2 between the forms, with and without
+    a concatenated condition, and the VAE encoder (Cin = 2) stays inside the oracle's noise-floor gate."""
+    from oracle import autoencoder as oa
+    cfg = dict(spatial_dims=3, in_channels=8, out_channels=4, channels=[64], attention_levels=[False], num_head_channels=64,
+               num_res_blocks=1, norm_num_groups=32)
+    g = torch.Generator().manual_seed(51)
+    x, cond = torch.randn((2, 4, 6, 5, 7), generator=g), torch.randn((2, 4, 6, 5, 7), generator=g)
+    xfull = torch.randn((1, 8, 6, 6, 6), generator=g)
+    t = torch.tensor([100.0, 800.0])
+    img = torch.rand((1, cfgs.VAE_TINY["in_channels"], 16, 8, 12), generator=g)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("LDM_CONV_IM2COL", mode)
+        m, sd = _unet_pair(cfg, 5, cuda)
+        v, vsd = _vae_pair(cfgs.VAE_TINY, 7, cuda)
+        with torch.no_grad():
+            outs[mode] = (m(x=x.to(cuda), timesteps=t.to(cuda), cond=cond.to(cuda)).cpu(), m(x=xfull.to(cuda), timesteps=t[:1].to(cuda)).cpu(),
+                          v.encode(img.to(cuda))[0].cpu())
+    assert rel_l2(outs["1"][0], outs["0"][0]) <= 1e-2 and rel_l2(outs["1"][1], outs["0"][1]) <= 1e-2
+    assert not torch.equal(outs["1"][0], outs["0"][0])
+    mu_bf, _ = oa.encode(vsd, cfgs.VAE_TINY, img, emulate_bf16=True)
+    mu_32, _ = oa.encode(vsd, cfgs.VAE_TINY, img, emulate_bf16=False)
+    for mode in ("1", "0"):
+        floor_gate(outs[mode][2], mu_bf, mu_32, f"VAE encode mu, LDM_CONV_IM2COL={mode}")
