@@ -500,7 +500,7 @@ struct Builder {
         auto blocks_of = [&](const Act& t) { return t.stats_nrb > 0 ? t.stats_nrb : (N == 1 ? (DHW + 31) / 32 : DHW / 32); };
         const bool fused = blocks_ok(xa) && (!xb.valid || blocks_ok(xb));
         const int nrb_tot = fused ? blocks_of(xa) + (xb.valid ? blocks_of(xb) : 0) : 0;
-        if (fused && C / groups <= 64 && nrb_tot <= 256) {   // few slab rows: ONE launch folds them per block and applies
+        if (fused && C / groups <= 64 && nrb_tot <= 512) {   // few slab rows: ONE launch folds them per block and applies
             Act out = new_act(N, xa.D, xa.H, xa.W, C);
             const int slices = (C + 63) / 64;
             static const int gn_blocks = [] { const char* e = getenv("LDM_GN_BLOCKS"); return e ? atoi(e) : 256; }();   // tuning knob
