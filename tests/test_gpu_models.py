@@ -373,6 +373,7 @@ def test_first_conv_im2col_form_matches_3x3x3_form(cuda, monkeypatch):
     t = torch.tensor([100.0, 800.0])
     img = torch.rand((1, cfgs.VAE_TINY["in_channels"], 16, 8, 12), generator=g)
     outs = {}
+    monkeypatch.setenv("LDM_GEMM_LIGHT", "1")                   # the im2col form needs the light GEMM
     for mode in ("1", "0"):
         monkeypatch.setenv("LDM_CONV_IM2COL", mode)
         m, sd = _unet_pair(cfg, 5, cuda)
