@@ -58,6 +58,8 @@ SIGNATURES = {
     "ldm_grad_sq_norm": (C.c_int, [_P, C.c_int64, _P, _P]),
     "ldm_adam_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, _P,
                                 C.c_float, _P]),
+    "ldm_model_adam_step": (C.c_int, [_P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, _P,
+                                      C.c_float, _P]),
     "ldm_model_set_graph_mode": (C.c_int, [_P, C.c_int]),
     "ldm_vae_encode_workspace_bytes": (C.c_size_t, [_P, C.c_int, C.c_int, C.c_int, C.c_int]),
     "ldm_vae_decode_workspace_bytes": (C.c_size_t, [_P, C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -1946,9 +1946,7 @@ int ldm_model_load_params_device(ldm_model* m, const float* const* ptrs, int n, 
 
 /* The same from ONE flat fp32 device buffer holding every parameter at ldm_model_param_offset(i) (the layout of the flat
  * gradient buffer): a single descriptor-driven launch. */
-int ldm_model_load_params_flat(ldm_model* m, const float* flat, void* stream) {
-    if (!m || !flat) return fail(LDM_ERR_BAD_ARG, "null argument");
-    LDM_TRY(ensure_arena(m));
+static int ensure_pack_tab(ldm_model* m) {
     if (!m->pack_tab.nblocks) {
         std::vector<PackDesc> descs; std::vector<int2> map;
         for (const ParamDesc& d : m->params) {
@@ -1962,6 +1960,13 @@ int ldm_model_load_params_flat(ldm_model* m, const float* flat, void* stream) {
         }
         if (m->pack_tab.upload(descs, map)) return fail(LDM_ERR_HIP, "descriptor table upload failed");
     }
+    return 0;
+}
+
+int ldm_model_load_params_flat(ldm_model* m, const float* flat, void* stream) {
+    if (!m || !flat) return fail(LDM_ERR_BAD_ARG, "null argument");
+    LDM_TRY(ensure_arena(m));
+    LDM_TRY(ensure_pack_tab(m));
     hipLaunchKernelGGL(param_pack_batched_kernel, dim3(m->pack_tab.nblocks), dim3(256), 0, (hipStream_t)stream,
                        (const PackDesc*)m->pack_tab.descs, (const int2*)m->pack_tab.map, flat, m->arena);
     HIP_TRY(hipGetLastError());
@@ -2056,6 +2061,24 @@ int ldm_adam_step(float* params, const float* grads, float* exp_avg, float* exp_
     hipLaunchKernelGGL(adam_step_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq,
                        (long)n, k, sq_norm);
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+/* The same optimizer step over the model's flat parameter buffer (layout of ldm_model_param_offset) that ALSO re-packs the bf16
+ * arena from the updated values in the same pass: replaces ldm_adam_step + ldm_model_load_params_flat after it. */
+int ldm_model_adam_step(ldm_model* m, float* params_flat, const float* grads_flat, float* exp_avg, float* exp_avg_sq, float lr,
+                        float beta1, float beta2, float eps, float weight_decay, int step, const float* sq_norm, float max_norm,
+                        void* stream) {
+    if (!m || !params_flat || !grads_flat || !exp_avg || !exp_avg_sq || step < 1) return fail(LDM_ERR_BAD_ARG, "bad argument");
+    LDM_TRY(ensure_arena(m));
+    LDM_TRY(ensure_pack_tab(m));
+    AdamCoef k{lr, beta1, beta2, eps, 1.0f - powf(beta1, (float)step), sqrtf(1.0f - powf(beta2, (float)step)), max_norm, lr * weight_decay};
+    hipLaunchKernelGGL(adam_pack_batched_kernel, dim3(m->pack_tab.nblocks), dim3(256), 0, (hipStream_t)stream,
+                       (const PackDesc*)m->pack_tab.descs, (const int2*)m->pack_tab.map, params_flat, grads_flat, exp_avg, exp_avg_sq,
+                       m->arena, k, sq_norm);
+    HIP_TRY(hipGetLastError());
+    for (ParamDesc& d : m->params) if (!d.loaded) { d.loaded = true; m->loaded_count++; }
+    m->derived_dirty = true;
     return 0;
 }
 

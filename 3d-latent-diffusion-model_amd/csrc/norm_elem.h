@@ -969,6 +969,48 @@ __global__ __launch_bounds__(256) void param_pack_batched_kernel(const PackDesc*
     }
 }
 
+// Adam(W) and the bf16 re-pack in ONE pass over the parameters (training step tail): the block that packs a (cout row, 64-cin chunk)
+// of a matrix -- or 1024 elements of a vector -- first updates exactly those flat fp32 elements (p, m, v in place, same arithmetic as
+// adam_step_kernel) and packs the NEW values, so the 765 MB of updated master weights are not read a second time.
+__global__ __launch_bounds__(256) void adam_pack_batched_kernel(const PackDesc* __restrict__ descs, const int2* __restrict__ blockmap,
+                                                                float* __restrict__ flat_p, const float* __restrict__ flat_g,
+                                                                float* __restrict__ flat_m, float* __restrict__ flat_v,
+                                                                char* __restrict__ arena, AdamCoef k, const float* __restrict__ sq_norm) {
+    __shared__ float tile[64 * 27];
+    const int2 bm = blockmap[blockIdx.x];
+    const PackDesc e = descs[bm.x];
+    const int tid = threadIdx.x;
+    float clip = 1.f;
+    if (sq_norm && k.max_norm > 0.f) { const float c = k.max_norm / (sqrtf(*sq_norm) + 1e-6f); clip = c < 1.f ? c : 1.f; }
+    const float step = k.lr / k.bc1;
+    auto update = [&](long i) -> float {
+        const float gi = flat_g[i] * clip;
+        const float mi = k.b1 * flat_m[i] + (1.f - k.b1) * gi;
+        const float vi = k.b2 * flat_v[i] + (1.f - k.b2) * gi * gi;
+        flat_m[i] = mi; flat_v[i] = vi;
+        const float pi = flat_p[i] * (1.f - k.decay);
+        const float pn = pi - step * mi / (sqrtf(vi) / k.bc2_sqrt + k.eps);
+        flat_p[i] = pn;
+        return pn;
+    };
+    if (e.kind == 1) {                                   // fp32 vector: 1024 elements per block
+        float* dst = reinterpret_cast<float*>(arena + e.dst_off);
+        for (int i = bm.y * 1024 + tid; i < e.cout && i < (bm.y + 1) * 1024; i += 256) dst[i] = update(e.src_off + i);
+        return;
+    }
+    bf16_t* dst = reinterpret_cast<bf16_t*>(arena + e.dst_off);
+    const int nchunk = (e.cin_s + 63) / 64;
+    const int co = bm.y / nchunk, ci0 = (bm.y - co * nchunk) * 64;
+    int nci = e.cin - ci0; if (nci > 64) nci = 64; if (nci < 0) nci = 0;
+    const long s0 = e.src_off + ((long)co * e.cin + ci0) * e.taps;
+    for (int i = tid; i < nci * e.taps; i += 256) tile[i] = update(s0 + i);
+    __syncthreads();
+    for (int i = tid; i < e.taps * 64; i += 256) {
+        const int t = i >> 6, c = i & 63, ci = ci0 + c;
+        if (ci < e.cin_s) dst[((size_t)t * e.cout_pad + e.row_off + co) * e.cin_s + ci] = (c < nci) ? f2bf(tile[c * e.taps + t]) : (bf16_t)0;
+    }
+}
+
 struct ExportDesc { long src_off; long dst_off; long slab_stride; int taps, rows_total, ld, row_off, col_off, cout, cin, nsplit; };
 __global__ __launch_bounds__(256) void grad_export_batched_kernel(const ExportDesc* __restrict__ descs, const int2* __restrict__ blockmap,
                                                                   const char* __restrict__ ws, float* __restrict__ flat) {

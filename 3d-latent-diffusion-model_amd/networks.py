@@ -106,7 +106,8 @@ class _LdmModule(nn.Module):
         return r
 
     def train(self, mode: bool = True):
-        self._dirty = True
+        if mode != self.training:                      # a mode switch re-checks the weights once; repeated .train() calls do not
+            self._dirty = True
         return super().train(mode)
 
     def _param_list(self):

@@ -33,6 +33,7 @@ class FlatAdam(torch.optim.Optimizer):
         self._flat = torch.nn.Parameter(flat, requires_grad=False)      # shares storage with module.flat_params
         super().__init__([self._flat], dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
         self.max_grad_norm = max_grad_norm
+        self.fuse_repack = True                        # Adam + bf16 re-pack in one kernel (ldm_model_adam_step)
         self.exp_avg = torch.zeros_like(flat)
         self.exp_avg_sq = torch.zeros_like(flat)
         self.sq_norm = torch.zeros((1,), dtype=torch.float32, device=flat.device)
@@ -61,10 +62,14 @@ class FlatAdam(torch.optim.Optimizer):
         with torch.cuda.device(p.device):
             if clip:
                 _lib.check(L.ldm_grad_sq_norm(g.data_ptr(), g.numel(), self.sq_norm.data_ptr(), _lib.current_stream()))
-            _lib.check(L.ldm_adam_step(p.data_ptr(), g.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), p.numel(),
-                                       float(grp["lr"]), float(grp["betas"][0]), float(grp["betas"][1]), float(grp["eps"]),
-                                       float(grp.get("weight_decay", 0.0)), self.steps,
-                                       self.sq_norm.data_ptr() if clip else None, float(self.max_grad_norm or 0.0),
-                                       _lib.current_stream()))
+            args = (float(grp["lr"]), float(grp["betas"][0]), float(grp["betas"][1]), float(grp["eps"]),
+                    float(grp.get("weight_decay", 0.0)), self.steps, self.sq_norm.data_ptr() if clip else None,
+                    float(self.max_grad_norm or 0.0), _lib.current_stream())
+            h = getattr(self.module, "_h", None)
+            if self.fuse_repack and h is not None and not getattr(self.module, "_dirty", True):
+                # one pass: Adam on the flat master weights + the bf16 re-pack of the library's arena from the new values
+                _lib.check(L.ldm_model_adam_step(h, p.data_ptr(), g.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), *args))
+                return None
+            _lib.check(L.ldm_adam_step(p.data_ptr(), g.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), p.numel(), *args))
         self.module.mark_weights_dirty()               # the bf16 arena is re-packed before the next forward
         return None

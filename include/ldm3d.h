@@ -129,6 +129,11 @@ int ldm_vae_train_backward(ldm_model* m, const float* d_recon, const float* d_mu
 int ldm_grad_sq_norm(const float* flat_grads, int64_t n, float* out, void* stream);
 int ldm_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int step, const float* sq_norm, float max_norm, void* stream);
+/* Adam(W) over a model's flat fp32 parameter buffer (layout of ldm_model_param_offset) that re-packs the library's bf16 weight
+ * arena from the updated values in the same pass (optimizer.step() + the implicit "weights changed", train_diffusion.py:219). */
+int ldm_model_adam_step(ldm_model* m, float* params_flat, const float* grads_flat, float* exp_avg, float* exp_avg_sq, float lr,
+                        float beta1, float beta2, float eps, float weight_decay, int step, const float* sq_norm, float max_norm,
+                        void* stream);
 
 /* HIP-graph replay of the UNet forward plan (the sampling loop of 3d_ldm/inference.py:88-99 calls the UNet 1000 times per
  * volume with the same shapes): with on != 0, ldm_unet_forward records its launches into a hipGraph the second time it sees

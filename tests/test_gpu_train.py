@@ -314,3 +314,33 @@ def test_training_step_matches_committed_golden(cuda):
     # Adam's first step moves every element by ~lr * sign(g): the checksum pins the layout / export of every gradient
     assert abs(sa - gold["param_abs_sum_after_adam_fp32"]) <= 1e-4 * gold["param_abs_sum_after_adam_fp32"]
     assert abs(s - gold["param_sum_after_adam_fp32"]) <= 0.02 * m.flat_params.numel() * 1e-3 + 1e-3 * abs(gold["param_sum_after_adam_fp32"])
+
+
+def test_fused_adam_repack_equals_adam_then_repack(cuda):
+    """FlatAdam's default step (ldm_model_adam_step: Adam + bf16 re-pack of the arena in one kernel) leaves the same master
+    weights and moments (to fp32 rounding) and the same network output (to bf16 noise) as the two-kernel form (ldm_adam_step, then the re-pack at the next forward)."""
+    from ldm3d.optim import FlatAdam
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn((2, 4, 8, 8, 8), generator=g).to(cuda)
+    t = torch.tensor([10.0, 600.0], device=cuda)
+    target = torch.randn((2, 4, 8, 8, 8), generator=g).to(cuda)
+    res = {}
+    from ldm3d.networks import DiffusionModelUNet
+    from oracle import unet as ou
+    sd = ou.init_state_dict(ou.unet_param_shapes(cfgs.UNET_TINY), 9, gain=0.5)
+    for fused in (True, False):
+        m = DiffusionModelUNet(**cfgs.UNET_TINY)
+        m.load_state_dict(sd)
+        m = m.to(cuda).train()
+        opt = FlatAdam(m, lr=1e-3, max_grad_norm=1.0, weight_decay=1e-2)
+        opt.fuse_repack = fused
+        loss = F.mse_loss(m(x=x, timesteps=t), target)   # ONE step: from the second on the two runs see different rounding noise
+        loss.backward()
+        opt.step()
+        m.eval()
+        with torch.no_grad():
+            out = m(x=x, timesteps=t).clone()
+        res[fused] = (m.flat_params.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), out)
+    for a, b in zip(res[True][:3], res[False][:3]):          # same arithmetic up to FMA contraction: ulp-level differences
+        assert torch.allclose(a, b, rtol=2e-5, atol=1e-8)
+    assert rel_l2(res[True][3], res[False][3]) <= 1e-2
