@@ -70,6 +70,12 @@ def _dp_worker(rank, world, port, q):
         grads[:12] = w.grad.reshape(-1)
         grads[12:] = float(rank + 1)
         sync.mean_(grads)
+        low = GradSync(chunk_elems=1000, grad_dtype=torch.bfloat16)     # opt-in bf16 wire format: same mean to bf16 precision
+        g16 = torch.zeros(4097)
+        g16[:12] = w.grad.reshape(-1)
+        g16[12:] = float(rank + 1)
+        low.mean_(g16)
+        assert torch.allclose(g16, grads, rtol=2e-2, atol=1e-3) and g16.dtype == torch.float32
         nan_flag = sync.any(torch.tensor(1.0 if rank == 1 else 0.0))     # one rank saw a NaN loss -> everyone skips
         sf = sync.mean_scalar(torch.tensor(2.0 + rank))
         q.put((rank, flat[:12].tolist(), grads[:12].tolist(), float(grads[-1]), float(nan_flag), float(sf)))

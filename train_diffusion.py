@@ -31,6 +31,8 @@ def main():
     parser.add_argument("--synthetic", type=int, default=0)
     parser.add_argument("--max-steps", type=int, default=0)
     parser.add_argument("--reference-rng-order", action="store_true")
+    parser.add_argument("--grad-allreduce-dtype", default="fp32", choices=["fp32", "bf16"],
+                        help="wire format of the data-parallel gradient all-reduce (the reference's DDP uses fp32)")
     args = parser.parse_args()
 
     import torch
@@ -109,7 +111,8 @@ def main():
     scheduler = DDPMScheduler(num_train_timesteps=ns["num_train_timesteps"], schedule="scaled_linear_beta",
                               beta_start=ns["beta_start"], beta_end=ns["beta_end"])
     inferer = LatentDiffusionInferer(scheduler, scale_factor=float(scale_factor))
-    trainer = DiffusionTrainer(unet, autoencoder, inferer, lr=tcfg["lr"], reference_rng_order=args.reference_rng_order)
+    trainer = DiffusionTrainer(unet, autoencoder, inferer, lr=tcfg["lr"], reference_rng_order=args.reference_rng_order,
+                               grad_dtype=torch.bfloat16 if args.grad_allreduce_dtype == "bf16" else torch.float32)
 
     total_step, best_val, done = 0, float("inf"), False
     for epoch in range(tcfg["max_epochs"]):
