@@ -1,6 +1,7 @@
 """Diagnostic: phase timeline of conv_igemm_kernel from in-kernel s_memrealtime stamps (LDM_CONV_DBG=512)."""
 import os, sys
 os.environ["LDM_CONV_DBG"] = "512"
+os.environ["LDM_CONV_HALO"] = "0"        # this tool reads conv_igemm_kernel's stamps (tools/stamp_halo.py has the halo kernel's)
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
