@@ -387,3 +387,37 @@ def test_first_conv_im2col_form_matches_3x3x3_form(cuda, monkeypatch):
     mu_32, _ = oa.encode(vsd, cfgs.VAE_TINY, img, emulate_bf16=False)
     for mode in ("1", "0"):
         floor_gate(outs[mode][2], mu_bf, mu_32, f"VAE encode mu, LDM_CONV_IM2COL={mode}")
+
+
+def test_baseline_config1_full_unet_16cube_ddim10_teacher_forced(cuda):
+    """BASELINE configs[0] at full size: the benchmark UNet (191 M parameters, SURVEY.md section 8d config 1: seeded N(0, .) weights,
+    conv2 / out NOT zero) on a 1x4x16^3 latent, 10 DDIM steps (900, 800, ..., 0).  Every GPU step is teacher-forced with the
+    fp32 oracle's x_t; eps is gated against the oracle's bf16 noise floor (measured at the first and the last step), the
+    scheduler step against the oracle's to 1e-6."""
+    from ldm3d.schedulers import DDIMScheduler
+    from oracle import unet as ou
+    from oracle.schedulers import OracleDDIM
+    cfg = cfgs.UNET_FULL
+    unet, sd = _unet_pair(cfg, 0, cuda)
+    x = torch.randn((1, 4, 16, 16, 16), generator=torch.Generator().manual_seed(0))
+    sch, osch = DDIMScheduler(**cfgs.SCHED), OracleDDIM(**cfgs.SCHED)
+    sch.set_timesteps(10); osch.set_timesteps(10)
+    assert osch.timesteps.tolist() == list(range(900, -1, -100))
+    floor = None
+    for t in osch.timesteps.tolist():
+        ts = torch.tensor([float(t)])
+        e_32 = ou.unet_forward(sd, cfg, x, ts, emulate_bf16=False)
+        with torch.no_grad():
+            e_gpu = unet(x=x.to(cuda), timesteps=ts.to(cuda))
+            p_gpu, _ = sch.step(e_gpu, t, x.to(cuda))
+        if t in (900, 0):
+            f, _, _ = floor_gate(e_gpu.cpu(), ou.unet_forward(sd, cfg, x, ts, emulate_bf16=True), e_32, f"config 1, t={t}")
+            floor = f if floor is None else max(floor, f)
+        else:
+            err = rel_l2(e_gpu.cpu(), e_32)
+            print(f"config 1, t={t}: GPU vs fp32-oracle {err:.2e}")
+            assert torch.isfinite(e_gpu).all() and err <= 2.5 * floor + 1e-3, (t, err, floor)
+        p_ref, _ = osch.step(e_gpu.cpu(), t, x)
+        assert rel_l2(p_gpu, p_ref) <= 1e-6
+        x, _ = osch.step(e_32, t, x)
+    assert torch.isfinite(x).all() and float(x.abs().max()) <= 1.0 + 1e-6          # clip_sample keeps x0 in [-1, 1]; the last step returns x0

@@ -185,3 +185,27 @@ def test_training_golden_is_reproducible_from_its_seeds():
     assert abs(float(total) - gold["total_grad_norm_fp32"]) <= 1e-4 * gold["total_grad_norm_fp32"]
     name = "middle_block.resnet_1.conv1.conv.weight"
     assert abs(float(leaves[name].grad.norm()) - gold["grad_norm_fp32"][name]) <= 1e-4 * gold["grad_norm_fp32"][name]
+
+
+def test_baseline_config1_cpu_plumbing_full_unet_ddim10():
+    """BASELINE configs[0] (CPU plumbing, no GPU): the benchmark UNet definition (191 M parameters, seeded non-zero weights) and the
+    DDIM schedule run end to end in the oracle on a 1x4x16^3 latent: 10 steps at t = 900 ... 0, finite, reproducible from the seed,
+    final sample = the clamped x0 estimate."""
+    from oracle import unet as ou
+    from oracle.schedulers import OracleDDIM
+    cfg = cfgs.UNET_FULL
+    sd = ou.init_state_dict(ou.unet_param_shapes(cfg), 0)
+
+    def chain():
+        x = torch.randn((1, 4, 16, 16, 16), generator=torch.Generator().manual_seed(0))
+        sch = OracleDDIM(**cfgs.SCHED)
+        sch.set_timesteps(10)
+        assert sch.timesteps.tolist() == list(range(900, -1, -100))
+        for t in sch.timesteps.tolist():
+            eps = ou.unet_forward(sd, cfg, x, torch.tensor([float(t)]), emulate_bf16=False)
+            assert eps.shape == x.shape and torch.isfinite(eps).all()
+            x, x0 = sch.step(eps, t, x)
+        return x, x0
+    torch.manual_seed(123)
+    a, a0 = chain()
+    assert torch.isfinite(a).all() and float(a.abs().max()) <= 1.0 + 1e-6 and torch.equal(a, a0)
