@@ -421,3 +421,22 @@ def test_baseline_config1_full_unet_16cube_ddim10_teacher_forced(cuda):
         assert rel_l2(p_gpu, p_ref) <= 1e-6
         x, _ = osch.step(e_32, t, x)
     assert torch.isfinite(x).all() and float(x.abs().max()) <= 1.0 + 1e-6          # clip_sample keeps x0 in [-1, 1]; the last step returns x0
+
+
+def test_vae_full_size_96cube_golden(cuda):
+    """BASELINE configs[1] at full size (AutoencoderKL 64/128/256, 1x1x96^3) against the committed oracle golden
+    (tests/golden/make_golden.py vae): encoder mean, and the decoder on the fp32 oracle's latent (stride-4 sub-lattice + moments)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import make_golden
+    gold = torch.load(os.path.join(os.path.dirname(__file__), "golden", "vae_full_96.pt"), weights_only=False)
+    m, _ = _vae_pair(cfgs.VAE_FULL, gold["weight_seed"], cuda)
+    with torch.no_grad():
+        mu, _ = m.encode(make_golden.vae_case().to(cuda))
+        rec = m.decode(gold["mu_for_decode"].to(cuda)).cpu()
+    floor_gate(mu.cpu(), gold["mu_bf16"], gold["mu_fp32"], "VAE_FULL 96^3 encode mu (golden)")
+    floor_gate(rec[..., ::4, ::4, ::4], gold["rec_sub_bf16"], gold["rec_sub_fp32"], "VAE_FULL 96^3 decode, stride-4 sub-lattice (golden)")
+    tol = 3.0 * abs(gold["rec_mean_bf16"] - gold["rec_mean_fp32"]) + 1e-3 * abs(gold["rec_mean_fp32"]) + 1e-4
+    assert abs(float(rec.double().mean()) - gold["rec_mean_fp32"]) <= tol
+    assert abs(float((rec.double() ** 2).mean()) - gold["rec_msq_fp32"]) <= 3.0 * abs(gold["rec_msq_bf16"] - gold["rec_msq_fp32"]) + 1e-2 * gold["rec_msq_fp32"]

@@ -209,3 +209,18 @@ def test_baseline_config1_cpu_plumbing_full_unet_ddim10():
     torch.manual_seed(123)
     a, a0 = chain()
     assert torch.isfinite(a).all() and float(a.abs().max()) <= 1.0 + 1e-6 and torch.equal(a, a0)
+
+
+def test_vae_golden_regenerates_from_its_seeds():
+    """tests/golden/vae_full_96.pt (BASELINE configs[1]: 1x1x96^3 through the full AutoencoderKL): the fp32 half regenerates bit for bit
+    from the stored seed and the recipe in make_golden.vae_case (same torch build), and the two oracles differ by a sane bf16 floor."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import make_golden
+    gold = torch.load(os.path.join(os.path.dirname(__file__), "golden", "vae_full_96.pt"), weights_only=False)
+    assert gold["mu_fp32"].shape == (1, 4, 24, 24, 24) and gold["rec_sub_fp32"].shape == (1, 1, 24, 24, 24)
+    assert 1e-3 < rel_l2(gold["mu_bf16"], gold["mu_fp32"]) < 5e-2 and 1e-3 < rel_l2(gold["rec_sub_bf16"], gold["rec_sub_fp32"]) < 1e-1
+    sd = ou.init_state_dict(oa.ae_param_shapes(cfgs.VAE_FULL), gold["weight_seed"])
+    mu, _ = oa.encode(sd, cfgs.VAE_FULL, make_golden.vae_case(), emulate_bf16=False)
+    assert rel_l2(mu, gold["mu_fp32"]) <= (0.0 if gold["torch_version"] == torch.__version__ else 1e-5)
