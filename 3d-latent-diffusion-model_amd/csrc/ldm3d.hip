@@ -72,6 +72,7 @@ enum OpKind { OP_PACK, OP_CONV, OP_FINALIZE, OP_GN_STATS, OP_GN_FINALIZE, OP_GN_
               // backward (training plans only)
               OP_WT, OP_WT_BATCH, OP_WGRAD, OP_EXPORT, OP_EXPORT_BATCH, OP_COLSUM, OP_GNB, OP_ATTN_BWD, OP_ADD, OP_SUMPOOL, OP_LIN_DX, OP_LIN_DW, OP_VAE_HEADS_BWD,
               OP_GEMM_LIGHT,                       // 1x1 convolution with short K (gemm_light.h)
+              OP_COLSUM_BATCH,                     // every column-sum finalize of a backward plan in one launch
               OP_IM2COL };                         // fp32 NCDHW inputs -> bf16 patch matrix of the first conv (pack_im2col_kernel)
 
 struct ConvCfg { int wgm, wgn, bk, splitk; int halo = 0, mtps = 0, qps = 0; };   // halo: conv3_halo_kernel (126-row tiles)
@@ -140,7 +141,7 @@ struct Plan {
     size_t ws_bytes = 0;
     size_t bwd_begin = 0;                            // training plans: ops [0, bwd_begin) = forward, the rest = backward
     bool train = false;
-    DevTable wt_tab, exp_tab;                        // training plans: all weight transposes / all gradient exports in one launch each
+    DevTable wt_tab, exp_tab, cs_tab;                // training plans: all weight transposes / gradient exports / column-sum finalizes in one launch each
 };
 
 // ================================================================================================ parameters
@@ -693,14 +694,29 @@ struct Builder {
         const int cvec = C / 8, rows_par = std::max(1, 256 / cvec);
         int nslab = std::min((DHW + rows_par - 1) / rows_par, std::max(1, 512 / N));
         const int rps = (DHW + nslab - 1) / nslab; nslab = (DHW + rps - 1) / rps;
-        gnpart_bytes = std::max(gnpart_bytes, (size_t)N * nslab * C * 2 * 4);
         Op st{}; st.kind = OP_GN_STATS; st.r[0] = ws_ref(g.off);
         st.i[0] = C; st.i[1] = 0; st.i[2] = DHW; st.i[3] = nslab; st.i[4] = rps; st.i[5] = N;
+        if (colsum_batched() && out.base == BASE_WS) {
+            // the partials get their own block (kept to the end of the plan) and the finalize joins ONE batched launch
+            // (flush_colsums) in front of the first consumer of any of these sums
+            const size_t poff = pool.alloc((size_t)N * nslab * C * 2 * 4);
+            st.r[4] = ws_ref(poff); plan->ops.push_back(st);
+            ColsumDesc d{}; d.partial_off = (long)poff; d.out_off = (long)out.off; d.N = N; d.nslab = nslab; d.C = C;
+            d.accumulate_over_n = per_sample ? 0 : 1; d.count = count; d.out_stride = out_stride; d.gx = (count + 15) / 16;
+            const int nb = d.gx * (per_sample ? N : 1);
+            for (int b = 0; b < nb; ++b) cs_map.push_back(make_int2((int)cs_descs.size(), b));
+            cs_descs.push_back(d);
+            return;
+        }
+        gnpart_bytes = std::max(gnpart_bytes, (size_t)N * nslab * C * 2 * 4);
         gnpart_fixups.push_back(plan->ops.size()); plan->ops.push_back(st);
         Op cs{}; cs.kind = OP_COLSUM; cs.r[0] = out;
         cs.i[0] = N; cs.i[1] = nslab; cs.i[2] = C; cs.i[3] = per_sample ? 0 : 1; cs.i[4] = count; cs.i[5] = out_stride;
         gnpart_fixups.push_back(plan->ops.size()); plan->ops.push_back(cs);
     }
+    std::vector<ColsumDesc> cs_descs; std::vector<int2> cs_map;
+    static bool colsum_batched() { const char* e = getenv("LDM_COLSUM_BATCH"); return e ? atoi(e) != 0 : true; }
+    void flush_colsums() { if (!cs_descs.empty()) { Op o{}; o.kind = OP_COLSUM_BATCH; plan->ops.push_back(o); } }
     void emit_wgrad(const Act& dy, const Act& x, int cout, int cin, int ld, int ci_off, int k, int stride, int pad, int ups) {
         Op o{}; o.kind = OP_WGRAD; o.r[0] = ws_ref(dy.off); o.r[1] = ws_ref(x.off); o.r[2] = ws_ref(dw_off);
         int* i = o.i;
@@ -1073,6 +1089,7 @@ static int unet_build(ldm_model* m, int B, int D, int H, int W, Plan* plan, bool
         { Op o{}; o.kind = OP_PACK; o.r[0] = io_ref(0); o.r[1] = Ref(); o.r[2] = ws_ref(dout.off);
           o.i[0] = B; o.i[1] = c.out_channels; o.i[2] = cos_; o.i[3] = D * H * W; plan->ops.push_back(o); }
         if (!b.backward_all(dout)) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
+        b.flush_colsums();                              // bias gradients and the time-embedding rows the MLP backward reads next
         // stacked projections  temb_all = Wt silu(e2) + bt
         const Ref dtemb = ws_ref(b.dtemb_off);
         b.dw_off = b.pool.alloc((size_t)rows * temb * 4); b.vec_off = b.pool.alloc((size_t)rows * 4);
@@ -1094,7 +1111,8 @@ static int unet_build(ldm_model* m, int B, int D, int H, int W, Plan* plan, bool
                       B, ch[0], temb, temb, ch[0], 0);
         if (!b.err.empty()) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
         { Op o{}; o.kind = OP_EXPORT_BATCH; plan->ops.push_back(o); }      // every staged parameter gradient -> flat buffer, one launch
-        if (plan->wt_tab.upload(b.wt_descs, b.wt_map) || plan->exp_tab.upload(b.exp_descs, b.exp_map))
+        if (plan->wt_tab.upload(b.wt_descs, b.wt_map) || plan->exp_tab.upload(b.exp_descs, b.exp_map) ||
+            (!b.cs_descs.empty() && plan->cs_tab.upload(b.cs_descs, b.cs_map)))
             return fail(LDM_ERR_HIP, "descriptor table upload failed");
     }
     b.finish();
@@ -1294,8 +1312,10 @@ static int vae_build_train(ldm_model* m, int B, int D, int H, int W, Plan* plan)
     { Op o{}; o.kind = OP_PACK; o.r[0] = io_ref(0); o.r[1] = Ref(); o.r[2] = ws_ref(dout.off);
       o.i[0] = B; o.i[1] = c.out_channels; o.i[2] = cos_; o.i[3] = D * H * W; o.i[4] = 1; plan->ops.push_back(o); }
     if (!b.backward_all(dout)) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
+    b.flush_colsums();
     { Op o{}; o.kind = OP_EXPORT_BATCH; plan->ops.push_back(o); }
-    if (plan->wt_tab.upload(b.wt_descs, b.wt_map) || plan->exp_tab.upload(b.exp_descs, b.exp_map))
+    if (plan->wt_tab.upload(b.wt_descs, b.wt_map) || plan->exp_tab.upload(b.exp_descs, b.exp_map) ||
+        (!b.cs_descs.empty() && plan->cs_tab.upload(b.cs_descs, b.cs_map)))
         return fail(LDM_ERR_HIP, "descriptor table upload failed");
     b.finish();
     return 0;
@@ -1612,6 +1632,11 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                 if (plan.wt_tab.nblocks)
                     hipLaunchKernelGGL(weight_flip_transpose_batched_kernel, dim3(plan.wt_tab.nblocks), dim3(256), 0, s,
                                        (const WtDesc*)plan.wt_tab.descs, (const int2*)plan.wt_tab.map, (const char*)bs.p[BASE_W], bs.p[BASE_WS]);
+                break;
+            case OP_COLSUM_BATCH:
+                if (plan.cs_tab.nblocks)
+                    hipLaunchKernelGGL(colsum_finalize_batched_kernel, dim3(plan.cs_tab.nblocks), dim3(256), 0, s,
+                                       (const ColsumDesc*)plan.cs_tab.descs, (const int2*)plan.cs_tab.map, (char*)bs.p[BASE_WS]);
                 break;
             case OP_EXPORT_BATCH:
                 if (!bs.p[BASE_IO4]) return fail(LDM_ERR_BAD_ARG, "backward without a gradient buffer");

@@ -748,6 +748,34 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
     }
 }
 
+// All column-sum finalizes of a backward plan in ONE launch (79 bias gradients + 17 time-embedding rows for the benchmark UNet: each is
+// a launch at its floor otherwise).  blockmap[b] = (descriptor, block inside it); block layout as colsum_finalize_kernel.
+struct ColsumDesc { long partial_off; long out_off; int N, nslab, C, accumulate_over_n, count, out_stride, gx, pad_; };
+__global__ __launch_bounds__(256) void colsum_finalize_batched_kernel(const ColsumDesc* __restrict__ descs, const int2* __restrict__ blockmap,
+                                                                      char* __restrict__ ws) {
+    __shared__ float red[256];
+    const int2 bm = blockmap[blockIdx.x];
+    const ColsumDesc e = descs[bm.x];
+    const float* partial = reinterpret_cast<const float*>(ws + e.partial_off);
+    float* out = reinterpret_cast<float*>(ws + e.out_off);
+    const int bx = bm.y % e.gx, by = bm.y / e.gx;
+    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int c = bx * 16 + cl;
+    const int n0 = e.accumulate_over_n ? 0 : by, n1 = e.accumulate_over_n ? e.N : by + 1;
+    float t = 0.f;
+    if (c < e.count)
+        for (int n = n0; n < n1; ++n)
+            for (int s = sl; s < e.nslab; s += 16) t += partial[(((size_t)n * e.nslab + s) * e.C + c) * 2];
+    red[threadIdx.x] = t;
+    __syncthreads();
+    if (sl == 0 && c < e.count) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a += red[k * 16 + cl];
+        out[e.accumulate_over_n ? (size_t)c : (size_t)by * e.out_stride + c] = a;
+    }
+}
+
 // 2x2x2 sum pooling (adjoint of the nearest x2 upsample): out[n][d][h][w][c] = sum of the 8 fine voxels, bf16 NDHWC.
 __global__ __launch_bounds__(256) void sumpool2_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out,
                                                        int N, int D, int H, int W, int C) {   // D,H,W = COARSE dims
