@@ -24,13 +24,14 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
 // 16-byte store; WT = true: write-through (sc1): the bytes leave the XCD's L2 while the kernel still runs instead of in the
-// write-back at its end (short launches whose consumers run on every XCD anyway).  Experiment knob: LDM_WT_STORES.
-#ifndef LDM_WT_CONV
-#define LDM_WT_CONV 0           // experiment: write-through stores in the conv / GEMM / attention epilogues too
-#endif
+// write-back at its end (short launches whose consumers run on every XCD anyway).  Knob: LDM_WT_STORES (GroupNorm / finalize).
+// Not used in the MFMA conv / light-GEMM epilogues: there the same store left NaNs in unsplit launches (parity tests; cause not
+// found: the ISA around the store looks right) although it measured +0.3 ... 1.2 % on the step.
 template <bool WT>
 __device__ __forceinline__ void store16(void* ptr, u32x4 v) {
-    if constexpr (WT) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(ptr), "v"(v) : "memory");
+    // s_nop 1: hipcc's hazard recognizer cannot see that this asm reads %1 as >64-bit VMEM store data (a VALU write right in front of it
+    // needs a wait state on gfx9-class hardware); without it the store picked up stale registers when nothing else separated the two
+    if constexpr (WT) asm volatile("s_nop 1\n\tglobal_store_dwordx4 %0, %1, off sc1" ::"v"(ptr), "v"(v) : "memory");
     else *reinterpret_cast<u32x4*>(ptr) = v;
 }
 

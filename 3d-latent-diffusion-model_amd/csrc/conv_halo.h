@@ -370,7 +370,7 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
                 ssum[h * 8 + 2 * q] += lo; ssq[h * 8 + 2 * q] += lo * lo;
                 ssum[h * 8 + 2 * q + 1] += hi; ssq[h * 8 + 2 * q + 1] += hi * hi;
             }
-            store16<LDM_WT_CONV != 0>(&op[h], o);
+            op[h] = o;
         }
     }
     if (do_stats) {

@@ -595,7 +595,7 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_igemm_kernel(const ConvParam
                     ssum[h * 8 + 2 * q] += lo; ssq[h * 8 + 2 * q] += lo * lo;
                     ssum[h * 8 + 2 * q + 1] += hi; ssq[h * 8 + 2 * q + 1] += hi * hi;
                 }
-                store16<LDM_WT_CONV != 0>(&op[h], o);
+                op[h] = o;
             }
         }
     }

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(64) void gemm_light_kernel(const LightParams p) {
                     ssum[h * 8 + 2 * q] += lo; ssq[h * 8 + 2 * q] += lo * lo;
                     ssum[h * 8 + 2 * q + 1] += hi; ssq[h * 8 + 2 * q + 1] += hi * hi;
                 }
-                store16<LDM_WT_CONV != 0>(p.out + (size_t)m * p.CoutS + cb + 8 * h, o);
+                *reinterpret_cast<u32x4*>(p.out + (size_t)m * p.CoutS + cb + 8 * h) = o;
             }
         }
     }
