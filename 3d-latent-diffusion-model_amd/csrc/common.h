@@ -25,13 +25,13 @@ __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)
 
 // 16-byte store; WT = true: write-through (sc1): the bytes leave the XCD's L2 while the kernel still runs instead of in the
 // write-back at its end (short launches whose consumers run on every XCD anyway).  Knob: LDM_WT_STORES (GroupNorm / finalize).
-// Not used in the MFMA conv / light-GEMM epilogues: there the same store left NaNs in unsplit launches (parity tests; cause not
-// found: the ISA around the store looks right) although it measured +0.3 ... 1.2 % on the step.
+// Measured in the conv / light-GEMM epilogues too (with the wait state): no gain there (475 vs 478 steps/s), so they store plainly.
 template <bool WT>
 __device__ __forceinline__ void store16(void* ptr, u32x4 v) {
-    // s_nop 1: hipcc's hazard recognizer cannot see that this asm reads %1 as >64-bit VMEM store data (a VALU write right in front of it
-    // needs a wait state on gfx9-class hardware); without it the store picked up stale registers when nothing else separated the two
-    if constexpr (WT) asm volatile("s_nop 1\n\tglobal_store_dwordx4 %0, %1, off sc1" ::"v"(ptr), "v"(v) : "memory");
+    // s_nop 1 BEHIND the store: a VMEM store of more than 64 bits reads its data VGPRs over several cycles, and a VALU write to
+    // them in the next wait state corrupts the lanes read last (hipcc's hazard recognizer inserts the wait state for its own stores but
+    // cannot see into this asm: without it lanes 12-15 of every 16-lane group stored the NEXT value: found in the conv epilogue)
+    if constexpr (WT) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
     else *reinterpret_cast<u32x4*>(ptr) = v;
 }
 
