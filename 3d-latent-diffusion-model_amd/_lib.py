@@ -61,6 +61,17 @@ SIGNATURES = {
     "ldm_model_adam_step": (C.c_int, [_P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, _P,
                                       C.c_float, _P]),
     "ldm_model_set_graph_mode": (C.c_int, [_P, C.c_int]),
+    "ldm_model_set_precision": (C.c_int, [_P, C.c_int]),
+    "ldm_model_get_precision": (C.c_int, [_P]),
+    "ldm_model_tap_count": (C.c_int, [_P, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "ldm_model_tap_elems": (C.c_int64, [_P, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "ldm_model_tap_info": (C.c_int, [_P, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int,
+                                     C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
+    "ldm_model_taps_workspace_bytes": (C.c_size_t, [_P, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "ldm_unet_forward_taps": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P,
+                                        _P, C.c_size_t, _P]),
+    "ldm_vae_encode_taps": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, C.c_size_t, _P]),
+    "ldm_vae_decode_taps": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, C.c_size_t, _P]),
     "ldm_vae_encode_workspace_bytes": (C.c_size_t, [_P, C.c_int, C.c_int, C.c_int, C.c_int]),
     "ldm_vae_decode_workspace_bytes": (C.c_size_t, [_P, C.c_int, C.c_int, C.c_int, C.c_int]),
     "ldm_vae_encode": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_size_t, _P]),

@@ -27,6 +27,7 @@
 #include "gemm_light.h"
 #include "conv_wgrad.h"
 #include "norm_elem.h"
+#include "f32_path.h"
 
 #ifndef CONV_STAGES
 #define CONV_STAGES 4     // depth of the conv kernel's LDS ring (prefetch distance = stages - 1 K steps)
@@ -53,17 +54,20 @@ static inline uint16_t host_f2bf(float f) {            // round-to-nearest-even,
 }
 
 // ================================================================================================ plan IR
-enum BaseId { BASE_NULL = 0, BASE_WS, BASE_W, BASE_IO0, BASE_IO1, BASE_IO2, BASE_IO3, BASE_IO4, BASE_IO5, BASE_COUNT };
+enum BaseId { BASE_NULL = 0, BASE_WS, BASE_W, BASE_IO0, BASE_IO1, BASE_IO2, BASE_IO3, BASE_IO4, BASE_IO5, BASE_W32, BASE_TAPO, BASE_TAPI, BASE_COUNT };
 struct Ref { int base = BASE_NULL; size_t off = 0; };
 static inline Ref ws_ref(size_t off) { Ref r; r.base = BASE_WS; r.off = off; return r; }
 static inline Ref w_ref(size_t off) { Ref r; r.base = BASE_W; r.off = off; return r; }
 static inline Ref io_ref(int i) { Ref r; r.base = BASE_IO0 + i; r.off = 0; return r; }
+// fp32 precision mode: the matrix at byte offset `off` of the bf16 arena lives unrounded at 2 * off of the fp32 arena
+static inline Ref w32_ref(size_t off) { Ref r; r.base = BASE_W32; r.off = 2 * off; return r; }
 
 struct Act {                                         // NDHWC bf16 activation living in the workspace
     size_t off = 0; int C = 0; int N = 0, D = 0, H = 0, W = 0; bool valid = false;
     size_t stats_off = 0; bool has_stats = false;   // GroupNorm partials [blocks][C][2] written by the producer
     int stats_nrb = 0;                               // blocks per sample (0: one per 32 rows of the whole tensor)
-    size_t bytes() const { return (size_t)N * D * H * W * C * 2; }
+    int esz = 2;                                     // bytes per element: 2 = bf16, 4 = fp32 (LDM_PREC_FP32 plans)
+    size_t bytes() const { return (size_t)N * D * H * W * C * esz; }
     long rows() const { return (long)N * D * H * W; }
 };
 
@@ -73,7 +77,10 @@ enum OpKind { OP_PACK, OP_CONV, OP_FINALIZE, OP_GN_STATS, OP_GN_FINALIZE, OP_GN_
               OP_WT, OP_WT_BATCH, OP_WGRAD, OP_EXPORT, OP_EXPORT_BATCH, OP_COLSUM, OP_GNB, OP_ATTN_BWD, OP_ADD, OP_SUMPOOL, OP_LIN_DX, OP_LIN_DW, OP_VAE_HEADS_BWD,
               OP_GEMM_LIGHT,                       // 1x1 convolution with short K (gemm_light.h)
               OP_COLSUM_BATCH,                     // every column-sum finalize of a backward plan in one launch
-              OP_IM2COL };                         // fp32 NCDHW inputs -> bf16 patch matrix of the first conv (pack_im2col_kernel)
+              OP_IM2COL,                           // fp32 NCDHW inputs -> bf16 patch matrix of the first conv (pack_im2col_kernel)
+              // fp32 precision mode (f32_path.h)
+              OP_PACK32, OP_CONV32, OP_FIN32, OP_GN_STATS32, OP_GN_APPLY32, OP_ATTN32, OP_GEMV32,
+              OP_TAP };                            // debug tap: export an activation as fp32 NCDHW and / or overwrite it (teacher forcing)
 
 struct ConvCfg { int wgm, wgn, bk, splitk; int halo = 0, mtps = 0, qps = 0; };   // halo: conv3_halo_kernel (126-row tiles)
 
@@ -136,8 +143,11 @@ struct DevTable {
     }
 };
 
+struct TapInfo { std::string name; int dims[5]; size_t off; };   // dims = B, C, D, H, W; off = element offset in the tap buffers
+
 struct Plan {
     std::vector<Op> ops;
+    std::vector<TapInfo> taps; size_t tap_elems = 0;
     size_t ws_bytes = 0;
     size_t bwd_begin = 0;                            // training plans: ops [0, bwd_begin) = forward, the rest = backward
     bool train = false;
@@ -166,6 +176,8 @@ struct ldm_model {
     std::map<std::string, int> pindex;
     size_t arena_bytes = 8192;                       // first 8 KiB: the zero page (one padded input row, C <= 4096)
     char* arena = nullptr;
+    // fp32 precision mode (ldm_model_set_precision): unrounded copies of every matrix, allocated on first use
+    int precision = 0; char* arena32 = nullptr;
     int loaded_count = 0;
     std::map<std::string, ConvW> convs; std::map<std::string, GnW> gns; std::map<std::string, LinW> lins;
     std::map<std::string, std::shared_ptr<Plan>> plans;
@@ -275,7 +287,22 @@ struct Builder {
     std::string err;
 
     Act new_act(int N, int D, int H, int W, int C) {
-        Act a; a.N = N; a.D = D; a.H = H; a.W = W; a.C = C; a.valid = true; a.off = pool.alloc(a.bytes()); return a;
+        Act a; a.N = N; a.D = D; a.H = H; a.W = W; a.C = C; a.valid = true; a.esz = hp ? 4 : 2; a.off = pool.alloc(a.bytes()); return a;
+    }
+    bool hp = false;                                  // fp32 precision plan (f32_path.h kernels, fp32 activations)
+    // debug taps (ldm_*_taps entry points): 0 = none, 1 = export every block output, 2 = export, then overwrite it with the
+    // caller's tensor (teacher forcing: the next block sees the reference's input)
+    int tap_mode = 0;
+    void tap(const std::string& name, Act& h, int c_real) {
+        if (!tap_mode) return;
+        TapInfo t; t.name = name; t.dims[0] = h.N; t.dims[1] = c_real; t.dims[2] = h.D; t.dims[3] = h.H; t.dims[4] = h.W; t.off = plan->tap_elems;
+        plan->tap_elems += (size_t)h.N * c_real * h.D * h.H * h.W;
+        Op o{}; o.kind = OP_TAP; o.r[0] = ws_ref(h.off);
+        o.r[1].base = BASE_TAPO; o.r[1].off = t.off * 4; o.r[2].base = BASE_TAPI; o.r[2].off = t.off * 4;
+        o.i[0] = h.N; o.i[1] = c_real; o.i[2] = h.C; o.i[3] = h.D * h.H * h.W; o.i[4] = h.esz; o.i[5] = tap_mode;
+        plan->ops.push_back(o);
+        plan->taps.push_back(t);
+        if (tap_mode == 2 && h.has_stats) { pool.release(h.stats_off); h.has_stats = false; }   // the producer's GroupNorm partials describe the overwritten tensor
     }
     void free_act(Act& a) {
         if (train) return;                            // training plans keep every activation for the backward pass
@@ -379,7 +406,46 @@ struct Builder {
         return best;
     }
 
+    // fp32 precision: every conv form the inference plans use on conv_f32_kernel (the 1x1 skip runs as its own conv -> residual)
+    Act conv32(const ConvArgs& a, const std::string& tag) {
+        const ConvW& w = *a.w;
+        if (a.w1 || a.w_over.base != BASE_NULL || train) { err = "fp32 precision: unsupported conv form (" + tag + ")"; return Act(); }
+        const int cin0 = a.xa.C + (a.xb.valid ? a.xb.C : 0);
+        if (cin0 != w.cin_s || cin0 % 16 || a.xa.C % 16) { err = "conv " + tag + ": channel bookkeeping mismatch"; return Act(); }
+        const int N = a.xa.N;
+        const long M = (long)N * a.Do * a.Ho * a.Wo;
+        if (M >= (1L << 31)) { err = "conv " + tag + ": M too large"; return Act(); }
+        const int taps = a.k * a.k * a.k, nchunk = cin0 / 16, steps = taps * nchunk;
+        const int mtiles = (int)((M + 127) / 128), ntiles = (w.cout_pad + 127) / 128;
+        const long tiles = (long)mtiles * ntiles;
+        int sk = 1;
+        if (tiles < 192) {                               // fill the 256 CUs: K split into deterministic fp32 slabs
+            sk = (int)std::min<long>(std::max<long>(1, 256 / tiles), std::max(1, steps / 8));
+            const int sps = (steps + sk - 1) / sk; sk = (steps + sps - 1) / sps;
+        }
+        const int couts = a.f32_out ? 0 : rup(w.cout, 32);
+        Act out;
+        if (!a.f32_out) out = new_act(N, a.Do, a.Ho, a.Wo, couts);
+        Op op{}; op.kind = OP_CONV32; op.cc = ConvCfg{2, 2, 16, sk};
+        op.r[0] = ws_ref(a.xa.off); op.r[1] = a.xb.valid ? ws_ref(a.xb.off) : Ref();
+        op.r[2] = w32_ref(w.w_off);
+        op.r[6] = a.no_bias ? Ref() : w_ref(w.b_off);
+        op.r[8] = a.temb; op.r[9] = a.residual.valid ? ws_ref(a.residual.off) : Ref();
+        op.r[10] = a.f32_out ? a.out_ref : ws_ref(out.off);
+        int* i = op.i;
+        i[0] = a.xa.C; i[1] = a.xb.valid ? a.xb.C : 0;
+        i[4] = N; i[5] = a.xa.D; i[6] = a.xa.H; i[7] = a.xa.W; i[8] = a.Do; i[9] = a.Ho; i[10] = a.Wo;
+        i[11] = a.k; i[12] = a.stride; i[13] = a.pad; i[14] = a.ups | (a.exact << 1); i[15] = (int)M;
+        i[16] = a.f32_out ? rup(w.cout, 32) : couts; i[17] = w.cout_pad; i[18] = a.cout_real ? a.cout_real : w.cout;
+        i[19] = nchunk; i[21] = a.temb_stride; i[22] = a.f32_out ? 1 : 0; i[23] = mtiles; i[20] = ntiles;
+        if (sk > 1) { partial_bytes = std::max(partial_bytes, (size_t)sk * M * w.cout_pad * 4); partial_fixups.push_back(plan->ops.size()); }
+        plan->ops.push_back(op);
+        if (sk > 1) { Op f = op; f.kind = OP_FIN32; partial_fixups.push_back(plan->ops.size()); plan->ops.push_back(f); }
+        return out;
+    }
+
     Act conv(const ConvArgs& a, std::string tag = "") {
+        if (hp) return conv32(a, tag);
         const ConvW& w = *a.w;
         const int cin0 = a.xa.C + (a.xb.valid ? a.xb.C : 0);
         int bk = 64;
@@ -494,7 +560,7 @@ struct Builder {
         if (train) { ab_off = pool.alloc((size_t)N * C * 2 * 4); mr_off = pool.alloc((size_t)N * groups * 2 * 4); }
         else gnab_bytes = std::max(gnab_bytes, (size_t)N * C * 2 * 4);
         auto ab_ref = [&](Op& o_) {
-            if (train) { o_.r[5] = ws_ref(ab_off); if (o_.kind != OP_GN_APPLY) o_.r[6] = ws_ref(mr_off); }
+            if (train) { o_.r[5] = ws_ref(ab_off); if (o_.kind != OP_GN_APPLY && o_.kind != OP_GN_APPLY32) o_.r[6] = ws_ref(mr_off); }
             else gnab_fixups.push_back(plan->ops.size());
         };
         auto blocks_ok = [&](const Act& t) { return t.has_stats && (t.stats_nrb > 0 || N == 1 || DHW % 32 == 0); };
@@ -535,7 +601,7 @@ struct Builder {
             int rps = (DHW + nslab - 1) / nslab;
             nslab = (DHW + rps - 1) / rps;
             gnpart_bytes = std::max(gnpart_bytes, (size_t)N * nslab * C * 2 * 4);
-            Op st{}; st.kind = OP_GN_STATS;
+            Op st{}; st.kind = hp ? OP_GN_STATS32 : OP_GN_STATS;
             st.r[0] = ws_ref(xa.off); st.r[1] = xb.valid ? ws_ref(xb.off) : Ref();
             st.i[0] = xa.C; st.i[1] = xb.valid ? xb.C : 0; st.i[2] = DHW; st.i[3] = nslab; st.i[4] = rps; st.i[5] = N;
             gnpart_fixups.push_back(plan->ops.size()); plan->ops.push_back(st);
@@ -545,7 +611,7 @@ struct Builder {
             gnpart_fixups.push_back(plan->ops.size()); ab_ref(f); plan->ops.push_back(f);
         }
         Act out = new_act(N, xa.D, xa.H, xa.W, C);
-        Op ap{}; ap.kind = OP_GN_APPLY;
+        Op ap{}; ap.kind = hp ? OP_GN_APPLY32 : OP_GN_APPLY;
         ap.r[0] = ws_ref(xa.off); ap.r[1] = xb.valid ? ws_ref(xb.off) : Ref(); ap.r[3] = ws_ref(out.off);
         ap.i[0] = xa.C; ap.i[1] = xb.valid ? xb.C : 0; ap.i[2] = DHW; ap.i[3] = N; ap.i[4] = silu ? 1 : 0;
         ab_ref(ap); plan->ops.push_back(ap);
@@ -561,7 +627,7 @@ struct Builder {
     static bool im2col_enabled() { const char* e = getenv("LDM_CONV_IM2COL"); return e ? atoi(e) != 0 : true; }
     Act conv_in_im2col(const std::string& name, Ref r0, Ref r1, int N, int D, int H, int W, int cin, bool internal) {
         auto it = m->convs.find(name + ".im2col");
-        if (train || it == m->convs.end() || !im2col_enabled() || !light_enabled()) return Act();
+        if (train || hp || it == m->convs.end() || !im2col_enabled() || !light_enabled()) return Act();
         const ConvW& wi = it->second;
         Act pm = new_act(N, D, H, W, wi.cin_s);
         Op o{}; o.kind = OP_IM2COL; o.r[0] = r0; o.r[1] = r1; o.r[2] = ws_ref(pm.off);
@@ -590,12 +656,12 @@ struct Builder {
         // inference: the 1x1 skip projection runs as a light GEMM on the side lane, concurrently with norm1 / conv1 / norm2, and
         // enters conv2 as its residual: conv2 stays a single-source 3^3 conv (halo kernel) instead of the fused two-group form
         Act sk;
-        if (cin != cout && !train && side_lane_enabled() && cin % 128 == 0) {
+        if (cin != cout && !train && (hp || (side_lane_enabled() && cin % 128 == 0))) {
             ConvArgs cs; cs.xa = xa; cs.xb = xb; cs.w = &m->convs.at(p + skip_name); cs.k = 1; cs.pad = 0;
-            cs.Do = xa.D; cs.Ho = xa.H; cs.Wo = xa.W; cs.want_stats = false; cs.lane = 1; cs.sync = true;
+            cs.Do = xa.D; cs.Ho = xa.H; cs.Wo = xa.W; cs.want_stats = false; cs.lane = hp ? 0 : 1; cs.sync = !hp;
             sk = conv(cs, p + skip_name);
             if (!sk.valid) return Act();
-            if (plan->ops.back().kind != OP_GEMM_LIGHT) { err = "resblock: side-lane skip needs the light GEMM"; return Act(); }
+            if (!hp && plan->ops.back().kind != OP_GEMM_LIGHT) { err = "resblock: side-lane skip needs the light GEMM"; return Act(); }
         }
         Act h0 = gn_apply(m->gns.at(p + ".norm1"), xa, xb, groups, eps, true);
         if (!h0.valid) return Act();
@@ -612,7 +678,7 @@ struct Builder {
         free_act(h1);
         if (!h2.valid) return Act();
         ConvArgs c2; c2.xa = h2; c2.w = &m->convs.at(p + ".conv2"); c2.Do = xa.D; c2.Ho = xa.H; c2.Wo = xa.W;
-        if (sk.valid) { c2.residual = sk; c2.sync = true; }
+        if (sk.valid) { c2.residual = sk; c2.sync = !hp; }
         else if (cin != cout) { c2.g1a = xa; c2.g1b = xb; c2.w1 = &m->convs.at(p + skip_name); }
         else { if (xb.valid) { err = "resblock: identity skip with concat input"; return Act(); } c2.residual = xa; }
         Act out = conv(c2, p + ".conv2");
@@ -621,8 +687,33 @@ struct Builder {
         return out;
     }
 
+    Act attention32(const std::string& p, const Act& x, int head_ch, int groups, float eps) {
+        const int C = x.C;
+        if (head_ch <= 0) head_ch = C;                  // single head (AutoencoderKL attention blocks)
+        if (C % head_ch || (head_ch != 32 && head_ch != 64 && head_ch != 128 && head_ch != 256)) {
+            err = "attention: head dimension must be 32, 64, 128 or 256 (" + p + ")"; return Act();
+        }
+        Act hn = gn_apply(m->gns.at(p + ".norm"), x, Act(), groups, eps, false);
+        if (!hn.valid) return Act();
+        ConvArgs q; q.xa = hn; q.w = &m->convs.at(p + ".attn.qkv"); q.k = 1; q.pad = 0; q.Do = x.D; q.Ho = x.H; q.Wo = x.W;
+        Act qkv = conv(q, p + ".qkv");
+        free_act(hn);
+        if (!qkv.valid) return Act();
+        Act o = new_act(x.N, x.D, x.H, x.W, C);
+        Op at{}; at.kind = OP_ATTN32; at.r[0] = ws_ref(qkv.off); at.r[1] = ws_ref(o.off);
+        at.i[0] = x.N; at.i[1] = x.D * x.H * x.W; at.i[2] = C; at.i[3] = C / head_ch; at.i[4] = head_ch; at.f[0] = 1.0f / sqrtf((float)head_ch);
+        plan->ops.push_back(at);
+        free_act(qkv);
+        ConvArgs pr; pr.xa = o; pr.w = &m->convs.at(p + ".attn.out_proj"); pr.k = 1; pr.pad = 0;
+        pr.Do = x.D; pr.Ho = x.H; pr.Wo = x.W; pr.residual = x;
+        Act out = conv(pr, p + ".out_proj");
+        free_act(o);
+        return out;
+    }
+
     Act attention(const std::string& p, const Act& x, int head_ch, int groups, float eps) {
         const int C = x.C;
+        if (hp) return attention32(p, x, head_ch, groups, eps);
         if (head_ch != 64 || C % 64) { err = "attention: only num_head_channels == 64 is implemented (" + p + ")"; return Act(); }
         Act hn = gn_apply(m->gns.at(p + ".norm"), x, Act(), groups, eps, false);
         if (!hn.valid) return Act();
@@ -972,11 +1063,12 @@ static int unet_register(ldm_model* m) {
     return 0;
 }
 
-static int unet_build(ldm_model* m, int B, int D, int H, int W, Plan* plan, bool train) {
+static int unet_build(ldm_model* m, int B, int D, int H, int W, Plan* plan, bool train, bool hp = false, int tap_mode = 0) {
     const ldm_unet_cfg& c = m->ucfg;
     const int L = c.num_levels; const int* ch = c.channels;
     const int temb = ch[0] * 4, G = c.norm_num_groups; const float eps = c.norm_eps;
-    Builder b; b.m = m; b.plan = plan; b.train = train; b.recording = train;
+    if (train && (hp || tap_mode)) return fail(LDM_ERR_UNSUPPORTED, "the fp32 precision mode and debug taps are inference-only");
+    Builder b; b.m = m; b.plan = plan; b.train = train; b.recording = train; b.hp = hp; b.tap_mode = tap_mode;
     // ---- time embedding: sinusoid -> Linear -> SiLU -> Linear -> (SiLU -> stacked projections)
     const size_t sin_off = b.pool.alloc((size_t)B * ch[0] * 4);
     const size_t e1_off = b.pool.alloc((size_t)B * temb * 4);
@@ -988,7 +1080,7 @@ static int unet_build(ldm_model* m, int B, int D, int H, int W, Plan* plan, bool
     { Op o{}; o.kind = OP_SINUSOID; o.r[0] = io_ref(2); o.r[1] = ws_ref(sin_off); o.i[0] = B; o.i[1] = ch[0]; o.lane = tlane; o.sync = tlane != 0;
       plan->ops.push_back(o); }
     auto gemv = [&](size_t w_off, size_t b_off, size_t x_off, size_t y_off, int I, int O, int xs, int ys, int silu) {
-        Op o{}; o.kind = OP_GEMV; o.r[0] = w_ref(w_off); o.r[1] = w_ref(b_off); o.r[2] = ws_ref(x_off); o.r[3] = ws_ref(y_off);
+        Op o{}; o.kind = hp ? OP_GEMV32 : OP_GEMV; o.r[0] = hp ? w32_ref(w_off) : w_ref(w_off); o.r[1] = w_ref(b_off); o.r[2] = ws_ref(x_off); o.r[3] = ws_ref(y_off);
         o.i[0] = I; o.i[1] = O; o.i[2] = xs; o.i[3] = ys; o.i[4] = silu; o.i[5] = B; o.lane = tlane; plan->ops.push_back(o);
     };
     b.temb_pending = tlane != 0;
@@ -1003,13 +1095,14 @@ static int unet_build(ldm_model* m, int B, int D, int H, int W, Plan* plan, bool
     if (!h.valid) {
         if (!b.err.empty()) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
         Act xin = b.new_act(B, D, H, W, cin_s);
-        { Op o{}; o.kind = OP_PACK; o.r[0] = io_ref(0); o.r[1] = io_ref(1); o.r[2] = ws_ref(xin.off);
+        { Op o{}; o.kind = hp ? OP_PACK32 : OP_PACK; o.r[0] = io_ref(0); o.r[1] = io_ref(1); o.r[2] = ws_ref(xin.off);
           o.i[0] = B; o.i[1] = c.in_channels; o.i[2] = cin_s; o.i[3] = D * H * W; plan->ops.push_back(o); }
         h = b.conv3("conv_in", xin);
         if (train && !b.tape.empty()) b.tape.back().leaf_input = true;        // no gradient w.r.t. the network input
         b.free_act(xin);
     }
     if (!h.valid) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
+    b.tap("conv_in", h, ch[0]);
     std::vector<Act> skips; skips.push_back(h);
     char p[96];
     for (int i = 0; i < L; ++i) {
@@ -1017,12 +1110,14 @@ static int unet_build(ldm_model* m, int B, int D, int H, int W, Plan* plan, bool
             snprintf(p, sizeof p, "down_blocks.%d.resnets.%d", i, j);
             Act hn = b.resblock(p, h, Act(), ch[i], G, eps, ".skip_connection", true);
             if (!hn.valid) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
+            b.tap(p, hn, ch[i]);
             if (c.attention_levels[i]) {
                 snprintf(p, sizeof p, "down_blocks.%d.attentions.%d", i, j);
                 Act ha = b.attention(p, hn, c.num_head_channels[i], G, eps);
                 b.free_act(hn);
                 if (!ha.valid) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
                 hn = ha;
+                b.tap(p, hn, ch[i]);
             }
             skips.push_back(hn); h = hn;
         }
@@ -1031,18 +1126,22 @@ static int unet_build(ldm_model* m, int B, int D, int H, int W, Plan* plan, bool
             snprintf(p, sizeof p, "down_blocks.%d.downsampler.op", i);
             Act hd = b.conv3(p, h, 2, 1);
             if (!hd.valid) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
+            b.tap(p, hd, ch[i]);
             skips.push_back(hd); h = hd;
         }
     }
     {   // middle: Res, Attn, Res.  `h` is also the last skip and stays alive.
         Act h1 = b.resblock("middle_block.resnet_1", h, Act(), ch[L - 1], G, eps, ".skip_connection", true);
         if (!h1.valid) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
+        b.tap("middle_block.resnet_1", h1, ch[L - 1]);
         Act h2 = b.attention("middle_block.attention", h1, c.num_head_channels[L - 1], G, eps);
         b.free_act(h1);
         if (!h2.valid) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
+        b.tap("middle_block.attention", h2, ch[L - 1]);
         Act h3 = b.resblock("middle_block.resnet_2", h2, Act(), ch[L - 1], G, eps, ".skip_connection", true);
         b.free_act(h2);
         if (!h3.valid) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
+        b.tap("middle_block.resnet_2", h3, ch[L - 1]);
         h = h3;
     }
     for (int i = 0; i < L; ++i) {
@@ -1053,12 +1152,14 @@ static int unet_build(ldm_model* m, int B, int D, int H, int W, Plan* plan, bool
             Act hn = b.resblock(p, h, s, ch[lvl], G, eps, ".skip_connection", true);
             b.free_act(h); b.free_act(s);
             if (!hn.valid) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
+            b.tap(p, hn, ch[lvl]);
             if (c.attention_levels[lvl]) {
                 snprintf(p, sizeof p, "up_blocks.%d.attentions.%d", i, j);
                 Act ha = b.attention(p, hn, c.num_head_channels[lvl], G, eps);
                 b.free_act(hn);
                 if (!ha.valid) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
                 hn = ha;
+                b.tap(p, hn, ch[lvl]);
             }
             h = hn;
         }
@@ -1067,6 +1168,7 @@ static int unet_build(ldm_model* m, int B, int D, int H, int W, Plan* plan, bool
             Act hu = b.conv3(p, h, 1, 1, 1);
             b.free_act(h);
             if (!hu.valid) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
+            b.tap(p, hu, ch[lvl]);
             h = hu;
         }
     }
@@ -1171,7 +1273,7 @@ static int vae_register(ldm_model* m) {
                     m->reg_gn(std::string(p) + ".norm2", bl.b); m->reg_conv(std::string(p) + ".conv2", bl.b, bl.b, bl.b, 3);
                     if (bl.a != bl.b) m->reg_conv(std::string(p) + ".nin_shortcut", bl.a, bl.a, bl.b, 1);
                     break;
-                case 2: return fail(LDM_ERR_UNSUPPORTED, "AutoencoderKL attention blocks (single head, d = C) are not implemented");
+                case 2: m->reg_attn(p, bl.a); break;      // SpatialAttentionBlock, single head (d = C)
                 case 3: m->reg_conv(std::string(p) + ".conv", bl.a, bl.a, bl.a, 3); break;
                 case 4: m->reg_conv(std::string(p) + ".postconv", bl.a, bl.a, bl.a, 3, true); break;
                 case 5: m->reg_gn(p, bl.a); break;
@@ -1210,6 +1312,8 @@ static int vae_run_layout(Builder& b, const char* prefix, const std::vector<AeBl
             hn = b.conv3(p, h);
         } else if (bl.kind == 1) {
             hn = b.resblock(p, h, Act(), bl.b, G, eps, ".nin_shortcut", false);
+        } else if (bl.kind == 2) {
+            hn = b.attention(p, h, 0, G, eps);              // head_ch 0 = one head over all channels
         } else if (bl.kind == 3) {
             if ((h.D | h.H | h.W) & 1) return fail(LDM_ERR_UNSUPPORTED, "odd spatial size at an AutoencoderKL downsample");
             hn = b.conv3(std::string(p) + ".conv", h, 2, 0);
@@ -1220,24 +1324,26 @@ static int vae_run_layout(Builder& b, const char* prefix, const std::vector<AeBl
         } else return fail(LDM_ERR_UNSUPPORTED, "unsupported AutoencoderKL block");
         b.free_act(h);
         if (!hn.valid) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
+        b.tap(p, hn, bl.b);
         h = hn;
     }
     *out = h;
     return 0;
 }
 
-static int vae_build_encode(ldm_model* m, int B, int D, int H, int W, Plan* plan) {
+static int vae_build_encode(ldm_model* m, int B, int D, int H, int W, Plan* plan, bool hp = false, int tap_mode = 0) {
     const ldm_vae_cfg& c = m->vcfg;
-    Builder b; b.m = m; b.plan = plan;
+    Builder b; b.m = m; b.plan = plan; b.hp = hp; b.tap_mode = tap_mode;
     const int cs = rup(c.in_channels, 32);
     Act h;
     Act first = b.conv_in_im2col("encoder.blocks.0", io_ref(0), Ref(), B, D, H, W, c.in_channels, true);
     if (first.valid) {
+        b.tap("encoder.blocks.0", first, c.channels[0]);
         LDM_TRY(vae_run_layout(b, "encoder", ae_encoder_layout(c), first, c.norm_num_groups, c.norm_eps, false, 0, &h, 1));
     } else {
         if (!b.err.empty()) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
         Act xin = b.new_act(B, D, H, W, cs);
-        { Op o{}; o.kind = OP_PACK; o.r[0] = io_ref(0); o.r[1] = Ref(); o.r[2] = ws_ref(xin.off);
+        { Op o{}; o.kind = hp ? OP_PACK32 : OP_PACK; o.r[0] = io_ref(0); o.r[1] = Ref(); o.r[2] = ws_ref(xin.off);
           o.i[0] = B; o.i[1] = c.in_channels; o.i[2] = cs; o.i[3] = D * H * W; plan->ops.push_back(o); }
         LDM_TRY(vae_run_layout(b, "encoder", ae_encoder_layout(c), xin, c.norm_num_groups, c.norm_eps, false, 0, &h));
     }
@@ -1255,17 +1361,18 @@ static int vae_build_encode(ldm_model* m, int B, int D, int H, int W, Plan* plan
     return 0;
 }
 
-static int vae_build_decode(ldm_model* m, int B, int d, int h_, int w, Plan* plan) {
+static int vae_build_decode(ldm_model* m, int B, int d, int h_, int w, Plan* plan, bool hp = false, int tap_mode = 0) {
     const ldm_vae_cfg& c = m->vcfg;
-    Builder b; b.m = m; b.plan = plan;
+    Builder b; b.m = m; b.plan = plan; b.hp = hp; b.tap_mode = tap_mode;
     const int ls = rup(c.latent_channels, 32);
     Act zin = b.new_act(B, d, h_, w, ls);
-    { Op o{}; o.kind = OP_PACK; o.r[0] = io_ref(0); o.r[1] = Ref(); o.r[2] = ws_ref(zin.off);
+    { Op o{}; o.kind = hp ? OP_PACK32 : OP_PACK; o.r[0] = io_ref(0); o.r[1] = Ref(); o.r[2] = ws_ref(zin.off);
       o.i[0] = B; o.i[1] = c.latent_channels; o.i[2] = ls; o.i[3] = d * h_ * w; plan->ops.push_back(o); }
     Builder::ConvArgs a; a.xa = zin; a.w = &m->convs.at("post_quant_conv"); a.k = 1; a.pad = 0; a.Do = d; a.Ho = h_; a.Wo = w;
     Act z2 = b.conv(a, "post_quant_conv");
     b.free_act(zin);
     if (!z2.valid) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
+    b.tap("post_quant_conv", z2, c.latent_channels);
     Act out;
     LDM_TRY(vae_run_layout(b, "decoder", ae_decoder_layout(c), z2, c.norm_num_groups, c.norm_eps, true, 1, &out));
     b.finish();
@@ -1531,6 +1638,64 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                 hipLaunchKernelGGL(pack_im2col_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0, s, (const float*)rp(bs, o.r[0]), cx,
                                    (const float*)rp(bs, o.r[1]), cc, (bf16_t*)rp(bs, o.r[2]), i[0], i[3], i[4], i[5], i[2]);
                 break; }
+            case OP_PACK32: {
+                const long total = (long)i[0] * i[3] * i[2];
+                int cx = rt[0], cc = rt[1];
+                if (i[4]) { cx = i[1]; cc = 0; }
+                if (cx + cc != i[1]) return fail(LDM_ERR_BAD_ARG, "x_channels + cond_channels = %d, model expects %d", cx + cc, i[1]);
+                hipLaunchKernelGGL(pack2_ncdhw_f32_kernel, dim3(grid_for(total)), dim3(256), 0, s, (const float*)rp(bs, o.r[0]), cx,
+                                   (const float*)rp(bs, o.r[1]), cc, (float*)rp(bs, o.r[2]), i[0], i[2], i[3]);
+                break; }
+            case OP_CONV32: case OP_FIN32: {
+                Conv32Params p{};
+                p.xa = (const float*)rp(bs, o.r[0]); p.xb = (const float*)rp(bs, o.r[1]); p.ca = i[0]; p.cb = i[1];
+                p.w = (const float*)rp(bs, o.r[2]);
+                if (!p.w) return fail(LDM_ERR_NOT_LOADED, "fp32 precision: the fp32 weight arena is empty (re-upload the parameters after ldm_model_set_precision)");
+                p.N = i[4]; p.Din = i[5]; p.Hin = i[6]; p.Win = i[7]; p.Dout = i[8]; p.Hout = i[9]; p.Wout = i[10];
+                p.ksize = i[11]; p.stride = i[12]; p.pad = i[13]; p.ups = i[14] & 1; p.exact = (i[14] >> 1) & 1; p.M = i[15];
+                p.CoutS = i[16]; p.CoutPad = i[17]; p.CoutReal = i[18]; p.nchunk = i[19]; p.steps = i[11] * i[11] * i[11] * i[19];
+                p.splitk = o.cc.splitk; p.steps_per_split = (p.steps + p.splitk - 1) / p.splitk; p.mtiles = i[23]; p.ntiles = i[20];
+                p.bias = (const float*)rp(bs, o.r[6]); p.temb = (const float*)rp(bs, o.r[8]); p.temb_stride = i[21];
+                p.residual = (const float*)rp(bs, o.r[9]);
+                if (i[22]) p.out_ncdhw = (float*)rp(bs, o.r[10]); else p.out = (float*)rp(bs, o.r[10]);
+                p.partial = (float*)rp(bs, o.r[11]);
+                if (o.kind == OP_CONV32) hipLaunchKernelGGL(conv_f32_kernel, dim3(p.mtiles * p.ntiles * p.splitk), dim3(256), 0, s, p);
+                else hipLaunchKernelGGL(finalize_f32_kernel, dim3(grid_for((long)p.M * (p.CoutPad / 4), 256, 4096)), dim3(256), 0, s, p);
+                break; }
+            case OP_GN_STATS32: case OP_GN_APPLY32: {
+                Gn32Params p{}; p.xa = (const float*)rp(bs, o.r[0]); p.xb = (const float*)rp(bs, o.r[1]); p.ca = i[0]; p.cb = i[1];
+                if (o.kind == OP_GN_STATS32) {
+                    p.DHW = i[2]; p.nslab = i[3]; p.rows_per_slab = i[4]; p.N = i[5]; p.partial = (float*)rp(bs, o.r[4]);
+                    hipLaunchKernelGGL(gn_stats_f32_kernel, dim3(i[3], i[5]), dim3(256), 0, s, p);
+                } else {
+                    p.DHW = i[2]; p.N = i[3]; p.silu = i[4]; p.ab = (const float*)rp(bs, o.r[5]); p.out = (float*)rp(bs, o.r[3]);
+                    hipLaunchKernelGGL(gn_apply_f32_kernel, dim3(grid_for((long)i[3] * i[2] * ((i[0] + i[1]) / 4), 256, 4096)), dim3(256), 0, s, p);
+                }
+                break; }
+            case OP_ATTN32: {
+                Attn32Params p{}; p.qkv = (const float*)rp(bs, o.r[0]); p.out = (float*)rp(bs, o.r[1]);
+                p.B = i[0]; p.N = i[1]; p.C = i[2]; p.heads = i[3]; p.d = i[4]; p.scale = o.f[0];
+                HIP_TRY(launch_attn_f32(p, s));
+                break; }
+            case OP_GEMV32: {
+                const float* w = (const float*)rp(bs, o.r[0]);
+                if (!w) return fail(LDM_ERR_NOT_LOADED, "fp32 precision: the fp32 weight arena is empty");
+                hipLaunchKernelGGL(gemv_f32_kernel, dim3((i[1] + 3) / 4, i[5]), dim3(256), 0, s, w, (const float*)rp(bs, o.r[1]),
+                                   (const float*)rp(bs, o.r[2]), (float*)rp(bs, o.r[3]), i[0], i[1], i[2], i[3], i[4]);
+                break; }
+            case OP_TAP: {               // i: N, C real, C stored, DHW, element size, mode
+                float* dst = (float*)rp(bs, o.r[1]); const float* src = (const float*)rp(bs, o.r[2]);
+                const long total = (long)i[0] * i[1] * i[3];
+                if (dst) {
+                    if (i[4] == 4) hipLaunchKernelGGL(tap_export_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)rp(bs, o.r[0]), dst, i[0], i[1], i[2], i[3]);
+                    else hipLaunchKernelGGL(tap_export_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)rp(bs, o.r[0]), dst, i[0], i[1], i[2], i[3]);
+                }
+                if (src && i[5] == 2) {
+                    const long tot2 = (long)i[0] * i[3] * i[2];
+                    if (i[4] == 4) hipLaunchKernelGGL(pack2_ncdhw_f32_kernel, dim3(grid_for(tot2)), dim3(256), 0, s, src, i[1], (const float*)nullptr, 0, (float*)rp(bs, o.r[0]), i[0], i[2], i[3]);
+                    else hipLaunchKernelGGL(pack2_ncdhw_kernel, dim3(grid_for(tot2)), dim3(256), 0, s, src, i[1], (const float*)nullptr, 0, (bf16_t*)rp(bs, o.r[0]), i[0], i[2], i[3]);
+                }
+                break; }
             case OP_CONV: case OP_FINALIZE: {
                 ConvParams p{};
                 p.x0a = (const bf16_t*)rp(bs, o.r[0]); p.x0b = (const bf16_t*)rp(bs, o.r[1]); p.c0a = i[0]; p.c0b = i[1];
@@ -1778,6 +1943,7 @@ void ldm_model_destroy(ldm_model* m) {
     if (m->side_stream) (void)hipStreamDestroy(m->side_stream);
     for (auto e : m->lane_events) (void)hipEventDestroy(e);
     if (m->arena) (void)hipFree(m->arena);
+    if (m->arena32) (void)hipFree(m->arena32);
     delete m;
 }
 
@@ -1807,6 +1973,23 @@ static int ensure_arena(ldm_model* m) {
     return 0;
 }
 
+static int ensure_arena32(ldm_model* m) {
+    if (m->arena32) return 0;
+    HIP_TRY(hipMalloc((void**)&m->arena32, 2 * m->arena_bytes));
+    HIP_TRY(hipMemset(m->arena32, 0, 2 * m->arena_bytes));
+    HIP_TRY(hipDeviceSynchronize());
+    return 0;
+}
+// device-side re-pack of one parameter (fp32 MONAI layout) into the fp32 arena
+static void pack32_device(ldm_model* m, const ParamDesc& d, const float* src, hipStream_t s) {
+    if (d.kind == PK_VEC_F32) return;
+    float* dst = (float*)(m->arena32 + 2 * d.dst_off);
+    const bool lin = d.kind == PK_LINEAR_W;
+    const int taps = lin ? 1 : d.k * d.k * d.k, cin_s = lin ? d.cin : d.cin_s, cout_pad = lin ? d.cout : d.cout_pad, row_off = lin ? 0 : d.row_off;
+    const long total = (long)taps * d.cout * cin_s;
+    hipLaunchKernelGGL(param_pack_f32_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, s, src, dst, taps, d.cout, d.cin, cin_s, cout_pad, row_off);
+}
+
 int ldm_model_load_param(ldm_model* m, const char* name, const float* src, size_t numel) {
     if (!m || !name || !src) return fail(LDM_ERR_BAD_ARG, "null argument");
     auto it = m->pindex.find(name);
@@ -1833,6 +2016,23 @@ int ldm_model_load_param(ldm_model* m, const char* name, const float* src, size_
             HIP_TRY(hipMemcpy(dst, tmp.data(), tmp.size() * 2, hipMemcpyHostToDevice));
         }
     }
+    if (m->precision == 1 && d.kind != PK_VEC_F32) {     // the unrounded copy for the fp32 precision mode
+        LDM_TRY(ensure_arena32(m));
+        if (d.kind == PK_LINEAR_W) {
+            HIP_TRY(hipMemcpy(m->arena32 + 2 * d.dst_off, src, numel * 4, hipMemcpyHostToDevice));
+        } else {
+            const int taps = d.k * d.k * d.k;
+            std::vector<float> tmp((size_t)d.cout * d.cin_s);
+            for (int t = 0; t < taps; ++t) {
+                std::fill(tmp.begin(), tmp.end(), 0.f);
+                for (int co = 0; co < d.cout; ++co)
+                    for (int ci = 0; ci < d.cin; ++ci)
+                        tmp[(size_t)co * d.cin_s + ci] = src[((size_t)co * d.cin + ci) * taps + t];
+                char* dst = m->arena32 + 2 * (d.dst_off + ((size_t)t * d.cout_pad + d.row_off) * d.cin_s * 2);
+                HIP_TRY(hipMemcpy(dst, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice));
+            }
+        }
+    }
     if (!d.loaded) { d.loaded = true; m->loaded_count++; }
     m->derived_dirty = true;
     return 0;
@@ -1854,16 +2054,19 @@ static int ensure_derived(ldm_model* m, hipStream_t s) {
     return 0;
 }
 
-static int get_plan(ldm_model* m, const char* kind, int B, int D, int H, int W, std::shared_ptr<Plan>* out) {
+static int get_plan(ldm_model* m, const char* kind, int B, int D, int H, int W, std::shared_ptr<Plan>* out, int tap_mode = 0) {
     if (B < 1 || D < 1 || H < 1 || W < 1 || D > 255 * 8 || H > 255 * 8 || W > 255 * 8) return fail(LDM_ERR_BAD_ARG, "bad shape");
-    char key[96]; snprintf(key, sizeof key, "%s:%d:%d:%d:%d", kind, B, D, H, W);
+    const bool train = kind[0] == 't';
+    const bool hp = m->precision == 1;
+    if (train && hp) return fail(LDM_ERR_UNSUPPORTED, "the fp32 precision mode is inference-only (training runs the bf16 plans)");
+    char key[96]; snprintf(key, sizeof key, "%s:%d:%d:%d:%d:p%d:t%d", kind, B, D, H, W, hp ? 1 : 0, tap_mode);
     auto it = m->plans.find(key);
     if (it != m->plans.end()) { *out = it->second; return 0; }
     std::shared_ptr<Plan> p(new Plan());
-    if (m->type == 0) LDM_TRY(unet_build(m, B, D, H, W, p.get(), kind[0] == 't'));
-    else if (kind[0] == 't') LDM_TRY(vae_build_train(m, B, D, H, W, p.get()));
-    else if (kind[0] == 'e') LDM_TRY(vae_build_encode(m, B, D, H, W, p.get()));
-    else LDM_TRY(vae_build_decode(m, B, D, H, W, p.get()));
+    if (m->type == 0) LDM_TRY(unet_build(m, B, D, H, W, p.get(), train, hp, tap_mode));
+    else if (train) LDM_TRY(vae_build_train(m, B, D, H, W, p.get()));
+    else if (kind[0] == 'e') LDM_TRY(vae_build_encode(m, B, D, H, W, p.get(), hp, tap_mode));
+    else LDM_TRY(vae_build_decode(m, B, D, H, W, p.get(), hp, tap_mode));
     m->plans[key] = p; *out = p;
     return 0;
 }
@@ -1893,7 +2096,7 @@ int ldm_unet_forward(ldm_model* m, const float* x, int x_channels, const float* 
     if (!cond) cond_channels = 0;
     std::shared_ptr<Plan> p; LDM_TRY(get_plan(m, "unet", B, D, H, W, &p));
     LDM_TRY(check_ready(m, workspace, workspace_bytes, *p));
-    Bases bs{}; bs.p[BASE_WS] = (char*)workspace; bs.p[BASE_W] = m->arena;
+    Bases bs{}; bs.p[BASE_WS] = (char*)workspace; bs.p[BASE_W] = m->arena; bs.p[BASE_W32] = m->arena32;
     bs.p[BASE_IO0] = (char*)x; bs.p[BASE_IO1] = (char*)cond; bs.p[BASE_IO2] = (char*)timesteps; bs.p[BASE_IO3] = (char*)out;
     const int rt[2] = {x_channels, cond_channels};
     LDM_TRY(ensure_derived(m, (hipStream_t)stream));
@@ -1938,6 +2141,77 @@ int ldm_model_set_graph_mode(ldm_model* m, int on) {
     return 0;
 }
 
+/* Arithmetic of the INFERENCE plans (ldm_unet_forward, ldm_vae_encode, ldm_vae_decode and their *_taps forms):
+ *   LDM_PREC_BF16 (0, default): bf16 storage, bf16 MFMA, fp32 accumulation (the headline path);
+ *   LDM_PREC_FP32 (1): fp32 activations and weights on the fp32 matrix instruction (f32_path.h): the reference's own
+ *   arithmetic (3d_ldm/train_diffusion.py:177: autocast off), within ~1e-5 rel-L2 of the CPU path instead of ~3e-2.
+ * Switching to fp32 needs the parameters uploaded again (the unrounded copies are made at upload time): every ldm_model_load_*
+ * call after the switch fills both arenas; forward calls fail with LDM_ERR_NOT_LOADED until then. */
+int ldm_model_set_precision(ldm_model* m, int precision) {
+    if (!m) return fail(LDM_ERR_BAD_ARG, "null model");
+    if (precision != 0 && precision != 1) return fail(LDM_ERR_BAD_ARG, "precision must be LDM_PREC_BF16 (0) or LDM_PREC_FP32 (1)");
+    if (precision == 1 && m->precision != 1) {          // every matrix must be uploaded again
+        for (ParamDesc& d : m->params) d.loaded = false;
+        m->loaded_count = 0;
+    }
+    m->precision = precision;
+    return 0;
+}
+int ldm_model_get_precision(const ldm_model* m) { return m ? m->precision : -1; }
+
+/* Debug taps: kind = "unet" | "enc" | "dec".  ldm_model_tap_count builds (and caches) the tapped plan of that shape and returns
+ * the number of taps (or a negative status); ldm_model_tap_info describes tap i: name (block prefix in the MONAI state_dict),
+ * dims = {B, C, D, H, W} and the element offset of its fp32 NCDHW tensor inside the taps_out / taps_in buffers of the
+ * *_taps entry points (total elements = ldm_model_tap_elems). */
+static const char* tap_kind(ldm_model* m, const char* kind) {
+    if (!kind) return nullptr;
+    if (m->type == 0) return strcmp(kind, "unet") == 0 ? "unet" : nullptr;
+    return strcmp(kind, "enc") == 0 ? "enc" : strcmp(kind, "dec") == 0 ? "dec" : nullptr;
+}
+int ldm_model_tap_count(ldm_model* m, const char* kind, int B, int D, int H, int W) {
+    if (!m || !tap_kind(m, kind)) return fail(LDM_ERR_BAD_ARG, "bad model / plan kind");
+    std::shared_ptr<Plan> p; LDM_TRY(get_plan(m, tap_kind(m, kind), B, D, H, W, &p, 1));
+    return (int)p->taps.size();
+}
+int64_t ldm_model_tap_elems(ldm_model* m, const char* kind, int B, int D, int H, int W) {
+    if (!m || !tap_kind(m, kind)) return fail(LDM_ERR_BAD_ARG, "bad model / plan kind");
+    std::shared_ptr<Plan> p; LDM_TRY(get_plan(m, tap_kind(m, kind), B, D, H, W, &p, 1));
+    return (int64_t)p->tap_elems;
+}
+int ldm_model_tap_info(ldm_model* m, const char* kind, int B, int D, int H, int W, int i, char* name, int name_cap, int dims[5], int64_t* offset) {
+    if (!m || !tap_kind(m, kind) || !name || name_cap < 1 || !dims || !offset) return fail(LDM_ERR_BAD_ARG, "bad argument");
+    std::shared_ptr<Plan> p; LDM_TRY(get_plan(m, tap_kind(m, kind), B, D, H, W, &p, 1));
+    if (i < 0 || i >= (int)p->taps.size()) return fail(LDM_ERR_BAD_ARG, "tap index out of range");
+    const TapInfo& t = p->taps[i];
+    snprintf(name, (size_t)name_cap, "%s", t.name.c_str());
+    for (int k = 0; k < 5; ++k) dims[k] = t.dims[k];
+    *offset = (int64_t)t.off;
+    return 0;
+}
+/* ldm_unet_forward that also writes every block output to taps_out (fp32 NCDHW, layout from ldm_model_tap_info) and, when
+ * taps_in is given, then OVERWRITES each block output with the caller's tensor, so that every block is computed from the
+ * reference's input (teacher forcing: per-block parity without compounding rounding noise).  Eager launches only. */
+int ldm_unet_forward_taps(ldm_model* m, const float* x, int x_channels, const float* cond, int cond_channels,
+                          const float* timesteps, float* out, int B, int D, int H, int W, float* taps_out, const float* taps_in,
+                          void* workspace, size_t workspace_bytes, void* stream) {
+    if (!m || m->type != 0) return fail(LDM_ERR_BAD_ARG, "not a UNet handle");
+    if (!x || !timesteps || !out || !taps_out) return fail(LDM_ERR_BAD_ARG, "null tensor argument");
+    if (!cond) cond_channels = 0;
+    std::shared_ptr<Plan> p; LDM_TRY(get_plan(m, "unet", B, D, H, W, &p, taps_in ? 2 : 1));
+    LDM_TRY(check_ready(m, workspace, workspace_bytes, *p));
+    Bases bs{}; bs.p[BASE_WS] = (char*)workspace; bs.p[BASE_W] = m->arena; bs.p[BASE_W32] = m->arena32;
+    bs.p[BASE_IO0] = (char*)x; bs.p[BASE_IO1] = (char*)cond; bs.p[BASE_IO2] = (char*)timesteps; bs.p[BASE_IO3] = (char*)out;
+    bs.p[BASE_TAPO] = (char*)taps_out; bs.p[BASE_TAPI] = (char*)taps_in;
+    const int rt[2] = {x_channels, cond_channels};
+    LDM_TRY(ensure_derived(m, (hipStream_t)stream));
+    return run_plan(*p, bs, rt, (hipStream_t)stream);
+}
+size_t ldm_model_taps_workspace_bytes(ldm_model* m, const char* kind, int B, int D, int H, int W, int force) {
+    if (!m || !tap_kind(m, kind)) { fail(LDM_ERR_BAD_ARG, "bad model / plan kind"); return 0; }
+    std::shared_ptr<Plan> p; if (get_plan(m, tap_kind(m, kind), B, D, H, W, &p, force ? 2 : 1)) return 0;
+    return p->ws_bytes;
+}
+
 // ---- training: forward that keeps the tape, backward into one flat fp32 gradient buffer --------------------------
 int64_t ldm_model_param_offset(const ldm_model* m, int i) {
     return (m && i >= 0 && i < (int)m->params.size()) ? m->params[i].flat_off : -1;
@@ -1962,6 +2236,7 @@ int ldm_model_load_params_device(ldm_model* m, const float* const* ptrs, int n, 
             hipLaunchKernelGGL(param_pack_kernel, dim3((d.cin_s + 63) / 64, d.cout), dim3(256), 0, s, ptrs[k], (bf16_t*)(m->arena + d.dst_off),
                                d.k * d.k * d.k, d.cout, d.cin, d.cin_s, d.cout_pad, d.row_off);
         }
+        if (m->precision == 1) { LDM_TRY(ensure_arena32(m)); pack32_device(m, d, ptrs[k], s); }
         if (!d.loaded) { d.loaded = true; m->loaded_count++; }
     }
     HIP_TRY(hipGetLastError());
@@ -1994,6 +2269,10 @@ int ldm_model_load_params_flat(ldm_model* m, const float* flat, void* stream) {
     LDM_TRY(ensure_pack_tab(m));
     hipLaunchKernelGGL(param_pack_batched_kernel, dim3(m->pack_tab.nblocks), dim3(256), 0, (hipStream_t)stream,
                        (const PackDesc*)m->pack_tab.descs, (const int2*)m->pack_tab.map, flat, m->arena);
+    if (m->precision == 1) {
+        LDM_TRY(ensure_arena32(m));
+        for (const ParamDesc& d : m->params) pack32_device(m, d, flat + d.flat_off, (hipStream_t)stream);
+    }
     HIP_TRY(hipGetLastError());
     for (ParamDesc& d : m->params) if (!d.loaded) { d.loaded = true; m->loaded_count++; }
     m->derived_dirty = true;
@@ -2016,7 +2295,7 @@ int ldm_unet_train_forward(ldm_model* m, const float* x, int x_channels, const f
     if (!cond) cond_channels = 0;
     std::shared_ptr<Plan> p; LDM_TRY(get_plan(m, "train", B, D, H, W, &p));
     LDM_TRY(check_ready(m, workspace, workspace_bytes, *p));
-    Bases bs{}; bs.p[BASE_WS] = (char*)workspace; bs.p[BASE_W] = m->arena;
+    Bases bs{}; bs.p[BASE_WS] = (char*)workspace; bs.p[BASE_W] = m->arena; bs.p[BASE_W32] = m->arena32;
     bs.p[BASE_IO0] = (char*)x; bs.p[BASE_IO1] = (char*)cond; bs.p[BASE_IO2] = (char*)timesteps; bs.p[BASE_IO3] = (char*)out;
     const int rt[2] = {x_channels, cond_channels};
     return run_plan(*p, bs, rt, (hipStream_t)stream, 0, p->bwd_begin);
@@ -2030,7 +2309,7 @@ int ldm_unet_train_backward(ldm_model* m, const float* grad_out, float* flat_gra
     if (!grad_out || !flat_grads) return fail(LDM_ERR_BAD_ARG, "null tensor argument");
     std::shared_ptr<Plan> p; LDM_TRY(get_plan(m, "train", B, D, H, W, &p));
     LDM_TRY(check_ready(m, workspace, workspace_bytes, *p));
-    Bases bs{}; bs.p[BASE_WS] = (char*)workspace; bs.p[BASE_W] = m->arena;
+    Bases bs{}; bs.p[BASE_WS] = (char*)workspace; bs.p[BASE_W] = m->arena; bs.p[BASE_W32] = m->arena32;
     bs.p[BASE_IO0] = (char*)grad_out; bs.p[BASE_IO4] = (char*)flat_grads;
     const int rt[2] = {m->ucfg.out_channels, 0};
     return run_plan(*p, bs, rt, (hipStream_t)stream, p->bwd_begin, p->ops.size());
@@ -2050,7 +2329,7 @@ int ldm_vae_train_forward(ldm_model* m, const float* x, const float* eps, float*
     if (D % f || H % f || W % f) return fail(LDM_ERR_UNSUPPORTED, "image size must be a multiple of %d", f);
     std::shared_ptr<Plan> p; LDM_TRY(get_plan(m, "train", B, D, H, W, &p));
     LDM_TRY(check_ready(m, workspace, workspace_bytes, *p));
-    Bases bs{}; bs.p[BASE_WS] = (char*)workspace; bs.p[BASE_W] = m->arena;
+    Bases bs{}; bs.p[BASE_WS] = (char*)workspace; bs.p[BASE_W] = m->arena; bs.p[BASE_W32] = m->arena32;
     bs.p[BASE_IO0] = (char*)x; bs.p[BASE_IO1] = (char*)eps; bs.p[BASE_IO2] = (char*)z_mu; bs.p[BASE_IO3] = (char*)z_sigma; bs.p[BASE_IO5] = (char*)recon;
     const int rt[2] = {m->vcfg.in_channels, 0};
     return run_plan(*p, bs, rt, (hipStream_t)stream, 0, p->bwd_begin);
@@ -2062,7 +2341,7 @@ int ldm_vae_train_backward(ldm_model* m, const float* d_recon, const float* d_mu
     if (!d_recon || !flat_grads) return fail(LDM_ERR_BAD_ARG, "null tensor argument");
     std::shared_ptr<Plan> p; LDM_TRY(get_plan(m, "train", B, D, H, W, &p));
     LDM_TRY(check_ready(m, workspace, workspace_bytes, *p));
-    Bases bs{}; bs.p[BASE_WS] = (char*)workspace; bs.p[BASE_W] = m->arena;
+    Bases bs{}; bs.p[BASE_WS] = (char*)workspace; bs.p[BASE_W] = m->arena; bs.p[BASE_W32] = m->arena32;
     bs.p[BASE_IO0] = (char*)d_recon; bs.p[BASE_IO1] = (char*)d_mu; bs.p[BASE_IO2] = (char*)d_sigma; bs.p[BASE_IO4] = (char*)flat_grads;
     const int rt[2] = {m->vcfg.out_channels, 0};
     return run_plan(*p, bs, rt, (hipStream_t)stream, p->bwd_begin, p->ops.size());
@@ -2101,6 +2380,10 @@ int ldm_model_adam_step(ldm_model* m, float* params_flat, const float* grads_fla
     hipLaunchKernelGGL(adam_pack_batched_kernel, dim3(m->pack_tab.nblocks), dim3(256), 0, (hipStream_t)stream,
                        (const PackDesc*)m->pack_tab.descs, (const int2*)m->pack_tab.map, params_flat, grads_flat, exp_avg, exp_avg_sq,
                        m->arena, k, sq_norm);
+    if (m->precision == 1) {
+        LDM_TRY(ensure_arena32(m));
+        for (const ParamDesc& d : m->params) pack32_device(m, d, params_flat + d.flat_off, (hipStream_t)stream);
+    }
     HIP_TRY(hipGetLastError());
     for (ParamDesc& d : m->params) if (!d.loaded) { d.loaded = true; m->loaded_count++; }
     m->derived_dirty = true;
@@ -2120,32 +2403,55 @@ size_t ldm_vae_decode_workspace_bytes(ldm_model* m, int B, int d, int h, int w) 
     return p->ws_bytes;
 }
 
-int ldm_vae_encode(ldm_model* m, const float* x, const float* eps, float* z_mu, float* z_sigma, float* z,
-                   int B, int D, int H, int W, void* workspace, size_t workspace_bytes, void* stream) {
+static int vae_encode_impl(ldm_model* m, const float* x, const float* eps, float* z_mu, float* z_sigma, float* z,
+                           int B, int D, int H, int W, float* taps_out, const float* taps_in, int tap_mode,
+                           void* workspace, size_t workspace_bytes, void* stream) {
     if (!m || m->type != 1) return fail(LDM_ERR_BAD_ARG, "not an AutoencoderKL handle");
     if (!x) return fail(LDM_ERR_BAD_ARG, "null tensor argument");
     const int f = vae_factor(m);
     if (D % f || H % f || W % f) return fail(LDM_ERR_UNSUPPORTED, "image size must be a multiple of %d", f);
-    std::shared_ptr<Plan> p; LDM_TRY(get_plan(m, "enc", B, D, H, W, &p));
+    std::shared_ptr<Plan> p; LDM_TRY(get_plan(m, "enc", B, D, H, W, &p, tap_mode));
     LDM_TRY(check_ready(m, workspace, workspace_bytes, *p));
-    Bases bs{}; bs.p[BASE_WS] = (char*)workspace; bs.p[BASE_W] = m->arena;
+    Bases bs{}; bs.p[BASE_WS] = (char*)workspace; bs.p[BASE_W] = m->arena; bs.p[BASE_W32] = m->arena32;
     bs.p[BASE_IO0] = (char*)x; bs.p[BASE_IO1] = (char*)eps; bs.p[BASE_IO2] = (char*)z_mu; bs.p[BASE_IO3] = (char*)z_sigma; bs.p[BASE_IO4] = (char*)z;
+    bs.p[BASE_TAPO] = (char*)taps_out; bs.p[BASE_TAPI] = (char*)taps_in;
     const int rt[2] = {m->vcfg.in_channels, 0};
     LDM_TRY(ensure_derived(m, (hipStream_t)stream));
     return run_plan(*p, bs, rt, (hipStream_t)stream);
 }
+int ldm_vae_encode(ldm_model* m, const float* x, const float* eps, float* z_mu, float* z_sigma, float* z,
+                   int B, int D, int H, int W, void* workspace, size_t workspace_bytes, void* stream) {
+    return vae_encode_impl(m, x, eps, z_mu, z_sigma, z, B, D, H, W, nullptr, nullptr, 0, workspace, workspace_bytes, stream);
+}
+/* ldm_vae_encode / ldm_vae_decode with debug taps (see ldm_unet_forward_taps) */
+int ldm_vae_encode_taps(ldm_model* m, const float* x, const float* eps, float* z_mu, float* z_sigma, float* z,
+                        int B, int D, int H, int W, float* taps_out, const float* taps_in,
+                        void* workspace, size_t workspace_bytes, void* stream) {
+    if (!taps_out) return fail(LDM_ERR_BAD_ARG, "null tensor argument");
+    return vae_encode_impl(m, x, eps, z_mu, z_sigma, z, B, D, H, W, taps_out, taps_in, taps_in ? 2 : 1, workspace, workspace_bytes, stream);
+}
 
-int ldm_vae_decode(ldm_model* m, const float* z, float* out, int B, int d, int h, int w,
-                   void* workspace, size_t workspace_bytes, void* stream) {
+static int vae_decode_impl(ldm_model* m, const float* z, float* out, int B, int d, int h, int w, float* taps_out, const float* taps_in,
+                           int tap_mode, void* workspace, size_t workspace_bytes, void* stream) {
     if (!m || m->type != 1) return fail(LDM_ERR_BAD_ARG, "not an AutoencoderKL handle");
     if (!z || !out) return fail(LDM_ERR_BAD_ARG, "null tensor argument");
-    std::shared_ptr<Plan> p; LDM_TRY(get_plan(m, "dec", B, d, h, w, &p));
+    std::shared_ptr<Plan> p; LDM_TRY(get_plan(m, "dec", B, d, h, w, &p, tap_mode));
     LDM_TRY(check_ready(m, workspace, workspace_bytes, *p));
-    Bases bs{}; bs.p[BASE_WS] = (char*)workspace; bs.p[BASE_W] = m->arena;
+    Bases bs{}; bs.p[BASE_WS] = (char*)workspace; bs.p[BASE_W] = m->arena; bs.p[BASE_W32] = m->arena32;
     bs.p[BASE_IO0] = (char*)z; bs.p[BASE_IO1] = (char*)out;
+    bs.p[BASE_TAPO] = (char*)taps_out; bs.p[BASE_TAPI] = (char*)taps_in;
     const int rt[2] = {m->vcfg.latent_channels, 0};
     LDM_TRY(ensure_derived(m, (hipStream_t)stream));
     return run_plan(*p, bs, rt, (hipStream_t)stream);
+}
+int ldm_vae_decode(ldm_model* m, const float* z, float* out, int B, int d, int h, int w,
+                   void* workspace, size_t workspace_bytes, void* stream) {
+    return vae_decode_impl(m, z, out, B, d, h, w, nullptr, nullptr, 0, workspace, workspace_bytes, stream);
+}
+int ldm_vae_decode_taps(ldm_model* m, const float* z, float* out, int B, int d, int h, int w, float* taps_out, const float* taps_in,
+                        void* workspace, size_t workspace_bytes, void* stream) {
+    if (!taps_out) return fail(LDM_ERR_BAD_ARG, "null tensor argument");
+    return vae_decode_impl(m, z, out, B, d, h, w, taps_out, taps_in, taps_in ? 2 : 1, workspace, workspace_bytes, stream);
 }
 
 // ---- scheduler element-wise launches --------------------------------------------------------------------

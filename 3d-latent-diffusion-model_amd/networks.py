@@ -182,6 +182,75 @@ class _LdmModule(nn.Module):
         self._dirty = True
         return flat
 
+    # -- precision of the inference plans ---------------------------------------------------------------------
+    def set_precision(self, precision: str = "bf16"):
+        """``"bf16"`` (default): bf16 storage / bf16 MFMA / fp32 accumulate, the headline path.  ``"fp32"``: the
+        reference's own arithmetic (autocast is off at 3d_ldm/train_diffusion.py:177 and absent from inference.py:91-99):
+        fp32 activations and weights on the fp32 matrix instruction, ~1e-5 rel-L2 from the CPU path at about a quarter of
+        the bf16 throughput.  Inference plans only; training always runs the bf16 plans.  Environment default:
+        ``LDM_PRECISION=fp32``."""
+        code = {"bf16": 0, "fp32": 1}.get(str(precision).lower())
+        if code is None:
+            raise ValueError(f"precision must be 'bf16' or 'fp32', got {precision!r}")
+        _lib.check(_lib.lib().ldm_model_set_precision(self._h, code))
+        self.precision = "fp32" if code else "bf16"
+        self._uploaded_versions.clear()                # the unrounded copies are made at upload time
+        self._dev_sig = None
+        self._dirty = True
+        return self
+
+    def _default_precision(self):
+        import os
+        self.precision = "bf16"
+        if os.environ.get("LDM_PRECISION", "").lower() == "fp32":
+            self.set_precision("fp32")
+
+    # -- debug taps (stage-wise parity tests) ---------------------------------------------------------------------
+    def _tap_layout(self, kind: str, B, D, H, W):
+        L = _lib.lib()
+        n = L.ldm_model_tap_count(self._h, kind.encode(), B, D, H, W)
+        if n < 0:
+            raise _lib.LdmError((L.ldm_last_error() or b"tap query failed").decode())
+        total = int(L.ldm_model_tap_elems(self._h, kind.encode(), B, D, H, W))
+        out = []
+        name = C.create_string_buffer(128)
+        dims = (C.c_int * 5)()
+        off = C.c_int64()
+        for i in range(n):
+            _lib.check(L.ldm_model_tap_info(self._h, kind.encode(), B, D, H, W, i, name, 128, dims, C.byref(off)))
+            out.append((name.value.decode(), tuple(int(v) for v in dims), int(off.value)))
+        return out, total
+
+    def _tap_buffers(self, kind, B, D, H, W, force, device):
+        layout, total = self._tap_layout(kind, B, D, H, W)
+        taps_out = torch.zeros(max(total, 1), dtype=torch.float32, device=device)
+        taps_in = None
+        if force is not None:
+            taps_in = torch.zeros(max(total, 1), dtype=torch.float32, device=device)
+            for name, dims, off in layout:
+                if name not in force:
+                    raise KeyError(f"force is missing the tap '{name}'")
+                t = force[name].to(device=device, dtype=torch.float32).contiguous()
+                if tuple(t.shape) != dims:
+                    raise ValueError(f"force['{name}'] has shape {tuple(t.shape)}, expected {dims}")
+                taps_in[off:off + t.numel()] = t.reshape(-1)
+        L = _lib.lib()
+        nbytes = L.ldm_model_taps_workspace_bytes(self._h, kind.encode(), B, D, H, W, 1 if force is not None else 0)
+        if nbytes == 0:
+            raise _lib.LdmError((L.ldm_last_error() or b"workspace query failed").decode())
+        ws = self._workspace((kind + "-taps", B, D, H, W, force is not None), nbytes, device)
+        return layout, taps_out, taps_in, ws
+
+    @staticmethod
+    def _tap_dict(layout, taps_out):
+        out = {}
+        for name, dims, off in layout:
+            n = 1
+            for v in dims:
+                n *= v
+            out[name] = taps_out[off:off + n].view(dims).clone()
+        return out
+
     def _workspace(self, key: tuple, nbytes: int, device) -> torch.Tensor:
         ws = self._ws.get(key)
         if ws is None or ws.numel() < nbytes or ws.device != device:
@@ -255,6 +324,7 @@ class DiffusionModelUNet(_LdmModule):
         self.block_out_channels = list(channels)
         _lib.check(_lib.lib().ldm_unet_create(C.byref(cfg), C.byref(self._h)))
         self._build_params()
+        self._default_precision()
 
     def _zero_init(self):
         # MONAI zero_module(): every ResBlock conv2 and the output conv start at zero
@@ -322,6 +392,23 @@ class DiffusionModelUNet(_LdmModule):
                                           B, D, H, W, ws.data_ptr(), ws.numel(), _lib.current_stream()))
         return out
 
+
+    def forward_taps(self, x: torch.Tensor, timesteps: torch.Tensor, cond: Optional[torch.Tensor] = None,
+                     force: Optional[Dict[str, torch.Tensor]] = None):
+        """Debug: ``(eps_hat, {block name: output as fp32 NCDHW})``.  With ``force`` (a dict holding a tensor for EVERY tap)
+        each block output is overwritten with the given tensor after it has been exported, so every block runs on the
+        reference's input (teacher forcing; tests/test_gpu_taps.py)."""
+        self._need_cuda(x, "DiffusionModelUNet.forward_taps")
+        x, cx, cond, cc, t = self._prep(x, timesteps, cond)
+        B, _, D, H, W = x.shape
+        self._sync_weights()
+        layout, taps_out, taps_in, ws = self._tap_buffers("unet", B, D, H, W, force, x.device)
+        out = torch.empty((B, self.out_channels, D, H, W), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().ldm_unet_forward_taps(self._h, x.data_ptr(), cx, _lib.ptr(cond), cc, t.data_ptr(), out.data_ptr(),
+                                                        B, D, H, W, taps_out.data_ptr(), _lib.ptr(taps_in), ws.data_ptr(), ws.numel(),
+                                                        _lib.current_stream()))
+        return out, self._tap_dict(layout, taps_out)
 
     def enable_graph_replay(self, on: bool = True):
         """Inference: replay the forward plan as ONE HIP graph launch per call instead of ~150 kernel launches (same
@@ -441,6 +528,7 @@ class AutoencoderKL(_LdmModule):
         self.factor = 2 ** (n - 1)
         _lib.check(_lib.lib().ldm_vae_create(C.byref(cfg), C.byref(self._h)))
         self._build_params()
+        self._default_precision()
 
     # -- encode ----------------------------------------------------------------------------------------
     def _encode(self, x: torch.Tensor, eps: Optional[torch.Tensor], want_z: bool):
@@ -508,6 +596,36 @@ class AutoencoderKL(_LdmModule):
             _lib.check(L.ldm_vae_decode(self._h, z.data_ptr(), out.data_ptr(), B, d, h, w, ws.data_ptr(), ws.numel(),
                                         _lib.current_stream()))
         return out
+
+    def encode_taps(self, x: torch.Tensor, force: Optional[Dict[str, torch.Tensor]] = None):
+        """Debug: ``(z_mu, z_sigma, {block name: output})`` (see DiffusionModelUNet.forward_taps)."""
+        self._need_cuda(x, "AutoencoderKL.encode_taps")
+        B, _, D, H, W = x.shape
+        x = x.detach().to(torch.float32).contiguous()
+        self._sync_weights()
+        layout, taps_out, taps_in, ws = self._tap_buffers("enc", B, D, H, W, force, x.device)
+        f = self.factor
+        z_mu = torch.empty((B, self.latent_channels, D // f, H // f, W // f), dtype=torch.float32, device=x.device)
+        z_sigma = torch.empty_like(z_mu)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().ldm_vae_encode_taps(self._h, x.data_ptr(), None, z_mu.data_ptr(), z_sigma.data_ptr(), None, B, D, H, W,
+                                                      taps_out.data_ptr(), _lib.ptr(taps_in), ws.data_ptr(), ws.numel(),
+                                                      _lib.current_stream()))
+        return z_mu, z_sigma, self._tap_dict(layout, taps_out)
+
+    def decode_taps(self, z: torch.Tensor, force: Optional[Dict[str, torch.Tensor]] = None):
+        """Debug: ``(reconstruction, {block name: output})``."""
+        self._need_cuda(z, "AutoencoderKL.decode_taps")
+        B, _, d, h, w = z.shape
+        z = z.detach().to(torch.float32).contiguous()
+        self._sync_weights()
+        layout, taps_out, taps_in, ws = self._tap_buffers("dec", B, d, h, w, force, z.device)
+        f = self.factor
+        out = torch.empty((B, self.out_channels, d * f, h * f, w * f), dtype=torch.float32, device=z.device)
+        with torch.cuda.device(z.device):
+            _lib.check(_lib.lib().ldm_vae_decode_taps(self._h, z.data_ptr(), out.data_ptr(), B, d, h, w, taps_out.data_ptr(),
+                                                      _lib.ptr(taps_in), ws.data_ptr(), ws.numel(), _lib.current_stream()))
+        return out, self._tap_dict(layout, taps_out)
 
     def decode_stage_2_outputs(self, z: torch.Tensor) -> torch.Tensor:
         return self.decode(z)

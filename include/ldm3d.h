@@ -140,6 +140,32 @@ int ldm_model_adam_step(ldm_model* m, float* params_flat, const float* grads_fla
  * a (x, cond, timesteps, out, workspace, stream) pointer set and replays it afterwards.  Results are identical. */
 int ldm_model_set_graph_mode(ldm_model* m, int on);
 
+/* ---- precision of the inference plans.  The reference computes in fp32 (autocast off: 3d_ldm/train_diffusion.py:177,237;
+ *      3d_ldm/inference.py:91-99 has no autocast): LDM_PREC_FP32 runs the same plans on fp32 activations / weights with the
+ *      fp32 matrix instruction (v_mfma_f32_32x32x2_f32) and stays within ~1e-5 rel-L2 of the CPU path; LDM_PREC_BF16 (default)
+ *      is the bf16-MFMA headline path (~3e-2 at the benchmark depth, its own rounding floor).  After switching to fp32 upload the
+ *      parameters again (the unrounded copies are made at upload time). ------------------------------------------------- */
+#define LDM_PREC_BF16 0
+#define LDM_PREC_FP32 1
+int ldm_model_set_precision(ldm_model* m, int precision);
+int ldm_model_get_precision(const ldm_model* m);
+
+/* ---- debug taps: every block output of an inference plan as fp32 NCDHW, optionally followed by overwriting it with the
+ *      caller's tensor (teacher forcing), for stage-wise parity tests against the oracle.  kind = "unet" | "enc" | "dec". ---- */
+int ldm_model_tap_count(ldm_model* m, const char* kind, int B, int D, int H, int W);
+int64_t ldm_model_tap_elems(ldm_model* m, const char* kind, int B, int D, int H, int W);
+int ldm_model_tap_info(ldm_model* m, const char* kind, int B, int D, int H, int W, int i, char* name, int name_cap, int dims[5],
+                       int64_t* offset);
+size_t ldm_model_taps_workspace_bytes(ldm_model* m, const char* kind, int B, int D, int H, int W, int force);
+int ldm_unet_forward_taps(ldm_model* m, const float* x, int x_channels, const float* cond, int cond_channels,
+                          const float* timesteps, float* out, int B, int D, int H, int W, float* taps_out, const float* taps_in,
+                          void* workspace, size_t workspace_bytes, void* stream);
+int ldm_vae_encode_taps(ldm_model* m, const float* x, const float* eps, float* z_mu, float* z_sigma, float* z,
+                        int B, int D, int H, int W, float* taps_out, const float* taps_in,
+                        void* workspace, size_t workspace_bytes, void* stream);
+int ldm_vae_decode_taps(ldm_model* m, const float* z, float* out, int B, int d, int h, int w, float* taps_out, const float* taps_in,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- AutoencoderKL.encode / sampling / decode (3d_ldm/train_diffusion.py:104,180,195,249,258,310,324;
  *      3d_ldm/train_autoencoder.py:366,579).  encode: x:[B,Cin,D,H,W] -> z_mu, z_sigma, z = mu + sigma*eps
  *      (each [B,L,D/f,H/f,W/f], any of the three outputs may be NULL; eps NULL means eps = 0).

@@ -21,8 +21,13 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
 this package.  The product (3d-latent-diffusion-model_amd/, networks/) never
 does; it has no CPU fallback and fails loudly without the HIP library.
 
-``emulate_bf16=True`` reproduces the rounding points of the HIP path (bf16
-weights, bf16 activation storage, fp32 accumulation) so that GPU-vs-oracle
-parity can be gated at 1e-3 rel-L2; ``emulate_bf16=False`` is the pure fp32
-reference.
+``emulate_bf16=False`` is the pure fp32 reference: the reference's own
+arithmetic (autocast off, 3d_ldm/train_diffusion.py:177) and what the library's
+fp32 precision mode (ldm_model_set_precision) is gated against at 1e-3 rel-L2.
+``emulate_bf16=True`` reproduces the rounding points of the bf16 HIP path (bf16
+weights, bf16 activation storage, fp32 accumulation); a bf16 network of this
+depth is chaotic under rounding, so that emulation only measures the bf16 noise
+floor (~3e-2 at the benchmark shape) that the bf16 path is gated against, and
+the bf16 path is pinned tightly per block by the teacher-forced tap tests
+(tests/test_gpu_taps.py).
 """

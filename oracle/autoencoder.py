@@ -92,10 +92,13 @@ def _res_block(sd: SD, p: str, x, c, bf):
     return rbf(skip + h, bf)
 
 
-def _run(sd: SD, prefix: str, layout, x, c, bf):
+def _run(sd: SD, prefix: str, layout, x, c, bf, taps=None):
+    """``taps`` (optional dict) receives every block output under "<prefix>.blocks.<k>" (ldm_model_tap_info's names)."""
     h = x
     for k, (kind, _args) in enumerate(layout):
         p = f"{prefix}.blocks.{k}"
+        if taps is not None and k > 0:
+            taps[f"{prefix}.blocks.{k - 1}"] = h.detach().clone()
         if kind == "conv":
             last = k == len(layout) - 1
             h = conv(sd, p, h, bf)
@@ -117,11 +120,13 @@ def _run(sd: SD, prefix: str, layout, x, c, bf):
     return h
 
 
-def encode(sd: SD, cfg: dict, x: torch.Tensor, emulate_bf16: bool = False):
+def encode(sd: SD, cfg: dict, x: torch.Tensor, emulate_bf16: bool = False, taps=None):
     """-> (z_mu, z_sigma).  log-variance clamped to [-30, 20] before exp(./2)."""
     c = norm_cfg(cfg)
     bf = emulate_bf16
-    h = _run(sd, "encoder", encoder_layout(c), rbf(x, bf), c, bf)
+    h = _run(sd, "encoder", encoder_layout(c), rbf(x, bf), c, bf, taps)
+    if taps is not None:
+        taps[f"encoder.blocks.{len(encoder_layout(c)) - 1}"] = h.detach().clone()
     h = rbf(h, bf)                                  # encoder output is stored bf16 before the 1x1 heads
     z_mu = conv(sd, "quant_conv_mu", h, bf, padding=0)
     z_log_var = conv(sd, "quant_conv_log_sigma", h, bf, padding=0)
@@ -135,11 +140,13 @@ def sampling(z_mu, z_sigma, eps):
     return z_mu + eps * z_sigma
 
 
-def decode(sd: SD, cfg: dict, z: torch.Tensor, emulate_bf16: bool = False) -> torch.Tensor:
+def decode(sd: SD, cfg: dict, z: torch.Tensor, emulate_bf16: bool = False, taps=None) -> torch.Tensor:
     c = norm_cfg(cfg)
     bf = emulate_bf16
     h = rbf(conv(sd, "post_quant_conv", rbf(z, bf), bf, padding=0), bf)
-    return _run(sd, "decoder", decoder_layout(c), h, c, bf)
+    if taps is not None:
+        taps["post_quant_conv"] = h.detach().clone()
+    return _run(sd, "decoder", decoder_layout(c), h, c, bf, taps)
 
 
 def encode_stage_2_inputs(sd, cfg, x, eps, emulate_bf16=False):

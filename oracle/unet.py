@@ -148,10 +148,14 @@ def upsample_nearest_conv(sd: SD, name: str, x: torch.Tensor, bf: bool) -> torch
 
 # ----------------------------------------------------------------------------- model
 def unet_forward(sd: SD, cfg: dict, x: torch.Tensor, timesteps: torch.Tensor,
-                 emulate_bf16: bool = False, taps: dict | None = None) -> torch.Tensor:
+                 emulate_bf16: bool = False, taps: dict | None = None, force: dict | None = None) -> torch.Tensor:
     """eps_hat = UNet(x_t, t).  x: [B, C_in, D, H, W] fp32; timesteps: [B].
 
-    ``taps`` (optional dict) receives named intermediate tensors for per-op parity tests.
+    ``taps`` (optional dict) receives named intermediate tensors for per-op parity tests: the coarse ones
+    ("emb", "conv_in", "down{i}", "mid", "up{i}") and every block output under the block's state_dict prefix
+    ("down_blocks.0.resnets.1", "middle_block.attention", "up_blocks.1.upsampler.conv", ...: the names
+    ldm_model_tap_info reports).  ``force`` (optional dict with the same block names) replaces each block output
+    after it has been recorded: teacher forcing, the mirror of ldm_unet_forward_taps(taps_in=...).
     """
     c = norm_cfg(cfg)
     bf = emulate_bf16
@@ -162,39 +166,45 @@ def unet_forward(sd: SD, cfg: dict, x: torch.Tensor, timesteps: torch.Tensor,
         if taps is not None:
             taps[name] = t.detach().clone()
 
+    def blk(name, t):
+        tap(name, t)
+        return force[name].to(t.dtype) if force is not None else t
+
     t_emb = timestep_embedding(timesteps, ch[0])
     emb = linear(sd, "time_embed.0", t_emb, bf)
     emb = linear(sd, "time_embed.2", F.silu(emb), bf)
     tap("emb", emb)
 
-    h = rbf(conv(sd, "conv_in", rbf(x, bf), bf), bf)
-    tap("conv_in", h)
+    h = blk("conv_in", rbf(conv(sd, "conv_in", rbf(x, bf), bf), bf))
     skips: List[torch.Tensor] = [h]
     for i in range(nlev):
         for j in range(c["num_res_blocks"][i]):
-            h = resnet_block(sd, f"down_blocks.{i}.resnets.{j}", h, emb, c, bf)
+            h = blk(f"down_blocks.{i}.resnets.{j}", resnet_block(sd, f"down_blocks.{i}.resnets.{j}", h, emb, c, bf))
             if c["attention_levels"][i]:
-                h = attention_block(sd, f"down_blocks.{i}.attentions.{j}", h, c["num_head_channels"][i], c, bf)
+                h = blk(f"down_blocks.{i}.attentions.{j}",
+                        attention_block(sd, f"down_blocks.{i}.attentions.{j}", h, c["num_head_channels"][i], c, bf))
             skips.append(h)
         tap(f"down{i}", h)
         if i != nlev - 1:
-            h = rbf(conv(sd, f"down_blocks.{i}.downsampler.op", h, bf, stride=2, padding=1), bf)
+            h = blk(f"down_blocks.{i}.downsampler.op",
+                    rbf(conv(sd, f"down_blocks.{i}.downsampler.op", h, bf, stride=2, padding=1), bf))
             skips.append(h)
 
-    h = resnet_block(sd, "middle_block.resnet_1", h, emb, c, bf)
-    h = attention_block(sd, "middle_block.attention", h, c["num_head_channels"][-1], c, bf)
-    h = resnet_block(sd, "middle_block.resnet_2", h, emb, c, bf)
+    h = blk("middle_block.resnet_1", resnet_block(sd, "middle_block.resnet_1", h, emb, c, bf))
+    h = blk("middle_block.attention", attention_block(sd, "middle_block.attention", h, c["num_head_channels"][-1], c, bf))
+    h = blk("middle_block.resnet_2", resnet_block(sd, "middle_block.resnet_2", h, emb, c, bf))
     tap("mid", h)
 
     for i in range(nlev):
         lvl = nlev - 1 - i
         for j in range(c["num_res_blocks"][lvl] + 1):
             h = torch.cat([h, skips.pop()], dim=1)
-            h = resnet_block(sd, f"up_blocks.{i}.resnets.{j}", h, emb, c, bf)
+            h = blk(f"up_blocks.{i}.resnets.{j}", resnet_block(sd, f"up_blocks.{i}.resnets.{j}", h, emb, c, bf))
             if c["attention_levels"][lvl]:
-                h = attention_block(sd, f"up_blocks.{i}.attentions.{j}", h, c["num_head_channels"][lvl], c, bf)
+                h = blk(f"up_blocks.{i}.attentions.{j}",
+                        attention_block(sd, f"up_blocks.{i}.attentions.{j}", h, c["num_head_channels"][lvl], c, bf))
         if i != nlev - 1:
-            h = upsample_nearest_conv(sd, f"up_blocks.{i}.upsampler.conv", h, bf)
+            h = blk(f"up_blocks.{i}.upsampler.conv", upsample_nearest_conv(sd, f"up_blocks.{i}.upsampler.conv", h, bf))
         tap(f"up{i}", h)
     assert not skips
 

@@ -47,7 +47,7 @@ def train_golden():
     import torch.nn.functional as F
     cfg, sd, x, t, target = train_case()
     dirs = directions(sd)
-    out = dict(torch_version=torch.__version__)
+    out = dict(torch_version=str(torch.__version__))
     for tag, bf in (("fp32", False), ("bf16", True)):
         leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
         loss = F.mse_loss(ou.unet_forward(leaves, cfg, x, t, emulate_bf16=bf), target)
@@ -82,7 +82,7 @@ def vae_golden():
     wseed = 3
     sd = ou.init_state_dict(oa.ae_param_shapes(cfg), wseed)
     x = vae_case()
-    out = dict(weight_seed=wseed, torch_version=torch.__version__)
+    out = dict(weight_seed=wseed, torch_version=str(torch.__version__))
     for tag, bf in (("fp32", False), ("bf16", True)):
         t0 = time.time()
         mu, _ = oa.encode(sd, cfg, x, emulate_bf16=bf)
@@ -111,7 +111,7 @@ def main():
     print(f"oracle 24^3: bf16-emulated {t1 - t0:.1f}s, fp32 {t2 - t1:.1f}s, rel-L2 between them "
           f"{float((e_bf - e_32).norm() / e_32.norm()):.3e}")
     torch.save(dict(weight_seed=wseed, input_seed=iseed, t=t, eps_bf16_oracle=e_bf, eps_fp32_oracle=e_32,
-                    torch_version=torch.__version__), os.path.join(HERE, "unet_full_24.pt"))
+                    torch_version=str(torch.__version__)), os.path.join(HERE, "unet_full_24.pt"))
     train_golden()
     vae_golden()
     s = OracleDDPM(**cfgs.SCHED)

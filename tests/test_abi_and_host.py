@@ -85,8 +85,13 @@ def test_unsupported_configs_fail_loudly(built_lib):
         DiffusionModelUNet(**dict(cfgs.UNET_TINY, with_conditioning=True, cross_attention_dim=64))
     with pytest.raises(_lib.LdmError):
         DiffusionModelUNet(**dict(cfgs.UNET_TINY, num_head_channels=[0, 32, 32]))       # head_dim 64 only
-    with pytest.raises(_lib.LdmError):
-        AutoencoderKL(**dict(cfgs.VAE_TINY, attention_levels=[False, False, True]))
+    # AutoencoderKL attention blocks (level flags and the non-local ones) construct with the oracle's MONAI-shaped names
+    from oracle import autoencoder as oa
+    acfg = dict(cfgs.VAE_TINY, attention_levels=[False, False, True], with_encoder_nonlocal_attn=True, with_decoder_nonlocal_attn=True)
+    sd = AutoencoderKL(**acfg).state_dict()
+    shapes = oa.ae_param_shapes(acfg)
+    assert set(sd) == set(shapes) and all(tuple(sd[k].shape) == tuple(v) for k, v in shapes.items())
+    assert "encoder.blocks.7.attn.to_q.weight" in sd and "decoder.blocks.2.attn.out_proj.bias" in sd
 
 
 REFERENCE_STYLE_CONFIG = {

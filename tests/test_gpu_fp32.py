@@ -1,0 +1,164 @@
+"""fp32 precision mode (-m gpu): BASELINE.json's parity bar, "outputs within 1e-3 rel-L2 of the CPU reference".
+
+The reference computes in fp32 (autocast off: 3d_ldm/train_diffusion.py:177,237; 3d_ldm/inference.py:91-99), so the pure
+fp32 oracle is the CPU reference.  ``set_precision("fp32")`` runs the same launch plans on fp32 activations / weights with
+the fp32 matrix instruction (csrc/f32_path.h); every case below is gated at 1e-3 WITHOUT any noise-floor allowance
+(measured values are ~1e-5 and printed).  The bf16 path's own gates are in test_gpu_models.py / test_gpu_taps.py.
+"""
+import os
+import sys
+
+import pytest
+import torch
+
+import cfgs
+from util import rel_l2
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3          # north_star: "outputs within 1e-3 rel-L2 of the CPU reference"
+
+
+def _unet(cfg, seed, cuda):
+    from ldm3d.networks import DiffusionModelUNet
+    from oracle import unet as ou
+    sd = ou.init_state_dict(ou.unet_param_shapes(cfg), seed)
+    m = DiffusionModelUNet(**cfg)
+    m.load_state_dict(sd)
+    return m.to(cuda).eval().set_precision("fp32"), sd
+
+
+def _vae(cfg, seed, cuda):
+    from ldm3d.networks import AutoencoderKL
+    from oracle import autoencoder as oa
+    from oracle.unet import init_state_dict
+    sd = init_state_dict(oa.ae_param_shapes(cfg), seed)
+    m = AutoencoderKL(**cfg)
+    m.load_state_dict(sd)
+    return m.to(cuda).eval().set_precision("fp32"), sd
+
+
+def gate(got, ref, what, tol=TOL):
+    e = rel_l2(got, ref)
+    print(f"{what}: fp32 mode vs fp32 CPU oracle {e:.2e} (gate {tol:.0e})")
+    assert torch.isfinite(got).all(), what
+    assert e <= tol, (what, e)
+    return e
+
+
+@pytest.mark.parametrize("name,dims,b", [("UNET_TINY", (8, 8, 8), 1), ("UNET_TINY", (8, 12, 4), 2), ("UNET_TINY_ALT", (6, 10, 8), 2),
+                                         ("UNET_TINY_COND", (8, 8, 8), 2)])
+def test_unet_tiny_fp32_meets_1e3(cuda, name, dims, b):
+    from oracle import unet as ou
+    cfg = getattr(cfgs, name)
+    m, sd = _unet(cfg, 1, cuda)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn((b, cfg["in_channels"], *dims), generator=g)
+    t = torch.tensor([37.0, 911.0][:b])
+    with torch.no_grad():
+        got = m(x=x.to(cuda), timesteps=t.to(cuda)).cpu()
+    gate(got, ou.unet_forward(sd, cfg, x, t), f"{name} {dims} B={b}")
+
+
+def test_unet_full_24cube_golden_fp32_meets_1e3(cuda):
+    """The headline shape 1x4x24^3 against the committed golden eps_hat of the fp32 CPU oracle."""
+    gold = torch.load(os.path.join(os.path.dirname(__file__), "golden", "unet_full_24.pt"), weights_only=True)
+    m, _ = _unet(cfgs.UNET_FULL, gold["weight_seed"], cuda)
+    x = torch.randn((1, 4, 24, 24, 24), generator=torch.Generator().manual_seed(gold["input_seed"]))
+    with torch.no_grad():
+        got = m(x=x.to(cuda), timesteps=torch.tensor([gold["t"]], device=cuda)).cpu()
+        again = m(x=x.to(cuda), timesteps=torch.tensor([gold["t"]], device=cuda)).cpu()
+    gate(got, gold["eps_fp32_oracle"].float(), "UNET_FULL 24^3 (golden)")
+    assert torch.equal(got, again)                        # split-K slabs are summed in a fixed order
+
+
+def test_vae_full_96cube_golden_fp32_meets_1e3(cuda):
+    """BASELINE configs[1] (AutoencoderKL 64/128/256 on 1x1x96^3) against the committed fp32 oracle golden."""
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import make_golden
+    gold = torch.load(os.path.join(os.path.dirname(__file__), "golden", "vae_full_96.pt"), weights_only=True)
+    m, _ = _vae(cfgs.VAE_FULL, gold["weight_seed"], cuda)
+    with torch.no_grad():
+        mu, _ = m.encode(make_golden.vae_case().to(cuda))
+        rec = m.decode(gold["mu_for_decode"].to(cuda)).cpu()
+    gate(mu.cpu(), gold["mu_fp32"], "VAE_FULL 96^3 encode mu (golden)")
+    gate(rec[..., ::4, ::4, ::4], gold["rec_sub_fp32"], "VAE_FULL 96^3 decode, stride-4 sub-lattice (golden)")
+    assert abs(float(rec.double().mean()) - gold["rec_mean_fp32"]) <= 1e-3 * abs(gold["rec_mean_fp32"]) + 1e-5
+    assert abs(float((rec.double() ** 2).mean()) - gold["rec_msq_fp32"]) <= 2e-3 * gold["rec_msq_fp32"]
+
+
+@pytest.mark.parametrize("name,dims,b", [("VAE_TINY", (16, 16, 16), 1), ("VAE_TINY", (8, 16, 12), 2)])
+def test_vae_tiny_fp32_meets_1e3(cuda, name, dims, b):
+    from oracle import autoencoder as oa
+    cfg = getattr(cfgs, name)
+    m, sd = _vae(cfg, 7, cuda)
+    g = torch.Generator().manual_seed(8)
+    x = torch.rand((b, cfg["in_channels"], *dims), generator=g)
+    f = 2 ** (len(cfg["channels"]) - 1)
+    eps = torch.randn((b, cfg["latent_channels"], *[d // f for d in dims]), generator=g)
+    with torch.no_grad():
+        mu, sigma = m.encode(x.to(cuda))
+        z = m.encode_stage_2_inputs(x.to(cuda), eps.to(cuda))
+    f_mu, f_sigma = oa.encode(sd, cfg, x)
+    gate(mu.cpu(), f_mu, f"{name} encode mu")
+    gate(sigma.cpu(), f_sigma, f"{name} encode sigma")
+    r_z = oa.sampling(f_mu, f_sigma, eps)
+    gate(z.cpu(), r_z, f"{name} encode z")
+    with torch.no_grad():
+        rec = m.decode_stage_2_outputs(r_z.to(cuda)).cpu()
+    gate(rec, oa.decode(sd, cfg, r_z), f"{name} decode")
+
+
+def test_config0_ddim_teacher_forced_fp32_meets_1e3_per_step(cuda):
+    """BASELINE configs[0] at full size (benchmark UNet, 1x4x16^3, 10 DDIM steps 900..0): every step's eps_hat within 1e-3
+    of the fp32 oracle on the oracle's trajectory (teacher forced); the free-running chain is reported beside it."""
+    from ldm3d.schedulers import DDIMScheduler
+    from oracle import unet as ou
+    from oracle.schedulers import OracleDDIM
+    cfg = cfgs.UNET_FULL
+    unet, sd = _unet(cfg, 0, cuda)
+    x = torch.randn((1, 4, 16, 16, 16), generator=torch.Generator().manual_seed(0))
+    sch, osch = DDIMScheduler(**cfgs.SCHED), OracleDDIM(**cfgs.SCHED)
+    sch.set_timesteps(10); osch.set_timesteps(10)
+    x_free = x.to(cuda)
+    worst = 0.0
+    for t in osch.timesteps.tolist():
+        ts = torch.tensor([float(t)])
+        e_32 = ou.unet_forward(sd, cfg, x, ts)
+        with torch.no_grad():
+            e_gpu = unet(x=x.to(cuda), timesteps=ts.to(cuda))
+            e_free = unet(x=x_free, timesteps=ts.to(cuda))
+            x_free, _ = sch.step(e_free, t, x_free)
+        worst = max(worst, gate(e_gpu.cpu(), e_32, f"config 0, t={t}"))
+        x, _ = osch.step(e_32, t, x)
+    # reported, not gated: with random weights the chain is chaotic (x0_hat = (x - sqrt(1 - abar) eps) / sqrt(abar) amplifies an
+    # eps error by up to 1 / sqrt(abar_900) = 27 before the clamp, every step), so 1e-5 per step does not stay 1e-5 over 10 steps
+    print(f"config 0: worst per-step error {worst:.2e}; free-running final x0 vs oracle chain {rel_l2(x_free.cpu(), x):.2e} (not gated)")
+    assert torch.isfinite(x_free).all() and float(x_free.abs().max()) <= 1.0 + 1e-6
+
+
+def test_precision_switch_back_and_forth_is_consistent(cuda):
+    """bf16 -> fp32 -> bf16 on one module: the bf16 results are bit-identical before and after, the fp32 result differs from
+    them by the bf16 noise floor, and training plans refuse the fp32 mode loudly."""
+    from ldm3d import _lib
+    from oracle import unet as ou
+    cfg = cfgs.UNET_TINY
+    m, sd = _unet(cfg, 5, cuda)
+    x = torch.randn((1, 4, 8, 8, 8), device=cuda)
+    t = torch.tensor([100.0], device=cuda)
+    with torch.no_grad():
+        hi = m(x=x, timesteps=t)
+        m.set_precision("bf16")
+        lo1 = m(x=x, timesteps=t)
+        m.set_precision("fp32")
+        hi2 = m(x=x, timesteps=t)
+        m.set_precision("bf16")
+        lo2 = m(x=x, timesteps=t)
+    assert torch.equal(hi, hi2) and torch.equal(lo1, lo2)
+    assert 1e-4 < rel_l2(lo1, hi) < 0.2
+    assert rel_l2(hi.cpu(), ou.unet_forward(sd, cfg, x.cpu(), t.cpu())) <= TOL
+    m.set_precision("fp32")
+    m.train()
+    for p in m.parameters():
+        p.requires_grad_(True)
+    with pytest.raises(_lib.LdmError, match="inference-only"):
+        m(x=x, timesteps=t)

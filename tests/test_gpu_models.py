@@ -134,7 +134,7 @@ def test_unet_full_size_24cube_golden(cuda):
     """Headline shape 1x4x24^3 against the committed golden vector (tests/golden/make_golden.py)."""
     import os
     path = os.path.join(os.path.dirname(__file__), "golden", "unet_full_24.pt")
-    gold = torch.load(path, weights_only=False)
+    gold = torch.load(path, weights_only=True)
     cfg = cfgs.UNET_FULL
     m, _ = _unet_pair(cfg, gold["weight_seed"], cuda)
     g = torch.Generator().manual_seed(gold["input_seed"])
@@ -430,7 +430,7 @@ def test_vae_full_size_96cube_golden(cuda):
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
     import make_golden
-    gold = torch.load(os.path.join(os.path.dirname(__file__), "golden", "vae_full_96.pt"), weights_only=False)
+    gold = torch.load(os.path.join(os.path.dirname(__file__), "golden", "vae_full_96.pt"), weights_only=True)
     m, _ = _vae_pair(cfgs.VAE_FULL, gold["weight_seed"], cuda)
     with torch.no_grad():
         mu, _ = m.encode(make_golden.vae_case().to(cuda))

@@ -280,7 +280,7 @@ def test_training_step_matches_committed_golden(cuda):
     import make_golden as mg
     from ldm3d.networks import DiffusionModelUNet
     from ldm3d.optim import FlatAdam
-    gold = torch.load(os.path.join(here, "golden", "train_step_tiny.pt"), weights_only=False)
+    gold = torch.load(os.path.join(here, "golden", "train_step_tiny.pt"), weights_only=True)
     cfg, sd, x, t, target = mg.train_case()
     dirs = mg.directions(sd)
     m = DiffusionModelUNet(**cfg)

@@ -157,11 +157,11 @@ def test_bf16_network_noise_floor():
 def test_golden_vector_is_reproducible_from_its_seeds():
     """The committed golden only stores outputs; check its inputs regenerate and a cheap slice of the recipe holds."""
     import os
-    gold = torch.load(os.path.join(os.path.dirname(__file__), "golden", "unet_full_24.pt"), weights_only=False)
+    gold = torch.load(os.path.join(os.path.dirname(__file__), "golden", "unet_full_24.pt"), weights_only=True)
     assert gold["eps_bf16_oracle"].shape == (1, 4, 24, 24, 24)
     floor = rel_l2(gold["eps_bf16_oracle"], gold["eps_fp32_oracle"])
     assert 5e-3 < floor < 0.1
-    tabs = torch.load(os.path.join(os.path.dirname(__file__), "golden", "sched_tables.pt"), weights_only=False)
+    tabs = torch.load(os.path.join(os.path.dirname(__file__), "golden", "sched_tables.pt"), weights_only=True)
     s = OracleDDPM(**cfgs.SCHED)
     assert torch.equal(tabs["betas"], s.betas) and torch.equal(tabs["alphas_cumprod"], s.alphas_cumprod)
 
@@ -175,7 +175,7 @@ def test_training_golden_is_reproducible_from_its_seeds():
     sys.path.insert(0, os.path.join(here, "golden"))
     import make_golden as mg
     from oracle import unet as ou
-    gold = torch.load(os.path.join(here, "golden", "train_step_tiny.pt"), weights_only=False)
+    gold = torch.load(os.path.join(here, "golden", "train_step_tiny.pt"), weights_only=True)
     cfg, sd, x, t, target = mg.train_case()
     leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     loss = F.mse_loss(ou.unet_forward(leaves, cfg, x, t), target)
@@ -218,7 +218,7 @@ def test_vae_golden_regenerates_from_its_seeds():
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
     import make_golden
-    gold = torch.load(os.path.join(os.path.dirname(__file__), "golden", "vae_full_96.pt"), weights_only=False)
+    gold = torch.load(os.path.join(os.path.dirname(__file__), "golden", "vae_full_96.pt"), weights_only=True)
     assert gold["mu_fp32"].shape == (1, 4, 24, 24, 24) and gold["rec_sub_fp32"].shape == (1, 1, 24, 24, 24)
     assert 1e-3 < rel_l2(gold["mu_bf16"], gold["mu_fp32"]) < 5e-2 and 1e-3 < rel_l2(gold["rec_sub_bf16"], gold["rec_sub_fp32"]) < 1e-1
     sd = ou.init_state_dict(oa.ae_param_shapes(cfgs.VAE_FULL), gold["weight_seed"])
