@@ -95,6 +95,8 @@ SIGNATURES = {
     "ldm_op_group_norm": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P, C.c_int, C.c_float, C.c_int, _P, C.c_int, C.c_int,
                                     _P, C.c_size_t, _P]),
     "ldm_op_attention": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "ldm_op_attention_hd": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "ldm_op_attention_bwd_hd": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "ldm_op_attention_train": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "ldm_op_attention_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "ldm_profile_start": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -332,7 +332,7 @@ struct Builder {
         int kind = 0;                                 // 0 conv, 1 GroupNorm(+SiLU), 2 attention
         ConvArgs c; Act out; bool leaf_input = false;
         const GnW* g = nullptr; Act xa, xb; size_t ab_off = 0, mr_off = 0; int groups = 0; bool silu = false;
-        Act qkv, o; size_t lse_off = 0;
+        Act qkv, o; size_t lse_off = 0; int head_ch = 64;
     };
     std::vector<Tape> tape;
 
@@ -714,7 +714,10 @@ struct Builder {
     Act attention(const std::string& p, const Act& x, int head_ch, int groups, float eps) {
         const int C = x.C;
         if (hp) return attention32(p, x, head_ch, groups, eps);
-        if (head_ch != 64 || C % 64) { err = "attention: only num_head_channels == 64 is implemented (" + p + ")"; return Act(); }
+        if (head_ch <= 0) head_ch = C;                  // single head (AutoencoderKL attention blocks)
+        if (C % head_ch || (head_ch != 32 && head_ch != 64 && head_ch != 128 && head_ch != 256)) {
+            err = "attention: head dimension must be 32, 64, 128 or 256 (" + p + ": " + std::to_string(head_ch) + ")"; return Act();
+        }
         Act hn = gn_apply(m->gns.at(p + ".norm"), x, Act(), groups, eps, false);
         if (!hn.valid) return Act();
         ConvArgs q; q.xa = hn; q.w = &m->convs.at(p + ".attn.qkv"); q.k = 1; q.pad = 0; q.Do = x.D; q.Ho = x.H; q.Wo = x.W;
@@ -724,11 +727,11 @@ struct Builder {
         if (!qkv.valid) return Act();
         Act o = new_act(x.N, x.D, x.H, x.W, C);
         Op at{}; at.kind = OP_ATTN; at.r[0] = ws_ref(qkv.off); at.r[1] = ws_ref(o.off);
-        at.i[0] = x.N; at.i[1] = x.D * x.H * x.W; at.i[2] = C; at.i[3] = C / 64; at.f[0] = 1.0f / sqrtf(64.0f);
+        at.i[0] = x.N; at.i[1] = x.D * x.H * x.W; at.i[2] = C; at.i[3] = C / head_ch; at.i[4] = head_ch; at.f[0] = 1.0f / sqrtf((float)head_ch);
         size_t lse_off = 0;
-        if (train) { lse_off = pool.alloc((size_t)x.N * (C / 64) * at.i[1] * 4); at.r[2] = ws_ref(lse_off); }
+        if (train) { lse_off = pool.alloc((size_t)x.N * (C / head_ch) * at.i[1] * 4); at.r[2] = ws_ref(lse_off); }
         plan->ops.push_back(at);
-        if (recording) { Tape t; t.kind = 2; t.qkv = qkv; t.o = o; t.lse_off = lse_off; tape.push_back(t); }
+        if (recording) { Tape t; t.kind = 2; t.qkv = qkv; t.o = o; t.lse_off = lse_off; t.head_ch = head_ch; tape.push_back(t); }
         free_act(qkv);
         ConvArgs pr; pr.xa = o; pr.w = &m->convs.at(p + ".attn.out_proj"); pr.k = 1; pr.pad = 0;
         pr.Do = x.D; pr.Ho = x.H; pr.Wo = x.W; pr.residual = x;
@@ -929,11 +932,11 @@ struct Builder {
         const Act& q = t.qkv;
         const int C = t.o.C, N = q.D * q.H * q.W;
         Act dqkv = new_act(q.N, q.D, q.H, q.W, q.C);
-        const size_t delta = pool.alloc((size_t)q.N * (C / 64) * N * 4);
+        const size_t delta = pool.alloc((size_t)q.N * (C / t.head_ch) * N * 4);
         Op o{}; o.kind = OP_ATTN_BWD;
         o.r[0] = ws_ref(q.off); o.r[1] = ws_ref(t.o.off); o.r[2] = ws_ref(d_o.off); o.r[3] = ws_ref(t.lse_off); o.r[4] = ws_ref(delta);
         o.r[5] = ws_ref(dqkv.off);
-        o.i[0] = q.N; o.i[1] = N; o.i[2] = C; o.f[0] = 1.0f / sqrtf(64.0f);
+        o.i[0] = q.N; o.i[1] = N; o.i[2] = C; o.i[3] = t.head_ch; o.f[0] = 1.0f / sqrtf((float)t.head_ch);
         plan->ops.push_back(o);
         gslot[q.off] = dqkv;
         return true;
@@ -1769,7 +1772,7 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                 break; }
             case OP_ATTN: {
                 AttnParams p{}; p.qkv = (const bf16_t*)rp(bs, o.r[0]); p.out = (bf16_t*)rp(bs, o.r[1]);
-                p.B = i[0]; p.N = i[1]; p.C = i[2]; p.heads = i[3]; p.scale = o.f[0]; p.lse = (float*)rp(bs, o.r[2]);
+                p.B = i[0]; p.N = i[1]; p.C = i[2]; p.heads = i[3]; p.d = i[4]; p.scale = o.f[0]; p.lse = (float*)rp(bs, o.r[2]);
                 HIP_TRY(launch_attn_fwd(p, s));
                 break; }
             case OP_SINUSOID:
@@ -1862,10 +1865,8 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
             case OP_ATTN_BWD: {
                 AttnBwdParams p{}; p.qkv = (const bf16_t*)rp(bs, o.r[0]); p.o = (const bf16_t*)rp(bs, o.r[1]); p.d_o = (const bf16_t*)rp(bs, o.r[2]);
                 p.lse = (const float*)rp(bs, o.r[3]); p.delta = (float*)rp(bs, o.r[4]); p.dqkv = (bf16_t*)rp(bs, o.r[5]);
-                p.B = i[0]; p.N = i[1]; p.C = i[2]; p.heads = i[2] / 64; p.scale = o.f[0];
-                hipLaunchKernelGGL(attn_delta_kernel, dim3(grid_for((long)p.B * p.N * p.heads * 8, 256, 1 << 20)), dim3(256), 0, s, p);
-                hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((p.N + 63) / 64, p.heads, p.B), dim3(256), 0, s, p);
-                hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((p.N + 63) / 64, p.heads, p.B), dim3(256), 0, s, p);
+                p.B = i[0]; p.N = i[1]; p.C = i[2]; p.d = i[3]; p.heads = i[2] / i[3]; p.scale = o.f[0];
+                HIP_TRY(launch_attn_bwd(p, s));
                 break; }
             case OP_ADD:
                 hipLaunchKernelGGL(add_bf16_kernel, dim3(grid_for(i[0], 256, 2048)), dim3(256), 0, s, (const bf16_t*)rp(bs, o.r[0]),
@@ -1911,11 +1912,12 @@ int ldm_unet_create(const ldm_unet_cfg* cfg, ldm_model** out) {
     if (cfg->in_channels < 1 || cfg->out_channels < 1 || cfg->norm_num_groups < 1) return fail(LDM_ERR_BAD_ARG, "bad channel counts");
     for (int i = 0; i < cfg->num_levels; ++i) {
         if (cfg->num_res_blocks[i] < 1) return fail(LDM_ERR_BAD_ARG, "num_res_blocks[%d] < 1", i);
-        if (cfg->attention_levels[i] && cfg->num_head_channels[i] != 64)
-            return fail(LDM_ERR_UNSUPPORTED, "attention level %d: num_head_channels must be 64 (got %d)", i, cfg->num_head_channels[i]);
+        const int hc = cfg->num_head_channels[i];
+        const bool used = cfg->attention_levels[i] || i == cfg->num_levels - 1;          // the middle block always attends (MONAI)
+        if (used && ((hc != 32 && hc != 64 && hc != 128 && hc != 256) || cfg->channels[i] % hc))
+            return fail(LDM_ERR_UNSUPPORTED, "attention level %d: num_head_channels must be 32, 64, 128 or 256 and divide the level's "
+                        "%d channels (got %d)", i, cfg->channels[i], hc);
     }
-    if (cfg->num_head_channels[cfg->num_levels - 1] != 64)
-        return fail(LDM_ERR_UNSUPPORTED, "middle-block attention needs num_head_channels[-1] == 64");
     std::unique_ptr<ldm_model> m(new ldm_model());
     m->type = 0; m->ucfg = *cfg;
     LDM_TRY(unet_register(m.get()));
@@ -2746,33 +2748,36 @@ int ldm_op_group_norm_bwd(const void* dy, const void* xa, int ca, const void* xb
     return 0;
 }
 
-int ldm_op_attention(const void* qkv, void* out, int B, int N, int C, void* stream) {
-    if (!qkv || !out || B < 1 || N < 1 || C < 64 || C % 64) return fail(LDM_ERR_BAD_ARG, "bad argument (head_dim is 64, C % 64 == 0)");
-    AttnParams p{}; p.qkv = (const bf16_t*)qkv; p.out = (bf16_t*)out; p.B = B; p.N = N; p.C = C; p.heads = C / 64; p.scale = 0.125f; p.lse = nullptr;
+static bool head_dim_ok(int C, int d) { return (d == 32 || d == 64 || d == 128 || d == 256) && C >= d && C % d == 0; }
+/* head_dim = 32 | 64 | 128 | 256 (C % head_dim == 0); lse may be NULL */
+int ldm_op_attention_hd(const void* qkv, void* out, float* lse, int B, int N, int C, int head_dim, void* stream) {
+    if (!qkv || !out || B < 1 || N < 1 || !head_dim_ok(C, head_dim)) return fail(LDM_ERR_BAD_ARG, "bad argument (head_dim 32|64|128|256, C % head_dim == 0)");
+    AttnParams p{}; p.qkv = (const bf16_t*)qkv; p.out = (bf16_t*)out; p.B = B; p.N = N; p.C = C; p.d = head_dim; p.heads = C / head_dim;
+    p.scale = 1.0f / sqrtf((float)head_dim); p.lse = lse;
     HIP_TRY(launch_attn_fwd(p, (hipStream_t)stream));
     HIP_TRY(hipGetLastError());
     return 0;
 }
-
-/* attention forward that also saves the log-sum-exp rows, and its backward: dqkv [B*N][3C] from dO [B*N][C]. */
-int ldm_op_attention_train(const void* qkv, void* out, float* lse, int B, int N, int C, void* stream) {
-    if (!qkv || !out || !lse || B < 1 || N < 1 || C < 64 || C % 64) return fail(LDM_ERR_BAD_ARG, "bad argument");
-    AttnParams p{}; p.qkv = (const bf16_t*)qkv; p.out = (bf16_t*)out; p.B = B; p.N = N; p.C = C; p.heads = C / 64; p.scale = 0.125f; p.lse = lse;
-    HIP_TRY(launch_attn_fwd(p, (hipStream_t)stream));
-    HIP_TRY(hipGetLastError());
+int ldm_op_attention_bwd_hd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta_scratch, void* dqkv,
+                            int B, int N, int C, int head_dim, void* stream) {
+    if (!qkv || !o || !d_o || !lse || !delta_scratch || !dqkv || B < 1 || N < 1 || !head_dim_ok(C, head_dim)) return fail(LDM_ERR_BAD_ARG, "bad argument");
+    AttnBwdParams p{}; p.qkv = (const bf16_t*)qkv; p.o = (const bf16_t*)o; p.d_o = (const bf16_t*)d_o; p.lse = lse; p.delta = delta_scratch;
+    p.dqkv = (bf16_t*)dqkv; p.B = B; p.N = N; p.C = C; p.d = head_dim; p.heads = C / head_dim; p.scale = 1.0f / sqrtf((float)head_dim);
+    HIP_TRY(launch_attn_bwd(p, (hipStream_t)stream));
     return 0;
+}
+int ldm_op_attention(const void* qkv, void* out, int B, int N, int C, void* stream) {
+    return ldm_op_attention_hd(qkv, out, nullptr, B, N, C, 64, stream);
+}
+
+/* attention forward that also saves the log-sum-exp rows, and its backward: dqkv [B*N][3C] from dO [B*N][C] (head_dim 64). */
+int ldm_op_attention_train(const void* qkv, void* out, float* lse, int B, int N, int C, void* stream) {
+    if (!lse) return fail(LDM_ERR_BAD_ARG, "bad argument");
+    return ldm_op_attention_hd(qkv, out, lse, B, N, C, 64, stream);
 }
 int ldm_op_attention_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta_scratch, void* dqkv,
                          int B, int N, int C, void* stream) {
-    if (!qkv || !o || !d_o || !lse || !delta_scratch || !dqkv || B < 1 || N < 1 || C < 64 || C % 64) return fail(LDM_ERR_BAD_ARG, "bad argument");
-    AttnBwdParams p{}; p.qkv = (const bf16_t*)qkv; p.o = (const bf16_t*)o; p.d_o = (const bf16_t*)d_o; p.lse = lse; p.delta = delta_scratch;
-    p.dqkv = (bf16_t*)dqkv; p.B = B; p.N = N; p.C = C; p.heads = C / 64; p.scale = 0.125f;
-    hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3(grid_for((long)B * N * p.heads * 8, 256, 1 << 20)), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((N + 63) / 64, p.heads, B), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((N + 63) / 64, p.heads, B), dim3(256), 0, s, p);
-    HIP_TRY(hipGetLastError());
-    return 0;
+    return ldm_op_attention_bwd_hd(qkv, o, d_o, lse, delta_scratch, dqkv, B, N, C, 64, stream);
 }
 
 // ---- RCCL (loaded lazily so the library itself has no hard dependency on librccl) -----------------------

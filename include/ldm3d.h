@@ -226,6 +226,11 @@ int ldm_op_group_norm(const void* xa, int ca, const void* xb, int cb, const floa
                       void* stream);
 /* softmax(q k^T / 8) v with head_dim 64: qkv [B*N][3C] bf16 (q|k|v, channel = head*64 + d) -> out [B*N][C] bf16. */
 int ldm_op_attention(const void* qkv, void* out, int B, int N, int C, void* stream);
+/* the same for head_dim = 32 | 64 | 128 | 256 (num_head_channels 32: 3d_ldm/config/config_train_stable.json:45-46; the AutoencoderKL
+ * attention blocks are single-head, head_dim = C: config_train_32g.json:21-25); lse (optional) receives the log-sum-exp rows */
+int ldm_op_attention_hd(const void* qkv, void* out, float* lse, int B, int N, int C, int head_dim, void* stream);
+int ldm_op_attention_bwd_hd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta_scratch, void* dqkv,
+                            int B, int N, int C, int head_dim, void* stream);
 /*      training form (also writes lse [B][C/64][N] fp32) and backward: dqkv [B*N][3C] bf16 from d_o [B*N][C] bf16;
  *      delta_scratch: B * (C/64) * N floats. */
 int ldm_op_attention_train(const void* qkv, void* out, float* lse, int B, int N, int C, void* stream);

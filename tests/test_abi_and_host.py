@@ -84,7 +84,10 @@ def test_unsupported_configs_fail_loudly(built_lib):
     with pytest.raises(NotImplementedError):
         DiffusionModelUNet(**dict(cfgs.UNET_TINY, with_conditioning=True, cross_attention_dim=64))
     with pytest.raises(_lib.LdmError):
-        DiffusionModelUNet(**dict(cfgs.UNET_TINY, num_head_channels=[0, 32, 32]))       # head_dim 64 only
+        DiffusionModelUNet(**dict(cfgs.UNET_TINY, num_head_channels=[0, 48, 48]))       # head_dim must be 32 | 64 | 128 | 256
+    with pytest.raises(_lib.LdmError):
+        DiffusionModelUNet(**dict(cfgs.UNET_TINY, num_head_channels=[0, 128, 256]))     # ... and divide the level's channels (64, 128)
+    DiffusionModelUNet(**dict(cfgs.UNET_TINY, num_head_channels=[0, 32, 32]))           # config_train_stable.json:45-46
     # AutoencoderKL attention blocks (level flags and the non-local ones) construct with the oracle's MONAI-shaped names
     from oracle import autoencoder as oa
     acfg = dict(cfgs.VAE_TINY, attention_levels=[False, False, True], with_encoder_nonlocal_attn=True, with_decoder_nonlocal_attn=True)
@@ -145,3 +148,32 @@ def test_host_scheduler_tables_equal_oracle(built_lib):
         i.set_timesteps(1001)
     with pytest.raises(Exception):                                                       # CUDA tensors only
         d.step(torch.zeros(2), 5, torch.zeros(2))
+
+
+REF_CFG_DIR = "/root/reference/3d_ldm/config"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_CFG_DIR), reason="the reference checkout is only present in the authoring container")
+def test_every_reference_config_constructs(built_lib):
+    """define_instance on autoencoder_def / diffusion_def of ALL shipped reference configs, read in place (never copied):
+    attention levels + non-local attention in the AutoencoderKL (config_train_32g.json:21-25, config_train_multigpu.json:21-27,
+    config_optimized.json:25-31), num_head_channels 32 (config_train_stable.json:45-46).  Parameter names / shapes must equal the
+    oracle's MONAI-shaped layout for the same kwargs."""
+    import glob
+    from ldm3d.config import ConfigResolver, define_instance
+    from oracle import autoencoder as oa, unet as ou
+    files = sorted(glob.glob(os.path.join(REF_CFG_DIR, "config_*.json")))
+    assert len(files) >= 5
+    seen = 0
+    for f in files:
+        cfg = json.load(open(f))
+        for key, shapes_of in (("autoencoder_def", oa.ae_param_shapes), ("diffusion_def", ou.unet_param_shapes)):
+            if key not in cfg:
+                continue                                  # config_optimized.json (written by check_system.py) has no diffusion_def
+            m = define_instance(cfg, key)
+            kwargs = {k: v for k, v in ConfigResolver(cfg).get_parsed_content(key, instantiate=False).items() if k != "_target_"}
+            want = shapes_of(kwargs)
+            got = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+            assert got == {k: tuple(v) for k, v in want.items()}, (f, key)
+            seen += 1
+    assert seen >= 9

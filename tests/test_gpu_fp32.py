@@ -46,7 +46,7 @@ def gate(got, ref, what, tol=TOL):
 
 
 @pytest.mark.parametrize("name,dims,b", [("UNET_TINY", (8, 8, 8), 1), ("UNET_TINY", (8, 12, 4), 2), ("UNET_TINY_ALT", (6, 10, 8), 2),
-                                         ("UNET_TINY_COND", (8, 8, 8), 2)])
+                                         ("UNET_TINY_COND", (8, 8, 8), 2), ("UNET_TINY_HEAD32", (8, 8, 8), 1)])
 def test_unet_tiny_fp32_meets_1e3(cuda, name, dims, b):
     from oracle import unet as ou
     cfg = getattr(cfgs, name)
@@ -86,7 +86,8 @@ def test_vae_full_96cube_golden_fp32_meets_1e3(cuda):
     assert abs(float((rec.double() ** 2).mean()) - gold["rec_msq_fp32"]) <= 2e-3 * gold["rec_msq_fp32"]
 
 
-@pytest.mark.parametrize("name,dims,b", [("VAE_TINY", (16, 16, 16), 1), ("VAE_TINY", (8, 16, 12), 2)])
+@pytest.mark.parametrize("name,dims,b", [("VAE_TINY", (16, 16, 16), 1), ("VAE_TINY", (8, 16, 12), 2), ("VAE_TINY_ATTN", (16, 16, 16), 2),
+                                         ("VAE_FULL_ATTN", (32, 32, 32), 1)])
 def test_vae_tiny_fp32_meets_1e3(cuda, name, dims, b):
     from oracle import autoencoder as oa
     cfg = getattr(cfgs, name)

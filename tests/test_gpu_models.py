@@ -41,7 +41,8 @@ def _unet_pair(cfg, seed, cuda):
     return m.to(cuda).eval(), sd
 
 
-@pytest.mark.parametrize("name,dims,b", [("UNET_TINY", (8, 8, 8), 1), ("UNET_TINY", (8, 12, 4), 2), ("UNET_TINY_ALT", (6, 10, 8), 2)])
+@pytest.mark.parametrize("name,dims,b", [("UNET_TINY", (8, 8, 8), 1), ("UNET_TINY", (8, 12, 4), 2), ("UNET_TINY_ALT", (6, 10, 8), 2),
+                                         ("UNET_TINY_HEAD32", (8, 8, 8), 2)])
 def test_unet_tiny_matches_oracle(cuda, name, dims, b):
     from oracle import unet as ou
     cfg = getattr(cfgs, name)
@@ -155,7 +156,8 @@ def _vae_pair(cfg, seed, cuda):
     return m.to(cuda).eval(), sd
 
 
-@pytest.mark.parametrize("name,dims,b", [("VAE_TINY", (16, 16, 16), 1), ("VAE_TINY", (8, 16, 12), 2), ("VAE_FULL", (32, 32, 32), 1)])
+@pytest.mark.parametrize("name,dims,b", [("VAE_TINY", (16, 16, 16), 1), ("VAE_TINY", (8, 16, 12), 2), ("VAE_FULL", (32, 32, 32), 1),
+                                         ("VAE_TINY_ATTN", (16, 16, 16), 2), ("VAE_FULL_ATTN", (32, 32, 32), 1)])
 def test_vae_encode_decode_match_oracle(cuda, name, dims, b):
     from oracle import autoencoder as oa
     cfg = getattr(cfgs, name)

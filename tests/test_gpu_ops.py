@@ -409,3 +409,44 @@ def test_conv3_tall_halo_tile(cuda, built_lib, cin, cout, dims, n, splitk):
     (forced here with wgn = 1; ragged last tiles, several samples, split K, channel padding, all epilogue inputs)."""
     err, tol = _conv_case(cuda, built_lib, cin=(cin, 0), cout=cout, dims=dims, n=n, wgn=1, splitk=splitk, temb=True, residual=True, seed=13)
     assert err <= tol, err
+
+
+@pytest.mark.parametrize("b,n,c,d", [(1, 216, 256, 32), (2, 100, 64, 32), (1, 512, 128, 128), (1, 1000, 256, 256), (2, 216, 256, 128),
+                                     (1, 130, 64, 64)])
+def test_attention_any_head_dim_forward_backward(cuda, built_lib, b, n, c, d):
+    """head_dim 32 (num_head_channels of config_train_stable.json:45-46) and the single-head AutoencoderKL blocks (d = C = 64 / 128 /
+    256, config_train_32g.json:21-25): forward, log-sum-exp rows and dq | dk | dv against fp32 softmax attention + torch autograd
+    on the same bf16 q, k, v, dO."""
+    from ldm3d import _lib
+    g = torch.Generator().manual_seed(n + c + d)
+    qkv = torch.randn((b, n, 3 * c), generator=g)
+    qkv[..., :2 * c] *= (64.0 / d) ** 0.25 * 1.5          # keep the score spread comparable across head dims
+    qkv = bf16_round(qkv).requires_grad_(True)
+    h, scale = c // d, d ** -0.5
+
+    def split(z):
+        return z.reshape(b, n, h, d).permute(0, 2, 1, 3)
+    q, k, v = split(qkv[..., :c]), split(qkv[..., c:2 * c]), split(qkv[..., 2 * c:])
+    o = (torch.softmax(q @ k.transpose(-1, -2) * scale, dim=-1) @ v).permute(0, 2, 1, 3).reshape(b, n, c)
+    do = bf16_round(torch.randn(o.shape, generator=g))
+    (ref,) = torch.autograd.grad(o, qkv, do)
+    st = torch.cuda.current_stream().cuda_stream
+    dq = qkv.detach().to(torch.bfloat16).to(cuda)
+    out = torch.full((b, n, c), float("nan"), dtype=torch.bfloat16, device=cuda)
+    lse = torch.empty((b, h, n), dtype=torch.float32, device=cuda)
+    _lib.check(built_lib.ldm_op_attention_hd(dq.data_ptr(), out.data_ptr(), lse.data_ptr(), b, n, c, d, st))
+    dod = do.to(torch.bfloat16).to(cuda)
+    delta = torch.empty((b, h, n), dtype=torch.float32, device=cuda)
+    dqkv = torch.full((b, n, 3 * c), float("nan"), dtype=torch.bfloat16, device=cuda)
+    _lib.check(built_lib.ldm_op_attention_bwd_hd(dq.data_ptr(), out.data_ptr(), dod.data_ptr(), lse.data_ptr(), delta.data_ptr(),
+                                                 dqkv.data_ptr(), b, n, c, d, st))
+    torch.cuda.synchronize()
+    assert rel_l2(out.float().cpu(), o.detach()) <= 8e-3
+    ref_lse = torch.logsumexp(q.detach() @ k.detach().transpose(-1, -2) * scale, dim=-1)
+    assert rel_l2(lse.cpu(), ref_lse) <= 1e-5
+    got = dqkv.float().cpu()
+    for name, sl in (("dq", slice(0, c)), ("dk", slice(c, 2 * c)), ("dv", slice(2 * c, 3 * c))):
+        e = rel_l2(got[..., sl], ref[..., sl])
+        assert e <= 1.5e-2, (name, e)
+    with pytest.raises(_lib.LdmError):
+        _lib.check(built_lib.ldm_op_attention_hd(dq.data_ptr(), out.data_ptr(), None, b, n, c, 48, st))

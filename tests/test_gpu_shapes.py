@@ -80,3 +80,48 @@ def test_vae_encode_brats_patch(cuda):
     with torch.no_grad():
         z = v.encode_stage_2_inputs(x)
     assert z.shape == (1, 8, 36, 44, 28) and torch.isfinite(z).all()
+
+
+@pytest.mark.parametrize("name", sorted(cfgs.REF_CONFIGS))
+def test_every_reference_config_runs_at_its_own_patch_size(cuda, name):
+    """autoencoder_def / diffusion_def of each shipped reference config (kwargs in tests/cfgs.py REF_CONFIGS, from 3d_ldm/config/*.json)
+    at the patch sizes of its own autoencoder_train / diffusion_train sections: AutoencoderKL encode -> decode and one UNet forward
+    (concat-conditioned where in_channels = 2 x latent).  The CPU oracle is too slow here; the bf16 result is checked against the
+    library's fp32 precision mode (itself gated at 1e-3 against the oracle on small shapes) within the bf16 noise floor."""
+    from ldm3d.networks import AutoencoderKL, DiffusionModelUNet
+    from oracle import autoencoder as oa, unet as ou
+    rc = cfgs.REF_CONFIGS[name]
+    g = torch.Generator().manual_seed(5)
+    ae = AutoencoderKL(**rc["ae"])
+    ae.load_state_dict(ou.init_state_dict(oa.ae_param_shapes(rc["ae"]), 6))
+    ae = ae.to(cuda).eval()
+    x = torch.rand((1, rc["ae"]["in_channels"], *rc["ae_patch"]), generator=g).to(cuda)
+    with torch.no_grad():
+        mu, sigma = ae.encode(x)
+        rec = ae.decode(mu)
+        ae.set_precision("fp32")
+        mu32, _ = ae.encode(x)
+        rec32 = ae.decode(mu)
+    assert rec.shape == x.shape and torch.isfinite(rec).all() and torch.isfinite(sigma).all()
+    e_mu, e_rec = rel_l2(mu, mu32), rel_l2(rec, rec32)
+    print(f"{name}: AutoencoderKL {rc['ae_patch']} bf16 vs fp32 mode: mu {e_mu:.2e}, decode {e_rec:.2e}")
+    assert e_mu <= 0.1 and e_rec <= 0.1
+    del ae
+    if rc["unet"] is None:
+        return
+    ucfg = rc["unet"]
+    un = DiffusionModelUNet(**ucfg)
+    un.load_state_dict(ou.init_state_dict(ou.unet_param_shapes(ucfg), 7))
+    un = un.to(cuda).eval()
+    lat = tuple(p // 4 for p in rc["unet_patch"])
+    z = torch.randn((1, ucfg["out_channels"], *lat), generator=g).to(cuda)
+    cc = ucfg["in_channels"] - ucfg["out_channels"]
+    cond = torch.randn((1, cc, *lat), generator=g).to(cuda) if cc else None
+    t = torch.tensor([321.0], device=cuda)
+    with torch.no_grad():
+        e = un(x=z, timesteps=t, cond=cond)
+        un.set_precision("fp32")
+        e32 = un(x=z, timesteps=t, cond=cond)
+    err = rel_l2(e, e32)
+    print(f"{name}: UNet latent {lat} bf16 vs fp32 mode {err:.2e}")
+    assert e.shape == z.shape and torch.isfinite(e).all() and err <= 0.15

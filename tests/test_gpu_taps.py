@@ -47,7 +47,8 @@ def _check_blocks(got, ref, tol, what, attn=()):
     print(f"{what}: {len(got)} blocks, worst " + ", ".join(f"{k}: {v[0]} {v[1]:.2e}" for k, v in worst.items()) + f" (gate {tol:.0e})")
 
 
-@pytest.mark.parametrize("name,dims,b", [("UNET_TINY", (8, 8, 8), 2), ("UNET_TINY_ALT", (6, 10, 8), 1), ("UNET_FULL", (16, 16, 16), 1)])
+@pytest.mark.parametrize("name,dims,b", [("UNET_TINY", (8, 8, 8), 2), ("UNET_TINY_ALT", (6, 10, 8), 1), ("UNET_FULL", (16, 16, 16), 1),
+                                         ("UNET_TINY_HEAD32", (8, 8, 8), 1)])
 def test_unet_blocks_teacher_forced(cuda, name, dims, b):
     from oracle import unet as ou
     cfg = getattr(cfgs, name)
@@ -106,7 +107,8 @@ def test_export_only_taps_do_not_change_the_result(cuda):
         assert rel_l2(got[name].cpu(), ref[name]) <= 0.1, name
 
 
-@pytest.mark.parametrize("name,dims", [("VAE_TINY", (16, 16, 16)), ("VAE_FULL", (32, 32, 32))])
+@pytest.mark.parametrize("name,dims", [("VAE_TINY", (16, 16, 16)), ("VAE_FULL", (32, 32, 32)), ("VAE_TINY_ATTN", (16, 16, 16)),
+                                       ("VAE_FULL_ATTN", (32, 32, 32))])
 def test_vae_blocks_teacher_forced(cuda, name, dims):
     from ldm3d.networks import AutoencoderKL
     from oracle import autoencoder as oa
@@ -117,14 +119,16 @@ def test_vae_blocks_teacher_forced(cuda, name, dims):
     m.load_state_dict(sd)
     m = m.to(cuda).eval()
     x = torch.rand((1, cfg["in_channels"], *dims), generator=torch.Generator().manual_seed(16))
+    attn = {f"{pre}.blocks.{k}" for pre, lay in (("encoder", oa.encoder_layout(oa.norm_cfg(cfg))), ("decoder", oa.decoder_layout(oa.norm_cfg(cfg))))
+            for k, (kind, _) in enumerate(lay) if kind == "attn"}
     etaps, dtaps = {}, {}
     mu, sigma = oa.encode(sd, cfg, x, taps=etaps)
     rec = oa.decode(sd, cfg, mu, taps=dtaps)
     with torch.no_grad():
         g_mu, g_sigma, got_e = m.encode_taps(x.to(cuda), force=etaps)
         g_rec, got_d = m.decode_taps(mu.to(cuda), force=dtaps)
-    _check_blocks(got_e, etaps, BLOCK_TOL_BF16, f"{name} encoder bf16, teacher forced")
-    _check_blocks(got_d, dtaps, BLOCK_TOL_BF16, f"{name} decoder bf16, teacher forced")
+    _check_blocks(got_e, etaps, BLOCK_TOL_BF16, f"{name} encoder bf16, teacher forced", attn)
+    _check_blocks(got_d, dtaps, BLOCK_TOL_BF16, f"{name} decoder bf16, teacher forced", attn)
     assert rel_l2(g_mu.cpu(), mu) <= BLOCK_TOL_BF16 and rel_l2(g_rec.cpu(), rec) <= BLOCK_TOL_BF16
     with torch.no_grad():
         m.set_precision("fp32")

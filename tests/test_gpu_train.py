@@ -31,7 +31,7 @@ def _cat(gd, names):
 
 
 @pytest.mark.parametrize("name,dims,b,cond", [("UNET_TINY", (8, 8, 8), 2, 0), ("UNET_TINY_ALT", (6, 10, 8), 1, 0),
-                                              ("UNET_TINY_COND", (8, 12, 4), 1, 4)])
+                                              ("UNET_TINY_COND", (8, 12, 4), 1, 4), ("UNET_TINY_HEAD32", (8, 8, 8), 2, 0)])
 def test_unet_parameter_gradients_match_oracle_autograd(cuda, name, dims, b, cond):
     from ldm3d.networks import DiffusionModelUNet
     from oracle import unet as ou
@@ -181,7 +181,7 @@ def test_full_size_unet_backward_runs_and_is_finite(cuda):
 
 
 # ------------------------------------------------------------------------------------------------ AutoencoderKL (stage 1)
-@pytest.mark.parametrize("name,dims,b", [("VAE_TINY", (16, 16, 16), 1), ("VAE_TINY", (8, 16, 12), 2)])
+@pytest.mark.parametrize("name,dims,b", [("VAE_TINY", (16, 16, 16), 1), ("VAE_TINY", (8, 16, 12), 2), ("VAE_TINY_ATTN", (16, 16, 16), 2)])
 def test_autoencoder_parameter_gradients_match_oracle_autograd(cuda, name, dims, b):
     """loss_g = L1(recon, x) + kl_weight * KL(z_mu, z_sigma) as in train_autoencoder.py:374-424 (without the perceptual /
     adversarial terms), differentiated by the HIP backward plan vs torch autograd through the CPU oracle."""
@@ -223,7 +223,7 @@ def test_autoencoder_parameter_gradients_match_oracle_autograd(cuda, name, dims,
           f"vs bf16-oracle {ebf:.2e}, cosine {cos:.5f}")
     assert e32 <= 2.0 * floor + 5e-3, (e32, floor)
     assert ebf <= 2.5 * floor + 5e-3, (ebf, floor)
-    for fam in ("encoder", "decoder", "quant_conv_mu", "quant_conv_log_sigma", "post_quant_conv", "norm", "nin_shortcut"):
+    for fam in ("encoder", "decoder", "quant_conv_mu", "quant_conv_log_sigma", "post_quant_conv", "norm", "nin_shortcut", "attn.to_", "attn.out_proj"):
         sel = [n for n in names if fam in n]
         if sel and _cat(g32, sel).norm() > 0:
             fl = rel_l2(_cat(gbf, sel), _cat(g32, sel))
