@@ -91,6 +91,9 @@ SIGNATURES = {
     "ldm_op_group_norm_bwd_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "ldm_op_group_norm_bwd": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P, _P, C.c_int, C.c_float, C.c_int, _P, _P, _P, _P, _P, _P,
                                         C.c_int, C.c_int, _P, C.c_size_t, _P]),
+    "ldm_op_conv3d_gn_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "ldm_op_conv3d_gn": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_int, C.c_float, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_size_t, _P]),
     "ldm_op_group_norm_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "ldm_op_group_norm": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P, C.c_int, C.c_float, C.c_int, _P, C.c_int, C.c_int,
                                     _P, C.c_size_t, _P]),

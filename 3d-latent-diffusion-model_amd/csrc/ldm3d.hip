@@ -2549,11 +2549,14 @@ static int ensure_zero_page() {
     return 0;
 }
 
-int ldm_op_conv3d(const void* xa, int ca, const void* xb, int cb, const void* w, const float* bias,
-                  const void* x1a, int c1a, const void* x1b, int c1b, const void* w1, const float* bias2,
-                  const float* temb, int temb_stride, const void* residual, void* out_bf16, float* out_f32,
-                  int N, int Din, int Hin, int Win, int ksize, int stride, int pad, int ups,
-                  int cout, int cout_pad, int wgn, int splitk, void* scratch, size_t scratch_bytes, void* stream) {
+// stats (optional): GroupNorm partial slabs of the bf16 output, exactly as the plans request them from the producing kernel;
+// *stats_nrb receives the slab rows per sample.  With stats the split-K finalize is the write-through variant the plans launch.
+static int op_conv3d_impl(const void* xa, int ca, const void* xb, int cb, const void* w, const float* bias,
+                          const void* x1a, int c1a, const void* x1b, int c1b, const void* w1, const float* bias2,
+                          const float* temb, int temb_stride, const void* residual, void* out_bf16, float* out_f32,
+                          int N, int Din, int Hin, int Win, int ksize, int stride, int pad, int ups,
+                          int cout, int cout_pad, int wgn, int splitk, void* scratch, size_t scratch_bytes, void* stream,
+                          float* stats, int* stats_nrb) {
     if (!xa || !w || (!out_bf16 && !out_f32)) return fail(LDM_ERR_BAD_ARG, "null tensor argument");
     if (!xb) cb = 0;
     if (!x1a) { c1a = 0; c1b = 0; }
@@ -2574,7 +2577,7 @@ int ldm_op_conv3d(const void* xa, int ca, const void* xb, int cb, const void* w,
               Wo = (Wu + pad_total - ksize) / stride + 1;
     const long M = (long)N * Do * Ho * Wo;
     if (M >= (1L << 31) || M < 1) return fail(LDM_ERR_BAD_ARG, "bad output size");
-    if (!wgn && !splitk && out_bf16 && !out_f32 && gemm_light_ok(ksize, stride, ups, cin0, cin1 == 0, !temb && !bias2) &&
+    if (!stats && !wgn && !splitk && out_bf16 && !out_f32 && gemm_light_ok(ksize, stride, ups, cin0, cin1 == 0, !temb && !bias2) &&
         Builder::light_enabled() && M * (long)cin0 * 2 < (1L << 31)) {
         LightParams lp{}; lp.x = (const bf16_t*)xa; lp.w = (const bf16_t*)w; lp.bias = bias; lp.residual = (const bf16_t*)residual;
         lp.out = (bf16_t*)out_bf16; lp.stats = nullptr; lp.M = (int)M; lp.K = cin0; lp.CoutS = rup(cout, 32);
@@ -2616,6 +2619,14 @@ int ldm_op_conv3d(const void* xa, int ca, const void* xb, int cb, const void* w,
         if (!scratch || scratch_bytes < need) return fail(LDM_ERR_WORKSPACE, "split-K scratch too small: need %zu bytes", need);
         p.partial = (float*)scratch;
     }
+    if (stats) {                                     // slab geometry as Builder::conv lays it out
+        const long dhwo = (long)Do * Ho * Wo; const int bm = 64 * cc.wgm;
+        if (out_f32 || !stats_nrb) return fail(LDM_ERR_BAD_ARG, "statistics need the bf16 output form");
+        if (cc.splitk > 1) { if (N > 1 && dhwo % 32) return fail(LDM_ERR_UNSUPPORTED, "statistics: DHW %% 32 != 0 with a batch"); *stats_nrb = (int)(N == 1 ? (M + 31) / 32 : dhwo / 32); }
+        else if (cc.halo) *stats_nrb = cc.mtps;
+        else { if (N > 1 && dhwo % bm) return fail(LDM_ERR_UNSUPPORTED, "statistics: tiles straddle samples"); *stats_nrb = (int)(N == 1 ? (M + bm - 1) / bm : dhwo / bm); }
+        p.stats = stats;
+    }
     { const char* e = getenv("LDM_CONV_DBG"); p.dbg = e ? atoi(e) : 0; }
     if (p.dbg & 512) {                          // diagnostic stamps go to the caller's scratch (needs nwg * 64 bytes)
         if (cc.splitk > 1 || !scratch || scratch_bytes < (size_t)p.mtiles * p.ntiles * (64 + 4096)) return fail(LDM_ERR_BAD_ARG, "stamps need scratch and splitk 1");
@@ -2625,9 +2636,55 @@ int ldm_op_conv3d(const void* xa, int ca, const void* xb, int cb, const void* w,
     if (cc.splitk > 1) {
         FinalizeParams f{}; f.partial = p.partial; f.splitk = p.splitk; f.M = p.M; f.CoutPad = p.CoutPad; f.CoutS = p.CoutS;
         f.CoutReal = p.CoutReal; f.DHWo = Do * Ho * Wo; f.bias = bias; f.bias2 = bias2; f.temb = temb; f.temb_stride = temb_stride;
-        f.residual = p.residual; f.out = p.out; f.out_f32 = p.out_f32; f.stats = nullptr;
-        hipLaunchKernelGGL(splitk_finalize_kernel<false>, dim3((p.M + 31) / 32, (p.CoutS + 63) / 64), dim3(256), 0, (hipStream_t)stream, f);
+        f.residual = p.residual; f.out = p.out; f.out_f32 = p.out_f32; f.stats = stats;
+        if (stats && wt_stores()) hipLaunchKernelGGL(splitk_finalize_kernel<true>, dim3((p.M + 31) / 32, (p.CoutS + 63) / 64), dim3(256), 0, (hipStream_t)stream, f);
+        else hipLaunchKernelGGL(splitk_finalize_kernel<false>, dim3((p.M + 31) / 32, (p.CoutS + 63) / 64), dim3(256), 0, (hipStream_t)stream, f);
     }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ldm_op_conv3d(const void* xa, int ca, const void* xb, int cb, const void* w, const float* bias,
+                  const void* x1a, int c1a, const void* x1b, int c1b, const void* w1, const float* bias2,
+                  const float* temb, int temb_stride, const void* residual, void* out_bf16, float* out_f32,
+                  int N, int Din, int Hin, int Win, int ksize, int stride, int pad, int ups,
+                  int cout, int cout_pad, int wgn, int splitk, void* scratch, size_t scratch_bytes, void* stream) {
+    return op_conv3d_impl(xa, ca, xb, cb, w, bias, x1a, c1a, x1b, c1b, w1, bias2, temb, temb_stride, residual, out_bf16, out_f32, N, Din, Hin, Win,
+                          ksize, stride, pad, ups, cout, cout_pad, wgn, splitk, scratch, scratch_bytes, stream, nullptr, nullptr);
+}
+
+/* The producer -> GroupNorm pair exactly as the inference plans launch it: a 3^3 stride-1 conv (bias only) whose epilogue - or whose
+ * write-through split-K finalize - leaves the GroupNorm partial slabs of its bf16 output, then the ONE-launch GroupNorm(+SiLU)
+ * (gn_fused_apply_kernel, write-through stores) that folds those slabs.  conv_out [M][round32(cout)] and gn_out (same shape) are bf16
+ * NDHWC.  scratch: split-K slabs + statistics slabs (ldm_op_conv3d_gn_scratch_bytes).  Returns LDM_ERR_UNSUPPORTED where the plans
+ * would not take the one-launch path (channels per group > 64, more than 512 slab rows per sample). */
+size_t ldm_op_conv3d_gn_scratch_bytes(int N, int D, int H, int W, int cout_pad, int splitk) {
+    const size_t M = (size_t)N * D * H * W;
+    return (size_t)(splitk > 1 ? splitk : 0) * M * cout_pad * 4 + ((M + 31) / 32 + 64) * cout_pad * 2 * 4 + 1024;
+}
+int ldm_op_conv3d_gn(const void* x, int cin, const void* w, const float* bias, const float* gamma, const float* beta, int groups, float eps,
+                     int silu, void* conv_out, void* gn_out, int N, int D, int H, int W, int cout, int cout_pad, int wgn, int splitk,
+                     void* scratch, size_t scratch_bytes, void* stream) {
+    if (!x || !w || !gamma || !beta || !conv_out || !gn_out || !scratch) return fail(LDM_ERR_BAD_ARG, "null tensor argument");
+    const int C = rup(cout, 32);
+    if (groups < 1 || C % groups || cout != C) return fail(LDM_ERR_BAD_ARG, "cout must be a multiple of 32 and of groups");
+    if (scratch_bytes < ldm_op_conv3d_gn_scratch_bytes(N, D, H, W, cout_pad, splitk)) return fail(LDM_ERR_WORKSPACE, "scratch too small");
+    const size_t M = (size_t)N * D * H * W;
+    const size_t slab_bytes = (size_t)(splitk > 1 ? splitk : 0) * M * cout_pad * 4;
+    float* stats = (float*)((char*)scratch + rup_sz(slab_bytes, 256));
+    int nrb = 0;
+    LDM_TRY(op_conv3d_impl(x, cin, nullptr, 0, w, bias, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, 0, nullptr, conv_out, nullptr,
+                           N, D, H, W, 3, 1, 1, 0, cout, cout_pad, wgn, splitk, scratch, slab_bytes, stream, stats, &nrb));
+    const int DHW = D * H * W;
+    if (C / groups > 64 || nrb > 512) return fail(LDM_ERR_UNSUPPORTED, "the plans use the two-launch GroupNorm here (%d channels per group, %d slab rows)", C / groups, nrb);
+    const int slices = (C + 63) / 64;
+    int chunks = std::max(1, std::min(256 / (slices * N), (DHW + 31) / 32));
+    const int rpb = rup((DHW + chunks - 1) / chunks, 32);
+    chunks = (DHW + rpb - 1) / rpb;
+    GnFusedParams g{}; g.xa = (const bf16_t*)conv_out; g.xb = nullptr; g.ca = C; g.cb = 0; g.sa = stats; g.sb = nullptr; g.nrb_a = nrb; g.nrb_b = 0;
+    g.groups = groups; g.DHW = DHW; g.N = N; g.silu = silu; g.rows_per_block = rpb; g.eps = eps; g.gamma = gamma; g.beta = beta; g.out = (bf16_t*)gn_out;
+    if (wt_stores()) hipLaunchKernelGGL(gn_fused_apply_kernel<true>, dim3(chunks, slices, N), dim3(256), 0, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL(gn_fused_apply_kernel<false>, dim3(chunks, slices, N), dim3(256), 0, (hipStream_t)stream, g);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -220,6 +220,12 @@ int ldm_op_group_norm_bwd(const void* dy, const void* xa, int ca, const void* xb
                           int groups, float eps, int silu, const void* acc_a, const void* acc_b, void* dxa, void* dxb,
                           float* dgamma, float* dbeta, int N, int DHW, void* scratch, size_t scratch_bytes, void* stream);
 /* GroupNorm(groups, eps, affine) over cat(xa, xb), optional fused SiLU -> out [N*DHW][ca+cb] bf16. */
+/* producer -> GroupNorm pair as the inference plans launch it (conv epilogue / write-through split-K finalize leave the statistics
+ * slabs, one-launch GroupNorm(+SiLU) with write-through stores folds them): the per-kernel gate of exactly those kernel variants */
+size_t ldm_op_conv3d_gn_scratch_bytes(int N, int D, int H, int W, int cout_pad, int splitk);
+int ldm_op_conv3d_gn(const void* x, int cin, const void* w, const float* bias, const float* gamma, const float* beta, int groups, float eps,
+                     int silu, void* conv_out, void* gn_out, int N, int D, int H, int W, int cout, int cout_pad, int wgn, int splitk,
+                     void* scratch, size_t scratch_bytes, void* stream);
 size_t ldm_op_group_norm_scratch_bytes(int N, int C, int DHW);
 int ldm_op_group_norm(const void* xa, int ca, const void* xb, int cb, const float* gamma, const float* beta,
                       int groups, float eps, int silu, void* out, int N, int DHW, void* scratch, size_t scratch_bytes,

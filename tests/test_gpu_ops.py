@@ -450,3 +450,54 @@ def test_attention_any_head_dim_forward_backward(cuda, built_lib, b, n, c, d):
         assert e <= 1.5e-2, (name, e)
     with pytest.raises(_lib.LdmError):
         _lib.check(built_lib.ldm_op_attention_hd(dq.data_ptr(), out.data_ptr(), None, b, n, c, 48, st))
+
+
+# the kernel variants the INFERENCE PLANS launch for a conv -> GroupNorm pair: statistics slabs from the conv epilogue or from
+# splitk_finalize_kernel<true> (inline-asm write-through stores), folded by gn_fused_apply_kernel<true> (same stores).  The shapes are
+# the benchmark UNet's: 24^3 / 12^3 / 6^3 voxels, every tile family (halo 126x128, tall 254x64, general 128x128 / 64x256 / 256x64).
+@pytest.mark.parametrize("cin,cout,dims,n,wgn,splitk,groups,silu", [
+    (256, 256, (12, 12, 12), 1, 2, 1, 32, True),        # halo tile, statistics from the conv epilogue
+    (256, 256, (12, 12, 12), 1, 2, 6, 32, True),        # halo tile, split-K: statistics from the write-through finalize
+    (512, 512, (6, 6, 6), 1, 2, 12, 32, True),          # the 6^3 level: 216 rows, ragged 32-row blocks
+    (128, 64, (16, 16, 16), 1, 1, 1, 32, False),        # tall halo tile (Cout = 64)
+    (64, 256, (8, 8, 8), 2, 4, 1, 32, True),            # general kernel 64 x 256 tile, batch 2
+    (96, 128, (8, 8, 8), 2, 2, 3, 16, True),            # general kernel (K step 32), split-K, batch 2 (DHW % 32 == 0)
+    (256, 256, (24, 24, 24), 1, 2, 1, 32, True),        # the headline 24^3 conv + norm
+])
+def test_conv_then_group_norm_as_the_plans_launch_them(cuda, built_lib, cin, cout, dims, n, wgn, splitk, groups, silu):
+    from ldm3d import _lib
+    g = torch.Generator().manual_seed(cin + cout + dims[0] + splitk)
+    x = bf16_round(torch.randn((n, cin, *dims), generator=g))
+    w = bf16_round(torch.randn((cout, cin, 3, 3, 3), generator=g) / (27 * cin) ** 0.5)
+    b = 0.1 * torch.randn((cout,), generator=g)
+    gamma = 1.0 + 0.1 * torch.randn((cout,), generator=g)
+    beta = 0.1 * torch.randn((cout,), generator=g)
+    y = bf16_round(F.conv3d(x, w, b, padding=1))                    # the conv output is stored bf16; the statistics are of the stored values
+    ref = F.group_norm(y, groups, gamma, beta, 1e-6)
+    if silu:
+        ref = F.silu(ref)
+    cout_pad = rup(cout, 64)
+    xa = to_ndhwc_bf16(x).to(cuda)
+    wp = pack_conv_weight(w, cin, cout_pad).to(cuda)
+    bp = pad_vec(b, cout_pad).to(cuda)
+    conv_out = torch.full((n, *dims, cout), float("nan"), dtype=torch.bfloat16, device=cuda)
+    gn_out = torch.full((n, *dims, cout), float("nan"), dtype=torch.bfloat16, device=cuda)
+    nb = built_lib.ldm_op_conv3d_gn_scratch_bytes(n, *dims, cout_pad, splitk)
+    scratch = torch.empty((nb,), dtype=torch.uint8, device=cuda)
+    gd, bd = gamma.to(cuda), beta.to(cuda)
+    _lib.check(built_lib.ldm_op_conv3d_gn(xa.data_ptr(), cin, wp.data_ptr(), bp.data_ptr(), gd.data_ptr(), bd.data_ptr(),
+                                          groups, 1e-6, int(silu), conv_out.data_ptr(), gn_out.data_ptr(), n, *dims, cout, cout_pad, wgn, splitk,
+                                          scratch.data_ptr(), scratch.numel(), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    e_conv = rel_l2(from_ndhwc(conv_out.cpu(), cout), y)
+    # the GroupNorm is checked on the KERNEL's conv output (identical input on both sides): only its own arithmetic + one rounding
+    yk = from_ndhwc(conv_out.cpu(), cout)
+    ref_k = F.group_norm(yk, groups, gamma, beta, 1e-6)
+    if silu:
+        ref_k = F.silu(ref_k)
+    e_gn = rel_l2(from_ndhwc(gn_out.cpu(), cout), bf16_round(ref_k))
+    e_pair = rel_l2(from_ndhwc(gn_out.cpu(), cout), bf16_round(ref))
+    print(f"conv {cin}->{cout} {dims} n={n} wgn={wgn} splitk={splitk}: conv {e_conv:.2e}, GroupNorm on the kernel's input {e_gn:.2e}, pair {e_pair:.2e}")
+    assert e_conv <= TOL_SAME_ROUNDING, e_conv
+    assert e_gn <= TOL_SAME_ROUNDING, e_gn
+    assert e_pair <= TOL_SAME_ROUNDING, e_pair
