@@ -112,6 +112,10 @@ SIGNATURES = {
     "ldm_comm_broadcast": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int, _P]),
     "ldm_comm_barrier": (C.c_int, [_P, _P]),
     "ldm_comm_destroy": (None, [_P]),
+    "ldm_comm_rank": (C.c_int, [_P]),
+    "ldm_comm_world": (C.c_int, [_P]),
+    "ldm_model_set_grad_sync": (C.c_int, [_P, _P]),
+    "ldm_model_grad_sync_trace": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]),
 }
 
 _lib = None

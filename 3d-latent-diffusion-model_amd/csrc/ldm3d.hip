@@ -80,7 +80,8 @@ enum OpKind { OP_PACK, OP_CONV, OP_FINALIZE, OP_GN_STATS, OP_GN_FINALIZE, OP_GN_
               OP_IM2COL,                           // fp32 NCDHW inputs -> bf16 patch matrix of the first conv (pack_im2col_kernel)
               // fp32 precision mode (f32_path.h)
               OP_PACK32, OP_CONV32, OP_FIN32, OP_GN_STATS32, OP_GN_APPLY32, OP_ATTN32, OP_GEMV32,
-              OP_TAP };                            // debug tap: export an activation as fp32 NCDHW and / or overwrite it (teacher forcing)
+              OP_TAP,
+              OP_BUCKET, OP_BUCKET_JOIN };         // training plans: a tail range of the flat gradient buffer is final (all-reduce it now) / wait for every bucket                            // debug tap: export an activation as fp32 NCDHW and / or overwrite it (teacher forcing)
 
 struct ConvCfg { int wgm, wgn, bk, splitk; int halo = 0, mtps = 0, qps = 0; };   // halo: conv3_halo_kernel (126-row tiles)
 
@@ -169,6 +170,18 @@ struct ConvW { size_t w_off = 0; size_t b_off = 0; int cout = 0, cout_pad = 0, c
 struct GnW { size_t g_off = 0, b_off = 0; int C = 0; };
 struct LinW { size_t w_off = 0, b_off = 0; int in = 0, out = 0; };
 
+// data-parallel gradient exchange overlapped with backward (ldm_model_set_grad_sync): every OP_BUCKET records an event on the launch
+// stream, makes the comm stream wait for it and queues the bucket's all-reduce (mean) there; OP_BUCKET_JOIN makes the launch stream
+// wait for the last one.  Timing events (issue point on the launch stream, completion on the comm stream) feed ldm_model_grad_sync_trace.
+struct ldm_comm;
+struct GradSyncState {
+    ldm_comm* comm = nullptr; hipStream_t stream = nullptr;
+    std::vector<hipEvent_t> ev;                      // per bucket: issue (launch stream), done (comm stream); [0] = backward start
+    size_t used = 0; std::vector<int64_t> elems;
+};
+static int grad_sync_begin(GradSyncState& g, hipStream_t s);
+static int grad_sync_bucket(GradSyncState& g, float* buf, int64_t count, hipStream_t s);
+static int grad_sync_join(GradSyncState& g, hipStream_t s);
 struct ldm_model {
     int type = 0;                                    // 0 = UNet, 1 = VAE
     ldm_unet_cfg ucfg{}; ldm_vae_cfg vcfg{};
@@ -189,6 +202,7 @@ struct ldm_model {
     std::vector<GraphEntry> graphs;
     hipStream_t side_stream = nullptr; std::vector<hipEvent_t> lane_events;     // side lane of the inference plans (run_plan)
     hipStream_t cap_stream = nullptr;        // capture happens on a private stream (the caller's may be the null stream, which cannot capture)
+    GradSyncState gsync;                     // ldm_model_set_grad_sync
     // UNet: stacked time_emb_proj GEMV
     size_t tproj_w_off = 0, tproj_b_off = 0; int tproj_rows = 0; std::map<std::string, int> tproj_row;
 
@@ -810,7 +824,33 @@ struct Builder {
     }
     std::vector<ColsumDesc> cs_descs; std::vector<int2> cs_map;
     static bool colsum_batched() { const char* e = getenv("LDM_COLSUM_BATCH"); return e ? atoi(e) != 0 : true; }
-    void flush_colsums() { if (!cs_descs.empty()) { Op o{}; o.kind = OP_COLSUM_BATCH; plan->ops.push_back(o); } }
+    size_t cs_flushed = 0, exp_flushed = 0;              // blocks of cs_map / exp_map already launched by an earlier flush
+    void flush_colsums() {
+        if (cs_map.size() > cs_flushed) {
+            Op o{}; o.kind = OP_COLSUM_BATCH; o.i[0] = (int)cs_flushed; o.i[1] = (int)cs_map.size(); plan->ops.push_back(o);
+            cs_flushed = cs_map.size();
+        }
+    }
+    void flush_exports() {
+        if (exp_map.size() > exp_flushed) {
+            Op o{}; o.kind = OP_EXPORT_BATCH; o.i[0] = (int)exp_flushed; o.i[1] = (int)exp_map.size(); plan->ops.push_back(o);
+            exp_flushed = exp_map.size();
+        }
+    }
+    // Gradient buckets: parameters are registered in execution order, so the backward walk finishes the flat gradient buffer from
+    // its end towards its front.  Whenever bucket_elems more elements are final, their staged gradients are exported and an OP_BUCKET
+    // marks the range: with a communicator attached (ldm_model_set_grad_sync) its all-reduce starts there, on the comm stream, while
+    // the launch stream carries on with backward (what DistributedDataParallel's bucketed hooks do: 3d_ldm/train_diffusion.py:147-149).
+    int64_t bucket_hi = 0, done_from = 0;
+    static int64_t bucket_elems() { const char* e = getenv("LDM_GRAD_BUCKET_MB"); const long mb = e ? atol(e) : 48; return (int64_t)(mb < 1 ? 1 : mb) * 262144; }
+    void note_done(int64_t flat_off) { if (flat_off < done_from) done_from = flat_off; }
+    void close_bucket(bool force) {
+        if (done_from >= bucket_hi) return;
+        if (!force && bucket_hi - done_from < bucket_elems()) return;
+        flush_colsums(); flush_exports();
+        Op o{}; o.kind = OP_BUCKET; o.i[0] = (int)done_from; o.i[1] = (int)(bucket_hi - done_from); plan->ops.push_back(o);
+        bucket_hi = done_from;
+    }
     void emit_wgrad(const Act& dy, const Act& x, int cout, int cin, int ld, int ci_off, int k, int stride, int pad, int ups) {
         Op o{}; o.kind = OP_WGRAD; o.r[0] = ws_ref(dy.off); o.r[1] = ws_ref(x.off); o.r[2] = ws_ref(dw_off);
         int* i = o.i;
@@ -854,6 +894,12 @@ struct Builder {
         const ConvArgs& a = t.c; const ConvW& w = *a.w;
         int cin_real = 0;
         for (const ParamDesc& d : m->params) if (d.kind == PK_CONV_W && d.dst_off == w.w_off) cin_real = d.cin;
+        for (const ParamDesc& d : m->params) {               // every parameter of the slot(s) this conv differentiates
+            const bool mine = (d.kind == PK_CONV_W && (d.dst_off == w.w_off || (a.w1 && d.dst_off == a.w1->w_off))) ||
+                              (d.kind == PK_VEC_F32 && ((d.dst_off >= w.b_off && d.dst_off < w.b_off + (size_t)w.cout_pad * 4) ||
+                                                        (a.w1 && d.dst_off >= a.w1->b_off && d.dst_off < a.w1->b_off + (size_t)a.w1->cout_pad * 4)));
+            if (mine) note_done(d.flat_off);
+        }
         if (!cin_real) { err = "backward: conv slot without parameters"; return false; }
         if (dout.C != rup(w.cout, 32)) { err = "backward: gradient channel mismatch"; return false; }
         // bias (both biases of a conv with a fused 1x1 skip see the same column sums) and the time-embedding rows
@@ -913,6 +959,7 @@ struct Builder {
             if (d.kind == PK_VEC_F32 && d.dst_off == t.g->b_off) bo = d.flat_off;
         }
         if (go < 0 || bo < 0) { err = "backward: GroupNorm parameters not found"; return false; }
+        note_done(std::min(go, bo));
         Op o{}; o.kind = OP_GNB;
         o.r[0] = ws_ref(dy.off); o.r[1] = ws_ref(xa.off); o.r[2] = xb.valid ? ws_ref(xb.off) : Ref(); o.r[3] = ws_ref(t.ab_off);
         o.r[5] = ws_ref(t.mr_off); o.r[6] = w_ref(t.g->g_off); o.r[7] = ws_ref(gsum); o.r[8] = ws_ref(dgn); o.r[9] = ws_ref(dbn);
@@ -981,6 +1028,7 @@ struct Builder {
             } else if (t.kind == 1) ok = backward_gn(t);
             else ok = backward_attn(t);
             if (!ok) return false;
+            close_bucket(false);
         }
         return true;
     }
@@ -1009,31 +1057,34 @@ static int unet_register(ldm_model* m) {
     const int temb = ch[0] * 4;
     for (int i = 0; i < L; ++i) if (ch[i] % 32 || ch[i] % c.norm_num_groups)
         return fail(LDM_ERR_UNSUPPORTED, "UNet channels must be multiples of 32 and of norm_num_groups (level %d: %d)", i, ch[i]);
-    std::vector<std::pair<std::string, int>> tprojs;        // (resblock prefix, cout) in registration order
+    // Parameter (= flat gradient buffer) order follows the order in which the BACKWARD pass finishes gradients, reversed: the time
+    // embedding MLP and every ResBlock's time_emb_proj come first (their gradients are the last ones produced), then conv_in, the
+    // down blocks, the middle block, the up blocks and out.  The flat gradient buffer therefore fills strictly from its end to its
+    // front, and the data-parallel exchange can reduce completed tail ranges while backward is still running (ldm_model_set_grad_sync).
+    std::vector<std::pair<std::string, int>> tprojs;        // (resblock prefix, cout) in execution order
+    bool collect = true;                                     // first pass: only list the ResBlocks (their projections are registered up front)
     auto reg_res = [&](const std::string& p, int cin, int cout) {
+        if (collect) { tprojs.push_back({p, cout}); return; }
         m->reg_gn(p + ".norm1", cin);
         m->reg_conv(p + ".conv1", cin, cin, cout, 3);
-        tprojs.push_back({p, cout});
         m->reg_gn(p + ".norm2", cout);
         m->reg_conv(p + ".conv2", cout, cout, cout, 3);
         if (cin != cout) m->reg_conv(p + ".skip_connection", cin, cin, cout, 1);
     };
-    m->reg_conv("conv_in", c.in_channels, rup(c.in_channels, 32), ch[0], 3);
-    m->reg_im2col("conv_in", c.in_channels);
-    m->reg_linear("time_embed.0", ch[0], temb);
-    m->reg_linear("time_embed.2", temb, temb);
+    auto walk = [&]() {
+    if (!collect) { m->reg_conv("conv_in", c.in_channels, rup(c.in_channels, 32), ch[0], 3); m->reg_im2col("conv_in", c.in_channels); }
     int oc = ch[0];
     for (int i = 0; i < L; ++i) {
         int ic = oc; oc = ch[i];
         for (int j = 0; j < c.num_res_blocks[i]; ++j) {
             char p[96]; snprintf(p, sizeof p, "down_blocks.%d.resnets.%d", i, j);
             reg_res(p, j == 0 ? ic : oc, oc);
-            if (c.attention_levels[i]) { snprintf(p, sizeof p, "down_blocks.%d.attentions.%d", i, j); m->reg_attn(p, oc); }
+            if (c.attention_levels[i] && !collect) { snprintf(p, sizeof p, "down_blocks.%d.attentions.%d", i, j); m->reg_attn(p, oc); }
         }
-        if (i != L - 1) { char p[96]; snprintf(p, sizeof p, "down_blocks.%d.downsampler.op", i); m->reg_conv(p, oc, oc, oc, 3); }
+        if (i != L - 1 && !collect) { char p[96]; snprintf(p, sizeof p, "down_blocks.%d.downsampler.op", i); m->reg_conv(p, oc, oc, oc, 3); }
     }
     reg_res("middle_block.resnet_1", ch[L - 1], ch[L - 1]);
-    m->reg_attn("middle_block.attention", ch[L - 1]);
+    if (!collect) m->reg_attn("middle_block.attention", ch[L - 1]);
     reg_res("middle_block.resnet_2", ch[L - 1], ch[L - 1]);
     oc = ch[L - 1];
     for (int i = 0; i < L; ++i) {
@@ -1046,12 +1097,15 @@ static int unet_register(ldm_model* m) {
             const int rin = (j == 0) ? prev : oc;
             char p[96]; snprintf(p, sizeof p, "up_blocks.%d.resnets.%d", i, j);
             reg_res(p, rin + skip_c, oc);
-            if (c.attention_levels[lvl]) { snprintf(p, sizeof p, "up_blocks.%d.attentions.%d", i, j); m->reg_attn(p, oc); }
+            if (c.attention_levels[lvl] && !collect) { snprintf(p, sizeof p, "up_blocks.%d.attentions.%d", i, j); m->reg_attn(p, oc); }
         }
-        if (i != L - 1) { char p[96]; snprintf(p, sizeof p, "up_blocks.%d.upsampler.conv", i); m->reg_conv(p, oc, oc, oc, 3, true); }
+        if (i != L - 1 && !collect) { char p[96]; snprintf(p, sizeof p, "up_blocks.%d.upsampler.conv", i); m->reg_conv(p, oc, oc, oc, 3, true); }
     }
-    m->reg_gn("out.0", ch[0]);
-    m->reg_conv("out.2", ch[0], ch[0], c.out_channels, 3);
+    if (!collect) { m->reg_gn("out.0", ch[0]); m->reg_conv("out.2", ch[0], ch[0], c.out_channels, 3); }
+    };
+    walk();                                                  // pass 1: the ResBlock list
+    m->reg_linear("time_embed.0", ch[0], temb);
+    m->reg_linear("time_embed.2", temb, temb);
     // stacked time_emb_proj: one GEMV for every ResBlock ([sum cout][temb] bf16)
     int rows = 0; for (auto& t : tprojs) rows += t.second;
     m->tproj_rows = rows;
@@ -1063,6 +1117,8 @@ static int unet_register(ldm_model* m) {
         m->reg_linear_at(t.first + ".time_emb_proj", temb, t.second, m->tproj_w_off + (size_t)r * temb * 2, m->tproj_b_off + (size_t)r * 4);
         r += t.second;
     }
+    collect = false;
+    walk();                                                  // pass 2: everything else, in execution order
     return 0;
 }
 
@@ -1193,6 +1249,7 @@ static int unet_build(ldm_model* m, int B, int D, int H, int W, Plan* plan, bool
         Act dout = b.new_act(B, D, H, W, cos_);
         { Op o{}; o.kind = OP_PACK; o.r[0] = io_ref(0); o.r[1] = Ref(); o.r[2] = ws_ref(dout.off);
           o.i[0] = B; o.i[1] = c.out_channels; o.i[2] = cos_; o.i[3] = D * H * W; plan->ops.push_back(o); }
+        b.bucket_hi = b.done_from = m->flat_total;
         if (!b.backward_all(dout)) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
         b.flush_colsums();                              // bias gradients and the time-embedding rows the MLP backward reads next
         // stacked projections  temb_all = Wt silu(e2) + bt
@@ -1215,7 +1272,8 @@ static int unet_build(ldm_model* m, int B, int D, int H, int W, Plan* plan, bool
         b.emit_lin_dw(ws_ref(de1), ws_ref(sin_off), Builder::grad_ref(P("time_embed.0.weight")), Builder::grad_ref(P("time_embed.0.bias")),
                       B, ch[0], temb, temb, ch[0], 0);
         if (!b.err.empty()) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
-        { Op o{}; o.kind = OP_EXPORT_BATCH; plan->ops.push_back(o); }      // every staged parameter gradient -> flat buffer, one launch
+        b.done_from = 0; b.close_bucket(true);          // the front of the buffer: time embedding MLP, projections, whatever is left
+        { Op o{}; o.kind = OP_BUCKET_JOIN; plan->ops.push_back(o); }
         if (plan->wt_tab.upload(b.wt_descs, b.wt_map) || plan->exp_tab.upload(b.exp_descs, b.exp_map) ||
             (!b.cs_descs.empty() && plan->cs_tab.upload(b.cs_descs, b.cs_map)))
             return fail(LDM_ERR_HIP, "descriptor table upload failed");
@@ -1284,8 +1342,8 @@ static int vae_register(ldm_model* m) {
         }
         return 0;
     };
+    // parameter order = execution order (encoder, heads, post_quant_conv, decoder): the flat gradient buffer fills back to front
     LDM_TRY(reg("encoder", ae_encoder_layout(c)));
-    LDM_TRY(reg("decoder", ae_decoder_layout(c)));
     const int Lc = c.latent_channels, Ls = rup(Lc, 32);
     ConvW heads = m->new_conv_slot(Ls, 2 * Lc, 1);                       // mu | log_sigma fused
     m->reg_conv_into("quant_conv_mu", heads, Lc, Lc, 1, 0, false);
@@ -1294,6 +1352,7 @@ static int vae_register(ldm_model* m) {
     ConvW pq = m->new_conv_slot(Ls, Lc, 1);
     m->reg_conv_into("post_quant_conv", pq, Lc, Lc, 1, 0, false);
     m->convs["post_quant_conv"] = pq;
+    LDM_TRY(reg("decoder", ae_decoder_layout(c)));
     return 0;
 }
 
@@ -1421,9 +1480,10 @@ static int vae_build_train(ldm_model* m, int B, int D, int H, int W, Plan* plan)
     Act dout = b.new_act(B, D, H, W, cos_);
     { Op o{}; o.kind = OP_PACK; o.r[0] = io_ref(0); o.r[1] = Ref(); o.r[2] = ws_ref(dout.off);
       o.i[0] = B; o.i[1] = c.out_channels; o.i[2] = cos_; o.i[3] = D * H * W; o.i[4] = 1; plan->ops.push_back(o); }
+    b.bucket_hi = b.done_from = m->flat_total;
     if (!b.backward_all(dout)) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
-    b.flush_colsums();
-    { Op o{}; o.kind = OP_EXPORT_BATCH; plan->ops.push_back(o); }
+    b.done_from = 0; b.close_bucket(true);
+    { Op o{}; o.kind = OP_BUCKET_JOIN; plan->ops.push_back(o); }
     if (plan->wt_tab.upload(b.wt_descs, b.wt_map) || plan->exp_tab.upload(b.exp_descs, b.exp_map) ||
         (!b.cs_descs.empty() && plan->cs_tab.upload(b.cs_descs, b.cs_map)))
         return fail(LDM_ERR_HIP, "descriptor table upload failed");
@@ -1569,7 +1629,7 @@ static int launch_wgrad(const WgradParams& p, hipStream_t s) {
 
 static bool wt_stores() { static const int v = [] { const char* e = getenv("LDM_WT_STORES"); return e ? atoi(e) : 1; }(); return v != 0; }   // GroupNorm / finalize outputs written through (sc1): -24 us per step
 
-struct LaneCtx { hipStream_t side = nullptr; std::vector<hipEvent_t>* events = nullptr; };
+struct LaneCtx { hipStream_t side = nullptr; std::vector<hipEvent_t>* events = nullptr; GradSyncState* sync = nullptr; };
 
 static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_t s, size_t begin = 0, size_t end = (size_t)-1,
                     LaneCtx lanes = LaneCtx()) {
@@ -1801,17 +1861,23 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                     hipLaunchKernelGGL(weight_flip_transpose_batched_kernel, dim3(plan.wt_tab.nblocks), dim3(256), 0, s,
                                        (const WtDesc*)plan.wt_tab.descs, (const int2*)plan.wt_tab.map, (const char*)bs.p[BASE_W], bs.p[BASE_WS]);
                 break;
-            case OP_COLSUM_BATCH:
-                if (plan.cs_tab.nblocks)
-                    hipLaunchKernelGGL(colsum_finalize_batched_kernel, dim3(plan.cs_tab.nblocks), dim3(256), 0, s,
-                                       (const ColsumDesc*)plan.cs_tab.descs, (const int2*)plan.cs_tab.map, (char*)bs.p[BASE_WS]);
+            case OP_COLSUM_BATCH:       // i: first block, end block of the table's block map
+                if (i[1] > i[0])
+                    hipLaunchKernelGGL(colsum_finalize_batched_kernel, dim3(i[1] - i[0]), dim3(256), 0, s,
+                                       (const ColsumDesc*)plan.cs_tab.descs, (const int2*)plan.cs_tab.map + i[0], (char*)bs.p[BASE_WS]);
                 break;
             case OP_EXPORT_BATCH:
                 if (!bs.p[BASE_IO4]) return fail(LDM_ERR_BAD_ARG, "backward without a gradient buffer");
-                if (plan.exp_tab.nblocks)
-                    hipLaunchKernelGGL(grad_export_batched_kernel, dim3(plan.exp_tab.nblocks), dim3(256), 0, s,
-                                       (const ExportDesc*)plan.exp_tab.descs, (const int2*)plan.exp_tab.map, (const char*)bs.p[BASE_WS],
+                if (i[1] > i[0])
+                    hipLaunchKernelGGL(grad_export_batched_kernel, dim3(i[1] - i[0]), dim3(256), 0, s,
+                                       (const ExportDesc*)plan.exp_tab.descs, (const int2*)plan.exp_tab.map + i[0], (const char*)bs.p[BASE_WS],
                                        (float*)bs.p[BASE_IO4]);
+                break;
+            case OP_BUCKET:             // i: first element, element count of a final tail range of the flat gradient buffer
+                if (lanes.sync) LDM_TRY(grad_sync_bucket(*lanes.sync, (float*)bs.p[BASE_IO4] + i[0], i[1], s));
+                break;
+            case OP_BUCKET_JOIN:
+                if (lanes.sync) LDM_TRY(grad_sync_join(*lanes.sync, s));
                 break;
             case OP_WGRAD: {
                 WgradParams p{}; p.dy = (const bf16_t*)rp(bs, o.r[0]); p.cdy = i[0]; p.x = (const bf16_t*)rp(bs, o.r[1]); p.cx = i[1];
@@ -1943,6 +2009,8 @@ void ldm_model_destroy(ldm_model* m) {
     for (auto& g : m->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
     if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
     if (m->side_stream) (void)hipStreamDestroy(m->side_stream);
+    if (m->gsync.stream) (void)hipStreamDestroy(m->gsync.stream);
+    for (auto e : m->gsync.ev) (void)hipEventDestroy(e);
     for (auto e : m->lane_events) (void)hipEventDestroy(e);
     if (m->arena) (void)hipFree(m->arena);
     if (m->arena32) (void)hipFree(m->arena32);
@@ -2314,7 +2382,9 @@ int ldm_unet_train_backward(ldm_model* m, const float* grad_out, float* flat_gra
     Bases bs{}; bs.p[BASE_WS] = (char*)workspace; bs.p[BASE_W] = m->arena; bs.p[BASE_W32] = m->arena32;
     bs.p[BASE_IO0] = (char*)grad_out; bs.p[BASE_IO4] = (char*)flat_grads;
     const int rt[2] = {m->ucfg.out_channels, 0};
-    return run_plan(*p, bs, rt, (hipStream_t)stream, p->bwd_begin, p->ops.size());
+    LaneCtx lanes;
+    if (m->gsync.comm) { lanes.sync = &m->gsync; LDM_TRY(grad_sync_begin(m->gsync, (hipStream_t)stream)); }
+    return run_plan(*p, bs, rt, (hipStream_t)stream, p->bwd_begin, p->ops.size(), lanes);
 }
 
 size_t ldm_vae_train_workspace_bytes(ldm_model* m, int B, int D, int H, int W) {
@@ -2346,7 +2416,9 @@ int ldm_vae_train_backward(ldm_model* m, const float* d_recon, const float* d_mu
     Bases bs{}; bs.p[BASE_WS] = (char*)workspace; bs.p[BASE_W] = m->arena; bs.p[BASE_W32] = m->arena32;
     bs.p[BASE_IO0] = (char*)d_recon; bs.p[BASE_IO1] = (char*)d_mu; bs.p[BASE_IO2] = (char*)d_sigma; bs.p[BASE_IO4] = (char*)flat_grads;
     const int rt[2] = {m->vcfg.out_channels, 0};
-    return run_plan(*p, bs, rt, (hipStream_t)stream, p->bwd_begin, p->ops.size());
+    LaneCtx lanes;
+    if (m->gsync.comm) { lanes.sync = &m->gsync; LDM_TRY(grad_sync_begin(m->gsync, (hipStream_t)stream)); }
+    return run_plan(*p, bs, rt, (hipStream_t)stream, p->bwd_begin, p->ops.size(), lanes);
 }
 
 static float* g_norm_parts = nullptr;
@@ -2913,5 +2985,66 @@ void ldm_comm_destroy(ldm_comm* c) {
     if (c->token) (void)hipFree(c->token);
     delete c;
 }
+int ldm_comm_rank(const ldm_comm* c) { return c ? c->rank : -1; }
+int ldm_comm_world(const ldm_comm* c) { return c ? c->world : -1; }
+
+/* Attach (comm != NULL) or detach (NULL) the data-parallel gradient exchange of a model's training plans.  While attached,
+ * ldm_unet_train_backward / ldm_vae_train_backward all-reduce (mean over ranks, fp32) the flat gradient buffer in buckets of
+ * LDM_GRAD_BUCKET_MB (default 48) MB: a bucket's collective is queued on the communicator's own stream as soon as the backward pass
+ * has finished that tail range of the buffer, overlapped with the rest of backward, and `stream` waits for the last one before the call's
+ * work is complete in stream order.  Replaces DistributedDataParallel's bucketed hooks (3d_ldm/train_diffusion.py:147-149).
+ * The communicator must outlive the attachment. */
+int ldm_model_set_grad_sync(ldm_model* m, ldm_comm* comm) {
+    if (!m) return fail(LDM_ERR_BAD_ARG, "null model");
+    if (comm && !m->gsync.stream) HIP_TRY(hipStreamCreateWithFlags(&m->gsync.stream, hipStreamNonBlocking));
+    m->gsync.comm = comm;
+    return 0;
+}
+/* Timeline of the buckets of the LAST backward call (synchronises): issue_ms[k] = when bucket k was handed to the comm stream,
+ * done_ms[k] = when its all-reduce finished, both relative to the start of that backward call; elems[k] = its size; then, at index
+ * n (if max > n), the end of the backward call itself in issue_ms[n] (done_ms[n] = the same, elems[n] = 0).  Returns n. */
+int ldm_model_grad_sync_trace(ldm_model* m, double* issue_ms, double* done_ms, int64_t* elems, int max) {
+    if (!m || !issue_ms || !done_ms || !elems || max < 0) return fail(LDM_ERR_BAD_ARG, "bad argument");
+    GradSyncState& g = m->gsync;
+    const int n = (int)g.elems.size();
+    if (g.used < 2 + 2 * (size_t)n) return 0;
+    HIP_TRY(hipEventSynchronize(g.ev[1]));
+    for (int k = 0; k < n && k < max; ++k) {
+        float a = 0.f, b = 0.f;
+        HIP_TRY(hipEventSynchronize(g.ev[2 + 2 * k + 1]));
+        HIP_TRY(hipEventElapsedTime(&a, g.ev[0], g.ev[2 + 2 * k])); HIP_TRY(hipEventElapsedTime(&b, g.ev[0], g.ev[2 + 2 * k + 1]));
+        issue_ms[k] = a; done_ms[k] = b; elems[k] = g.elems[k];
+    }
+    if (max > n) { float e = 0.f; HIP_TRY(hipEventElapsedTime(&e, g.ev[0], g.ev[1])); issue_ms[n] = done_ms[n] = e; elems[n] = 0; }
+    return n;
+}
 
 }  // extern "C"
+
+// ---- gradient buckets (run_plan: OP_BUCKET / OP_BUCKET_JOIN) ----------------------------------------------------------------------
+static hipEvent_t* gs_event(GradSyncState& g, size_t k) {
+    while (g.ev.size() <= k) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; g.ev.push_back(e); }
+    return &g.ev[k];
+}
+static int grad_sync_begin(GradSyncState& g, hipStream_t s) {
+    g.used = 2; g.elems.clear();                     // ev[0] = start of this backward, ev[1] = its end (recorded by the join)
+    hipEvent_t* e0 = gs_event(g, 1); if (!e0) return fail(LDM_ERR_HIP, "hipEventCreate failed");
+    HIP_TRY(hipEventRecord(g.ev[0], s));
+    return 0;
+}
+static int grad_sync_bucket(GradSyncState& g, float* buf, int64_t count, hipStream_t s) {
+    if (!buf) return fail(LDM_ERR_BAD_ARG, "backward without a gradient buffer");
+    if (!gs_event(g, g.used + 1)) return fail(LDM_ERR_HIP, "hipEventCreate failed");
+    hipEvent_t issue = g.ev[g.used], done = g.ev[g.used + 1];
+    HIP_TRY(hipEventRecord(issue, s));
+    HIP_TRY(hipStreamWaitEvent(g.stream, issue, 0));
+    LDM_TRY(ldm_comm_allreduce(g.comm, buf, count, 0, 1, g.stream));                 // fp32, mean over ranks
+    HIP_TRY(hipEventRecord(done, g.stream));
+    g.used += 2; g.elems.push_back(count);
+    return 0;
+}
+static int grad_sync_join(GradSyncState& g, hipStream_t s) {
+    if (g.used > 2) HIP_TRY(hipStreamWaitEvent(s, g.ev[g.used - 1], 0));             // the comm stream is in order: the last bucket covers all
+    HIP_TRY(hipEventRecord(g.ev[1], s));
+    return 0;
+}

@@ -36,6 +36,38 @@ class GradSync:
         self._avg = self.on and dist.get_backend() == "nccl"
         self.grad_dtype = grad_dtype
 
+    def attach(self, module, force_single: bool = False) -> bool:
+        """Route the gradient exchange of ``module`` through the library's own RCCL communicator (``ldm_comm_*``) and overlap it
+        with backward: ``loss.backward()`` then all-reduces (mean, fp32) the flat gradient buffer bucket by bucket on a comm
+        stream while the backward plan is still running (``ldm_model_set_grad_sync``; DistributedDataParallel's bucketed hooks,
+        3d_ldm/train_diffusion.py:147-149), and ``mean_`` becomes a no-op for that module.  The 128-byte RCCL unique id is made
+        on rank 0 and broadcast over the existing torch.distributed group.  Only with the "nccl" backend on GPUs and fp32
+        gradients; ``force_single`` builds a world-size-1 communicator without torch.distributed (tests, single-GPU traces)."""
+        import ctypes as C
+        from . import _lib
+        single = force_single and not self.on
+        if not single and not (self.on and dist.get_backend() == "nccl" and self.grad_dtype == torch.float32):
+            return False
+        L = _lib.lib()
+        rank = 0 if single else dist.get_rank()
+        world = 1 if single else self.world
+        uid = C.create_string_buffer(128)
+        if rank == 0:
+            _lib.check(L.ldm_comm_unique_id(uid))
+        if not single:
+            t = torch.tensor(list(uid.raw), dtype=torch.uint8, device="cuda")
+            dist.broadcast(t, src=0)
+            uid = C.create_string_buffer(bytes(t.cpu().tolist()), 128)
+        comm = C.c_void_p()
+        _lib.check(L.ldm_comm_init(rank, world, uid, C.byref(comm)))
+        _lib.check(L.ldm_model_set_grad_sync(module._h, comm))
+        module._grad_comm = comm                         # keeps the handle alive as long as the module
+        self._attached = getattr(self, "_attached", set()) | {id(module)}
+        return True
+
+    def attached(self, module) -> bool:
+        return id(module) in getattr(self, "_attached", set())
+
     def broadcast(self, flat: torch.Tensor, src: int = 0) -> None:
         """Parameter broadcast at wrap time (what DistributedDataParallel.__init__ does)."""
         if self.on:
@@ -94,6 +126,8 @@ class DiffusionTrainer:
         self.optimizer = FlatAdam(unet, lr=lr, max_grad_norm=max_grad_norm)      # flattens the parameters
         self.sync.broadcast(unet.flat_params, 0)
         unet.mark_weights_dirty()
+        # RCCL through the library's C ABI, bucketed and overlapped with backward ("nccl" backend); else one all-reduce after it
+        self.overlap = self.sync.attach(unet)
         self.lr_scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optimizer, milestones=list(milestones), gamma=gamma)
         self.reference_rng_order = reference_rng_order
         self.factor = getattr(autoencoder, "factor", 4)
@@ -129,8 +163,9 @@ class DiffusionTrainer:
         bad = self.sync.any(torch.isnan(loss.detach()).to(torch.float32))
         if float(bad) > 0.0:                              # every rank skips together
             return loss.detach(), True
-        loss.backward()
-        self.sync.mean_(self.unet.flat_grads)
+        loss.backward()                                  # with self.overlap the buckets are reduced inside this call
+        if not self.overlap:
+            self.sync.mean_(self.unet.flat_grads)
         self.optimizer.step()
         return loss.detach(), False
 
@@ -178,8 +213,11 @@ class AutoencoderTrainer:
                  max_grad_norm: float = 0.5, weight_decay: float = 1e-5, warm_up_epochs: int = 5):
         from .optim import FlatAdam
         if perceptual_weight:
-            raise NotImplementedError("perceptual loss (pretrained SqueezeNet, train_autoencoder.py:236) is not available offline: "
-                                      "set autoencoder_train.perceptual_weight to 0")
+            # the reference's PerceptualLoss downloads a pretrained SqueezeNet (train_autoencoder.py:236): no weights, no network here.
+            # Every shipped config sets a (small: 1e-5 .. 1e-3) weight, so warn once and train without the term instead of refusing.
+            import warnings
+            warnings.warn(f"autoencoder_train.perceptual_weight = {perceptual_weight}: the perceptual term needs pretrained SqueezeNet "
+                          "weights that are not available offline; training continues WITHOUT it (reconstruction + KL + adversarial)")
         self.autoencoder = autoencoder
         self.sync = GradSync()
         world = self.sync.world
@@ -187,6 +225,7 @@ class AutoencoderTrainer:
         self.optimizer = FlatAdam(autoencoder, lr=lr, betas=(0.5, 0.9), eps=1e-8, weight_decay=weight_decay, max_grad_norm=max_grad_norm)
         self.sync.broadcast(autoencoder.flat_params, 0)
         autoencoder.mark_weights_dirty()
+        self.overlap = self.sync.attach(autoencoder)
         self.kl_weight, self.l2 = kl_weight, recon_loss == "l2"
         self.warm_up_epochs, self._warned = warm_up_epochs, False
 
@@ -212,7 +251,8 @@ class AutoencoderTrainer:
         if float(bad) > 0.0:
             return {}, True
         loss_g.backward()
-        self.sync.mean_(self.autoencoder.flat_grads)
+        if not self.overlap:
+            self.sync.mean_(self.autoencoder.flat_grads)
         self.optimizer.step()
         return {"recons": recons.detach(), "kl": kl.detach(), "loss_g": loss_g.detach()}, False
 

@@ -263,6 +263,15 @@ int ldm_comm_allreduce(ldm_comm* c, void* buf, int64_t count, int dtype, int op,
 int ldm_comm_broadcast(ldm_comm* c, void* buf, int64_t count, int dtype, int root, void* stream);
 int ldm_comm_barrier(ldm_comm* c, void* stream);
 void ldm_comm_destroy(ldm_comm* c);
+int ldm_comm_rank(const ldm_comm* c);
+int ldm_comm_world(const ldm_comm* c);
+/* Bucketed gradient all-reduce overlapped with backward (replaces DistributedDataParallel's bucket hooks,
+ * 3d_ldm/train_diffusion.py:147-149): while a communicator is attached, ldm_unet_train_backward / ldm_vae_train_backward average the
+ * flat gradient buffer over the ranks, bucket by bucket (LDM_GRAD_BUCKET_MB, default 48), each collective queued on the
+ * communicator's stream as soon as backward has finished that tail range of the buffer; `stream` waits for the last one.
+ * ldm_model_grad_sync_trace returns the bucket timeline of the last backward call (n buckets; entry n = end of the call). */
+int ldm_model_set_grad_sync(ldm_model* m, ldm_comm* comm);
+int ldm_model_grad_sync_trace(ldm_model* m, double* issue_ms, double* done_ms, int64_t* elems, int max);
 
 #ifdef __cplusplus
 }
