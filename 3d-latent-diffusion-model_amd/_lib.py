@@ -82,6 +82,13 @@ SIGNATURES = {
                                 C.c_float, C.c_int, _P]),
     "ldm_add_noise": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int64, _P]),
     "ldm_scale": (C.c_int, [_P, _P, C.c_int64, C.c_float, _P]),
+    "ldm_sampler_create": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_uint64, C.POINTER(_P)]),
+    "ldm_sampler_destroy": (None, [_P]),
+    "ldm_sampler_reset": (C.c_int, [_P, _P, C.c_int, _P]),
+    "ldm_sampler_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, _P, C.c_int, _P]),
+    "ldm_sampler_noise": (C.c_int, [_P, C.c_int, _P, C.c_int64, _P]),
+    "ldm_unet_denoise_step": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        _P, C.c_size_t, _P]),
     "ldm_op_conv3d": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P, _P, C.c_int, _P, C.c_int, _P, _P, _P, C.c_int, _P, _P, _P,
                                 C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_int, C.c_int, _P, C.c_size_t, _P]),

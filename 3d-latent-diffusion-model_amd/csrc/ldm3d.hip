@@ -198,7 +198,7 @@ struct ldm_model {
     // HIP-graph replay of the forward plan (ldm_model_set_graph_mode): one hipGraphLaunch instead of ~150 kernel launches
     // per step on the host.  A graph is instantiated per (plan, pointer set) the second time that set is seen.
     int graph_mode = 0;
-    struct GraphEntry { const Plan* plan; const void* ptr[6]; int rt[2]; int seen; hipGraphExec_t exec; };
+    struct GraphEntry { const Plan* plan; const void* ptr[8]; int rt[2]; int seen; hipGraphExec_t exec; };
     std::vector<GraphEntry> graphs;
     hipStream_t side_stream = nullptr; std::vector<hipEvent_t> lane_events;     // side lane of the inference plans (run_plan)
     hipStream_t cap_stream = nullptr;        // capture happens on a private stream (the caller's may be the null stream, which cannot capture)
@@ -2158,9 +2158,20 @@ size_t ldm_unet_workspace_bytes(ldm_model* m, int B, int D, int H, int W) {
     return p->ws_bytes;
 }
 
-int ldm_unet_forward(ldm_model* m, const float* x, int x_channels, const float* cond, int cond_channels,
-                     const float* timesteps, float* out, int B, int D, int H, int W,
-                     void* workspace, size_t workspace_bytes, void* stream) {
+// ---- device-resident sampler (fused scheduler step with in-kernel Philox noise) ----------------------------------------------
+struct ldm_sampler {
+    float* coef = nullptr; SamplerState* st = nullptr; int n_steps = 0, kind = 0, clip = 1; unsigned seed_lo = 0, seed_hi = 0;
+};
+static int sampler_launch(ldm_sampler* sp, const float* eps, float* x, float* x0_out, int64_t n, float* tbuf, int B, hipStream_t s) {
+    SamplerParams p{}; p.coef = sp->coef; p.st = sp->st; p.n_steps = sp->n_steps; p.kind = sp->kind; p.clip = sp->clip;
+    p.seed_lo = sp->seed_lo; p.seed_hi = sp->seed_hi; p.eps = eps; p.x = x; p.x0_out = x0_out; p.n = (long)n; p.tbuf = tbuf; p.B = B;
+    hipLaunchKernelGGL(sampler_step_kernel, dim3(grid_for((n + 3) / 4, 256, 1024)), dim3(256), 0, s, p);
+    return 0;
+}
+
+static int unet_forward_impl(ldm_model* m, const float* x, int x_channels, const float* cond, int cond_channels,
+                             const float* timesteps, float* out, int B, int D, int H, int W,
+                             void* workspace, size_t workspace_bytes, void* stream, ldm_sampler* sp, float* x_inout) {
     if (!m || m->type != 0) return fail(LDM_ERR_BAD_ARG, "not a UNet handle");
     if (!x || !timesteps || !out) return fail(LDM_ERR_BAD_ARG, "null tensor argument");
     if (!cond) cond_channels = 0;
@@ -2172,9 +2183,16 @@ int ldm_unet_forward(ldm_model* m, const float* x, int x_channels, const float* 
     LDM_TRY(ensure_derived(m, (hipStream_t)stream));
     if (!m->side_stream) HIP_TRY(hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking));
     LaneCtx lanes; lanes.side = m->side_stream; lanes.events = &m->lane_events;
-    if (!m->graph_mode || g_prof.on) return run_plan(*p, bs, rt, (hipStream_t)stream, 0, (size_t)-1, lanes);
+    const int64_t n_out = (int64_t)B * m->ucfg.out_channels * D * H * W;
+    // one denoising step = the forward plan, then (with a sampler) the fused scheduler step on the same stream
+    auto run_all = [&](hipStream_t s) -> int {
+        LDM_TRY(run_plan(*p, bs, rt, s, 0, (size_t)-1, lanes));
+        if (sp) LDM_TRY(sampler_launch(sp, out, x_inout, nullptr, n_out, (float*)timesteps, B, s));
+        return 0;
+    };
+    if (!m->graph_mode || g_prof.on) return run_all((hipStream_t)stream);
     // ---- graph replay: same launches, recorded once per pointer set
-    const void* key[6] = {x, cond, timesteps, out, workspace, stream};
+    const void* key[8] = {x, cond, timesteps, out, workspace, stream, sp, x_inout};
     ldm_model::GraphEntry* ge = nullptr;
     for (auto& g : m->graphs)
         if (g.plan == p.get() && !memcmp(g.ptr, key, sizeof key) && g.rt[0] == rt[0] && g.rt[1] == rt[1]) { ge = &g; break; }
@@ -2187,11 +2205,11 @@ int ldm_unet_forward(ldm_model* m, const float* x, int x_channels, const float* 
         m->graphs.push_back(g); ge = &m->graphs.back();
     }
     if (ge->exec) { HIP_TRY(hipGraphLaunch(ge->exec, (hipStream_t)stream)); return 0; }
-    if (ge->seen++ == 0) return run_plan(*p, bs, rt, (hipStream_t)stream, 0, (size_t)-1, lanes);   // first sight: eager (also warms one-time set-up)
+    if (ge->seen++ == 0) return run_all((hipStream_t)stream);   // first sight: eager (also warms one-time set-up)
     hipGraph_t graph = nullptr;
     if (!m->cap_stream) HIP_TRY(hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeThreadLocal));
-    const int rc = run_plan(*p, bs, rt, m->cap_stream, 0, (size_t)-1, lanes);
+    const int rc = run_all(m->cap_stream);
     const hipError_t ec = hipStreamEndCapture(m->cap_stream, &graph);
     if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
     if (ec != hipSuccess || !graph) return fail(LDM_ERR_HIP, "stream capture failed: %s", hipGetErrorString(ec));
@@ -2199,6 +2217,70 @@ int ldm_unet_forward(ldm_model* m, const float* x, int x_channels, const float* 
     (void)hipGraphDestroy(graph);
     HIP_TRY(hipGraphLaunch(ge->exec, (hipStream_t)stream));
     return 0;
+}
+
+int ldm_unet_forward(ldm_model* m, const float* x, int x_channels, const float* cond, int cond_channels,
+                     const float* timesteps, float* out, int B, int D, int H, int W,
+                     void* workspace, size_t workspace_bytes, void* stream) {
+    return unet_forward_impl(m, x, x_channels, cond, cond_channels, timesteps, out, B, D, H, W, workspace, workspace_bytes, stream, nullptr, nullptr);
+}
+
+/* Sampler: coef_host = [n_steps][6] fp32 rows {1/sqrt(abar_t), sqrt(1 - abar_t), c0, c1 (DDPM: coefficient of x_t | DDIM: direction
+ * coefficient of eps), sigma, t} in sampling order (the host mirror computes them exactly as MONAI does and as DDPMScheduler.step /
+ * DDIMScheduler.step pass them by value); kind 0 = DDPM, 1 = DDIM.  Noise: Philox4x32-10(counter = (element quad, step), key = seed). */
+int ldm_sampler_create(const float* coef_host, int n_steps, int kind, int clip, uint64_t seed, ldm_sampler** out) {
+    if (!coef_host || n_steps < 1 || kind < 0 || kind > 1 || !out) return fail(LDM_ERR_BAD_ARG, "bad argument");
+    std::unique_ptr<ldm_sampler> sp(new ldm_sampler());
+    std::vector<float> rows((size_t)n_steps * 8, 0.f);
+    for (int k = 0; k < n_steps; ++k) for (int j = 0; j < 6; ++j) rows[(size_t)k * 8 + j] = coef_host[(size_t)k * 6 + j];
+    HIP_TRY(hipMalloc((void**)&sp->coef, rows.size() * 4));
+    HIP_TRY(hipMemcpy(sp->coef, rows.data(), rows.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void**)&sp->st, 256));
+    HIP_TRY(hipMemset(sp->st, 0, 256));
+    HIP_TRY(hipDeviceSynchronize());
+    sp->n_steps = n_steps; sp->kind = kind; sp->clip = clip ? 1 : 0; sp->seed_lo = (unsigned)seed; sp->seed_hi = (unsigned)(seed >> 32);
+    *out = sp.release();
+    return 0;
+}
+void ldm_sampler_destroy(ldm_sampler* sp) {
+    if (!sp) return;
+    if (sp->coef) (void)hipFree(sp->coef);
+    if (sp->st) (void)hipFree(sp->st);
+    delete sp;
+}
+/* step counter := 0, tbuf[0..B) := t of the first step */
+int ldm_sampler_reset(ldm_sampler* sp, float* tbuf, int B, void* stream) {
+    if (!sp || !tbuf || B < 1) return fail(LDM_ERR_BAD_ARG, "bad argument");
+    hipLaunchKernelGGL(sampler_reset_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sp->st, (const float*)sp->coef, tbuf, B);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+/* x := scheduler step (x, eps) for the step the device counter points at (in place), x0_out (optional) := x0_hat; then the counter
+ * advances and tbuf[0..B) receives the next step's t.  Calls beyond n_steps leave x unchanged. */
+int ldm_sampler_step(ldm_sampler* sp, const float* eps, float* x, float* x0_out, int64_t n, float* tbuf, int B, void* stream) {
+    if (!sp || !eps || !x || !tbuf || n < 0 || B < 1) return fail(LDM_ERR_BAD_ARG, "bad argument");
+    SamplerParams p{}; p.coef = sp->coef; p.st = sp->st; p.n_steps = sp->n_steps; p.kind = sp->kind; p.clip = sp->clip;
+    p.seed_lo = sp->seed_lo; p.seed_hi = sp->seed_hi; p.eps = eps; p.x = x; p.x0_out = x0_out; p.n = (long)n; p.tbuf = tbuf; p.B = B;
+    hipLaunchKernelGGL(sampler_step_kernel, dim3(grid_for((n + 3) / 4, 256, 1024)), dim3(256), 0, (hipStream_t)stream, p);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+/* the N(0, 1) draws step `step` uses for a tensor of n elements (tests: statistics, reproducibility, fused == unfused) */
+int ldm_sampler_noise(const ldm_sampler* sp, int step, float* out, int64_t n, void* stream) {
+    if (!sp || !out || n < 0 || step < 0) return fail(LDM_ERR_BAD_ARG, "bad argument");
+    hipLaunchKernelGGL(sampler_noise_kernel, dim3(grid_for((n + 3) / 4, 256, 1024)), dim3(256), 0, (hipStream_t)stream, out, (long)n, step, sp->seed_lo, sp->seed_hi);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+/* One whole denoising step: eps_hat = UNet(x, tbuf) into eps_scratch, then ldm_sampler_step(x in place).  With
+ * ldm_model_set_graph_mode the forward plan AND the scheduler step replay as ONE hipGraphLaunch: no host-side per-step work at all
+ * (3d_ldm/inference.py:94-99's loop body). */
+int ldm_unet_denoise_step(ldm_model* m, ldm_sampler* sp, float* x, int x_channels, const float* cond, int cond_channels,
+                          float* tbuf, float* eps_scratch, int B, int D, int H, int W,
+                          void* workspace, size_t workspace_bytes, void* stream) {
+    if (!sp) return fail(LDM_ERR_BAD_ARG, "null sampler");
+    if (m && m->type == 0 && x_channels != m->ucfg.out_channels) return fail(LDM_ERR_BAD_ARG, "x must have the UNet's out_channels (%d)", m->ucfg.out_channels);
+    return unet_forward_impl(m, x, x_channels, cond, cond_channels, tbuf, eps_scratch, B, D, H, W, workspace, workspace_bytes, stream, sp, x);
 }
 
 /* on != 0: ldm_unet_forward replays a HIP graph of its launch plan whenever it sees the same (x, cond, timesteps, out,

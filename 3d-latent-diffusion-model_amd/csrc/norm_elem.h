@@ -495,6 +495,90 @@ __global__ __launch_bounds__(256) void vae_heads_kernel(const float* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Device-resident sampler (ldm_sampler_*): the scheduler step with its noise drawn INSIDE the kernel (Philox4x32-10, counter =
+// (element quad, step index), key = seed) and its per-step coefficients read from a device table indexed by a device step counter,
+// so that one denoising step (UNet forward + this kernel) is a fixed sequence of launches with fixed arguments: one HIP graph.
+// Replaces torch.randn + fill_ + the host-side coefficient lookup of DDPMScheduler.step / DDIMScheduler.step
+// (3d_ldm/inference.py:94-99 loop body).  coef row: {1/sqrt(abar_t), sqrt(1-abar_t), c0, c1 (DDPM) | dir (DDIM), sigma, t, 0, 0}.
+struct SamplerState { int k; unsigned done; };
+struct SamplerParams {
+    const float* coef; SamplerState* st; int n_steps; int kind;      // kind 0 = DDPM, 1 = DDIM
+    int clip; unsigned seed_lo, seed_hi;
+    const float* eps; float* x; float* x0_out; long n;               // x is updated in place
+    float* tbuf; int B;                                              // the UNet's timestep input: receives t of the NEXT step
+};
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+// four independent N(0, 1) draws for element quad `quad` of step `step` (Box-Muller on two pairs of uniforms in (0, 1])
+__device__ __forceinline__ float4 sampler_normal4(unsigned long long quad, unsigned step, unsigned seed_lo, unsigned seed_hi) {
+    unsigned r[4];
+    philox4x32_10((unsigned)quad, (unsigned)(quad >> 32), step, 0x5eedu, seed_lo, seed_hi, r);
+    const float u0 = ((float)(r[0] >> 8) + 1.0f) * (1.0f / 16777216.0f), u1 = (float)(r[1] >> 8) * (1.0f / 16777216.0f);
+    const float u2 = ((float)(r[2] >> 8) + 1.0f) * (1.0f / 16777216.0f), u3 = (float)(r[3] >> 8) * (1.0f / 16777216.0f);
+    const float ra = sqrtf(-2.0f * logf(u0)), rb = sqrtf(-2.0f * logf(u2));
+    float sa, ca, sb, cb;
+    sincosf(6.283185307179586f * u1, &sa, &ca); sincosf(6.283185307179586f * u3, &sb, &cb);
+    return make_float4(ra * ca, ra * sa, rb * cb, rb * sb);
+}
+__global__ __launch_bounds__(256) void sampler_noise_kernel(float* __restrict__ out, long n, int step, unsigned seed_lo, unsigned seed_hi) {
+    const long nq = (n + 3) / 4;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (long)gridDim.x * blockDim.x) {
+        const float4 z = sampler_normal4((unsigned long long)q, (unsigned)step, seed_lo, seed_hi);
+        const float zz[4] = {z.x, z.y, z.z, z.w};
+        for (int e = 0; e < 4; ++e) if (4 * q + e < n) out[4 * q + e] = zz[e];
+    }
+}
+__global__ __launch_bounds__(256) void sampler_step_kernel(const SamplerParams p) {
+    __shared__ int s_last;
+    const int k = p.st->k;                                  // every block reads the counter before it can bump `done`
+    const bool live = k < p.n_steps;
+    const float* c = p.coef + (size_t)(live ? k : p.n_steps - 1) * 8;
+    const float inv_sqrt_a = c[0], sqrt_b = c[1], c0 = c[2], c1 = c[3], sigma = c[4];
+    const long nq = (p.n + 3) / 4;
+    if (live)
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (long)gridDim.x * blockDim.x) {
+        float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (sigma != 0.f) z = sampler_normal4((unsigned long long)q, (unsigned)k, p.seed_lo, p.seed_hi);
+        const float zz[4] = {z.x, z.y, z.z, z.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const long i = 4 * q + e;
+            if (i >= p.n) break;
+            const float xe = p.x[i], ee = p.eps[i];
+            float x0 = (xe - sqrt_b * ee) * inv_sqrt_a;
+            if (p.clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+            float pv = (p.kind == 0) ? c0 * x0 + c1 * xe : c0 * x0 + c1 * ee;       // DDIM: c1 = sqrt(1 - abar_prev - sigma^2)
+            if (sigma != 0.f) pv += sigma * zz[e];
+            p.x[i] = pv;
+            if (p.x0_out) p.x0_out[i] = x0;
+        }
+    }
+    // the block that finishes last advances the step counter and publishes the next timestep (all blocks have read k by then)
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = (atomicAdd(&p.st->done, 1u) == gridDim.x - 1) ? 1 : 0;
+    __syncthreads();
+    if (s_last && threadIdx.x == 0) {
+        p.st->done = 0;
+        const int kn = live ? k + 1 : k;
+        p.st->k = kn;
+        const float tn = p.coef[(size_t)(kn < p.n_steps ? kn : p.n_steps - 1) * 8 + 5];
+        for (int b = 0; b < p.B; ++b) p.tbuf[b] = tn;
+    }
+}
+__global__ void sampler_reset_kernel(SamplerState* st, const float* coef, float* tbuf, int B) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { st->k = 0; st->done = 0; for (int b = 0; b < B; ++b) tbuf[b] = coef[5]; }
+}
+
 __global__ __launch_bounds__(256) void scale_kernel(const float* __restrict__ x, float* __restrict__ y, long n, float s) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = x[i] * s;
 }

@@ -40,9 +40,10 @@ class LatentDiffusionInferer:
     def sample(self, input_noise: torch.Tensor, autoencoder_model, diffusion_model, scheduler=None,
                save_intermediates: bool = False, intermediate_steps: int = 100,
                conditioning: Optional[torch.Tensor] = None, mode: str = "crossattn", verbose: bool = False,
-               seg: Optional[torch.Tensor] = None, step_noise: Optional[Callable[[int], torch.Tensor]] = None
-               ) -> Union[torch.Tensor, tuple]:
-        """Reverse diffusion over scheduler.timesteps then VAE decode of latent / scale_factor."""
+               seg: Optional[torch.Tensor] = None, step_noise: Optional[Callable[[int], torch.Tensor]] = None,
+               fused_seed: Optional[int] = None) -> Union[torch.Tensor, tuple]:
+        """Reverse diffusion over scheduler.timesteps then VAE decode of latent / scale_factor.  ``fused_seed`` (extension) runs
+        the loop on the device-resident sampler: noise from Philox(seed) inside the step kernel, one HIP graph per step."""
         if mode not in ("crossattn", "concat"):
             raise NotImplementedError(f"{mode} condition is not supported")
         if conditioning is not None and mode != "concat":
@@ -60,6 +61,16 @@ class LatentDiffusionInferer:
         intermediates: List[torch.Tensor] = []
         B = image.shape[0]
         tbuf = torch.empty((B,), dtype=torch.float32, device=image.device)
+        if fused_seed is not None and step_noise is None and hasattr(diffusion_model, "denoise_step"):
+            sampler = scheduler.device_sampler(fused_seed)
+            image = image.detach().to(torch.float32).contiguous().clone()
+            cond = None if conditioning is None else conditioning.detach().to(torch.float32).contiguous()
+            sampler.reset(tbuf)
+            for t in it:
+                diffusion_model.denoise_step(image, tbuf, sampler, cond=cond)
+                if save_intermediates and t % intermediate_steps == 0:
+                    intermediates.append(image.clone())
+            it = []
         for t in it:
             tbuf.fill_(float(t))
             if conditioning is not None:

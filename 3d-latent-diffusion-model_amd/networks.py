@@ -410,6 +410,35 @@ class DiffusionModelUNet(_LdmModule):
                                                         _lib.current_stream()))
         return out, self._tap_dict(layout, taps_out)
 
+    def denoise_step(self, x: torch.Tensor, tbuf: torch.Tensor, sampler, cond: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """One whole denoising step IN PLACE: ``x := sampler.step(UNet(x, tbuf), x)`` with the device-resident sampler
+        (``scheduler.device_sampler(seed)``; ``sampler.reset(tbuf)`` first).  ``x`` must be a persistent contiguous fp32 CUDA
+        tensor and ``tbuf`` a persistent fp32 [B] tensor: with ``enable_graph_replay`` the forward plan and the scheduler step
+        replay as ONE HIP graph launch per call, nothing else runs on the host or the device between steps."""
+        self._need_cuda(x, "DiffusionModelUNet.denoise_step")
+        if not (x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 5 and tbuf.dtype == torch.float32 and tbuf.is_cuda):
+            raise _lib.LdmError("denoise_step: x must be a contiguous fp32 [B, C, D, H, W] CUDA tensor and tbuf fp32 [B] on the same device")
+        B, cx, D, H, W = x.shape
+        cc = 0
+        if cond is not None:
+            if not (cond.is_cuda and cond.dtype == torch.float32 and cond.is_contiguous()):
+                raise _lib.LdmError("denoise_step: cond must be a contiguous fp32 CUDA tensor")
+            cc = cond.shape[1]
+        self._sync_weights()
+        L = _lib.lib()
+        nbytes = L.ldm_unet_workspace_bytes(self._h, B, D, H, W)
+        if nbytes == 0:
+            raise _lib.LdmError((L.ldm_last_error() or b"workspace query failed").decode())
+        ws = self._workspace(("unet", B, D, H, W), nbytes, x.device)
+        key = ("eps", B, D, H, W, str(x.device))
+        eps = self._ws.get(key)
+        if eps is None:
+            eps = self._ws[key] = torch.empty((B, self.out_channels, D, H, W), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(L.ldm_unet_denoise_step(self._h, sampler._h, x.data_ptr(), cx, _lib.ptr(cond), cc, tbuf.data_ptr(), eps.data_ptr(),
+                                               B, D, H, W, ws.data_ptr(), ws.numel(), _lib.current_stream()))
+        return x
+
     def enable_graph_replay(self, on: bool = True):
         """Inference: replay the forward plan as ONE HIP graph launch per call instead of ~150 kernel launches (same
         kernels and results; the host cost per step drops from ~1.6 ms to ~0.1 ms, which matters when many ranks share a

@@ -75,6 +75,10 @@ class _Scheduler:
                                                 out.data_ptr(), B, x0c.numel() // B, _lib.current_stream()))
         return out
 
+    def device_sampler(self, seed: int = 0, eta: float = 0.0) -> "DeviceSampler":
+        """The fused, device-resident form of ``step`` over ``self.timesteps`` (see DeviceSampler)."""
+        return DeviceSampler(self, seed, eta)
+
     @staticmethod
     def _draw(model_output: torch.Tensor, generator: Optional[torch.Generator]) -> torch.Tensor:
         # MONAI draws with the generator's device and moves to the sample; a None / CUDA generator draws in place.
@@ -170,3 +174,72 @@ class DDIMScheduler(_Scheduler):
                                                 x.numel(), float(1.0 / a_t ** 0.5), float(b_t ** 0.5), float(a_prev ** 0.5),
                                                 float(direction), float(std), int(self.clip_sample), _lib.current_stream()))
         return prev, x0
+
+
+class DeviceSampler:
+    """The scheduler step as ONE kernel with everything it needs on the device (``ldm_sampler_*``): the per-step coefficients
+    (computed here exactly as ``DDPMScheduler.step`` / ``DDIMScheduler.step`` pass them by value) live in a device table, the
+    current step index and the UNet's timestep input are device state advanced by the kernel itself, and the noise z is drawn
+    inside the kernel (Philox4x32-10, counter = (element, step), key = seed) instead of ``torch.randn``.  One denoising step
+    (``DiffusionModelUNet.denoise_step``) is then a fixed launch sequence with fixed arguments and replays as ONE HIP graph:
+    no ``fill_`` / ``normal_`` launches and no host work per step (3d_ldm/inference.py:94-99's loop body).
+
+    Not MONAI's RNG stream: a chain sampled this way is a different (equally distributed) draw than the same seed through
+    ``torch.randn``; ``noise(step, shape)`` returns the exact z of a step for reproducibility checks."""
+
+    def __init__(self, scheduler: _Scheduler, seed: int = 0, eta: float = 0.0):
+        import ctypes as C
+        self.scheduler = scheduler
+        self.timesteps = [int(t) for t in scheduler.timesteps.tolist()]
+        rows = []
+        if isinstance(scheduler, DDIMScheduler):
+            kind = 1
+            ratio = scheduler.num_train_timesteps // scheduler.num_inference_steps
+            for t in self.timesteps:
+                prev_t = t - ratio
+                a_t = scheduler.alphas_cumprod[t]
+                a_prev = scheduler.alphas_cumprod[prev_t] if prev_t >= 0 else scheduler.final_alpha_cumprod
+                var = (1 - a_prev) / (1 - a_t) * (1 - a_t / a_prev)
+                std = eta * var ** 0.5
+                rows.append([float(1.0 / a_t ** 0.5), float((1 - a_t) ** 0.5), float(a_prev ** 0.5),
+                             float((1 - a_prev - std ** 2) ** 0.5), float(std), float(t)])
+        elif isinstance(scheduler, DDPMScheduler):
+            kind = 0
+            for t in self.timesteps:
+                rows.append([scheduler._inv_sqrt_a[t], scheduler._sqrt_b[t], scheduler._c0[t], scheduler._c1[t],
+                             scheduler._sigma[t] if t > 0 else 0.0, float(t)])
+        else:
+            raise TypeError("DeviceSampler needs a DDPMScheduler or a DDIMScheduler")
+        coef = torch.tensor(rows, dtype=torch.float32).contiguous()
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().ldm_sampler_create(coef.data_ptr(), len(rows), kind, int(scheduler.clip_sample), int(seed) & (2 ** 64 - 1),
+                                                 C.byref(self._h)))
+        self.n_steps, self.seed = len(rows), int(seed)
+
+    def reset(self, tbuf: torch.Tensor) -> None:
+        """Step counter := 0 and ``tbuf`` (the UNet's fp32 timestep input, one entry per sample) := the first timestep."""
+        with torch.cuda.device(tbuf.device):
+            _lib.check(_lib.lib().ldm_sampler_reset(self._h, tbuf.data_ptr(), tbuf.numel(), _lib.current_stream()))
+
+    def step(self, eps: torch.Tensor, x: torch.Tensor, tbuf: torch.Tensor, x0_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x := step(x, eps) IN PLACE for the step the device counter points at; advances the counter and ``tbuf``."""
+        if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and eps.is_contiguous() and eps.dtype == torch.float32):
+            raise _lib.LdmError("DeviceSampler.step: contiguous fp32 CUDA tensors only")
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().ldm_sampler_step(self._h, eps.data_ptr(), x.data_ptr(), _lib.ptr(x0_out), x.numel(), tbuf.data_ptr(),
+                                                   tbuf.numel(), _lib.current_stream()))
+        return x
+
+    def noise(self, step: int, shape, device) -> torch.Tensor:
+        out = torch.empty(tuple(shape), dtype=torch.float32, device=device)
+        with torch.cuda.device(out.device):
+            _lib.check(_lib.lib().ldm_sampler_noise(self._h, int(step), out.data_ptr(), out.numel(), _lib.current_stream()))
+        return out
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                _lib.lib().ldm_sampler_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass

@@ -133,6 +133,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from the host instead of replaying the HIP graph")
+    ap.add_argument("--host-step", action="store_true", help="scheduler step driven from the host (torch.randn + coefficient lookup) instead of the fused device sampler")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the fp32 precision mode figure reported beside the bf16 one")
     args = ap.parse_args()
 
@@ -191,11 +192,20 @@ def main():
     tbuf = torch.empty((1,), dtype=torch.float32, device=dev)
     T = sch.num_train_timesteps
 
+    # the loop body of 3d_ldm/inference.py:94-99 on the device-resident sampler: UNet forward + DDPM step with the noise drawn inside
+    # the step kernel (Philox keyed by a seed) and the timestep advanced on the device: one HIP graph launch per step, no torch
+    # kernels (fill_ / normal_) and no host-side coefficient lookups in the timed region.  --host-step: DDPMScheduler.step from the host.
+    sampler = sch.device_sampler(seed=1234 + rank)
+
     def step(i, x):
-        t = (T - 1 - i) % T
-        tbuf.fill_(float(t))
-        eps = unet(x=x, timesteps=tbuf)
-        return sch.step(eps, t, x, generator=gen)[0]
+        if args.host_step:
+            t = (T - 1 - i) % T
+            tbuf.fill_(float(t))
+            eps = unet(x=x, timesteps=tbuf)
+            return sch.step(eps, t, x, generator=gen)[0]
+        if i % T == 0:
+            sampler.reset(tbuf)                  # a new 1000-step chain starts (never inside the default timed region)
+        return unet.denoise_step(x, tbuf, sampler)
 
     def fence():
         if dist is not None:
@@ -274,8 +284,9 @@ def main():
                    "per_gpu_batch": 1, "parallelism": f"replicas x{world} (independent chains, no collective)",
                    "weights": "random init, seeded",
                    "launch": ("eager (one C-ABI call per forward, ~150 kernel launches)" if args.eager else
-                              "HIP graph replay of the forward plan (one C-ABI call = one hipGraphLaunch of ~150 kernels; "
-                              "scheduler step eager)")},
+                              "one HIP graph launch per denoising step: forward plan (~150 kernels) + fused DDPM step with in-kernel "
+                              "Philox noise and device-resident timestep (ldm_unet_denoise_step)" if not args.host_step else
+                              "HIP graph replay of the forward plan; scheduler step driven from the host (torch.randn)")},
         "steps_per_s_per_gpu": args.steps / dt,
         "unet_step_tflops": UNET_STEP_GFLOP / ms_per_step,
         # SURVEY.md section 8d asks for the three fractions side by side (per GPU): whole step vs the dense bf16 MFMA peak,

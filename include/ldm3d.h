@@ -192,6 +192,20 @@ int ldm_add_noise(const float* x0, const float* eps, const float* sqrt_a, const 
                   int B, int64_t per_sample, void* stream);
 int ldm_scale(const float* x, float* y, int64_t n, float s, void* stream);
 
+/* ---- device-resident sampler: the scheduler step with its noise drawn inside the kernel (Philox4x32-10 keyed by a seed) and its
+ *      coefficients / current timestep read from device memory, so that the loop body of 3d_ldm/inference.py:94-99 (UNet forward +
+ *      scheduler.step) is one fixed launch sequence: ldm_unet_denoise_step replays it as ONE HIP graph in graph mode.
+ *      coef_host: [n_steps][6] = {1/sqrt(abar_t), sqrt(1 - abar_t), c0, c1 | dir, sigma, t} per step in sampling order. ---------- */
+typedef struct ldm_sampler ldm_sampler;
+int ldm_sampler_create(const float* coef_host, int n_steps, int kind /* 0 DDPM, 1 DDIM */, int clip, uint64_t seed, ldm_sampler** out);
+void ldm_sampler_destroy(ldm_sampler* sp);
+int ldm_sampler_reset(ldm_sampler* sp, float* tbuf, int B, void* stream);
+int ldm_sampler_step(ldm_sampler* sp, const float* eps, float* x, float* x0_out, int64_t n, float* tbuf, int B, void* stream);
+int ldm_sampler_noise(const ldm_sampler* sp, int step, float* out, int64_t n, void* stream);
+int ldm_unet_denoise_step(ldm_model* m, ldm_sampler* sp, float* x, int x_channels, const float* cond, int cond_channels,
+                          float* tbuf, float* eps_scratch, int B, int D, int H, int W,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- operator level: the kernels the plans are made of, on the library's internal layout (NDHWC bf16 device
  *      tensors, C % 32 == 0).  They replace torch.nn.functional.conv3d / group_norm+silu / softmax-attention as
  *      MONAI's blocks call them and exist for per-kernel parity tests and micro-benchmarks.
