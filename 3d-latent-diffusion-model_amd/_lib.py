@@ -98,6 +98,12 @@ SIGNATURES = {
     "ldm_op_group_norm_bwd_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "ldm_op_group_norm_bwd": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P, _P, C.c_int, C.c_float, C.c_int, _P, _P, _P, _P, _P, _P,
                                         C.c_int, C.c_int, _P, C.c_size_t, _P]),
+    "ldm_op_im2col": (C.c_int, [_P, _P] + [C.c_int] * 10 + [_P]),
+    "ldm_op_col2im": (C.c_int, [_P, _P] + [C.c_int] * 10 + [_P]),
+    "ldm_op_leaky_relu": (C.c_int, [_P, _P, C.c_int64, C.c_float, _P]),
+    "ldm_op_leaky_relu_bwd": (C.c_int, [_P, _P, _P, C.c_int64, C.c_float, _P]),
+    "ldm_op_pack_ncdhw": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int64, _P]),
+    "ldm_op_unpack_ndhwc": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int64, _P]),
     "ldm_op_conv3d_gn_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "ldm_op_conv3d_gn": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_int, C.c_float, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_size_t, _P]),

@@ -2716,8 +2716,10 @@ static int op_conv3d_impl(const void* xa, int ca, const void* xb, int cb, const 
     if (!x1a) { c1a = 0; c1b = 0; }
     if (!x1b) c1b = 0;
     const int cin0 = ca + cb, cin1 = c1a + c1b;
-    if (ca % 32 || cb % 32 || c1a % 32 || c1b % 32 || cout_pad % 64 || cout > cout_pad || cin0 > 4096 || cin1 > 4096)
-        return fail(LDM_ERR_BAD_ARG, "channel counts must be multiples of 32 (cout_pad of 64)");
+    // zero padding reads come from the 8 KiB zero page: at most 4096 channels per source row for a padded conv (1x1 GEMMs have none)
+    const int cmax = (ksize == 1 && stride == 1 && pad == 0 && ups == 0) ? 65536 : 4096;
+    if (ca % 32 || cb % 32 || c1a % 32 || c1b % 32 || cout_pad % 64 || cout > cout_pad || cin0 > cmax || cin1 > 4096)
+        return fail(LDM_ERR_BAD_ARG, "channel counts must be multiples of 32 (cout_pad of 64), at most %d per row", cmax);
     if (ksize != 1 && ksize != 3) return fail(LDM_ERR_UNSUPPORTED, "ksize must be 1 or 3");
     int exact = 0;
     if (ups == 2) { ups = 1; exact = 1; }            // ups = 2: zero-insertion upsample (transposed stride-2 conv)
@@ -2871,6 +2873,51 @@ int ldm_op_group_norm(const void* xa, int ca, const void* xb, int cb, const floa
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, N), dim3(64), 0, s, fp);
     GnApplyParams ap{}; ap.xa = sp.xa; ap.xb = sp.xb; ap.ca = ca; ap.cb = cb; ap.DHW = DHW; ap.N = N; ap.silu = silu; ap.ab = ab; ap.out = (bf16_t*)out;
     hipLaunchKernelGGL(gn_apply_kernel, dim3(grid_for((long)N * DHW * cvec, 256, 2048)), dim3(256), 0, s, ap);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+/* ---- PatchDiscriminator building blocks (stage-1 GAN tail): generic-kernel-size convs as im2col + the 1x1 GEMM kernels ---- */
+int ldm_op_im2col(const void* x, void* col, int N, int D, int H, int W, int Cs, int C, int k, int stride, int pad, int Kp, void* stream) {
+    if (!x || !col || N < 1 || C < 1 || C > Cs || k < 1 || stride < 1 || pad < 0 || Kp < k * k * k * C || Kp % 32) return fail(LDM_ERR_BAD_ARG, "bad argument");
+    const int Do = (D + 2 * pad - k) / stride + 1, Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+    if (Do < 1 || Ho < 1 || Wo < 1) return fail(LDM_ERR_BAD_ARG, "empty output");
+    hipLaunchKernelGGL(im2col_generic_kernel, dim3(grid_for((long)N * Do * Ho * Wo * Kp, 256, 16384)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, (bf16_t*)col, N, D, H, W, Cs, C, k, stride, pad, Do, Ho, Wo, Kp);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int ldm_op_col2im(const void* dcol, void* dx, int N, int D, int H, int W, int Cs, int C, int k, int stride, int pad, int Kp, void* stream) {
+    if (!dcol || !dx || N < 1 || C < 1 || C > Cs || k < 1 || stride < 1 || pad < 0 || Kp < k * k * k * C || Kp % 32) return fail(LDM_ERR_BAD_ARG, "bad argument");
+    const int Do = (D + 2 * pad - k) / stride + 1, Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+    if (Do < 1 || Ho < 1 || Wo < 1) return fail(LDM_ERR_BAD_ARG, "empty output");
+    hipLaunchKernelGGL(col2im_generic_kernel, dim3(grid_for((long)N * D * H * W * Cs, 256, 16384)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)dcol, (bf16_t*)dx, N, D, H, W, Cs, C, k, stride, pad, Do, Ho, Wo, Kp);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int ldm_op_leaky_relu(const void* x, void* y, int64_t n, float slope, void* stream) {
+    if (!x || !y || n < 0) return fail(LDM_ERR_BAD_ARG, "bad argument");
+    hipLaunchKernelGGL(leaky_relu_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, (long)n, slope);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int ldm_op_leaky_relu_bwd(const void* x, const void* dy, void* dx, int64_t n, float slope, void* stream) {
+    if (!x || !dy || !dx || n < 0) return fail(LDM_ERR_BAD_ARG, "bad argument");
+    hipLaunchKernelGGL(leaky_relu_bwd_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, (long)n, slope);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+/* fp32 NCDHW [N][C][DHW] <-> bf16 NDHWC [N][DHW][Cs] (channels zero-padded to Cs): the layout conversions the plans do internally */
+int ldm_op_pack_ncdhw(const float* x, void* out, int N, int C, int Cs, int64_t DHW, void* stream) {
+    if (!x || !out || N < 1 || C < 1 || C > Cs || DHW < 1 || DHW >= (1L << 31)) return fail(LDM_ERR_BAD_ARG, "bad argument");
+    hipLaunchKernelGGL(pack2_ncdhw_kernel, dim3(grid_for((long)N * DHW * Cs)), dim3(256), 0, (hipStream_t)stream, x, C, (const float*)nullptr, 0, (bf16_t*)out, N, Cs, (int)DHW);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int ldm_op_unpack_ndhwc(const void* act, float* out, int N, int C, int Cs, int64_t DHW, void* stream) {
+    if (!act || !out || N < 1 || C < 1 || C > Cs || DHW < 1 || DHW >= (1L << 31)) return fail(LDM_ERR_BAD_ARG, "bad argument");
+    hipLaunchKernelGGL(unpack_ndhwc_kernel, dim3(grid_for((long)N * C * DHW)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)act, out, N, C, Cs, (int)DHW);
     HIP_TRY(hipGetLastError());
     return 0;
 }

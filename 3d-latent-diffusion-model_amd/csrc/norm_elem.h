@@ -212,7 +212,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnApplyParams p) {
             const float4 ab = abp[k];
             float lo = __uint_as_float(v[k] << 16) * ab.x + ab.y;
             float hi = __uint_as_float(v[k] & 0xffff0000u) * ab.z + ab.w;
-            if (p.silu) { lo = silu_f(lo); hi = silu_f(hi); }
+            if (p.silu == 1) { lo = silu_f(lo); hi = silu_f(hi); }
+            else if (p.silu == 2) { lo = lo > 0.f ? lo : 0.2f * lo; hi = hi > 0.f ? hi : 0.2f * hi; }
             y[2 * k] = lo; y[2 * k + 1] = hi;
         }
         u32x4 o;
@@ -370,7 +371,8 @@ __global__ __launch_bounds__(256) void gn_fused_apply_kernel(const GnFusedParams
                 for (int j = 0; j < 4; ++j) {
                     float lo = __uint_as_float(v[k][j] << 16) * a[2 * j] + b[2 * j];
                     float hi = __uint_as_float(v[k][j] & 0xffff0000u) * a[2 * j + 1] + b[2 * j + 1];
-                    if (p.silu) { lo = silu_f(lo); hi = silu_f(hi); }
+                    if (p.silu == 1) { lo = silu_f(lo); hi = silu_f(hi); }
+                    else if (p.silu == 2) { lo = lo > 0.f ? lo : 0.2f * lo; hi = hi > 0.f ? hi : 0.2f * hi; }
                     o[j] = pack2bf(lo, hi);
                 }
                 store16<WT>(p.out + ((size_t)n * p.DHW + r) * C + c, o);
@@ -579,6 +581,76 @@ __global__ void sampler_reset_kernel(SamplerState* st, const float* coef, float*
     if (threadIdx.x == 0 && blockIdx.x == 0) { st->k = 0; st->done = 0; for (int b = 0; b < B; ++b) tbuf[b] = coef[5]; }
 }
 
+// ------------------------------------------------------------------------------------------------
+// PatchDiscriminator support (stage-1 GAN tail, 3d_ldm/train_autoencoder.py:150-158,407-424,454-494): its 4^3 convolutions run as
+// im2col + the 1x1 GEMM kernels.  col[m][tap * C + c] = x[voxel(m, tap)][c] (zero where the tap falls into the padding; columns
+// beyond taps * C up to Kp are zero), taps ordered (kd, kh, kw); x NDHWC bf16 with Cs stored channels of which C are used.
+__global__ __launch_bounds__(256) void im2col_generic_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ col, int N, int D, int H, int W,
+                                                             int Cs, int C, int k, int stride, int pad, int Do, int Ho, int Wo, int Kp) {
+    const long total = (long)N * Do * Ho * Wo * Kp;
+    const int taps = k * k * k;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int kk = (int)(i % Kp);
+        const long m = i / Kp;
+        bf16_t v = 0;
+        if (kk < taps * C) {
+            const int tap = kk / C, c = kk - tap * C;
+            const int kd = tap / (k * k), kh = (tap / k) % k, kw = tap % k;
+            const int ow = (int)(m % Wo); long r = m / Wo; const int oh = (int)(r % Ho); r /= Ho; const int od = (int)(r % Do); const int n = (int)(r / Do);
+            const int id = od * stride + kd - pad, ih = oh * stride + kh - pad, iw = ow * stride + kw - pad;
+            if ((unsigned)id < (unsigned)D && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
+                v = x[((((size_t)n * D + id) * H + ih) * W + iw) * Cs + c];
+        }
+        col[i] = v;
+    }
+}
+// adjoint: dx[voxel][c] = sum over the (output position, tap) pairs that read that voxel of dcol[m][tap * C + c] (gather form: no
+// atomics, fixed summation order); channels C..Cs of dx are written as zeros.
+__global__ __launch_bounds__(256) void col2im_generic_kernel(const bf16_t* __restrict__ dcol, bf16_t* __restrict__ dx, int N, int D, int H, int W,
+                                                             int Cs, int C, int k, int stride, int pad, int Do, int Ho, int Wo, int Kp) {
+    const long total = (long)N * D * H * W * Cs;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cs);
+        long r = i / Cs;
+        const int iw = (int)(r % W); r /= W; const int ih = (int)(r % H); r /= H; const int id = (int)(r % D); const int n = (int)(r / D);
+        float s = 0.f;
+        if (c < C)
+            for (int kd = 0; kd < k; ++kd) {
+                const int td = id + pad - kd; if (td < 0 || td % stride) continue; const int od = td / stride; if (od >= Do) continue;
+                for (int kh = 0; kh < k; ++kh) {
+                    const int th = ih + pad - kh; if (th < 0 || th % stride) continue; const int oh = th / stride; if (oh >= Ho) continue;
+                    for (int kw = 0; kw < k; ++kw) {
+                        const int tw = iw + pad - kw; if (tw < 0 || tw % stride) continue; const int ow = tw / stride; if (ow >= Wo) continue;
+                        const size_t m = (((size_t)n * Do + od) * Ho + oh) * Wo + ow;
+                        s += bf2f(dcol[m * Kp + ((kd * k + kh) * k + kw) * C + c]);
+                    }
+                }
+            }
+        dx[i] = f2bf(s);
+    }
+}
+__global__ __launch_bounds__(256) void leaky_relu_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, long n, float slope) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float v = bf2f(x[i]);
+        y[i] = f2bf(v > 0.f ? v : slope * v);
+    }
+}
+__global__ __launch_bounds__(256) void leaky_relu_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx,
+                                                             long n, float slope) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        dx[i] = f2bf(bf2f(x[i]) > 0.f ? bf2f(dy[i]) : slope * bf2f(dy[i]));
+}
+// bf16 NDHWC (Cs stored channels) -> fp32 NCDHW (first C channels): the op-level counterpart of pack2_ncdhw_kernel
+__global__ __launch_bounds__(256) void unpack_ndhwc_kernel(const bf16_t* __restrict__ act, float* __restrict__ out, int N, int C, int Cs, int DHW) {
+    const long total = (long)N * C * DHW;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int sp = (int)(i % DHW);
+        const long r = i / DHW;
+        const int c = (int)(r % C), n = (int)(r / C);
+        out[i] = bf2f(act[((size_t)n * DHW + sp) * Cs + c]);
+    }
+}
+
 __global__ __launch_bounds__(256) void scale_kernel(const float* __restrict__ x, float* __restrict__ y, long n, float s) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = x[i] * s;
 }
@@ -631,8 +703,11 @@ struct GnBwdParams {
     bf16_t* dxa; bf16_t* dxb;                      // outputs [N*DHW][ca], [N*DHW][cb]
 };
 
+// activation code of the GroupNorm kernels (fields named `silu`): 0 = none, 1 = SiLU, 2 = LeakyReLU(0.2) (PatchDiscriminator)
+__device__ __forceinline__ float gn_act(float u, int act) { return act == 1 ? silu_f(u) : (act == 2 ? (u > 0.f ? u : 0.2f * u) : u); }
 __device__ __forceinline__ float gn_bwd_g(float dy, float u, int silu) {
     if (!silu) return dy;
+    if (silu == 2) return u > 0.f ? dy : 0.2f * dy;
     const float sg = 1.0f / (1.0f + __expf(-u));
     return dy * sg * (1.0f + u * (1.0f - sg));
 }

@@ -73,3 +73,57 @@ class FlatAdam(torch.optim.Optimizer):
             _lib.check(L.ldm_adam_step(p.data_ptr(), g.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), p.numel(), *args))
         self.module.mark_weights_dirty()               # the bf16 arena is re-packed before the next forward
         return None
+
+
+class FlatModuleAdam:
+    """clip_grad_norm_ + AdamW for a plain ``nn.Module`` (the PatchDiscriminator of the stage-1 trainer,
+    3d_ldm/train_autoencoder.py:277-279,487-494) on the same two HIP launches as ``FlatAdam``: the module's parameters are re-homed
+    as views of one flat fp32 buffer, their ``.grad`` as views of a second one that autograd accumulates into."""
+
+    def __init__(self, module: torch.nn.Module, lr: float, betas=(0.5, 0.9), eps: float = 1e-8, weight_decay: float = 1e-5,
+                 max_grad_norm: float | None = 0.5):
+        params = [p for p in module.parameters() if p.requires_grad]
+        if not params or not params[0].is_cuda:
+            raise _lib.LdmError("FlatModuleAdam needs the module on the GPU (no CPU fallback)")
+        dev = params[0].device
+        total = sum(p.numel() for p in params)
+        self.flat_params = torch.empty(total, dtype=torch.float32, device=dev)
+        self.flat_grads = torch.zeros(total, dtype=torch.float32, device=dev)
+        off = 0
+        with torch.no_grad():
+            for p in params:
+                n = p.numel()
+                v = self.flat_params[off:off + n].view(p.shape)
+                v.copy_(p.detach().float())
+                p.data = v
+                p.grad = self.flat_grads[off:off + n].view(p.shape)
+                off += n
+        self.params = params
+        self.lr, self.betas, self.eps, self.weight_decay, self.max_grad_norm = lr, tuple(betas), eps, weight_decay, max_grad_norm
+        self.exp_avg, self.exp_avg_sq = torch.zeros_like(self.flat_params), torch.zeros_like(self.flat_params)
+        self.sq_norm = torch.zeros((1,), dtype=torch.float32, device=dev)
+        self.steps = 0
+        self.param_groups = [dict(lr=lr)]
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.flat_grads.zero_()
+        off = 0
+        for p in self.params:                              # a caller may have dropped the views (set_to_none elsewhere): restore them
+            n = p.numel()
+            if p.grad is None or p.grad.data_ptr() != self.flat_grads.data_ptr() + 4 * off:
+                p.grad = self.flat_grads[off:off + n].view(p.shape)
+            off += n
+
+    @torch.no_grad()
+    def step(self):
+        L = _lib.lib()
+        p, g = self.flat_params, self.flat_grads
+        clip = self.max_grad_norm is not None and self.max_grad_norm > 0
+        self.steps += 1
+        with torch.cuda.device(p.device):
+            if clip:
+                _lib.check(L.ldm_grad_sq_norm(g.data_ptr(), g.numel(), self.sq_norm.data_ptr(), _lib.current_stream()))
+            _lib.check(L.ldm_adam_step(p.data_ptr(), g.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), p.numel(),
+                                       float(self.param_groups[0]["lr"]), float(self.betas[0]), float(self.betas[1]), float(self.eps),
+                                       float(self.weight_decay), self.steps, self.sq_norm.data_ptr() if clip else None,
+                                       float(self.max_grad_norm or 0.0), _lib.current_stream()))

@@ -199,19 +199,22 @@ def kl_loss(z_mu: torch.Tensor, z_sigma: torch.Tensor) -> torch.Tensor:
 
 
 class AutoencoderTrainer:
-    """Generator step of the stage-1 trainer (3d_ldm/train_autoencoder.py:352-451) on the HIP forward/backward plans:
+    """The stage-1 (VAE-GAN) training step (3d_ldm/train_autoencoder.py:352-494) on the HIP forward / backward plans:
     clamp the images to [0, 1] (:362), ``reconstruction, z_mu, z_sigma = autoencoder(images)`` (:366), reconstruction L1 / L2
-    (:226-233,374), KL (:375,386) * kl_weight, NaN-skip agreed over ranks, ``loss_g.backward()``, ``clip_grad_norm_(0.5)`` and
-    AdamW(betas (0.5, 0.9), weight_decay 1e-5) (:274-279,440-451), lr scaled by sqrt(world) * 0.5 under DDP (:246-259).
+    (:226-233,374), KL (:375,386) * kl_weight, and after ``warm_up_epochs`` (:304,409) the LSGAN generator term
+    ``adv_weight * mse(D(reconstruction)[-1], 1)`` (:410-424); NaN-skip agreed over ranks, ``loss_g.backward()``,
+    ``clip_grad_norm_(0.5)`` and AdamW(betas (0.5, 0.9), weight_decay 1e-5) (:274-279,440-451), lr scaled by sqrt(world) * 0.5
+    under DDP (:246-259); then the discriminator step ``adv_weight * 0.5 * (mse(D(recon.detach())[-1], 0) + mse(D(images)[-1], 1))``
+    with its own clip 0.5 + AdamW (:454-494).  The PatchDiscriminator runs on the same HIP kernels (``ldm3d.discriminator``).
 
-    Not on this path (stated where it matters): the perceptual term needs a downloaded SqueezeNet
-    (no network here: its weight must be 0, otherwise construction fails loudly) and the PatchDiscriminator /
-    adversarial term that the reference switches on after 5 warm-up epochs is not implemented: training stays in the
-    reference's warm-up regime and says so once."""
+    Not reproduced: the perceptual term needs a downloaded SqueezeNet (no network here): a non-zero ``perceptual_weight`` is
+    reported once and the term is left out."""
 
     def __init__(self, autoencoder, lr: float, kl_weight: float, recon_loss: str = "l1", perceptual_weight: float = 0.0,
-                 max_grad_norm: float = 0.5, weight_decay: float = 1e-5, warm_up_epochs: int = 5):
-        from .optim import FlatAdam
+                 max_grad_norm: float = 0.5, weight_decay: float = 1e-5, warm_up_epochs: int = 5, adv_weight: float = 0.01,
+                 discriminator=None):
+        from .discriminator import PatchAdversarialLoss, PatchDiscriminator
+        from .optim import FlatAdam, FlatModuleAdam
         if perceptual_weight:
             # the reference's PerceptualLoss downloads a pretrained SqueezeNet (train_autoencoder.py:236): no weights, no network here.
             # Every shipped config sets a (small: 1e-5 .. 1e-3) weight, so warn once and train without the term instead of refusing.
@@ -227,26 +230,39 @@ class AutoencoderTrainer:
         autoencoder.mark_weights_dirty()
         self.overlap = self.sync.attach(autoencoder)
         self.kl_weight, self.l2 = kl_weight, recon_loss == "l2"
-        self.warm_up_epochs, self._warned = warm_up_epochs, False
+        self.warm_up_epochs, self.adv_weight = warm_up_epochs, adv_weight
+        # the reference hard-codes in_channels=1 (:155); the image channel count of the autoencoder keeps 2-channel configs working
+        dev = autoencoder.flat_params.device
+        self.discriminator = discriminator if discriminator is not None else PatchDiscriminator(
+            spatial_dims=3, num_layers_d=3, channels=32, in_channels=autoencoder.out_channels, out_channels=1, norm="INSTANCE")
+        self.discriminator = self.discriminator.to(dev)
+        self.adv_loss = PatchAdversarialLoss(criterion="least_squares")
+        self.optimizer_d = FlatModuleAdam(self.discriminator, lr=lr, betas=(0.5, 0.9), eps=1e-8, weight_decay=weight_decay,
+                                          max_grad_norm=max_grad_norm)
+        self.sync.broadcast(self.optimizer_d.flat_params, 0)
 
     def intensity_loss(self, a, b):
         return F.mse_loss(a, b) if self.l2 else F.l1_loss(a, b)
 
     def train_step(self, images: torch.Tensor, epoch: int = 0, eps: Optional[torch.Tensor] = None):
         """-> (dict of detached scalar losses, skipped)."""
-        if epoch > self.warm_up_epochs and not self._warned:
-            print("note: the adversarial term (PatchDiscriminator, train_autoencoder.py:407-424,454-494) is not implemented on "
-                  "this path; continuing with reconstruction + KL only")
-            self._warned = True
         self.autoencoder.train()
         images = torch.clamp(images.float(), 0.0, 1.0)
         bad_in = self.sync.any((~torch.isfinite(images)).any().to(torch.float32))
         if float(bad_in) > 0.0:
             return {}, True
+        adversarial = epoch > self.warm_up_epochs
         reconstruction, z_mu, z_sigma = self.autoencoder(images, eps=eps)
         recons = self.intensity_loss(reconstruction, images)
         kl = kl_loss(z_mu, z_sigma).mean()
         loss_g = recons + self.kl_weight * kl
+        out = {"recons": recons.detach(), "kl": kl.detach()}
+        if adversarial:
+            logits_fake = self.discriminator(reconstruction.contiguous().float())[-1]
+            generator_loss = self.adv_loss(logits_fake, target_is_real=True, for_discriminator=False)
+            if bool(torch.isfinite(generator_loss.detach())):                      # a NaN adversarial term is dropped (:417-422)
+                loss_g = loss_g + self.adv_weight * generator_loss
+                out["adv_g"] = generator_loss.detach()
         bad = self.sync.any((~torch.isfinite(loss_g.detach())).to(torch.float32))
         if float(bad) > 0.0:
             return {}, True
@@ -254,7 +270,23 @@ class AutoencoderTrainer:
         if not self.overlap:
             self.sync.mean_(self.autoencoder.flat_grads)
         self.optimizer.step()
-        return {"recons": recons.detach(), "kl": kl.detach(), "loss_g": loss_g.detach()}, False
+        out["loss_g"] = loss_g.detach()
+        if adversarial:
+            # discriminator step (:454-494): fake = the detached reconstruction, real = the images
+            self.optimizer_d.zero_grad()
+            logits_fake = self.discriminator(reconstruction.contiguous().detach())[-1]
+            loss_d_fake = self.adv_loss(logits_fake, target_is_real=False, for_discriminator=True)
+            logits_real = self.discriminator(images.contiguous().detach())[-1]
+            loss_d_real = self.adv_loss(logits_real, target_is_real=True, for_discriminator=True)
+            discriminator_loss = (loss_d_fake + loss_d_real) * 0.5
+            loss_d = self.adv_weight * discriminator_loss
+            bad_d = self.sync.any((~torch.isfinite(loss_d.detach())).to(torch.float32))
+            if float(bad_d) == 0.0:
+                loss_d.backward()
+                self.sync.mean_(self.optimizer_d.flat_grads)
+                self.optimizer_d.step()
+                out["adv_d"] = discriminator_loss.detach()
+        return out, False
 
     @torch.no_grad()
     def validate(self, loader, device) -> float:

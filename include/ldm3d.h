@@ -234,6 +234,15 @@ int ldm_op_group_norm_bwd(const void* dy, const void* xa, int ca, const void* xb
                           int groups, float eps, int silu, const void* acc_a, const void* acc_b, void* dxa, void* dxb,
                           float* dgamma, float* dbeta, int N, int DHW, void* scratch, size_t scratch_bytes, void* stream);
 /* GroupNorm(groups, eps, affine) over cat(xa, xb), optional fused SiLU -> out [N*DHW][ca+cb] bf16. */
+/* ---- PatchDiscriminator building blocks (stage-1 GAN tail, 3d_ldm/train_autoencoder.py:150-158,407-424,454-494): 4^3 strided convs as
+ *      im2col + the 1x1 GEMM kernels (forward, data gradient through col2im, weight gradient through ldm_op_conv3d_wgrad with ksize 1);
+ *      InstanceNorm + LeakyReLU(0.2) = ldm_op_group_norm(_bwd) with groups = C and activation code 2 (0 none, 1 SiLU, 2 LeakyReLU 0.2). */
+int ldm_op_im2col(const void* x, void* col, int N, int D, int H, int W, int Cs, int C, int k, int stride, int pad, int Kp, void* stream);
+int ldm_op_col2im(const void* dcol, void* dx, int N, int D, int H, int W, int Cs, int C, int k, int stride, int pad, int Kp, void* stream);
+int ldm_op_leaky_relu(const void* x, void* y, int64_t n, float slope, void* stream);
+int ldm_op_leaky_relu_bwd(const void* x, const void* dy, void* dx, int64_t n, float slope, void* stream);
+int ldm_op_pack_ncdhw(const float* x, void* out_bf16_ndhwc, int N, int C, int Cs, int64_t DHW, void* stream);
+int ldm_op_unpack_ndhwc(const void* act_bf16_ndhwc, float* out, int N, int C, int Cs, int64_t DHW, void* stream);
 /* producer -> GroupNorm pair as the inference plans launch it (conv epilogue / write-through split-K finalize leave the statistics
  * slabs, one-launch GroupNorm(+SiLU) with write-through stores folds them): the per-kernel gate of exactly those kernel variants */
 size_t ldm_op_conv3d_gn_scratch_bytes(int N, int D, int H, int W, int cout_pad, int splitk);

@@ -1,0 +1,134 @@
+"""Stage-1 GAN tail (-m gpu): PatchDiscriminator + LSGAN on the HIP kernels against the CPU oracle (oracle/discriminator.py)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import cfgs
+from util import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(cuda, in_channels=1, seed=0):
+    from ldm3d.discriminator import PatchDiscriminator
+    from oracle import discriminator as od
+    g = torch.Generator().manual_seed(seed)
+    sd = {k: (0.02 * torch.randn(v, generator=g) if k.endswith("weight") else 0.05 * torch.randn(v, generator=g))
+          for k, v in od.param_shapes(in_channels).items()}
+    d = PatchDiscriminator(spatial_dims=3, num_layers_d=3, channels=32, in_channels=in_channels, out_channels=1, norm="INSTANCE")
+    assert {k: tuple(v.shape) for k, v in d.state_dict().items()} == {k: tuple(v) for k, v in od.param_shapes(in_channels).items()}
+    d.load_state_dict(sd)
+    return d.to(cuda), sd
+
+
+@pytest.mark.parametrize("dims,b,cin", [((32, 32, 32), 2, 1), ((48, 32, 40), 1, 2)])
+def test_patch_discriminator_forward_and_gradients(cuda, dims, b, cin):
+    """All five layer outputs, the LSGAN generator-side gradient w.r.t. the INPUT (what flows back into the autoencoder) and every
+    parameter gradient of the discriminator step, against torch autograd through the fp32 oracle."""
+    from oracle import discriminator as od
+    d, sd = _pair(cuda, cin)
+    g = torch.Generator().manual_seed(3)
+    fake, real = torch.rand((b, cin, *dims), generator=g), torch.rand((b, cin, *dims), generator=g)
+    # ---- oracle
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xf = fake.clone().requires_grad_(True)
+    o_outs = od.forward(leaves, xf)
+    od.lsgan(o_outs[-1], True).backward()                       # generator term: d/d fake
+    gx_ref = xf.grad.clone()
+    for v in leaves.values():
+        v.grad = None
+    loss_d_ref = 0.5 * (od.lsgan(od.forward(leaves, fake)[-1], False) + od.lsgan(od.forward(leaves, real)[-1], True))
+    loss_d_ref.backward()
+    # ---- HIP
+    xd = fake.to(cuda).requires_grad_(True)
+    outs = d(xd)
+    assert len(outs) == 5 and [tuple(o.shape) for o in outs] == [tuple(o.shape) for o in o_outs]
+    errs = [rel_l2(a.detach().cpu(), r.detach()) for a, r in zip(outs, o_outs)]
+    print("PatchDiscriminator layer outputs vs fp32 oracle:", " ".join(f"{e:.2e}" for e in errs))
+    assert max(errs) <= 2.5e-2                                     # bf16 storage between five conv / norm layers
+    F.mse_loss(outs[-1], torch.ones_like(outs[-1])).backward()
+    e_gx = rel_l2(xd.grad.cpu(), gx_ref)
+    d.zero_grad(set_to_none=True)
+    loss_d = 0.5 * (torch.mean(d(fake.to(cuda))[-1] ** 2) + torch.mean((d(real.to(cuda))[-1] - 1.0) ** 2))
+    loss_d.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss_d) - float(loss_d_ref)) <= 2e-2 * abs(float(loss_d_ref))
+    errs = {k: rel_l2(p.grad.cpu(), leaves[k].grad) for k, p in d.named_parameters()}
+    print("parameter gradients vs fp32 autograd:", " ".join(f"{k.replace('.conv', '')} {e:.2e}" for k, e in errs.items()),
+          f"| input gradient {e_gx:.2e}")
+    # LeakyReLU has a kink: an element whose pre-activation changes sign between the bf16 and the fp32 forward (|u| below the ~1e-2
+    # bf16 noise: ~1 % of the elements) gets slope 0.2 instead of 1, so every LeakyReLU the gradient crosses adds a few 1e-2 that no
+    # implementation with bf16 storage can avoid (final_conv sits behind no kink: ~1e-2).  The layers are pinned tightly one by one
+    # in test_discriminator_layers_match_torch_on_identical_inputs; here: bounded, and the direction is right.
+    assert errs["final_conv.conv.weight"] <= 3e-2 and errs["final_conv.conv.bias"] <= 3e-2
+    assert max(errs.values()) <= 0.2 and e_gx <= 0.2
+    a = torch.cat([p.grad.reshape(-1).double().cpu() for _, p in d.named_parameters()])
+    r = torch.cat([leaves[k].grad.reshape(-1).double() for k, _ in d.named_parameters()])
+    assert float(a @ r / (a.norm() * r.norm())) >= 0.99
+
+
+def test_vae_gan_step_trains_both_networks(cuda):
+    """AutoencoderTrainer after the warm-up epochs: the adversarial term reaches the autoencoder's gradients (they differ from the
+    warm-up step's), the discriminator step lowers its own loss on a fixed batch, every loss is finite."""
+    from ldm3d.networks import AutoencoderKL
+    from ldm3d.trainer import AutoencoderTrainer
+    from oracle import autoencoder as oa
+    from oracle.unet import init_state_dict
+    cfg = cfgs.VAE_TINY_ATTN
+    ae = AutoencoderKL(**cfg)
+    ae.load_state_dict(init_state_dict(oa.ae_param_shapes(cfg), 3, gain=0.7))
+    ae = ae.to(cuda)
+    with pytest.warns(UserWarning, match="perceptual"):
+        tr = AutoencoderTrainer(ae, lr=1e-4, kl_weight=1e-6, perceptual_weight=1e-3, warm_up_epochs=1, adv_weight=0.5)
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand((2, 1, 32, 32, 32), generator=g).to(cuda)
+    eps = torch.randn((2, 8, 8, 8, 8), generator=g).to(cuda)
+    l0, skipped = tr.train_step(x, epoch=0, eps=eps)
+    assert not skipped and "adv_g" not in l0
+    g_warm = ae.flat_grads.clone()
+    d_before = tr.optimizer_d.flat_params.clone()
+    hist = []
+    for _ in range(6):
+        l, skipped = tr.train_step(x, epoch=2, eps=eps)
+        assert not skipped and all(bool(torch.isfinite(v)) for v in l.values())
+        hist.append(float(l["adv_d"]))
+    assert "adv_g" in l and not torch.equal(g_warm, ae.flat_grads)
+    assert not torch.equal(d_before, tr.optimizer_d.flat_params)
+    print("discriminator loss over 6 steps:", " ".join(f"{v:.4f}" for v in hist))
+    assert hist[-1] < hist[0]
+
+
+@pytest.mark.parametrize("cin,cout,dims,stride,n", [(1, 32, (16, 16, 16), 2, 2), (32, 64, (12, 10, 8), 2, 1), (64, 32, (7, 7, 7), 1, 2), (128, 1, (6, 6, 6), 1, 1)])
+def test_discriminator_layers_match_torch_on_identical_inputs(cuda, cin, cout, dims, stride, n):
+    """The building blocks one by one against torch autograd on the SAME bf16-rounded inputs (no compounding, no kink flips):
+    the 4^3 conv as im2col + GEMM (output, dX through col2im, dW, db) and InstanceNorm + LeakyReLU (output, dX)."""
+    from ldm3d.discriminator import _ConvFn, _InstanceNormLeakyFn, _PackFn, _UnpackFn, _rup
+    g = torch.Generator().manual_seed(cin + cout)
+    bf = lambda t: t.to(torch.bfloat16).float()
+    x = bf(torch.randn((n, cin, *dims), generator=g)).requires_grad_(True)
+    w = bf(0.05 * torch.randn((cout, cin, 4, 4, 4), generator=g)).requires_grad_(True)
+    b = (0.1 * torch.randn((cout,), generator=g)).requires_grad_(True)
+    y = F.conv3d(x, w, b, stride=stride, padding=1)
+    dy = bf(torch.randn(y.shape, generator=g))
+    gx, gw, gb = torch.autograd.grad(y, (x, w, b), dy)
+    xd, wd, bd = x.detach().to(cuda).requires_grad_(True), w.detach().to(cuda).requires_grad_(True), b.detach().to(cuda).requires_grad_(True)
+    Cs = _rup(cin, 32)
+    h = _PackFn.apply(xd, Cs)
+    yk = _UnpackFn.apply(_ConvFn.apply(h, wd, bd, (n, *dims, Cs, cin, 4, stride, 1)), cout)
+    yk.backward(dy.to(cuda))
+    torch.cuda.synchronize()
+    e = dict(y=rel_l2(yk.detach().cpu(), y.detach()), dx=rel_l2(xd.grad.cpu(), gx), dw=rel_l2(wd.grad.cpu(), gw), db=rel_l2(bd.grad.cpu(), gb))
+    print(f"conv4 {cin}->{cout} {dims} s{stride}: " + " ".join(f"{k} {v:.2e}" for k, v in e.items()))
+    assert e["y"] <= 4e-3 and e["dx"] <= 6e-3 and e["dw"] <= 2e-3 and e["db"] <= 2e-3          # bf16 output / dcol / dx roundings only
+    if cout % 32 == 0:
+        c = cout
+        u = bf(torch.randn((n, c, 6, 5, 7), generator=g)).requires_grad_(True)
+        v = F.leaky_relu(F.instance_norm(u, eps=1e-5), 0.2)
+        dv = bf(torch.randn(v.shape, generator=g))
+        (gu,) = torch.autograd.grad(v, u, dv)
+        ud = u.detach().to(cuda).requires_grad_(True)
+        vk = _UnpackFn.apply(_InstanceNormLeakyFn.apply(_PackFn.apply(ud, c), c), c)
+        vk.backward(dv.to(cuda))
+        e_v, e_u = rel_l2(vk.detach().cpu(), v.detach()), rel_l2(ud.grad.cpu(), gu)
+        print(f"instance norm + leaky relu C={c}: y {e_v:.2e} dx {e_u:.2e}")
+        assert e_v <= 4e-3 and e_u <= 6e-3

@@ -5,9 +5,10 @@
 
     python train_autoencoder.py -e config/environment.json -c config/config_train_16g.json -g 1
 
-What is NOT reproduced (the "next" row): the perceptual loss (pretrained SqueezeNet download) and the
-PatchDiscriminator / adversarial phase after 5 warm-up epochs; `autoencoder_train.perceptual_weight` must be 0 and training
-stays in the reconstruction + KL regime (said once at run time).  --amp / --compile / --profile / --no-images are accepted
+The PatchDiscriminator / LSGAN adversarial phase after 5 warm-up epochs (:150-158,407-424,454-494) runs on the same HIP kernels
+(ldm3d/discriminator.py); checkpoints discriminator.pt / discriminator_last.pt as the reference (:183-186).  NOT reproduced: the
+perceptual loss needs a downloaded pretrained SqueezeNet: a non-zero `autoencoder_train.perceptual_weight` (every shipped config
+has one) is reported once and the term is left out.  --amp / --compile / --profile / --no-images are accepted
 and ignored (compute is bf16 on fp32 master weights; there is no tracing compiler on this path).
 Opt-in extras: --random-init, --synthetic N, --max-steps K (as train_diffusion.py)."""
 import argparse
@@ -69,7 +70,11 @@ def main():
         print(f"Rank {rank}: loaded {best_path}")
     autoencoder = autoencoder.to(device)
     trainer = AutoencoderTrainer(autoencoder, lr=tcfg["lr"], kl_weight=tcfg["kl_weight"], recon_loss=tcfg.get("recon_loss", "l1"),
-                                 perceptual_weight=tcfg.get("perceptual_weight", 0.0))
+                                 perceptual_weight=tcfg.get("perceptual_weight", 0.0),
+                                 warm_up_epochs=int(tcfg.get("warm_up_epochs", 5)))      # 5 in the reference (:304); the key is an extension
+    d_best = os.path.join(args.model_dir, "discriminator.pt")
+    if getattr(args, "resume_ckpt", False) and os.path.exists(d_best):
+        trainer.discriminator.load_state_dict(torch.load(d_best, map_location=device, weights_only=True))
     log = None
     if rank == 0:
         tb = os.path.join(getattr(args, "tfevent_path", os.path.join(args.model_dir, "tfevent")), "autoencoder")
@@ -113,9 +118,11 @@ def main():
                 scalar("val_recon_loss", val, epoch)
                 print(f"Epoch {epoch} val_recon_loss: {val:.4f}")
                 torch.save(autoencoder.state_dict(), last_path)
+                torch.save(trainer.discriminator.state_dict(), os.path.join(args.model_dir, "discriminator_last.pt"))
                 if val < best_val:                       # the reference saves "best" unconditionally: fixed
                     best_val = val
                     torch.save(autoencoder.state_dict(), best_path)
+                    torch.save(trainer.discriminator.state_dict(), os.path.join(args.model_dir, "discriminator.pt"))
                     print("Got best val recon loss. Saved", best_path)
         if done:
             break
