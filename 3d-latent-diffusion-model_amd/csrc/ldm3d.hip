@@ -1099,7 +1099,7 @@ static int unet_register(ldm_model* m) {
             reg_res(p, rin + skip_c, oc);
             if (c.attention_levels[lvl] && !collect) { snprintf(p, sizeof p, "up_blocks.%d.attentions.%d", i, j); m->reg_attn(p, oc); }
         }
-        if (i != L - 1 && !collect) { char p[96]; snprintf(p, sizeof p, "up_blocks.%d.upsampler.conv", i); m->reg_conv(p, oc, oc, oc, 3, true); }
+        if (i != L - 1 && !collect) { char p[96]; snprintf(p, sizeof p, "up_blocks.%d.upsampler.postconv", i); m->reg_conv(p, oc, oc, oc, 3, true); }
     }
     if (!collect) { m->reg_gn("out.0", ch[0]); m->reg_conv("out.2", ch[0], ch[0], c.out_channels, 3); }
     };
@@ -1223,7 +1223,7 @@ static int unet_build(ldm_model* m, int B, int D, int H, int W, Plan* plan, bool
             h = hn;
         }
         if (i != L - 1) {
-            snprintf(p, sizeof p, "up_blocks.%d.upsampler.conv", i);
+            snprintf(p, sizeof p, "up_blocks.%d.upsampler.postconv", i);
             Act hu = b.conv3(p, h, 1, 1, 1);
             b.free_act(h);
             if (!hu.valid) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());

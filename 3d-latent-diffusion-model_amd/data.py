@@ -64,13 +64,26 @@ class PairVolumes(Dataset):
     def __init__(self, files: Sequence[str], patch_size: Sequence[int], randcrop: bool = False, seed: int = 0,
                  dtype: torch.dtype = torch.float32):
         self.files, self.patch, self.randcrop, self.seed, self.dtype = list(files), list(patch_size), randcrop, seed, dtype
+        self._draws = {}                                   # per sample: how often it has been cropped (RandSpatialCropd draws afresh every time)
+        self.epoch = 0
 
     def __len__(self):
         return len(self.files)
 
+    def set_epoch(self, epoch: int) -> None:
+        """Optional: pins the crop stream to the epoch (workers that re-create the dataset each epoch stay reproducible)."""
+        self.epoch = int(epoch)
+        self._draws = {}
+
     def __getitem__(self, idx) -> Dict[str, torch.Tensor]:
         low, high = load_pair(self.files[idx])
-        rng = np.random.RandomState(self.seed * 1000003 + idx) if self.randcrop else None
+        rng = None
+        if self.randcrop:
+            # a fresh crop on EVERY access, as MONAI's RandSpatialCropd (3d_ldm/utils.py:87): the stream is keyed by (seed, sample,
+            # epoch, access count), so two epochs see different crops of a sample and a re-run with the same seed repeats them
+            k = self._draws.get(idx, 0)
+            self._draws[idx] = k + 1
+            rng = np.random.RandomState(((self.seed * 1000003 + idx) * 7919 + self.epoch * 104729 + k) % (2 ** 32))
         st = crop_start(low.shape[-3:], self.patch, rng)           # one start for both volumes of the pair
         out = {}
         for key, vol in (("image", low), ("label", high)):
@@ -99,11 +112,14 @@ def split_files(args) -> Tuple[List[str], List[str]]:
 
 
 def prepare_dataloader(args, batch_size: int, patch_size: Sequence[int], randcrop: bool = False, rank: int = 0,
-                       world_size: int = 1, num_workers: int = 0):
+                       world_size: int = 1, num_workers: int = 0, size_divisible: int = 16):
     train_files, val_files = split_files(args)
     seed = int(getattr(args, "seed", 0))
     train_ds = PairVolumes(train_files, patch_size, randcrop, seed)
-    val_ds = PairVolumes(val_files, patch_size, False, seed)
+    # validation is centre-cropped; when training uses random crops the reference validates on a 1.5x patch rounded up to a
+    # multiple of size_divisible (3d_ldm/utils.py:75,88; train_autoencoder.py:131 passes 2^(levels - 1), train_diffusion.py:69 16)
+    val_patch = [int(np.ceil(1.5 * p / float(size_divisible)) * size_divisible) for p in patch_size] if randcrop else list(patch_size)
+    val_ds = PairVolumes(val_files, val_patch, False, seed)
     ddp = world_size > 1
     ts = DistributedSampler(train_ds, num_replicas=world_size, rank=rank, shuffle=True) if ddp else None
     vs = DistributedSampler(val_ds, num_replicas=world_size, rank=rank, shuffle=False) if ddp else None

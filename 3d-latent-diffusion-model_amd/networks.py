@@ -95,8 +95,38 @@ class _LdmModule(nn.Module):
     def mark_weights_dirty(self):
         self._dirty = True
 
-    def load_state_dict(self, *a, **k):
-        r = super().load_state_dict(*a, **k)
+    # legacy (MONAI GenerativeModels / MONAI < 1.4 checkpoints) -> MONAI core >= 1.4 key names, as MONAI's own
+    # ``load_old_state_dict`` renames them: the attention block's q / k / v / output projections moved under ``.attn`` and the
+    # upsampling conv became ``postconv``.  ``state_dict()`` always emits the MONAI >= 1.4 names (what the reference's
+    # ``monai.networks.nets.*`` targets save: 3d_ldm/train_diffusion.py:92-95,129-136, inference.py:67-77).
+    _LEGACY_KEY_RULES = (
+        (r"\.upsampler\.conv\.conv\.", ".upsampler.postconv.conv."),                      # DiffusionModelUNet upsample conv
+        (r"^(decoder\.blocks\.\d+)\.conv\.conv\.", r"\1.postconv.conv."),                 # AutoencoderKL decoder upsample conv
+        (r"\.(to_q|to_k|to_v)\.(weight|bias)$", r".attn.\1.\2"),                         # attention projections
+        (r"\.proj_attn\.(weight|bias)$", r".attn.out_proj.\1"),
+    )
+
+    @classmethod
+    def remap_legacy_keys(cls, state_dict, own_keys):
+        """Returns ``state_dict`` with legacy key names translated, only where the translated name is one of ``own_keys`` and the
+        legacy name is not (so a current checkpoint passes through untouched)."""
+        import re
+        out = {}
+        for k, v in state_dict.items():
+            nk = k
+            if k not in own_keys:
+                for pat, rep in cls._LEGACY_KEY_RULES:
+                    cand = re.sub(pat, rep, nk)
+                    if cand != nk and (cand in own_keys or ".attn." not in cand):
+                        nk = cand
+                if nk not in own_keys:
+                    nk = k
+            out[nk] = v
+        return out
+
+    def load_state_dict(self, state_dict, *a, **k):
+        own = set(super().state_dict().keys())
+        r = super().load_state_dict(self.remap_legacy_keys(state_dict, own), *a, **k)
         self._dirty = True
         return r
 

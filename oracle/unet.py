@@ -153,7 +153,7 @@ def unet_forward(sd: SD, cfg: dict, x: torch.Tensor, timesteps: torch.Tensor,
 
     ``taps`` (optional dict) receives named intermediate tensors for per-op parity tests: the coarse ones
     ("emb", "conv_in", "down{i}", "mid", "up{i}") and every block output under the block's state_dict prefix
-    ("down_blocks.0.resnets.1", "middle_block.attention", "up_blocks.1.upsampler.conv", ...: the names
+    ("down_blocks.0.resnets.1", "middle_block.attention", "up_blocks.1.upsampler.postconv", ...: the names
     ldm_model_tap_info reports).  ``force`` (optional dict with the same block names) replaces each block output
     after it has been recorded: teacher forcing, the mirror of ldm_unet_forward_taps(taps_in=...).
     """
@@ -204,7 +204,7 @@ def unet_forward(sd: SD, cfg: dict, x: torch.Tensor, timesteps: torch.Tensor,
                 h = blk(f"up_blocks.{i}.attentions.{j}",
                         attention_block(sd, f"up_blocks.{i}.attentions.{j}", h, c["num_head_channels"][lvl], c, bf))
         if i != nlev - 1:
-            h = blk(f"up_blocks.{i}.upsampler.conv", upsample_nearest_conv(sd, f"up_blocks.{i}.upsampler.conv", h, bf))
+            h = blk(f"up_blocks.{i}.upsampler.postconv", upsample_nearest_conv(sd, f"up_blocks.{i}.upsampler.postconv", h, bf))
         tap(f"up{i}", h)
     assert not skips
 
@@ -276,7 +276,7 @@ def unet_param_shapes(cfg: dict) -> Dict[str, Sequence[int]]:
             if c["attention_levels"][lvl]:
                 attn_p(f"up_blocks.{i}.attentions.{j}", oc)
         if i != nlev - 1:
-            conv_p(f"up_blocks.{i}.upsampler.conv", oc, oc, 3)
+            conv_p(f"up_blocks.{i}.upsampler.postconv", oc, oc, 3)
     gn_p("out.0", ch[0])
     conv_p("out.2", ch[0], c["out_channels"], 3)
     return out

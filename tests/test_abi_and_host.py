@@ -177,3 +177,31 @@ def test_every_reference_config_constructs(built_lib):
             assert got == {k: tuple(v) for k, v in want.items()}, (f, key)
             seen += 1
     assert seen >= 9
+
+
+def test_state_dict_emits_monai_core_names_and_loads_legacy_checkpoints(built_lib):
+    """state_dict() emits the MONAI >= 1.4 ("core") names the reference's ``monai.networks.nets.*`` targets save
+    (3d_ldm/train_diffusion.py:92-95,129-136: ``upsampler.postconv``, ``attn.to_q / to_k / to_v / out_proj``), and load_state_dict
+    also accepts the legacy MONAI-GenerativeModels names (``upsampler.conv``, ``to_q`` ... ``proj_attn`` directly on the attention
+    block, ``decoder.blocks.N.conv``): the renames MONAI's own load_old_state_dict performs."""
+    from ldm3d.networks import AutoencoderKL, DiffusionModelUNet
+    from oracle import autoencoder as oa, unet as ou
+
+    def legacy(k):
+        k = k.replace("upsampler.postconv.", "upsampler.conv.").replace(".postconv.", ".conv.")
+        for n in ("to_q", "to_k", "to_v"):
+            k = k.replace(f".attn.{n}.", f".{n}.")
+        return k.replace(".attn.out_proj.", ".proj_attn.")
+    for cls, cfg, shapes in ((DiffusionModelUNet, cfgs.UNET_TINY, ou.unet_param_shapes), (AutoencoderKL, cfgs.VAE_TINY_ATTN, oa.ae_param_shapes)):
+        m = cls(**cfg)
+        sd = ou.init_state_dict(shapes(cfg), 1)
+        assert set(m.state_dict()) == set(sd)
+        assert any("postconv" in k for k in sd) and any(".attn.to_q." in k for k in sd) and not any("proj_attn" in k for k in sd)
+        old = {legacy(k): v for k, v in sd.items()}
+        assert len(set(old) - set(sd)) > 8
+        m.load_state_dict(old)                              # strict: every key must land
+        assert all(torch.equal(m.state_dict()[k], sd[k]) for k in sd)
+        m.load_state_dict({k: v + 1 for k, v in sd.items()})     # current names pass through untouched
+        assert torch.equal(m.state_dict()[next(iter(sd))], sd[next(iter(sd))] + 1)
+        with pytest.raises(RuntimeError):
+            m.load_state_dict({k.replace("norm1", "norm_one"): v for k, v in sd.items()})

@@ -42,8 +42,20 @@ def test_loader_split_crop_and_pairing(tmp_path):
     b = next(iter(tl))
     assert b["image"].shape == (2, 1, 8, 8, 8) and b["label"].shape == (2, 1, 8, 8, 8) and b["image"].dtype == torch.float32
     assert float(b["label"].min()) == 0.0
-    ds = data.PairVolumes(tr, (8, 8, 8), randcrop=True, seed=3)
-    assert torch.equal(ds[1]["label"], ds[1]["label"])                          # deterministic per (seed, index)
+    # random crops (train_autoencoder.py:133-145 asks for randcrop=True): a FRESH crop on every access, as MONAI's RandSpatialCropd
+    # (3d_ldm/utils.py:87); the stream is reproducible from the seed, pairs stay aligned, epochs differ
+    big = data.write_synthetic_pairs(str(tmp_path / "big"), 2, (24, 20, 16), seed=2)
+    ds, ds2 = data.PairVolumes(big, (8, 8, 8), randcrop=True, seed=3), data.PairVolumes(big, (8, 8, 8), randcrop=True, seed=3)
+    e0 = [ds[0]["label"] for _ in range(4)]
+    assert any(not torch.equal(e0[0], e) for e in e0[1:])                       # later accesses (= later epochs) see other crops
+    assert all(torch.equal(a, ds2[0]["label"]) for a in e0)                     # ... the same ones for the same seed
+    ds.set_epoch(5); ds2.set_epoch(5)
+    assert torch.equal(ds[1]["image"], ds2[1]["image"])
+    ds3 = data.PairVolumes(big, (8, 8, 8), randcrop=True, seed=4)
+    assert any(not torch.equal(ds3[0]["label"], e) for e in e0)
+    # validation under random-crop training: centre crop of 1.5 x patch rounded up to a multiple of 16 (3d_ldm/utils.py:88), clipped
+    _, vl2 = data.prepare_dataloader(argparse.Namespace(npz_dir=str(tmp_path / "big"), seed=0, val_fraction=0.5), 1, (8, 8, 8), randcrop=True)
+    assert next(iter(vl2))["image"].shape == (1, 1, 16, 16, 16)
     with pytest.raises(ValueError):
         data.split_files(argparse.Namespace(npz_dir=str(tmp_path / "none")))
 

@@ -125,3 +125,66 @@ def test_every_reference_config_runs_at_its_own_patch_size(cuda, name):
     err = rel_l2(e, e32)
     print(f"{name}: UNet latent {lat} bf16 vs fp32 mode {err:.2e}")
     assert e.shape == z.shape and torch.isfinite(e).all() and err <= 0.15
+
+
+def test_config3_full_training_step_at_brats_latent(cuda):
+    """BASELINE configs[3] on one rank: one whole train_diffusion step at the reference's patch 144x176x112 (latent 36x44x28,
+    3d_ldm/config/config_train_16g.json:50-52) through DiffusionTrainer: two no-grad VAE encodes (image -> condition, label -> latent),
+    add_noise, concat-conditioned UNet forward, MSE, hand-written backward, clip 1.0 + Adam (3d_ldm/train_diffusion.py:172-223).
+    Every parameter tensor receives a finite, non-zero gradient; two runs from the same state are bit-identical (no atomics)."""
+    from ldm3d.inferer import LatentDiffusionInferer
+    from ldm3d.networks import AutoencoderKL, DiffusionModelUNet
+    from ldm3d.schedulers import DDPMScheduler
+    from ldm3d.trainer import DiffusionTrainer
+    from oracle import autoencoder as oa, unet as ou
+    vcfg = cfgs.VAE_FULL
+    ucfg = dict(cfgs.UNET_FULL, in_channels=8)
+    vae = AutoencoderKL(**vcfg)
+    vae.load_state_dict(ou.init_state_dict(oa.ae_param_shapes(vcfg), 3))
+    vae = vae.to(cuda).eval()
+    usd = ou.init_state_dict(ou.unet_param_shapes(ucfg), 4, gain=0.5)
+    g = torch.Generator().manual_seed(9)
+    images, labels = torch.rand((1, 1, 144, 176, 112), generator=g).to(cuda), torch.rand((1, 1, 144, 176, 112), generator=g).to(cuda)
+    noise = torch.randn((1, 4, 36, 44, 28), generator=g).to(cuda)
+    t = torch.tensor([417], device=cuda)
+
+    def run():
+        unet = DiffusionModelUNet(**ucfg)
+        unet.load_state_dict(usd)
+        unet = unet.to(cuda)
+        tr = DiffusionTrainer(unet, vae, LatentDiffusionInferer(DDPMScheduler(**cfgs.SCHED), scale_factor=1.0), lr=1e-5)
+        torch.manual_seed(11)                               # the VAE's sampling draws
+        loss, skipped = tr.train_step(images, labels, noise=noise, timesteps=t)
+        torch.cuda.synchronize()
+        assert not skipped and bool(torch.isfinite(loss))
+        return float(loss), unet.flat_grads.clone(), unet.flat_params.clone(), {k: p.grad for k, p in unet.named_parameters()}
+    l1, g1, p1, named = run()
+    for k, gr in named.items():
+        assert gr is not None and torch.isfinite(gr).all() and float(gr.abs().max()) > 0.0, k
+    l2, g2, p2, _ = run()
+    assert l1 == l2 and torch.equal(g1, g2) and torch.equal(p1, p2)
+    print(f"configs[3] step at latent 36x44x28: loss {l1:.5f}, |g| {float(g1.norm()):.4f}")
+
+
+def test_config4_ddim50_chain_and_decode(cuda):
+    """BASELINE configs[4] per-GPU share: 50-step DDIM on a batch of 4x40x56x40 latents through LatentDiffusionInferer.sample, then the
+    VAE decode to 160x224x160; finite, in range, and bit-identical across two runs (batch 2 here keeps the test at a few seconds;
+    batch independence is covered above)."""
+    from ldm3d.inferer import LatentDiffusionInferer
+    from ldm3d.networks import AutoencoderKL
+    from ldm3d.schedulers import DDIMScheduler
+    from oracle import autoencoder as oa, unet as ou
+    m, _ = _unet(cfgs.UNET_FULL, 0, cuda)
+    vae = AutoencoderKL(**cfgs.VAE_FULL)
+    vae.load_state_dict(ou.init_state_dict(oa.ae_param_shapes(cfgs.VAE_FULL), 3))
+    vae = vae.to(cuda).eval()
+    sch = DDIMScheduler(**cfgs.SCHED)
+    sch.set_timesteps(50)
+    inf = LatentDiffusionInferer(sch, scale_factor=1.0)
+    z = torch.randn((2, 4, 40, 56, 40), generator=torch.Generator().manual_seed(3)).to(cuda)
+    a = inf.sample(z, vae, m)
+    b = inf.sample(z, vae, m)
+    assert a.shape == (2, 1, 160, 224, 160) and torch.isfinite(a).all() and torch.equal(a, b)
+    m.enable_graph_replay(True)
+    c = inf.sample(z, vae, m, fused_seed=0)                 # the fused device sampler + graph replay: the same chain (DDIM draws no noise)
+    assert rel_l2(c, a) <= 1e-4

@@ -60,7 +60,8 @@ def main():
         write_synthetic_pairs(args.npz_dir, args.synthetic, [int(1.25 * p) for p in tcfg["patch_size"]], seed=int(getattr(args, "seed", 0)))
     if ddp:
         torch.distributed.barrier()
-    train_loader, val_loader = prepare_dataloader(args, tcfg["batch_size"], tcfg["patch_size"], randcrop=True, rank=rank, world_size=world)
+    train_loader, val_loader = prepare_dataloader(args, tcfg["batch_size"], tcfg["patch_size"], randcrop=True, rank=rank, world_size=world,
+                                                  size_divisible=2 ** (len(args.autoencoder_def["channels"]) - 1))
 
     autoencoder = define_instance(args, "autoencoder_def")
     best_path = os.path.join(args.model_dir, "autoencoder.pt")
