@@ -78,25 +78,34 @@ def test_vae_gan_step_trains_both_networks(cuda):
     ae = AutoencoderKL(**cfg)
     ae.load_state_dict(init_state_dict(oa.ae_param_shapes(cfg), 3, gain=0.7))
     ae = ae.to(cuda)
+    torch.manual_seed(0)                                     # the discriminator's N(0, 0.02) initialisation
     with pytest.warns(UserWarning, match="perceptual"):
         tr = AutoencoderTrainer(ae, lr=1e-4, kl_weight=1e-6, perceptual_weight=1e-3, warm_up_epochs=1, adv_weight=0.5)
     g = torch.Generator().manual_seed(1)
     x = torch.rand((2, 1, 32, 32, 32), generator=g).to(cuda)
     eps = torch.randn((2, 8, 8, 8, 8), generator=g).to(cuda)
     l0, skipped = tr.train_step(x, epoch=0, eps=eps)
-    assert not skipped and "adv_g" not in l0
+    assert not skipped and "adv_g" not in l0 and "adv_d" not in l0          # warm-up: reconstruction + KL only
     g_warm = ae.flat_grads.clone()
     d_before = tr.optimizer_d.flat_params.clone()
+    l, skipped = tr.train_step(x, epoch=2, eps=eps)
+    assert not skipped and all(bool(torch.isfinite(v)) for v in l.values())
+    assert "adv_g" in l and "adv_d" in l and not torch.equal(g_warm, ae.flat_grads)   # the adversarial term reached the autoencoder
+    assert not torch.equal(d_before, tr.optimizer_d.flat_params)                      # ... and the discriminator took a step
+    # the discriminator step alone on a FIXED (fake, real) pair must make progress on its own objective
+    with torch.no_grad():
+        ae.eval()
+        fake = ae(x, eps=eps)[0].detach()
+        ae.train()
     hist = []
-    for _ in range(6):
-        l, skipped = tr.train_step(x, epoch=2, eps=eps)
-        assert not skipped and all(bool(torch.isfinite(v)) for v in l.values())
-        hist.append(float(l["adv_d"]))
-    assert "adv_g" in l and not torch.equal(g_warm, ae.flat_grads)
-    assert not torch.equal(d_before, tr.optimizer_d.flat_params)
-    print("discriminator loss over 6 steps:", " ".join(f"{v:.4f}" for v in hist))
-    assert hist[-1] < hist[0]
-
+    for _ in range(12):
+        tr.optimizer_d.zero_grad()
+        loss_d = 0.5 * (tr.adv_loss(tr.discriminator(fake), False) + tr.adv_loss(tr.discriminator(x), True))
+        loss_d.backward()
+        tr.optimizer_d.step()
+        hist.append(float(loss_d))
+    print("discriminator loss on a fixed batch:", " ".join(f"{v:.4f}" for v in hist))
+    assert all(v == v for v in hist) and min(hist[-3:]) < 0.7 * hist[0]
 
 @pytest.mark.parametrize("cin,cout,dims,stride,n", [(1, 32, (16, 16, 16), 2, 2), (32, 64, (12, 10, 8), 2, 1), (64, 32, (7, 7, 7), 1, 2), (128, 1, (6, 6, 6), 1, 1)])
 def test_discriminator_layers_match_torch_on_identical_inputs(cuda, cin, cout, dims, stride, n):
