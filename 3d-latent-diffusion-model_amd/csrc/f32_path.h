@@ -30,11 +30,13 @@ struct Conv32Params {
     float* partial;                                   // [splitk][M][CoutPad]         (splitk > 1)
 };
 
-// Workgroup = 128 voxels x 128 couts, 4 waves (2 x 2), wave tile 64 x 64 = 2 x 2 MFMA tiles of 32 x 32 (A = weights, B = voxels:
-// a lane ends with 4 x 4 consecutive couts of one voxel).  K step = 16 input channels of one tap.
+// Workgroup = 128 voxels x BN couts (128, or 64 for the layers with Cout % 128 != 0: no wasted MFMA rows), 4 waves (2 x 2), wave tile
+// 64 voxels x BN / 2 couts = 2 x NI MFMA tiles of 32 x 32 (A = weights, B = voxels: a lane ends with 4 consecutive couts per register
+// quad of one voxel).  K step = 16 input channels of one tap.
+template <int BN>
 __global__ __launch_bounds__(256, 2) void conv_f32_kernel(const Conv32Params p) {
-    constexpr int BM = 128, BN = 128, BK = 16, LDR = BK + 4;       // LDS row stride 80 B: conflict-free ds_read_b128
-    __shared__ __attribute__((aligned(16))) float sA[2][BN * LDR];  // weights
+    constexpr int BM = 128, BK = 16, LDR = BK + 4, NI = BN / 64;   // LDS row stride 80 B: conflict-free ds_read_b128
+    __shared__ __attribute__((aligned(16))) float sA[2][BN * LDR];  // weights (rows 64 .. 127 unused when BN == 64)
     __shared__ __attribute__((aligned(16))) float sB[2][BM * LDR];  // voxels
     __shared__ int tapv[27 * BM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -70,7 +72,7 @@ __global__ __launch_bounds__(256, 2) void conv_f32_kernel(const Conv32Params p) 
     __syncthreads();
 
     const int lc = tid & 3, lr = tid >> 2;              // loader: 16-byte chunk of the 16-channel row, rows lr and lr + 64
-    float4 ra[2], rb[2];
+    float4 ra[NI], rb[2];
     auto load_step = [&](int s) {
         const int tap = s / p.nchunk, ch = (s - tap * p.nchunk) * BK;
         const bool second = ch >= p.ca;
@@ -81,23 +83,25 @@ __global__ __launch_bounds__(256, 2) void conv_f32_kernel(const Conv32Params p) 
             const int row = lr + 64 * j;
             const int v = tapv[tap * BM + row];
             rb[j] = (v >= 0) ? *reinterpret_cast<const float4*>(src + (size_t)v * cs + cc) : make_float4(0.f, 0.f, 0.f, 0.f);
-            const int co = n0 + row;
-            ra[j] = (co < p.CoutPad) ? *reinterpret_cast<const float4*>(p.w + ((size_t)tap * p.CoutPad + co) * cin + ch + lc * 4)
-                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j < NI) {
+                const int co = n0 + row;
+                ra[j] = (co < p.CoutPad) ? *reinterpret_cast<const float4*>(p.w + ((size_t)tap * p.CoutPad + co) * cin + ch + lc * 4)
+                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
     };
     auto store_step = [&](int buf) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int row = lr + 64 * j;
-            *reinterpret_cast<float4*>(&sA[buf][row * LDR + lc * 4]) = ra[j];
+            if (j < NI) *reinterpret_cast<float4*>(&sA[buf][row * LDR + lc * 4]) = ra[j];
             *reinterpret_cast<float4*>(&sB[buf][row * LDR + lc * 4]) = rb[j];
         }
     };
 
-    f32x16 acc[2][2];                                   // [cout tile][voxel tile]
+    f32x16 acc[NI][2];                                  // [cout tile][voxel tile]
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -113,13 +117,13 @@ __global__ __launch_bounds__(256, 2) void conv_f32_kernel(const Conv32Params p) 
         for (int half = 0; half < 2; ++half) {
             // lane half fh reads 4 consecutive k (chunk 2 * half + fh); MFMA e pairs k = 8 half + e (lanes 0-31) with k = 8 half + 4 + e
             // (lanes 32-63) on BOTH operands, so the four MFMAs together cover the 8 k's of this half step
-            float4 a[2], b[2];
+            float4 a[NI], b[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const float4*>(&sA[buf][(wn * 64 + i * 32 + fr) * LDR + (2 * half + fh) * 4]);
+            for (int i = 0; i < NI; ++i) a[i] = *reinterpret_cast<const float4*>(&sA[buf][(wn * (BN / 2) + i * 32 + fr) * LDR + (2 * half + fh) * 4]);
 #pragma unroll
             for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const float4*>(&sB[buf][(wm * 64 + j * 32 + fr) * LDR + (2 * half + fh) * 4]);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
@@ -139,10 +143,10 @@ __global__ __launch_bounds__(256, 2) void conv_f32_kernel(const Conv32Params p) 
         if (m >= p.M) continue;
         const int n = m / DHWo, sp = m - n * DHWo;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int c = n0 + wn * 64 + i * 32 + 8 * g + 4 * fh;
+                const int c = n0 + wn * (BN / 2) + i * 32 + 8 * g + 4 * fh;
                 float4 v = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
                 if (p.splitk > 1) {
                     if (c < p.CoutPad) *reinterpret_cast<float4*>(p.partial + ((size_t)split * p.M + m) * p.CoutPad + c) = v;
@@ -347,7 +351,133 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const Attn32Params p) {
                 make_float4(o[t][4 * g] * inv, o[t][4 * g + 1] * inv, o[t][4 * g + 2] * inv, o[t][4 * g + 3] * inv);
 }
 
+// The same attention with the KEY range split over the workgroup's four waves (d <= 64): the plain kernel gives one wave per 32 queries,
+// i.e. 216 waves for 4 heads x 1728 tokens on a chip with 1024 SIMDs; here the four waves of a workgroup share the 32 queries, wave w
+// walks key tiles w, w + 4, ... with its own K / V images, and the (max, sum, O) partials are merged through LDS in a fixed order.
+template <int DT>
+__global__ __launch_bounds__(256) void attn_f32_split_kernel(const Attn32Params p) {
+    constexpr int D = DT * 32, LDQ = D + 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sQ = reinterpret_cast<float*>(smem);          // [32][LDQ]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* sK = sQ + 32 * LDQ + wave * (64 * LDQ);       // this wave's K image [32][LDQ], then its V image
+    float* sV = sK + 32 * LDQ;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int b = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * 32;
+    const int C3 = 3 * p.C;
+    const float* base = p.qkv + (size_t)b * p.N * C3 + head * D;
+    for (int e = tid; e < 32 * (D / 4); e += 256) {
+        const int row = e / (D / 4), c4 = (e - row * (D / 4)) * 4;
+        int q = q0 + row; if (q >= p.N) q = p.N - 1;
+        const float4 v = *reinterpret_cast<const float4*>(base + (size_t)q * C3 + c4);
+        float* dst = sQ + row * LDQ + c4; dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+    }
+    f32x16 o[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+    float mrow = -INFINITY, lrow = 0.f;
+    const float sl2 = p.scale * 1.4426950408889634f;
+    const int ntile = (p.N + 31) / 32, nround = (ntile + 3) / 4;
+    for (int it = 0; it < nround; ++it) {
+        const int t = it * 4 + wave, k0 = t * 32;
+        __syncthreads();                                 // Q written (first round) / the previous tile's reads are done
+        if (t < ntile)
+            for (int e = lane; e < 32 * (D / 4); e += 64) {
+                const int row = e / (D / 4), c4 = (e - row * (D / 4)) * 4;
+                int k = k0 + row; if (k >= p.N) k = p.N - 1;
+                const float4 kv = *reinterpret_cast<const float4*>(base + (size_t)k * C3 + p.C + c4);
+                const float4 vv = *reinterpret_cast<const float4*>(base + (size_t)k * C3 + 2 * p.C + c4);
+                float* dk = sK + row * LDQ + c4; dk[0] = kv.x; dk[1] = kv.y; dk[2] = kv.z; dk[3] = kv.w;
+                float* dv = sV + row * LDQ + c4; dv[0] = vv.x; dv[1] = vv.y; dv[2] = vv.z; dv[3] = vv.w;
+            }
+        __syncthreads();
+        if (t >= ntile) continue;
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        const float* kq = sK + fr * LDQ + fh;
+        const float* qq = sQ + fr * LDQ + fh;
+#pragma unroll 8
+        for (int kk = 0; kk < D / 2; ++kk) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kq[2 * kk], qq[2 * kk], s, 0, 0, 0);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+            s[r] = (key < p.N) ? s[r] * sl2 : -INFINITY;
+            mx = fmaxf(mx, s[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mnew = fmaxf(mrow, mx);
+        const float alpha = exp2f(mrow - mnew);
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = exp2f(s[r] - mnew); ps += s[r]; }
+        ps += __shfl_xor(ps, 32, 64);
+        lrow = lrow * alpha + ps; mrow = mnew;
+#pragma unroll
+        for (int tt = 0; tt < DT; ++tt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[tt][r] *= alpha;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float* vrow = sV + ((j & 3) + 8 * (j >> 2) + 4 * fh) * LDQ + fr;
+#pragma unroll
+            for (int tt = 0; tt < DT; ++tt) o[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[32 * tt], s[j], o[tt], 0, 0, 0);
+        }
+    }
+    // ---- merge the four waves' partials (waves 1..3 publish, wave 0 folds them in wave order: reproducible)
+    __syncthreads();
+    float* xo = sQ + 32 * LDQ + wave * (64 * LDQ);        // the wave's own (dead) tile area: DT * 16 * 64 floats of O, then m and l per lane
+    if (wave > 0) {
+#pragma unroll
+        for (int tt = 0; tt < DT; ++tt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xo[(tt * 16 + r) * 64 + lane] = o[tt][r];
+        xo[DT * 16 * 64 + lane] = mrow; xo[DT * 16 * 64 + 64 + lane] = lrow;
+    }
+    __syncthreads();
+    if (wave > 0) return;
+    for (int w = 1; w < 4; ++w) {
+        const float* xw = sQ + 32 * LDQ + w * (64 * LDQ);
+        const float mg = xw[DT * 16 * 64 + lane], lg = xw[DT * 16 * 64 + 64 + lane];
+        const float mnew = fmaxf(mrow, mg);               // wave 0 owns tile 0: mrow is finite
+        const float a0 = exp2f(mrow - mnew), a1 = exp2f(mg - mnew);      // a wave without a tile has mg = -inf -> a1 = 0
+        lrow = lrow * a0 + lg * a1; mrow = mnew;
+#pragma unroll
+        for (int tt = 0; tt < DT; ++tt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[tt][r] = o[tt][r] * a0 + xw[(tt * 16 + r) * 64 + lane] * a1;
+    }
+    const int q = q0 + fr;
+    if (q >= p.N) return;
+    const float inv = 1.0f / lrow;
+    float* dst = p.out + ((size_t)b * p.N + q) * p.C + head * D;
+#pragma unroll
+    for (int tt = 0; tt < DT; ++tt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(dst + 32 * tt + 8 * g + 4 * fh) =
+                make_float4(o[tt][4 * g] * inv, o[tt][4 * g + 1] * inv, o[tt][4 * g + 2] * inv, o[tt][4 * g + 3] * inv);
+}
+
 static hipError_t launch_attn_f32(const Attn32Params& p, hipStream_t s) {
+    if (p.d <= 64 && p.N >= 128) {                        // key range split over the four waves of a workgroup
+        const int lds = (32 + 4 * 64) * (p.d + 1) * 4;
+        const dim3 grid((p.N + 31) / 32, p.heads, p.B);
+        if (p.d == 64) {
+            static bool set64 = false;
+            if (!set64) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f32_split_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e; set64 = true; }
+            hipLaunchKernelGGL(attn_f32_split_kernel<2>, grid, dim3(256), lds, s, p);
+        } else {
+            static bool set32 = false;
+            if (!set32) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f32_split_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e; set32 = true; }
+            hipLaunchKernelGGL(attn_f32_split_kernel<1>, grid, dim3(256), lds, s, p);
+        }
+        return hipSuccess;
+    }
+
     const int dt = p.d / 32;
     const int nw = dt <= 4 ? 4 : 2;
     const int lds = ((nw * 32 + 64) * (p.d + 1)) * 4;

@@ -430,7 +430,8 @@ struct Builder {
         const long M = (long)N * a.Do * a.Ho * a.Wo;
         if (M >= (1L << 31)) { err = "conv " + tag + ": M too large"; return Act(); }
         const int taps = a.k * a.k * a.k, nchunk = cin0 / 16, steps = taps * nchunk;
-        const int mtiles = (int)((M + 127) / 128), ntiles = (w.cout_pad + 127) / 128;
+        const int bn = (w.cout_pad % 128) ? 64 : 128;    // 64-wide tiles where 128 would idle half of the MFMA rows
+        const int mtiles = (int)((M + 127) / 128), ntiles = (w.cout_pad + bn - 1) / bn;
         const long tiles = (long)mtiles * ntiles;
         int sk = 1;
         if (tiles < 192) {                               // fill the 256 CUs: K split into deterministic fp32 slabs
@@ -440,7 +441,7 @@ struct Builder {
         const int couts = a.f32_out ? 0 : rup(w.cout, 32);
         Act out;
         if (!a.f32_out) out = new_act(N, a.Do, a.Ho, a.Wo, couts);
-        Op op{}; op.kind = OP_CONV32; op.cc = ConvCfg{2, 2, 16, sk};
+        Op op{}; op.kind = OP_CONV32; op.cc = ConvCfg{2, bn / 64, 16, sk};
         op.r[0] = ws_ref(a.xa.off); op.r[1] = a.xb.valid ? ws_ref(a.xb.off) : Ref();
         op.r[2] = w32_ref(w.w_off);
         op.r[6] = a.no_bias ? Ref() : w_ref(w.b_off);
@@ -1722,7 +1723,8 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                 p.residual = (const float*)rp(bs, o.r[9]);
                 if (i[22]) p.out_ncdhw = (float*)rp(bs, o.r[10]); else p.out = (float*)rp(bs, o.r[10]);
                 p.partial = (float*)rp(bs, o.r[11]);
-                if (o.kind == OP_CONV32) hipLaunchKernelGGL(conv_f32_kernel, dim3(p.mtiles * p.ntiles * p.splitk), dim3(256), 0, s, p);
+                if (o.kind == OP_CONV32 && o.cc.wgn == 2) hipLaunchKernelGGL(conv_f32_kernel<128>, dim3(p.mtiles * p.ntiles * p.splitk), dim3(256), 0, s, p);
+                else if (o.kind == OP_CONV32) hipLaunchKernelGGL(conv_f32_kernel<64>, dim3(p.mtiles * p.ntiles * p.splitk), dim3(256), 0, s, p);
                 else hipLaunchKernelGGL(finalize_f32_kernel, dim3(grid_for((long)p.M * (p.CoutPad / 4), 256, 4096)), dim3(256), 0, s, p);
                 break; }
             case OP_GN_STATS32: case OP_GN_APPLY32: {
@@ -1807,7 +1809,7 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                 GnFinalizeParams p{}; p.partial = (const float*)rp(bs, o.r[4]); p.nslab = i[0]; p.C = i[1]; p.Creal = i[1]; p.groups = i[2];
                 p.DHW = i[3]; p.eps = o.f[0]; p.gamma = (const float*)rp(bs, o.r[1]); p.beta = (const float*)rp(bs, o.r[2]);
                 p.ab = (float*)rp(bs, o.r[5]); p.mr = (float*)rp(bs, o.r[6]);
-                hipLaunchKernelGGL(gn_finalize_kernel, dim3(i[2], i[4]), dim3(64), 0, s, p);
+                hipLaunchKernelGGL(gn_finalize_kernel, dim3(i[2], i[4]), dim3(256), 0, s, p);
                 break; }
             case OP_GN_PREP: {
                 GnPrepParams p{}; p.sa = (const float*)rp(bs, o.r[0]); p.sb = (const float*)rp(bs, o.r[1]); p.ca = i[0]; p.cb = i[1];
@@ -2870,7 +2872,7 @@ int ldm_op_group_norm(const void* xa, int ca, const void* xb, int cb, const floa
     hipLaunchKernelGGL(gn_stats_kernel, dim3(nslab, N), dim3(256), 0, s, sp);
     GnFinalizeParams fp{}; fp.partial = partial; fp.nslab = nslab; fp.C = C; fp.Creal = C; fp.groups = groups; fp.DHW = DHW; fp.eps = eps;
     fp.gamma = gamma; fp.beta = beta; fp.ab = ab;
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, N), dim3(64), 0, s, fp);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, N), dim3(256), 0, s, fp);
     GnApplyParams ap{}; ap.xa = sp.xa; ap.xb = sp.xb; ap.ca = ca; ap.cb = cb; ap.DHW = DHW; ap.N = N; ap.silu = silu; ap.ab = ab; ap.out = (bf16_t*)out;
     hipLaunchKernelGGL(gn_apply_kernel, dim3(grid_for((long)N * DHW * cvec, 256, 2048)), dim3(256), 0, s, ap);
     HIP_TRY(hipGetLastError());
@@ -2992,7 +2994,7 @@ int ldm_op_group_norm_bwd(const void* dy, const void* xa, int ca, const void* xb
     hipLaunchKernelGGL(gn_stats_kernel, dim3(nslab, N), dim3(256), 0, s, sp);
     GnFinalizeParams fp{}; fp.partial = partial; fp.nslab = nslab; fp.C = C; fp.Creal = C; fp.groups = groups; fp.DHW = DHW; fp.eps = eps;
     fp.gamma = gamma; fp.beta = beta; fp.ab = ab; fp.mr = mr;
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, N), dim3(64), 0, s, fp);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, N), dim3(256), 0, s, fp);
     GnBwdParams bp{}; bp.dy = (const bf16_t*)dy; bp.xa = sp.xa; bp.xb = sp.xb; bp.ca = ca; bp.cb = cb; bp.ab = ab; bp.mr = mr; bp.gamma = gamma;
     bp.groups = groups; bp.DHW = DHW; bp.N = N; bp.silu = silu; bp.nslab = nslab; bp.rows_per_slab = rps; bp.partial = partial; bp.gsum = gsum;
     bp.dgamma_n = dgn; bp.dbeta_n = dbn; bp.acc_a = (const bf16_t*)acc_a; bp.acc_b = (const bf16_t*)acc_b; bp.dxa = (bf16_t*)dxa; bp.dxb = (bf16_t*)dxb;

@@ -94,25 +94,30 @@ struct GnFinalizeParams {
     float* mr;                                     // optional [N][groups][2] mean, rstd (saved for the backward pass)
 };
 
-__global__ __launch_bounds__(64) void gn_finalize_kernel(const GnFinalizeParams p) {   // fallback path only
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const GnFinalizeParams p) {   // fallback path and the fp32 precision mode
+    __shared__ double red[2][4];
     const int n = blockIdx.y, g = blockIdx.x;
     const int cpg = p.Creal / p.groups;
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
     double s = 0.0, q = 0.0;
     const int items = p.nslab * cpg;
-    for (int i = lane; i < items; i += 64) {
+    for (int i = tid; i < items; i += nthr) {              // fixed assignment and fixed fold order below: reproducible
         const int slab = i / cpg, c = g * cpg + (i - slab * cpg);
         const float* src = p.partial + (((size_t)n * p.nslab + slab) * p.C + c) * 2;
         s += (double)src[0]; q += (double)src[1];
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+    if (lane == 0) { red[0][wave] = s; red[1][wave] = q; }
+    __syncthreads();
+    s = 0.0; q = 0.0;
+    for (int w = 0; w < (nthr + 63) / 64; ++w) { s += red[0][w]; q += red[1][w]; }
     const double cnt = (double)cpg * (double)p.DHW;
     const double mean = s / cnt;
     double var = q / cnt - mean * mean; if (var < 0.0) var = 0.0;
     const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
-    if (p.mr && lane == 0) { p.mr[((size_t)n * p.groups + g) * 2] = (float)mean; p.mr[((size_t)n * p.groups + g) * 2 + 1] = rstd; }
-    for (int c = g * cpg + lane; c < (g + 1) * cpg; c += 64) {
+    if (p.mr && tid == 0) { p.mr[((size_t)n * p.groups + g) * 2] = (float)mean; p.mr[((size_t)n * p.groups + g) * 2 + 1] = rstd; }
+    for (int c = g * cpg + tid; c < (g + 1) * cpg; c += nthr) {
         const float a = p.gamma[c] * rstd;
         p.ab[((size_t)n * p.C + c) * 2] = a;
         p.ab[((size_t)n * p.C + c) * 2 + 1] = p.beta[c] - (float)mean * a;

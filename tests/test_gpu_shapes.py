@@ -35,8 +35,17 @@ def test_unet_brats_latent_batch_independence(cuda):
         one = m(x=x[1:], timesteps=t[1:], cond=c[1:])
     assert torch.isfinite(both).all() and both.shape == (2, 4, 36, 44, 28)
     assert torch.equal(both, again)
-    # batch independence up to the split-K / tile decomposition the planner picks per problem size
+    # batch independence up to the split-K / tile decomposition the planner picks per problem size: in bf16 a different summation
+    # order is a different draw of the rounding noise (floor ~3e-2 at this depth) ...
     assert rel_l2(both[1:], one) < 8e-2
+    # ... so the property itself is pinned in the fp32 precision mode, where the same plans leave only fp32 summation-order noise
+    m.set_precision("fp32")
+    with torch.no_grad():
+        both32 = m(x=x, timesteps=t, cond=c)
+        one32 = m(x=x[1:], timesteps=t[1:], cond=c[1:])
+        zero32 = m(x=x[:1], timesteps=t[:1], cond=c[:1])
+    assert rel_l2(both32[1:], one32) < 2e-5 and rel_l2(both32[:1], zero32) < 2e-5
+    assert rel_l2(both[1:], one32) < 8e-2                     # and the bf16 batch result sits within its floor of the fp32 one
 
 
 def test_unet_config5_latent_runs(cuda):

@@ -78,6 +78,38 @@ def test_unet_parameter_gradients_match_oracle_autograd(cuda, name, dims, b, con
             assert e <= 2.5 * fl + 5e-3, (fam, e, fl)
 
 
+def test_unit_gain_gradients_sit_on_the_bf16_floor(cuda):
+    """The same comparison at UNIT weight gain, where the random-weight network is chaotic under rounding: the CPU oracle's OWN
+    bf16-emulated gradients are ~0.4 rel-L2 away from its fp32 ones.  The HIP backward must not be further from fp32 than that
+    floor allows, and it must point the same way as the bf16 oracle does (cosine to fp32 no worse than the oracle's own): what is
+    lost at unit gain is bf16 precision on an ill-conditioned function, not kernel arithmetic (the damped-gain test above and the
+    per-kernel 3e-4 / 1.5e-2 gates pin that)."""
+    from ldm3d.networks import DiffusionModelUNet
+    from oracle import unet as ou
+    cfg = cfgs.UNET_TINY
+    sd = ou.init_state_dict(ou.unet_param_shapes(cfg), 3, gain=1.0)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn((2, 4, 8, 8, 8), generator=g)
+    target = torch.randn((2, 4, 8, 8, 8), generator=g)
+    t = torch.tensor([211.0, 640.0])
+    _, _, g32 = _oracle_grads(sd, cfg, x, t, target, False)
+    _, _, gbf = _oracle_grads(sd, cfg, x, t, target, True)
+    m = DiffusionModelUNet(**cfg)
+    m.load_state_dict(sd)
+    m = m.to(cuda).train()
+    F.mse_loss(m(x=x.to(cuda), timesteps=t.to(cuda)).float(), target.to(cuda)).backward()
+    torch.cuda.synchronize()
+    names = list(sd.keys())
+    got = {k: p.grad for k, p in m.named_parameters()}
+    a, r, bfo = _cat(got, names), _cat(g32, names), _cat(gbf, names)
+    floor = rel_l2(bfo, r)
+    cos_gpu, cos_bf = float(a @ r / (a.norm() * r.norm())), float(bfo @ r / (bfo.norm() * r.norm()))
+    print(f"unit gain: oracle bf16-vs-fp32 floor {floor:.2e} (cosine {cos_bf:.4f}); GPU vs fp32 {rel_l2(a, r):.2e} (cosine {cos_gpu:.4f})")
+    assert torch.isfinite(a).all()
+    assert rel_l2(a, r) <= 2.0 * floor + 2e-3
+    assert cos_gpu >= cos_bf - 0.1
+
+
 def test_backward_requires_matching_forward(cuda):
     from ldm3d import _lib
     from ldm3d.networks import DiffusionModelUNet
