@@ -98,6 +98,8 @@ SIGNATURES = {
     "ldm_op_group_norm_bwd_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "ldm_op_group_norm_bwd": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P, _P, C.c_int, C.c_float, C.c_int, _P, _P, _P, _P, _P, _P,
                                         C.c_int, C.c_int, _P, C.c_size_t, _P]),
+    "ldm_op_scale_intensity_percentiles_scratch_bytes": (C.c_size_t, [C.c_int]),
+    "ldm_op_scale_intensity_percentiles": (C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, _P, C.c_size_t, _P]),
     "ldm_op_im2col": (C.c_int, [_P, _P] + [C.c_int] * 10 + [_P]),
     "ldm_op_col2im": (C.c_int, [_P, _P] + [C.c_int] * 10 + [_P]),
     "ldm_op_leaky_relu": (C.c_int, [_P, _P, C.c_int64, C.c_float, _P]),

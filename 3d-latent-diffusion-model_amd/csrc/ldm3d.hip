@@ -2924,6 +2924,29 @@ int ldm_op_unpack_ndhwc(const void* act, float* out, int N, int C, int Cs, int64
     return 0;
 }
 
+/* ---- data path: ScaleIntensityRangePercentiles(lower, upper -> b_min, b_max) of the reference's loader
+ * (3d_ldm/utils.py:94-107: lower 0, upper 99.5 -> [0, 1], no clipping) per volume, on the device: B volumes of n fp32 values each.
+ * Exact order statistics (radix select), percentile = linear interpolation between the two neighbouring ranks (numpy "linear"). */
+size_t ldm_op_scale_intensity_percentiles_scratch_bytes(int B) { return (size_t)(B < 1 ? 1 : B) * (4 * 4096 * 4 + sizeof(PctState)) + 256; }
+int ldm_op_scale_intensity_percentiles(const float* x, float* out, int B, int64_t n, float lower, float upper, float b_min, float b_max,
+                                       void* scratch, size_t scratch_bytes, void* stream) {
+    if (!x || !out || !scratch || B < 1 || n < 1 || n >= (1LL << 32) || lower < 0.f || upper > 100.f || lower > upper) return fail(LDM_ERR_BAD_ARG, "bad argument");
+    if (scratch_bytes < ldm_op_scale_intensity_percentiles_scratch_bytes(B)) return fail(LDM_ERR_WORKSPACE, "scratch too small");
+    hipStream_t s = (hipStream_t)stream;
+    unsigned* hist = (unsigned*)scratch;
+    PctState* st = (PctState*)((char*)scratch + (size_t)B * 4 * 4096 * 4);
+    HIP_TRY(hipMemsetAsync(hist, 0, (size_t)B * 4 * 4096 * 4, s));
+    hipLaunchKernelGGL(pct_init_kernel, dim3((B + 63) / 64), dim3(64), 0, s, st, B, (long)n, (double)lower, (double)upper);
+    const int gx = grid_for(n, 256 * 16, 512);
+    for (int pass = 0; pass < 3; ++pass) {
+        hipLaunchKernelGGL(pct_hist_kernel, dim3(gx, B), dim3(256), 0, s, x, (long)n, (const PctState*)st, hist, pass);
+        hipLaunchKernelGGL(pct_scan_kernel, dim3(B), dim3(256), 0, s, st, hist, pass);
+    }
+    hipLaunchKernelGGL(pct_apply_kernel, dim3(grid_for(n, 256 * 4, 2048), B), dim3(256), 0, s, x, out, (long)n, (const PctState*)st, b_min, b_max);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 /* Weights of the data-gradient conv: wt[tap'][ci][co] = w[taps-1-tap'][co][ci].  w: [taps][cout_pad][cin] bf16,
  * wt: [taps][round64(cin)][round32(cout)] bf16 (device memory, caller allocated). */
 int ldm_op_weight_flip_transpose(const void* w, void* wt, int ksize, int cout, int cout_pad, int cin, void* stream) {

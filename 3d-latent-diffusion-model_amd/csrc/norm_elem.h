@@ -656,6 +656,95 @@ __global__ __launch_bounds__(256) void unpack_ndhwc_kernel(const bf16_t* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Data path: MONAI's ScaleIntensityRangePercentiles(lower, upper, b_min, b_max) of the reference's loader
+// (3d_ldm/utils.py:94-107) on the device.  The two percentiles need exact order statistics of each volume: a three-pass radix
+// select (12 + 12 + 8 bits) on the order-preserving integer image of the fp32 values, for up to four ranks at once (floor / ceil
+// index of both percentiles), integer histograms in LDS + global integer atomics (exact and order independent), then one apply pass.
+struct PctState { unsigned prefix[4]; unsigned rank[4]; float value[4]; float t[2]; int n_ranks; int pad_; };
+__device__ __forceinline__ unsigned pct_key(float f) { const unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float pct_unkey(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+// pass 0: bits 31..20, pass 1: bits 19..8 (among keys whose top 12 bits equal the rank's prefix), pass 2: bits 7..0
+__global__ __launch_bounds__(256) void pct_hist_kernel(const float* __restrict__ x, long n, const PctState* __restrict__ st, unsigned* __restrict__ hist, int pass) {
+    __shared__ unsigned h[4 * 4096];
+    const int b = blockIdx.y;
+    const PctState s = st[b];
+    const int R = pass == 0 ? 1 : s.n_ranks;             // before any prefix is known all ranks share one histogram
+    const int bins = pass == 2 ? 256 : 4096;
+    for (int i = threadIdx.x; i < R * bins; i += 256) h[i] = 0;
+    __syncthreads();
+    const float* xb = x + (size_t)b * n;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const unsigned k = pct_key(xb[i]);
+        if (pass == 0) atomicAdd(&h[k >> 20], 1u);
+        else
+            for (int r = 0; r < R; ++r) {
+                if (pass == 1) { if ((k >> 20) == s.prefix[r]) atomicAdd(&h[r * 4096 + ((k >> 8) & 4095u)], 1u); }
+                else if ((k >> 8) == s.prefix[r]) atomicAdd(&h[r * 256 + (k & 255u)], 1u);
+            }
+    }
+    __syncthreads();
+    unsigned* hb = hist + (size_t)b * 4 * 4096;
+    for (int i = threadIdx.x; i < R * bins; i += 256) { const unsigned v = h[i]; if (v) atomicAdd(&hb[(i / bins) * 4096 + (i % bins)], v); }
+}
+// one block per volume: locate each rank's bin, extend its prefix, reduce its rank to the rank inside the bin; zero the histograms
+__global__ __launch_bounds__(256) void pct_scan_kernel(PctState* __restrict__ st, unsigned* __restrict__ hist, int pass) {
+    __shared__ unsigned part[256];
+    __shared__ unsigned found_bin, found_before;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    PctState* s = st + b;
+    unsigned* hb = hist + (size_t)b * 4 * 4096;
+    const int bins = pass == 2 ? 256 : 4096, per = bins / 256;
+    const int R = s->n_ranks;
+    for (int r = 0; r < R; ++r) {
+        const unsigned* hr = hb + (pass == 0 ? 0 : r) * 4096;
+        unsigned sum = 0;
+        for (int i = 0; i < per; ++i) sum += hr[tid * per + i];
+        part[tid] = sum;
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned rank = s->rank[r];
+            unsigned cum = 0; int t = 0;
+            while (t < 255 && cum + part[t] <= rank) { cum += part[t]; ++t; }
+            int bin = t * per;
+            while (bin < t * per + per - 1 && cum + hr[bin] <= rank) { cum += hr[bin]; ++bin; }
+            found_bin = (unsigned)bin; found_before = cum;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            s->prefix[r] = pass == 0 ? found_bin : ((s->prefix[r] << (pass == 2 ? 8 : 12)) | found_bin);
+            s->rank[r] -= found_before;
+            if (pass == 2) s->value[r] = pct_unkey(s->prefix[r]);
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < 4 * 4096; i += 256) hb[i] = 0;
+}
+__global__ __launch_bounds__(256) void pct_apply_kernel(const float* __restrict__ x, float* __restrict__ out, long n, const PctState* __restrict__ st,
+                                                        float b_min, float b_max) {
+    const int b = blockIdx.y;
+    const PctState s = st[b];
+    // value[0..1] = floor / ceil order statistics of the lower percentile, value[2..3] of the upper one (n_ranks == 4 always)
+    const float a_min = (float)((double)s.value[0] + ((double)s.value[1] - (double)s.value[0]) * (double)s.t[0]);
+    const float a_max = (float)((double)s.value[2] + ((double)s.value[3] - (double)s.value[2]) * (double)s.t[1]);
+    const float d = a_max - a_min;
+    const float* xb = x + (size_t)b * n; float* ob = out + (size_t)b * n;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        ob[i] = d == 0.f ? b_min : (xb[i] - a_min) / d * (b_max - b_min) + b_min;      // MONAI ScaleIntensityRange: constant image -> b_min
+}
+__global__ void pct_init_kernel(PctState* st, int B, long n, double lower, double upper) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    PctState s{};
+    const double pl = (double)(n - 1) * lower / 100.0, pu = (double)(n - 1) * upper / 100.0;
+    const long l0 = (long)floor(pl), u0 = (long)floor(pu);
+    s.rank[0] = (unsigned)l0; s.rank[1] = (unsigned)(l0 + 1 < n ? l0 + 1 : n - 1);
+    s.rank[2] = (unsigned)u0; s.rank[3] = (unsigned)(u0 + 1 < n ? u0 + 1 : n - 1);
+    s.t[0] = (float)(pl - (double)l0); s.t[1] = (float)(pu - (double)u0);
+    s.n_ranks = 4;
+    st[b] = s;
+}
+
 __global__ __launch_bounds__(256) void scale_kernel(const float* __restrict__ x, float* __restrict__ y, long n, float s) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = x[i] * s;
 }

@@ -234,6 +234,11 @@ int ldm_op_group_norm_bwd(const void* dy, const void* xa, int ca, const void* xb
                           int groups, float eps, int silu, const void* acc_a, const void* acc_b, void* dxa, void* dxb,
                           float* dgamma, float* dbeta, int N, int DHW, void* scratch, size_t scratch_bytes, void* stream);
 /* GroupNorm(groups, eps, affine) over cat(xa, xb), optional fused SiLU -> out [N*DHW][ca+cb] bf16. */
+/* ---- data path (3d_ldm/utils.py:94-107): ScaleIntensityRangePercentiles per volume on the device (exact order statistics by radix
+ *      select, numpy "linear" interpolation); x / out: B volumes of n fp32 values ------------------------------------------------ */
+size_t ldm_op_scale_intensity_percentiles_scratch_bytes(int B);
+int ldm_op_scale_intensity_percentiles(const float* x, float* out, int B, int64_t n, float lower, float upper, float b_min, float b_max,
+                                       void* scratch, size_t scratch_bytes, void* stream);
 /* ---- PatchDiscriminator building blocks (stage-1 GAN tail, 3d_ldm/train_autoencoder.py:150-158,407-424,454-494): 4^3 strided convs as
  *      im2col + the 1x1 GEMM kernels (forward, data gradient through col2im, weight gradient through ldm_op_conv3d_wgrad with ksize 1);
  *      InstanceNorm + LeakyReLU(0.2) = ldm_op_group_norm(_bwd) with groups = C and activation code 2 (0 none, 1 SiLU, 2 LeakyReLU 0.2). */

@@ -11,6 +11,7 @@ import subprocess
 import sys
 
 import pytest
+import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
@@ -31,7 +32,7 @@ def test_train_then_conditional_sampling(tmp_path):
         json.dump(env, fh)
     _run("train_autoencoder.py", env_file, "--random-init", "--synthetic", "8", "--max-steps", "4")
     assert os.path.exists(tmp_path / "ckpt" / "autoencoder.pt")
-    log = _run("train_diffusion.py", env_file, "--random-init", "--max-steps", "6")
+    log = _run("train_diffusion.py", env_file, "--random-init", "--max-steps", "6", "--gpu-transforms")
     assert "scale_factor" in log and os.path.exists(tmp_path / "ckpt" / "diffusion_unet.pt")
     sf = json.load(open(tmp_path / "ckpt" / "scale_factor.json"))["scale_factor"]
     assert sf > 0
@@ -51,3 +52,32 @@ def test_train_then_conditional_sampling(tmp_path):
     assert struct.unpack("<i", hdr[:4])[0] == 348
     dim = struct.unpack("<8h", hdr[40:56])
     assert dim[1] == dim[2] == dim[3] and dim[1] % 4 == 0 and dim[1] >= 64
+
+
+@pytest.mark.parametrize("shape,b", [((37, 41, 29), 2), ((64, 64, 64), 1), ((144, 176, 112), 1)])
+def test_percentile_scaling_on_device_matches_the_host_transform(cuda, shape, b):
+    """ScaleIntensityRangePercentiles(0, 99.5 -> 0, 1) (3d_ldm/utils.py:94-107) on the device against the numpy restatement of
+    ldm3d.data: the order statistics are exact (radix select); the interpolated percentile differs from numpy's by its float32 index
+    arithmetic (<= 2e-5 relative), so the scaled volumes agree to ~1e-5."""
+    import numpy as np
+    from ldm3d import data
+    rng = np.random.RandomState(sum(shape))
+    vols = rng.gamma(2.0, 1.0, size=(b, *shape)).astype(np.float32)
+    vols[0, 0, 0, :5] = [-3.0, 0.0, -0.0, 1e-30, 250.0]                     # negatives, signed zeros, a denormal-ish value, an outlier
+    got = data.scale_percentiles_gpu(torch.from_numpy(vols).to(cuda)).cpu().numpy()
+    for i in range(b):
+        ref = data.scale_percentiles(vols[i])
+        assert np.abs(got[i] - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+        s = np.sort(vols[i].reshape(-1))
+        n = s.size
+        pos = (n - 1) * 0.995
+        lo = int(np.floor(pos))
+        a_max = float(s[lo]) + (float(s[min(lo + 1, n - 1)]) - float(s[lo])) * (pos - lo)          # exact float64 statement of the percentile
+        a_min = float(s[0])
+        exact = ((vols[i].astype(np.float64) - a_min) / (np.float32(a_max) - np.float32(a_min))).astype(np.float32)
+        assert np.abs(got[i] - exact).max() <= 2e-6 * max(1.0, np.abs(exact).max())
+    const = torch.full((1, 4, 4, 4), 3.0, device=cuda)
+    assert float(data.scale_percentiles_gpu(const).abs().max()) == 0.0          # constant volume -> b_min (MONAI)
+    other = data.scale_percentiles_gpu(torch.from_numpy(vols).to(cuda), 5.0, 50.0, -1.0, 1.0).cpu().numpy()
+    ref = data.scale_percentiles(vols[0], 5.0, 50.0, -1.0, 1.0)
+    assert np.abs(other[0] - ref).max() <= 5e-5 * max(1.0, np.abs(ref).max())

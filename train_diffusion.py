@@ -31,6 +31,8 @@ def main():
     parser.add_argument("--synthetic", type=int, default=0)
     parser.add_argument("--max-steps", type=int, default=0)
     parser.add_argument("--reference-rng-order", action="store_true")
+    parser.add_argument("--gpu-transforms", action="store_true",
+                        help="percentile intensity scaling on the GPU (ldm_op_scale_intensity_percentiles) instead of in the host loader")
     parser.add_argument("--grad-allreduce-dtype", default="fp32", choices=["fp32", "bf16"],
                         help="wire format of the data-parallel gradient all-reduce (the reference's DDP uses fp32)")
     args = parser.parse_args()
@@ -63,7 +65,20 @@ def main():
     if ddp:
         torch.distributed.barrier()
     train_loader, val_loader = prepare_dataloader(args, tcfg["batch_size"], tcfg["patch_size"], randcrop=False, rank=rank,
-                                                  world_size=world)
+                                                  world_size=world, scale_on_host=not args.gpu_transforms)
+    if args.gpu_transforms:                                # raw crops from the loader; the scaling runs on the device, batch by batch
+        from ldm3d.data import gpu_scale_batch
+
+        class _OnDevice:
+            def __init__(self, loader):
+                self.loader, self.sampler = loader, getattr(loader, "sampler", None)
+
+            def __iter__(self):
+                return (gpu_scale_batch(b, device) for b in self.loader)
+
+            def __len__(self):
+                return len(self.loader)
+        train_loader, val_loader = _OnDevice(train_loader), _OnDevice(val_loader)
     log = None
     if rank == 0:
         tb = os.path.join(getattr(args, "tfevent_path", os.path.join(args.model_dir, "tfevent")), "diffusion")
