@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void gn_apply_f32_kernel(const Gn32Params p) {
 // A wave owns 32 queries; per 32-key tile  S^T = K Q^T  (32x32x2 MFMA over d) lands with the query on the lane and 16 of the 32 keys
 // in the lane's registers (the other 16 in lane ^ 32), so the softmax needs one cross-lane exchange per row statistic and P feeds
 // O^T += V^T P^T  as the B operand straight from those registers (k order permuted identically on the V^T operand).
-struct Attn32Params { const float* qkv; float* out; int B, N, C, heads, d; float scale; };
+struct Attn32Params { const float* qkv; float* out; int B, N, C, heads, d; float scale; float* lse; };   // lse (optional): [B][heads][N] natural log-sum-exp of the scaled scores
 
 template <int DT>                                        // DT = d / 32
 __global__ __launch_bounds__(256) void attn_f32_kernel(const Attn32Params p) {
@@ -341,6 +341,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const Attn32Params p) {
     if (!active) return;
     const int q = q0 + wave * 32 + fr;
     if (q >= p.N) return;
+    if (p.lse && fh == 0) p.lse[((size_t)b * p.heads + head) * p.N + q] = mrow * 0.6931471805599453f + logf(lrow);
     const float inv = 1.0f / lrow;
     float* dst = p.out + ((size_t)b * p.N + q) * p.C + head * D;
 #pragma unroll
@@ -452,6 +453,7 @@ __global__ __launch_bounds__(256) void attn_f32_split_kernel(const Attn32Params 
     }
     const int q = q0 + fr;
     if (q >= p.N) return;
+    if (p.lse && fh == 0) p.lse[((size_t)b * p.heads + head) * p.N + q] = mrow * 0.6931471805599453f + logf(lrow);
     const float inv = 1.0f / lrow;
     float* dst = p.out + ((size_t)b * p.N + q) * p.C + head * D;
 #pragma unroll

@@ -28,6 +28,7 @@
 #include "conv_wgrad.h"
 #include "norm_elem.h"
 #include "f32_path.h"
+#include "f32_train.h"
 
 #ifndef CONV_STAGES
 #define CONV_STAGES 4     // depth of the conv kernel's LDS ring (prefetch distance = stages - 1 K steps)
@@ -423,7 +424,7 @@ struct Builder {
     // fp32 precision: every conv form the inference plans use on conv_f32_kernel (the 1x1 skip runs as its own conv -> residual)
     Act conv32(const ConvArgs& a, const std::string& tag) {
         const ConvW& w = *a.w;
-        if (a.w1 || a.w_over.base != BASE_NULL || train) { err = "fp32 precision: unsupported conv form (" + tag + ")"; return Act(); }
+        if (a.w1) { err = "fp32 precision: unsupported conv form (" + tag + ")"; return Act(); }
         const int cin0 = a.xa.C + (a.xb.valid ? a.xb.C : 0);
         if (cin0 != w.cin_s || cin0 % 16 || a.xa.C % 16) { err = "conv " + tag + ": channel bookkeeping mismatch"; return Act(); }
         const int N = a.xa.N;
@@ -443,7 +444,7 @@ struct Builder {
         if (!a.f32_out) out = new_act(N, a.Do, a.Ho, a.Wo, couts);
         Op op{}; op.kind = OP_CONV32; op.cc = ConvCfg{2, bn / 64, 16, sk};
         op.r[0] = ws_ref(a.xa.off); op.r[1] = a.xb.valid ? ws_ref(a.xb.off) : Ref();
-        op.r[2] = w32_ref(w.w_off);
+        op.r[2] = a.w_over.base != BASE_NULL ? a.w_over : w32_ref(w.w_off);
         op.r[6] = a.no_bias ? Ref() : w_ref(w.b_off);
         op.r[8] = a.temb; op.r[9] = a.residual.valid ? ws_ref(a.residual.off) : Ref();
         op.r[10] = a.f32_out ? a.out_ref : ws_ref(out.off);
@@ -456,6 +457,7 @@ struct Builder {
         if (sk > 1) { partial_bytes = std::max(partial_bytes, (size_t)sk * M * w.cout_pad * 4); partial_fixups.push_back(plan->ops.size()); }
         plan->ops.push_back(op);
         if (sk > 1) { Op f = op; f.kind = OP_FIN32; partial_fixups.push_back(plan->ops.size()); plan->ops.push_back(f); }
+        if (recording) { Tape t; t.kind = 0; t.c = a; t.out = out; tape.push_back(t); }
         return out;
     }
 
@@ -671,7 +673,7 @@ struct Builder {
         // inference: the 1x1 skip projection runs as a light GEMM on the side lane, concurrently with norm1 / conv1 / norm2, and
         // enters conv2 as its residual: conv2 stays a single-source 3^3 conv (halo kernel) instead of the fused two-group form
         Act sk;
-        if (cin != cout && !train && (hp || (side_lane_enabled() && cin % 128 == 0))) {
+        if (cin != cout && ((hp) || (!train && side_lane_enabled() && cin % 128 == 0))) {
             ConvArgs cs; cs.xa = xa; cs.xb = xb; cs.w = &m->convs.at(p + skip_name); cs.k = 1; cs.pad = 0;
             cs.Do = xa.D; cs.Ho = xa.H; cs.Wo = xa.W; cs.want_stats = false; cs.lane = hp ? 0 : 1; cs.sync = !hp;
             sk = conv(cs, p + skip_name);
@@ -717,7 +719,13 @@ struct Builder {
         Act o = new_act(x.N, x.D, x.H, x.W, C);
         Op at{}; at.kind = OP_ATTN32; at.r[0] = ws_ref(qkv.off); at.r[1] = ws_ref(o.off);
         at.i[0] = x.N; at.i[1] = x.D * x.H * x.W; at.i[2] = C; at.i[3] = C / head_ch; at.i[4] = head_ch; at.f[0] = 1.0f / sqrtf((float)head_ch);
+        size_t lse_off = 0;
+        if (train) {
+            if (head_ch > 64) { err = "fp32 precision: the attention backward handles head dimensions 32 and 64 (" + p + ")"; return Act(); }
+            lse_off = pool.alloc((size_t)x.N * (C / head_ch) * at.i[1] * 4); at.r[2] = ws_ref(lse_off);
+        }
         plan->ops.push_back(at);
+        if (recording) { Tape t; t.kind = 2; t.qkv = qkv; t.o = o; t.lse_off = lse_off; t.head_ch = head_ch; tape.push_back(t); }
         free_act(qkv);
         ConvArgs pr; pr.xa = o; pr.w = &m->convs.at(p + ".attn.out_proj"); pr.k = 1; pr.pad = 0;
         pr.Do = x.D; pr.Ho = x.H; pr.Wo = x.W; pr.residual = x;
@@ -775,7 +783,7 @@ struct Builder {
         if (!cur.valid) { gslot[target.off] = g; return; }
         Act sum = new_act(g.N, g.D, g.H, g.W, g.C);
         Op o{}; o.kind = OP_ADD; o.r[0] = ws_ref(cur.off); o.r[1] = ws_ref(g.off); o.r[2] = ws_ref(sum.off);
-        o.i[0] = (int)(g.rows() * g.C / 8);
+        o.i[0] = (int)(g.rows() * g.C / (hp ? 4 : 8)); o.i[1] = hp ? 1 : 0;
         plan->ops.push_back(o);
         gslot[target.off] = sum;
     }
@@ -803,7 +811,7 @@ struct Builder {
         const int cvec = C / 8, rows_par = std::max(1, 256 / cvec);
         int nslab = std::min((DHW + rows_par - 1) / rows_par, std::max(1, 512 / N));
         const int rps = (DHW + nslab - 1) / nslab; nslab = (DHW + rps - 1) / rps;
-        Op st{}; st.kind = OP_GN_STATS; st.r[0] = ws_ref(g.off);
+        Op st{}; st.kind = hp ? OP_GN_STATS32 : OP_GN_STATS; st.r[0] = ws_ref(g.off);
         st.i[0] = C; st.i[1] = 0; st.i[2] = DHW; st.i[3] = nslab; st.i[4] = rps; st.i[5] = N;
         if (colsum_batched() && out.base == BASE_WS) {
             // the partials get their own block (kept to the end of the plan) and the finalize joins ONE batched launch
@@ -843,8 +851,9 @@ struct Builder {
     // marks the range: with a communicator attached (ldm_model_set_grad_sync) its all-reduce starts there, on the comm stream, while
     // the launch stream carries on with backward (what DistributedDataParallel's bucketed hooks do: 3d_ldm/train_diffusion.py:147-149).
     int64_t bucket_hi = 0, done_from = 0;
+    int64_t tail_reserved = 0;                           // parameters below this offset are produced after the tape walk (time-embedding MLP)
     static int64_t bucket_elems() { const char* e = getenv("LDM_GRAD_BUCKET_MB"); const long mb = e ? atol(e) : 48; return (int64_t)(mb < 1 ? 1 : mb) * 262144; }
-    void note_done(int64_t flat_off) { if (flat_off < done_from) done_from = flat_off; }
+    void note_done(int64_t) {}                            // superseded by the pending_end bookkeeping of backward_all
     void close_bucket(bool force) {
         if (done_from >= bucket_hi) return;
         if (!force && bucket_hi - done_from < bucket_elems()) return;
@@ -857,7 +866,7 @@ struct Builder {
         int* i = o.i;
         i[0] = dy.C; i[1] = x.C; i[2] = cout; i[3] = cin; i[4] = ld; i[5] = ci_off; i[6] = x.N; i[7] = x.D; i[8] = x.H; i[9] = x.W;
         i[10] = dy.D; i[11] = dy.H; i[12] = dy.W; i[13] = k; i[14] = stride; i[15] = pad; i[16] = ups; i[17] = (int)dy.rows();
-        i[18] = cur_ksplit; i[19] = cur_rows_total; i[20] = cur_w3;
+        i[18] = cur_ksplit; i[19] = cur_rows_total; i[20] = cur_w3; i[21] = hp ? 1 : 0;
         plan->ops.push_back(o);
     }
     int cur_ksplit = 1, cur_rows_total = 0, cur_w3 = 0;   // voxel split / slab rows / kw-triplet kernel of the gradient being staged
@@ -866,7 +875,7 @@ struct Builder {
         if (stride == 2 && !(k == 3 && (pad == 1 || pad == 0))) { err = "backward of a stride-2 conv needs k = 3, pad 0 | 1"; return false; }
         const int taps = k * k * k;
         const int rows = rup(src.C, 64), cols = rup(w.cout, 32);
-        const size_t wt_off = pool.alloc((size_t)taps * rows * cols * 2);
+        const size_t wt_off = pool.alloc((size_t)taps * rows * cols * (hp ? 4 : 2));
         {   // transposed once per backward by the batched kernel at the head of the backward plan
             WtDesc e{}; e.src_off = (long)w.w_off; e.dst_off = (long)wt_off; e.taps = taps; e.cout = w.cout; e.cout_pad = w.cout_pad;
             e.cin = w.cin_s; e.rows = rows; e.ci_off = ci_off; e.ci_cnt = src.C; e.col_tiles = (cols + 63) / 64; e.row_tiles = rows / 64;
@@ -885,7 +894,7 @@ struct Builder {
         if (ups) {                                      // adjoint of the fused nearest x2 upsample
             Act gc = new_act(src.N, src.D, src.H, src.W, src.C);
             Op sp{}; sp.kind = OP_SUMPOOL; sp.r[0] = ws_ref(g.off); sp.r[1] = ws_ref(gc.off);
-            sp.i[0] = src.N; sp.i[1] = src.D; sp.i[2] = src.H; sp.i[3] = src.W; sp.i[4] = src.C;
+            sp.i[0] = src.N; sp.i[1] = src.D; sp.i[2] = src.H; sp.i[3] = src.W; sp.i[4] = src.C; sp.i[5] = hp ? 1 : 0;
             plan->ops.push_back(sp);
             add_grad_alias(src, gc);
         } else gslot[src.off] = g;
@@ -910,7 +919,7 @@ struct Builder {
         if (a.w1) export_bias(*a.w1);
         if (a.temb_row >= 0) emit_colsum(dout, true, ws_ref(dtemb_off + (size_t)a.temb_row * 4), w.cout, tproj_stride);
         // weights
-        cur_w3 = (a.k == 3 && a.stride == 1 && a.pad == 1 && a.ups == 0 && wgrad3_enabled()) ? 1 : 0;
+        cur_w3 = (!hp && a.k == 3 && a.stride == 1 && a.pad == 1 && a.ups == 0 && wgrad3_enabled()) ? 1 : 0;
         cur_ksplit = cur_w3 ? wgrad3_ksplit((long)dout.N * dout.D * dout.H * (dout.W + 2), w.cout, cin_real)
                             : wgrad_ksplit(dout.rows(), a.k * a.k * a.k, w.cout, cin_real);
         cur_rows_total = w.cout;
@@ -968,7 +977,7 @@ struct Builder {
         o.r[12] = ws_ref(dxa.off); o.r[13] = xb.valid ? ws_ref(dxb.off) : Ref();
         int* i = o.i;
         i[0] = xa.C; i[1] = xb.valid ? xb.C : 0; i[2] = t.groups; i[3] = DHW; i[4] = N; i[5] = t.silu ? 1 : 0; i[6] = nslab; i[7] = rps;
-        i[8] = (int)go; i[9] = (int)bo;
+        i[8] = (int)go; i[9] = (int)bo; i[10] = hp ? 1 : 0;
         gnpart_fixups.push_back(plan->ops.size()); plan->ops.push_back(o);
         gslot[xa.off] = dxa;
         if (xb.valid) gslot[xb.off] = dxb;
@@ -984,21 +993,21 @@ struct Builder {
         Op o{}; o.kind = OP_ATTN_BWD;
         o.r[0] = ws_ref(q.off); o.r[1] = ws_ref(t.o.off); o.r[2] = ws_ref(d_o.off); o.r[3] = ws_ref(t.lse_off); o.r[4] = ws_ref(delta);
         o.r[5] = ws_ref(dqkv.off);
-        o.i[0] = q.N; o.i[1] = N; o.i[2] = C; o.i[3] = t.head_ch; o.f[0] = 1.0f / sqrtf((float)t.head_ch);
+        o.i[0] = q.N; o.i[1] = N; o.i[2] = C; o.i[3] = t.head_ch; o.i[4] = hp ? 1 : 0; o.f[0] = 1.0f / sqrtf((float)t.head_ch);
         plan->ops.push_back(o);
         gslot[q.off] = dqkv;
         return true;
     }
     void emit_lin_dw(Ref dy, Ref x_pre, Ref dW, Ref db, int B, int I, int O, int dy_stride, int x_stride, int silu) {
         Op o{}; o.kind = OP_LIN_DW; o.r[0] = dy; o.r[1] = x_pre; o.r[2] = dW; o.r[3] = db;
-        o.i[0] = B; o.i[1] = I; o.i[2] = O; o.i[3] = dy_stride; o.i[4] = x_stride; o.i[5] = silu;
+        o.i[0] = B; o.i[1] = I; o.i[2] = O; o.i[3] = dy_stride; o.i[4] = x_stride; o.i[5] = silu; o.i[6] = hp ? 1 : 0;
         plan->ops.push_back(o);
     }
     void emit_lin_dx(Ref W, Ref dy, Ref x_pre, Ref dx, int B, int I, int O, int dy_stride, int x_stride, int silu) {
         const int nz = std::max(1, std::min(64, O / 64));
         const size_t part = pool.alloc((size_t)nz * B * I * 4);
         Op o{}; o.kind = OP_LIN_DX; o.r[0] = W; o.r[1] = dy; o.r[2] = x_pre; o.r[3] = dx; o.r[4] = ws_ref(part);
-        o.i[0] = B; o.i[1] = I; o.i[2] = O; o.i[3] = dy_stride; o.i[4] = x_stride; o.i[5] = silu; o.i[6] = nz;
+        o.i[0] = B; o.i[1] = I; o.i[2] = O; o.i[3] = dy_stride; o.i[4] = x_stride; o.i[5] = silu; o.i[6] = nz; o.i[7] = hp ? 1 : 0;
         plan->ops.push_back(o);
     }
     // AutoencoderKL: gradient of the fused heads conv from dz (decoder side) and the KL-term gradients (I/O 1, 2)
@@ -1017,7 +1026,27 @@ struct Builder {
     }
     // Walk the tape backwards.  `dout_final` = the packed gradient of the network output (the last conv writes fp32
     // NCDHW straight to the caller, so its gradient arrives through the I/O table).
+    int64_t entry_param_end(const Tape& t) const {       // one past the last flat offset of the parameters this tape entry differentiates
+        int64_t end = 0;
+        auto upd = [&](const ParamDesc& d) { int64_t n = 1; for (auto v : d.shape) n *= v; end = std::max(end, d.flat_off + n); };
+        if (t.kind == 0) {
+            const ConvW& w = *t.c.w; const ConvW* w1 = t.c.w1;
+            for (const ParamDesc& d : m->params) {
+                const bool mine = (d.kind == PK_CONV_W && (d.dst_off == w.w_off || (w1 && d.dst_off == w1->w_off))) ||
+                                  (d.kind == PK_VEC_F32 && ((d.dst_off >= w.b_off && d.dst_off < w.b_off + (size_t)w.cout_pad * 4) ||
+                                                            (w1 && d.dst_off >= w1->b_off && d.dst_off < w1->b_off + (size_t)w1->cout_pad * 4)));
+                if (mine) upd(d);
+            }
+        } else if (t.kind == 1) {
+            for (const ParamDesc& d : m->params) if (d.kind == PK_VEC_F32 && (d.dst_off == t.g->g_off || d.dst_off == t.g->b_off)) upd(d);
+        }
+        return end;
+    }
     bool backward_all(const Act& dout_final) {
+        // pending_end[k] = the highest parameter end among tape entries BEFORE k: once entry k has been differentiated, the flat
+        // gradient range [pending_end[k], total) is final whatever order the entries were recorded in
+        std::vector<int64_t> pending_end(tape.size() + 1, 0);
+        for (size_t k = 0; k < tape.size(); ++k) pending_end[k + 1] = std::max(pending_end[k], entry_param_end(tape[k]));
         for (size_t k = tape.size(); k-- > 0;) {
             const Tape& t = tape[k];
             bool ok = true;
@@ -1029,6 +1058,7 @@ struct Builder {
             } else if (t.kind == 1) ok = backward_gn(t);
             else ok = backward_attn(t);
             if (!ok) return false;
+            done_from = std::min(done_from, std::max(pending_end[k], tail_reserved));
             close_bucket(false);
         }
         return true;
@@ -1127,7 +1157,7 @@ static int unet_build(ldm_model* m, int B, int D, int H, int W, Plan* plan, bool
     const ldm_unet_cfg& c = m->ucfg;
     const int L = c.num_levels; const int* ch = c.channels;
     const int temb = ch[0] * 4, G = c.norm_num_groups; const float eps = c.norm_eps;
-    if (train && (hp || tap_mode)) return fail(LDM_ERR_UNSUPPORTED, "the fp32 precision mode and debug taps are inference-only");
+    if (train && tap_mode) return fail(LDM_ERR_UNSUPPORTED, "debug taps are inference-only");
     Builder b; b.m = m; b.plan = plan; b.train = train; b.recording = train; b.hp = hp; b.tap_mode = tap_mode;
     // ---- time embedding: sinusoid -> Linear -> SiLU -> Linear -> (SiLU -> stacked projections)
     const size_t sin_off = b.pool.alloc((size_t)B * ch[0] * 4);
@@ -1245,12 +1275,13 @@ static int unet_build(ldm_model* m, int B, int D, int H, int W, Plan* plan, bool
         b.recording = false;
         const int rows = m->tproj_rows;
         b.dtemb_off = b.pool.alloc(((size_t)B * rows + 256) * 4);
-        { Op o{}; o.kind = OP_WT_BATCH; plan->ops.push_back(o); }          // every flipped / transposed weight matrix, one launch
+        { Op o{}; o.kind = OP_WT_BATCH; o.i[0] = hp ? 1 : 0; plan->ops.push_back(o); }          // every flipped / transposed weight matrix, one launch
         const int cos_ = rup(c.out_channels, 32);
         Act dout = b.new_act(B, D, H, W, cos_);
-        { Op o{}; o.kind = OP_PACK; o.r[0] = io_ref(0); o.r[1] = Ref(); o.r[2] = ws_ref(dout.off);
+        { Op o{}; o.kind = hp ? OP_PACK32 : OP_PACK; o.r[0] = io_ref(0); o.r[1] = Ref(); o.r[2] = ws_ref(dout.off);
           o.i[0] = B; o.i[1] = c.out_channels; o.i[2] = cos_; o.i[3] = D * H * W; plan->ops.push_back(o); }
         b.bucket_hi = b.done_from = m->flat_total;
+        b.tail_reserved = m->params[m->pindex.at("conv_in.conv.weight")].flat_off;     // the time-embedding parameters in front of it come last
         if (!b.backward_all(dout)) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
         b.flush_colsums();                              // bias gradients and the time-embedding rows the MLP backward reads next
         // stacked projections  temb_all = Wt silu(e2) + bt
@@ -1264,12 +1295,12 @@ static int unet_build(ldm_model* m, int B, int D, int H, int W, Plan* plan, bool
                 b.emit_export(b.vec_off, 1, 1, 0, 0, (int)((d.dst_off - m->tproj_b_off) / 4), 1, d.cout, d.flat_off);
         }
         const size_t de2 = b.pool.alloc((size_t)B * temb * 4), de1 = b.pool.alloc((size_t)B * temb * 4);
-        b.emit_lin_dx(w_ref(m->tproj_w_off), dtemb, ws_ref(e2_off), ws_ref(de2), B, temb, rows, rows, temb, 1);
+        b.emit_lin_dx(hp ? w32_ref(m->tproj_w_off) : w_ref(m->tproj_w_off), dtemb, ws_ref(e2_off), ws_ref(de2), B, temb, rows, rows, temb, 1);
         auto P = [&](const char* n) { return m->params[m->pindex.at(n)].flat_off; };
         // time_embed.2: e2 = L2 silu(e1) + b2;  time_embed.0: e1 = L0 sinusoid + b0
         b.emit_lin_dw(ws_ref(de2), ws_ref(e1_off), Builder::grad_ref(P("time_embed.2.weight")), Builder::grad_ref(P("time_embed.2.bias")),
                       B, temb, temb, temb, temb, 1);
-        b.emit_lin_dx(w_ref(l2.w_off), ws_ref(de2), ws_ref(e1_off), ws_ref(de1), B, temb, temb, temb, temb, 1);
+        b.emit_lin_dx(hp ? w32_ref(l2.w_off) : w_ref(l2.w_off), ws_ref(de2), ws_ref(e1_off), ws_ref(de1), B, temb, temb, temb, temb, 1);
         b.emit_lin_dw(ws_ref(de1), ws_ref(sin_off), Builder::grad_ref(P("time_embed.0.weight")), Builder::grad_ref(P("time_embed.0.bias")),
                       B, ch[0], temb, temb, ch[0], 0);
         if (!b.err.empty()) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
@@ -1739,7 +1770,7 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                 break; }
             case OP_ATTN32: {
                 Attn32Params p{}; p.qkv = (const float*)rp(bs, o.r[0]); p.out = (float*)rp(bs, o.r[1]);
-                p.B = i[0]; p.N = i[1]; p.C = i[2]; p.heads = i[3]; p.d = i[4]; p.scale = o.f[0];
+                p.B = i[0]; p.N = i[1]; p.C = i[2]; p.heads = i[3]; p.d = i[4]; p.scale = o.f[0]; p.lse = (float*)rp(bs, o.r[2]);
                 HIP_TRY(launch_attn_f32(p, s));
                 break; }
             case OP_GEMV32: {
@@ -1859,7 +1890,11 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                                    (const bf16_t*)rp(bs, o.r[0]), (bf16_t*)rp(bs, o.r[1]), i[0], i[1], i[2], i[3], i[4], i[5], i[6]);
                 break; }
             case OP_WT_BATCH:
-                if (plan.wt_tab.nblocks)
+                if (plan.wt_tab.nblocks && i[0]) {
+                    if (!bs.p[BASE_W32]) return fail(LDM_ERR_NOT_LOADED, "fp32 precision: the fp32 weight arena is empty");
+                    hipLaunchKernelGGL(weight_flip_transpose_batched_f32_kernel, dim3(plan.wt_tab.nblocks), dim3(256), 0, s,
+                                       (const WtDesc*)plan.wt_tab.descs, (const int2*)plan.wt_tab.map, (const char*)bs.p[BASE_W32], bs.p[BASE_WS]);
+                } else if (plan.wt_tab.nblocks)
                     hipLaunchKernelGGL(weight_flip_transpose_batched_kernel, dim3(plan.wt_tab.nblocks), dim3(256), 0, s,
                                        (const WtDesc*)plan.wt_tab.descs, (const int2*)plan.wt_tab.map, (const char*)bs.p[BASE_W], bs.p[BASE_WS]);
                 break;
@@ -1882,6 +1917,16 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                 if (lanes.sync) LDM_TRY(grad_sync_join(*lanes.sync, s));
                 break;
             case OP_WGRAD: {
+                if (i[21]) {                 // fp32 precision
+                    Wgrad32Params q{}; q.dy = (const float*)rp(bs, o.r[0]); q.cdy = i[0]; q.x = (const float*)rp(bs, o.r[1]); q.cx = i[1];
+                    q.dw = (float*)rp(bs, o.r[2]); q.Cout = i[2]; q.Cin = i[3]; q.dw_ld = i[4]; q.dw_ci_off = i[5];
+                    q.N = i[6]; q.Din = i[7]; q.Hin = i[8]; q.Win = i[9]; q.Dout = i[10]; q.Hout = i[11]; q.Wout = i[12];
+                    q.ksize = i[13]; q.stride = i[14]; q.pad = i[15]; q.ups = i[16]; q.M = i[17];
+                    q.co_tiles = (q.Cout + 127) / 128; q.ci_tiles = (q.Cin + 127) / 128; q.ksplit = i[18];
+                    q.slab_stride = (long)i[13] * i[13] * i[13] * i[19] * i[4];
+                    hipLaunchKernelGGL(wgrad_f32_kernel, dim3(q.co_tiles * q.ci_tiles * i[13] * i[13] * i[13] * q.ksplit), dim3(256), 0, s, q);
+                    break;
+                }
                 WgradParams p{}; p.dy = (const bf16_t*)rp(bs, o.r[0]); p.cdy = i[0]; p.x = (const bf16_t*)rp(bs, o.r[1]); p.cx = i[1];
                 p.dw = (float*)rp(bs, o.r[2]); p.Cout = i[2]; p.Cin = i[3]; p.dw_ld = i[4]; p.dw_ci_off = i[5];
                 p.N = i[6]; p.Din = i[7]; p.Hin = i[8]; p.Win = i[9]; p.Dout = i[10]; p.Hout = i[11]; p.Wout = i[12];
@@ -1911,6 +1956,27 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                                    (float*)rp(bs, o.r[0]), i[0], i[1], i[2], i[3], i[4], i[5]);
                 break; }
             case OP_GNB: {
+                if (i[10]) {                 // fp32 precision: stats and apply on fp32 tensors, the fold kernel is type agnostic
+                    float* flat = (float*)bs.p[BASE_IO4];
+                    if (!flat) return fail(LDM_ERR_BAD_ARG, "backward without a gradient buffer");
+                    const int C = i[0] + i[1];
+                    Gnb32Params q{}; q.dy = (const float*)rp(bs, o.r[0]); q.xa = (const float*)rp(bs, o.r[1]); q.xb = (const float*)rp(bs, o.r[2]);
+                    q.ca = i[0]; q.cb = i[1]; q.ab = (const float*)rp(bs, o.r[3]); q.mr = (const float*)rp(bs, o.r[5]); q.gamma = (const float*)rp(bs, o.r[6]);
+                    q.groups = i[2]; q.DHW = i[3]; q.N = i[4]; q.silu = i[5]; q.nslab = i[6]; q.rows_per_slab = i[7];
+                    q.partial = (float*)rp(bs, o.r[4]); q.gsum = (const float*)rp(bs, o.r[7]);
+                    q.acc_a = (const float*)rp(bs, o.r[10]); q.acc_b = (const float*)rp(bs, o.r[11]); q.dxa = (float*)rp(bs, o.r[12]); q.dxb = (float*)rp(bs, o.r[13]);
+                    GnBwdParams f{}; f.ca = i[0]; f.cb = i[1]; f.gamma = q.gamma; f.groups = i[2]; f.DHW = i[3]; f.N = i[4]; f.nslab = i[6];
+                    f.partial = q.partial; f.gsum = (float*)rp(bs, o.r[7]); f.dgamma_n = (float*)rp(bs, o.r[8]); f.dbeta_n = (float*)rp(bs, o.r[9]);
+                    if (i[4] == 1) { f.dgamma_n = flat + i[8]; f.dbeta_n = flat + i[9]; }
+                    hipLaunchKernelGGL(gnb32_stats_kernel, dim3(i[6], i[4]), dim3(256), 0, s, q);
+                    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(i[2], i[4]), dim3(256), 0, s, f);
+                    hipLaunchKernelGGL(gnb32_apply_kernel, dim3(grid_for((long)i[4] * i[3] * (C / 4), 256, 4096)), dim3(256), 0, s, q);
+                    if (i[4] > 1) {
+                        hipLaunchKernelGGL(rowsum_n_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)f.dgamma_n, flat + i[8], i[4], C);
+                        hipLaunchKernelGGL(rowsum_n_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)f.dbeta_n, flat + i[9], i[4], C);
+                    }
+                    break;
+                }
                 GnBwdParams p{}; p.dy = (const bf16_t*)rp(bs, o.r[0]); p.xa = (const bf16_t*)rp(bs, o.r[1]); p.xb = (const bf16_t*)rp(bs, o.r[2]);
                 p.ca = i[0]; p.cb = i[1]; p.ab = (const float*)rp(bs, o.r[3]); p.mr = (const float*)rp(bs, o.r[5]);
                 p.gamma = (const float*)rp(bs, o.r[6]); p.groups = i[2]; p.DHW = i[3]; p.N = i[4]; p.silu = i[5]; p.nslab = i[6];
@@ -1931,20 +1997,40 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                 }
                 break; }
             case OP_ATTN_BWD: {
+                if (i[4]) {                  // fp32 precision
+                    Attn32BwdParams q{}; q.qkv = (const float*)rp(bs, o.r[0]); q.o = (const float*)rp(bs, o.r[1]); q.d_o = (const float*)rp(bs, o.r[2]);
+                    q.lse = (const float*)rp(bs, o.r[3]); q.delta = (float*)rp(bs, o.r[4]); q.dqkv = (float*)rp(bs, o.r[5]);
+                    q.B = i[0]; q.N = i[1]; q.C = i[2]; q.d = i[3]; q.heads = i[2] / i[3]; q.scale = o.f[0];
+                    HIP_TRY(launch_attn32_bwd(q, s));
+                    break;
+                }
                 AttnBwdParams p{}; p.qkv = (const bf16_t*)rp(bs, o.r[0]); p.o = (const bf16_t*)rp(bs, o.r[1]); p.d_o = (const bf16_t*)rp(bs, o.r[2]);
                 p.lse = (const float*)rp(bs, o.r[3]); p.delta = (float*)rp(bs, o.r[4]); p.dqkv = (bf16_t*)rp(bs, o.r[5]);
                 p.B = i[0]; p.N = i[1]; p.C = i[2]; p.d = i[3]; p.heads = i[2] / i[3]; p.scale = o.f[0];
                 HIP_TRY(launch_attn_bwd(p, s));
                 break; }
             case OP_ADD:
+                if (i[1]) { hipLaunchKernelGGL(add_f32_kernel, dim3(grid_for(i[0], 256, 4096)), dim3(256), 0, s, (const float*)rp(bs, o.r[0]),
+                                               (const float*)rp(bs, o.r[1]), (float*)rp(bs, o.r[2]), (long)i[0]); break; }
                 hipLaunchKernelGGL(add_bf16_kernel, dim3(grid_for(i[0], 256, 2048)), dim3(256), 0, s, (const bf16_t*)rp(bs, o.r[0]),
                                    (const bf16_t*)rp(bs, o.r[1]), (bf16_t*)rp(bs, o.r[2]), (long)i[0]);
                 break;
             case OP_SUMPOOL:
+                if (i[5]) { hipLaunchKernelGGL(sumpool2_f32_kernel, dim3(grid_for((long)i[0] * i[1] * i[2] * i[3] * (i[4] / 4), 256, 4096)), dim3(256), 0, s,
+                                               (const float*)rp(bs, o.r[0]), (float*)rp(bs, o.r[1]), i[0], i[1], i[2], i[3], i[4]); break; }
                 hipLaunchKernelGGL(sumpool2_kernel, dim3(grid_for((long)i[0] * i[1] * i[2] * i[3] * (i[4] / 8), 256, 2048)), dim3(256), 0, s,
                                    (const bf16_t*)rp(bs, o.r[0]), (bf16_t*)rp(bs, o.r[1]), i[0], i[1], i[2], i[3], i[4]);
                 break;
-            case OP_LIN_DX: {       // i: B, I, O, dy_stride, x_stride, silu, nz
+            case OP_LIN_DX: {       // i: B, I, O, dy_stride, x_stride, silu, nz, fp32 weights
+                if (i[7]) {
+                    const float* w = (const float*)rp(bs, o.r[0]);
+                    if (!w) return fail(LDM_ERR_NOT_LOADED, "fp32 precision: the fp32 weight arena is empty");
+                    hipLaunchKernelGGL(linear_bwd_dx_part_f32w_kernel, dim3((i[1] + 255) / 256, i[0], i[6]), dim3(256), 0, s, w,
+                                       (const float*)rp(bs, o.r[1]), (float*)rp(bs, o.r[4]), i[1], i[2], i[3], i[0]);
+                    hipLaunchKernelGGL(linear_bwd_dx_fold_f32_kernel, dim3((i[1] + 255) / 256, i[0]), dim3(256), 0, s, (const float*)rp(bs, o.r[4]),
+                                       (const float*)rp(bs, o.r[2]), (float*)rp(bs, o.r[3]), i[1], i[6], i[4], i[0], i[5]);
+                    break;
+                }
                 hipLaunchKernelGGL(linear_bwd_dx_part_kernel, dim3((i[1] + 255) / 256, i[0], i[6]), dim3(256), 0, s, (const bf16_t*)rp(bs, o.r[0]),
                                    (const float*)rp(bs, o.r[1]), (float*)rp(bs, o.r[4]), i[1], i[2], i[3], i[0]);
                 hipLaunchKernelGGL(linear_bwd_dx_fold_kernel, dim3((i[1] + 255) / 256, i[0]), dim3(256), 0, s, (const float*)rp(bs, o.r[4]),
@@ -1956,7 +2042,10 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                                    (const float*)rp(bs, o.r[1]), (const float*)rp(bs, o.r[2]), (const float*)rp(bs, o.r[3]),
                                    (const float*)rp(bs, o.r[6]), (bf16_t*)rp(bs, o.r[7]), i[0], i[1], i[2], i[3]);
                 break; }
-            case OP_LIN_DW:         // i: B, I, O, dy_stride, x_stride, silu
+            case OP_LIN_DW:         // i: B, I, O, dy_stride, x_stride, silu, fp32 precision
+                if (i[6]) { hipLaunchKernelGGL(linear_bwd_dw_f32_kernel, dim3(grid_for((long)i[2] * i[1], 256, 1 << 24)), dim3(256), 0, s,
+                                               (const float*)rp(bs, o.r[0]), (const float*)rp(bs, o.r[1]), (float*)rp(bs, o.r[2]), (float*)rp(bs, o.r[3]),
+                                               i[0], i[1], i[2], i[3], i[4], i[5]); break; }
                 hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3(grid_for((long)i[2] * i[1], 256, 1 << 24)), dim3(256), 0, s,
                                    (const float*)rp(bs, o.r[0]), (const float*)rp(bs, o.r[1]), (float*)rp(bs, o.r[2]), (float*)rp(bs, o.r[3]),
                                    i[0], i[1], i[2], i[3], i[4], i[5]);
@@ -2130,7 +2219,8 @@ static int get_plan(ldm_model* m, const char* kind, int B, int D, int H, int W, 
     if (B < 1 || D < 1 || H < 1 || W < 1 || D > 255 * 8 || H > 255 * 8 || W > 255 * 8) return fail(LDM_ERR_BAD_ARG, "bad shape");
     const bool train = kind[0] == 't';
     const bool hp = m->precision == 1;
-    if (train && hp) return fail(LDM_ERR_UNSUPPORTED, "the fp32 precision mode is inference-only (training runs the bf16 plans)");
+    if (train && hp && m->type != 0)
+        return fail(LDM_ERR_UNSUPPORTED, "the fp32 precision mode trains the DiffusionModelUNet only (the AutoencoderKL training plans are bf16; its inference plans have both)");
     char key[96]; snprintf(key, sizeof key, "%s:%d:%d:%d:%d:p%d:t%d", kind, B, D, H, W, hp ? 1 : 0, tap_mode);
     auto it = m->plans.find(key);
     if (it != m->plans.end()) { *out = it->second; return 0; }

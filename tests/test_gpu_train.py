@@ -110,6 +110,57 @@ def test_unit_gain_gradients_sit_on_the_bf16_floor(cuda):
     assert cos_gpu >= cos_bf - 0.1
 
 
+@pytest.mark.parametrize("name,dims,b,cond", [("UNET_TINY", (8, 8, 8), 2, 0), ("UNET_TINY_ALT", (6, 10, 8), 1, 0),
+                                              ("UNET_TINY_COND", (8, 12, 4), 2, 4), ("UNET_TINY_HEAD32", (8, 8, 8), 1, 0)])
+def test_fp32_mode_gradients_match_the_fp32_reference_at_unit_gain(cuda, name, dims, b, cond):
+    """The reference trains in fp32 (3d_ldm/train_diffusion.py:177: autocast off).  set_precision("fp32") runs the training plans on
+    fp32 activations / weights and the fp32 matrix instruction (csrc/f32_train.h): at UNIT weight gain, where the bf16 plans sit on a
+    0.4 rounding floor, every parameter gradient agrees with torch autograd through the fp32 CPU oracle to 1e-3 (measured ~1e-5),
+    and so does one clip + Adam step."""
+    from ldm3d.networks import DiffusionModelUNet
+    from ldm3d.optim import FlatAdam
+    from oracle import unet as ou
+    cfg = getattr(cfgs, name)
+    sd = ou.init_state_dict(ou.unet_param_shapes(cfg), 3, gain=1.0)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn((b, cfg["in_channels"], *dims), generator=g)
+    target = torch.randn((b, cfg["out_channels"], *dims), generator=g)
+    t = torch.tensor([211.0, 640.0][:b])
+    out32, loss32, g32 = _oracle_grads(sd, cfg, x, t, target, False)
+    m = DiffusionModelUNet(**cfg)
+    m.load_state_dict(sd)
+    m = m.to(cuda).train().set_precision("fp32")
+    opt = FlatAdam(m, lr=1e-3, max_grad_norm=1.0)
+    xd = x.to(cuda)
+    if cond:
+        out = m(x=xd[:, :-cond].contiguous(), timesteps=t.to(cuda), cond=xd[:, -cond:].contiguous())
+    else:
+        out = m(x=xd, timesteps=t.to(cuda))
+    loss = F.mse_loss(out.float(), target.to(cuda))
+    loss.backward()
+    torch.cuda.synchronize()
+    names = list(sd.keys())
+    got = {k: p.grad.clone() for k, p in m.named_parameters()}
+    assert rel_l2(out.detach().cpu(), out32) <= 1e-4 and abs(float(loss) - loss32) <= 1e-5 * abs(loss32)
+    e_all = rel_l2(_cat(got, names), _cat(g32, names))
+    worst = max(((rel_l2(got[n], g32[n]), n) for n in names if g32[n].norm() > 1e-4 * _cat(g32, names).norm()), default=(0.0, ""))
+    print(f"{name} fp32 mode, unit gain: loss {float(loss):.6f} / oracle {loss32:.6f}; gradients vs fp32 autograd {e_all:.2e}, "
+          f"worst tensor {worst[0]:.2e} ({worst[1]})")
+    assert e_all <= 1e-3 and worst[0] <= 1e-3
+    # one optimizer step: clip_grad_norm_(1.0) + Adam against torch on the oracle's gradients
+    params = [sd[n].clone().requires_grad_(True) for n in names]
+    for p_, n in zip(params, names):
+        p_.grad = g32[n].clone()
+    topt = torch.optim.Adam(params, lr=1e-3)
+    torch.nn.utils.clip_grad_norm_(params, 1.0)
+    topt.step()
+    opt.step()
+    new = dict(m.named_parameters())
+    upd = torch.cat([(new[n].detach().cpu() - sd[n]).reshape(-1) for n in names])
+    ref = torch.cat([(p_.detach() - sd[n]).reshape(-1) for p_, n in zip(params, names)])
+    assert rel_l2(upd, ref) <= 5e-3                            # the first Adam step is ~ lr * sign(g): elements with |g| at the 1e-5 noise level may flip
+
+
 def test_backward_requires_matching_forward(cuda):
     from ldm3d import _lib
     from ldm3d.networks import DiffusionModelUNet
