@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cond", type=int, default=0, help="extra concat-conditioning channels (mode='concat')")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"], help="fp32: the reference's own training arithmetic (csrc/f32_train.h)")
     args = ap.parse_args()
 
     import torch
@@ -46,7 +47,7 @@ def main():
         for name, p in m.named_parameters():
             if p.dim() > 1:
                 p.copy_(torch.randn(p.shape, generator=g) * (0.5 / p[0].numel() ** 0.5))
-    m = m.to(dev).train()
+    m = m.to(dev).train().set_precision(args.precision)
     opt = FlatAdam(m, lr=5e-6, max_grad_norm=1.0)
     sync = GradSync()
     sync.broadcast(m.flat_params)
