@@ -639,14 +639,15 @@ struct FinalizeParams {
     bf16_t* out; float* out_f32; float* stats;
 };
 
+// The body is shared with fin_gn_kernel (fin_gn.h: slab fold + GroupNorm in one launch): bx / by = the block's 32-row granule and
+// 64-channel slice; o_keep returns the thread's packed bf16 output (row bx * 32 + tid / 8, channels by * 64 + (tid & 7) * 8 ...).
 template <bool WT>
-__global__ __launch_bounds__(256) void splitk_finalize_kernel(const FinalizeParams p) {
-    // block = 32 rows (blockIdx.x) x 64 channels (blockIdx.y); thread = one row x 8 channels
-    __shared__ float red[4][8][16];
+__device__ __forceinline__ void splitk_finalize_body(const FinalizeParams& p, const int bx, const int by, float (*red)[8][16], u32x4& o_keep) {
+    // block = 32 rows (bx) x 64 channels (by); thread = one row x 8 channels
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cv = tid & 7, rl = tid >> 3;
-    const int c = blockIdx.y * 64 + cv * 8;
-    const int m = blockIdx.x * 32 + rl;
+    const int c = by * 64 + cv * 8;
+    const int m = bx * 32 + rl;
     const bool do_stats = p.stats != nullptr && p.out != nullptr;
     float ss[8], sq[8];
 #pragma unroll
@@ -727,6 +728,7 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const FinalizePara
                 ss[2 * q] = lo; sq[2 * q] = lo * lo; ss[2 * q + 1] = hi; sq[2 * q + 1] = hi * hi;
             }
             store16<WT>(p.out + (size_t)m * p.CoutS + c, o);
+            o_keep = o;
         }
     }
     if (do_stats) {     // fold the 32 rows: 8 row lanes per wave by shuffles (lane = row*8 + cv), 4 waves through LDS
@@ -741,7 +743,7 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const FinalizePara
         }
         __syncthreads();
         if (tid < 8 && c < p.CoutS) {
-            float* dst = p.stats + ((size_t)blockIdx.x * p.CoutS + c) * 2;
+            float* dst = p.stats + ((size_t)bx * p.CoutS + c) * 2;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 dst[2 * q] = red[0][tid][q] + red[1][tid][q] + red[2][tid][q] + red[3][tid][q];
@@ -749,4 +751,11 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const FinalizePara
             }
         }
     }
+}
+
+template <bool WT>
+__global__ __launch_bounds__(256) void splitk_finalize_kernel(const FinalizeParams p) {
+    __shared__ float red[4][8][16];
+    u32x4 o;
+    splitk_finalize_body<WT>(p, blockIdx.x, blockIdx.y, red, o);
 }

@@ -240,40 +240,16 @@ struct GnFusedParams {
     float* ab; float* mr;                              // optional (training): [N][C][2] scale/shift, [N][G][2] mean/rstd
 };
 
-template <bool WT>
-__global__ __launch_bounds__(256) void gn_fused_apply_kernel(const GnFusedParams p) {
-    __shared__ __attribute__((aligned(16))) float part[8][96][4];
-    __shared__ double csum[192][2];
-    __shared__ float gstat[64][2];
-    const int tid = threadIdx.x, n = blockIdx.z;
-    const int C = p.ca + p.cb, cpg = C / p.groups;     // host guarantees cpg <= 64
-    const int c0 = blockIdx.y * 64;
+// Slab fold of gn_fused_apply_kernel / fin_gn_kernel: sums the partial (sum, sum of squares) rows of the channels that cover the block's
+// 64-channel slice `by` of sample n and leaves mean / rstd of those groups in gstat[g - g_lo].  Fixed summation order (reproducible).
+__device__ __forceinline__ void gn_fused_fold(const GnFusedParams& p, const int n, const int by, const bool first_block,
+                                              float (*part)[96][4], double (*csum)[2], float (*gstat)[2]) {
+    const int tid = threadIdx.x;
+    const int C = p.ca + p.cb, cpg = C / p.groups;
+    const int c0 = by * 64;
     int c1 = c0 + 64; if (c1 > C) c1 = C;
     const int g_lo = c0 / cpg, g_hi = (c1 + cpg - 1) / cpg;
     const int cov_lo = g_lo * cpg, ncov = g_hi * cpg - cov_lo;           // <= 64 + 2 * 63
-    // ---- the block's first rows are requested before the fold, so that their latency overlaps it
-    //      apply mapping: thread = (8-channel vector of the slice, row lane)
-    constexpr int PF = 8;
-    const int vec = tid & 7, rl = tid >> 3;
-    const int c = c0 + vec * 8;
-    const bool active = c < C;
-    const bool second_x = c >= p.ca;
-    const bf16_t* src = second_x ? p.xb : p.xa;
-    const int xcs = second_x ? p.cb : p.ca, xcl = second_x ? c - p.ca : c;
-    const int r0 = blockIdx.x * p.rows_per_block;
-    int r1 = r0 + p.rows_per_block; if (r1 > p.DHW) r1 = p.DHW;
-    u32x4 v[PF];
-    float4 gam[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)}, bet[2] = {gam[0], gam[0]};
-    if (active) {
-#pragma unroll
-        for (int k = 0; k < PF; ++k) {
-            int r = r0 + rl + 32 * k; if (r >= r1) r = r1 - 1;          // clamped: unconditional loads stay in flight together
-            v[k] = *reinterpret_cast<const u32x4*>(src + ((size_t)n * p.DHW + r) * xcs + xcl);
-        }
-        gam[0] = *reinterpret_cast<const float4*>(p.gamma + c); gam[1] = *reinterpret_cast<const float4*>(p.gamma + c + 4);
-        bet[0] = *reinterpret_cast<const float4*>(p.beta + c); bet[1] = *reinterpret_cast<const float4*>(p.beta + c + 4);
-    }
-    // ---- fold the slabs (fixed order: reproducible)
     if (((cpg | p.ca) & 1) == 0) {
         // thread = (channel pair of the cover, one of 8 slab lanes); 16 slab rows in flight per thread
         const int bl = tid >> 5;
@@ -339,11 +315,45 @@ __global__ __launch_bounds__(256) void gn_fused_apply_kernel(const GnFusedParams
         double var = q / cnt - mean * mean; if (var < 0.0) var = 0.0;
         const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
         gstat[tid][0] = (float)mean; gstat[tid][1] = rstd;
-        if (p.mr && blockIdx.x == 0) {
+        if (p.mr && first_block) {
             p.mr[((size_t)n * p.groups + g_lo + tid) * 2] = (float)mean; p.mr[((size_t)n * p.groups + g_lo + tid) * 2 + 1] = rstd;
         }
     }
     __syncthreads();
+}
+
+template <bool WT>
+__global__ __launch_bounds__(256) void gn_fused_apply_kernel(const GnFusedParams p) {
+    __shared__ __attribute__((aligned(16))) float part[8][96][4];
+    __shared__ double csum[192][2];
+    __shared__ float gstat[64][2];
+    const int tid = threadIdx.x, n = blockIdx.z;
+    const int C = p.ca + p.cb, cpg = C / p.groups;     // host guarantees cpg <= 64
+    const int c0 = blockIdx.y * 64;
+    const int g_lo = c0 / cpg;
+    // ---- the block's first rows are requested before the fold, so that their latency overlaps it
+    //      apply mapping: thread = (8-channel vector of the slice, row lane)
+    constexpr int PF = 8;
+    const int vec = tid & 7, rl = tid >> 3;
+    const int c = c0 + vec * 8;
+    const bool active = c < C;
+    const bool second_x = c >= p.ca;
+    const bf16_t* src = second_x ? p.xb : p.xa;
+    const int xcs = second_x ? p.cb : p.ca, xcl = second_x ? c - p.ca : c;
+    const int r0 = blockIdx.x * p.rows_per_block;
+    int r1 = r0 + p.rows_per_block; if (r1 > p.DHW) r1 = p.DHW;
+    u32x4 v[PF];
+    float4 gam[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)}, bet[2] = {gam[0], gam[0]};
+    if (active) {
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            int r = r0 + rl + 32 * k; if (r >= r1) r = r1 - 1;          // clamped: unconditional loads stay in flight together
+            v[k] = *reinterpret_cast<const u32x4*>(src + ((size_t)n * p.DHW + r) * xcs + xcl);
+        }
+        gam[0] = *reinterpret_cast<const float4*>(p.gamma + c); gam[1] = *reinterpret_cast<const float4*>(p.gamma + c + 4);
+        bet[0] = *reinterpret_cast<const float4*>(p.beta + c); bet[1] = *reinterpret_cast<const float4*>(p.beta + c + 4);
+    }
+    gn_fused_fold(p, n, blockIdx.y, blockIdx.x == 0, part, csum, gstat);
     // ---- apply
     if (!active) return;
     float a[8], b[8];

@@ -205,3 +205,26 @@ def test_state_dict_emits_monai_core_names_and_loads_legacy_checkpoints(built_li
         assert torch.equal(m.state_dict()[next(iter(sd))], sd[next(iter(sd))] + 1)
         with pytest.raises(RuntimeError):
             m.load_state_dict({k.replace("norm1", "norm_one"): v for k, v in sd.items()})
+
+
+def test_headline_plan_launch_count(built_lib, monkeypatch):
+    """Plans are host-side objects: the launch count of the headline step (BASELINE configs[2]) is checked without a GPU.  With
+    LDM_FIN_GN=1 every split-K conv that a GroupNorm directly follows folds and normalises in one launch (csrc/fin_gn.h: an experiment
+    that measured slower than the two launches and is therefore opt-in)."""
+    import ctypes as C
+    from ldm3d import _lib
+    from ldm3d.networks import DiffusionModelUNet
+    L = _lib.lib()
+    counts = {}
+    for knob in ("1", "0", None):
+        if knob is None:
+            monkeypatch.delenv("LDM_FIN_GN", raising=False)
+        else:
+            monkeypatch.setenv("LDM_FIN_GN", knob)
+        m = DiffusionModelUNet(**cfgs.UNET_FULL)
+        f = C.c_int(0)
+        n = L.ldm_model_plan_launches(m._h, b"unet", 1, 24, 24, 24, C.byref(f))
+        counts[knob] = (n, f.value)
+    assert counts[None] == counts["0"] and counts["0"][1] == 0 and counts["1"][1] >= 20
+    assert counts["0"][0] - counts["1"][0] == counts["1"][1]
+    assert counts["0"][0] <= 155 and counts["1"][0] <= 130, counts
