@@ -434,12 +434,16 @@ struct Builder {
         const long M = (long)N * a.Do * a.Ho * a.Wo;
         if (M >= (1L << 31)) { err = "conv " + tag + ": M too large"; return Act(); }
         const int taps = a.k * a.k * a.k, nchunk = cin0 / 16, steps = taps * nchunk;
-        const int bn = (w.cout_pad % 128) ? 64 : 128;    // 64-wide tiles where 128 would idle half of the MFMA rows
-        const int mtiles = (int)((M + 127) / 128), ntiles = (w.cout_pad + bn - 1) / bn;
+        static const int f32_bn = [] { const char* e = getenv("LDM_F32_BN"); return e ? atoi(e) : 0; }();        // tuning knobs
+        static const int f32_wgs = [] { const char* e = getenv("LDM_F32_WGS"); return e ? atoi(e) : 512; }();   // two workgroups per CU: 66 -> 73 TFLOP/s over the step
+        const int mtiles = (int)((M + 127) / 128);
+        int bn = (w.cout_pad % 128) ? 64 : 128;          // 64-wide tiles where 128 would idle half of the MFMA rows
+        if (f32_bn == 64 || (f32_bn == 1 && (long)mtiles * (w.cout_pad / 128) < 256)) bn = 64;
+        const int ntiles = (w.cout_pad + bn - 1) / bn;
         const long tiles = (long)mtiles * ntiles;
         int sk = 1;
-        if (tiles < 192) {                               // fill the 256 CUs: K split into deterministic fp32 slabs
-            sk = (int)std::min<long>(std::max<long>(1, 256 / tiles), std::max(1, steps / 8));
+        if (tiles < f32_wgs * 3 / 4) {                   // fill the CUs: K split into deterministic fp32 slabs
+            sk = (int)std::min<long>(std::max<long>(1, f32_wgs / tiles), std::max(1, steps / 8));
             const int sps = (steps + sk - 1) / sk; sk = (steps + sps - 1) / sps;
         }
         const int couts = a.f32_out ? 0 : rup(w.cout, 32);
