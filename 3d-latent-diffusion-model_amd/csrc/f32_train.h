@@ -243,23 +243,25 @@ __device__ __forceinline__ void attn32_load_tile(float* dst, const float* src, s
         float* d = dst + row * (D + 1) + c4; d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
 }
-template <int DT>
-__global__ __launch_bounds__(256) void attn32_bwd_dq_kernel(const Attn32BwdParams p) {
-    constexpr int D = DT * 32, LDQ = D + 1;
+// NW = waves per workgroup (each owns 32 queries / keys): 4 for d <= 64, 2 for d = 128, 1 for d = 256 (the AutoencoderKL's single-head blocks),
+// so that the row images stay inside the 160 KiB LDS
+template <int DT, int NW>
+__global__ __launch_bounds__(64 * NW) void attn32_bwd_dq_kernel(const Attn32BwdParams p) {
+    constexpr int D = DT * 32, LDQ = D + 1, NT = 64 * NW, ROWS = 32 * NW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* sQ = reinterpret_cast<float*>(smem);            // [4 waves * 32][LDQ]  Q rows of the workgroup's 128 queries
-    float* sO = sQ + 128 * LDQ;                            // dO rows
-    float* sK = sO + 128 * LDQ;                            // [32][LDQ] key tile
+    float* sQ = reinterpret_cast<float*>(smem);            // [NW waves * 32][LDQ]  Q rows of the workgroup's queries
+    float* sO = sQ + ROWS * LDQ;                           // dO rows
+    float* sK = sO + ROWS * LDQ;                           // [32][LDQ] key tile
     float* sV = sK + 32 * LDQ;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 31, fh = lane >> 5;
-    const int b = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * 128;
+    const int b = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * ROWS;
     const int C3 = 3 * p.C;
     const float* base = p.qkv + (size_t)b * p.N * C3 + head * D;
     const float* dob = p.d_o + (size_t)b * p.N * p.C + head * D;
-    for (int w = 0; w < 4; ++w) {
-        attn32_load_tile<D>(sQ + w * 32 * LDQ, base, C3, q0 + w * 32, p.N, tid, 256);
-        attn32_load_tile<D>(sO + w * 32 * LDQ, dob, p.C, q0 + w * 32, p.N, tid, 256);
+    for (int w = 0; w < NW; ++w) {
+        attn32_load_tile<D>(sQ + w * 32 * LDQ, base, C3, q0 + w * 32, p.N, tid, NT);
+        attn32_load_tile<D>(sO + w * 32 * LDQ, dob, p.C, q0 + w * 32, p.N, tid, NT);
     }
     int qi = q0 + wave * 32 + fr; const bool qok = qi < p.N; if (!qok) qi = p.N - 1;
     const float lse = p.lse[((size_t)b * p.heads + head) * p.N + qi];
@@ -271,8 +273,8 @@ __global__ __launch_bounds__(256) void attn32_bwd_dq_kernel(const Attn32BwdParam
         for (int r = 0; r < 16; ++r) dq[t][r] = 0.f;
     for (int k0 = 0; k0 < p.N; k0 += 32) {
         __syncthreads();
-        attn32_load_tile<D>(sK, base + p.C, C3, k0, p.N, tid, 256);
-        attn32_load_tile<D>(sV, base + 2 * p.C, C3, k0, p.N, tid, 256);
+        attn32_load_tile<D>(sK, base + p.C, C3, k0, p.N, tid, NT);
+        attn32_load_tile<D>(sV, base + 2 * p.C, C3, k0, p.N, tid, NT);
         __syncthreads();
         f32x16 s, dp;
 #pragma unroll
@@ -307,24 +309,24 @@ __global__ __launch_bounds__(256) void attn32_bwd_dq_kernel(const Attn32BwdParam
             *reinterpret_cast<float4*>(dst + 32 * t + 8 * g + 4 * fh) =
                 make_float4(dq[t][4 * g] * p.scale, dq[t][4 * g + 1] * p.scale, dq[t][4 * g + 2] * p.scale, dq[t][4 * g + 3] * p.scale);
 }
-template <int DT>
-__global__ __launch_bounds__(256) void attn32_bwd_dkv_kernel(const Attn32BwdParams p) {
-    constexpr int D = DT * 32, LDQ = D + 1;
+template <int DT, int NW>
+__global__ __launch_bounds__(64 * NW) void attn32_bwd_dkv_kernel(const Attn32BwdParams p) {
+    constexpr int D = DT * 32, LDQ = D + 1, NT = 64 * NW, ROWS = 32 * NW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* sK = reinterpret_cast<float*>(smem);            // [128][LDQ] K rows of the workgroup's 128 keys
-    float* sV = sK + 128 * LDQ;
-    float* sQ = sV + 128 * LDQ;                            // [32][LDQ] query tile
+    float* sK = reinterpret_cast<float*>(smem);            // [NW * 32][LDQ] K rows of the workgroup's keys
+    float* sV = sK + ROWS * LDQ;
+    float* sQ = sV + ROWS * LDQ;                            // [32][LDQ] query tile
     float* sO = sQ + 32 * LDQ;                             // dO tile
     float* sL = sO + 32 * LDQ;                             // [32] lse, [32] delta
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 31, fh = lane >> 5;
-    const int b = blockIdx.z, head = blockIdx.y, kv0 = blockIdx.x * 128;
+    const int b = blockIdx.z, head = blockIdx.y, kv0 = blockIdx.x * ROWS;
     const int C3 = 3 * p.C;
     const float* base = p.qkv + (size_t)b * p.N * C3 + head * D;
     const float* dob = p.d_o + (size_t)b * p.N * p.C + head * D;
-    for (int w = 0; w < 4; ++w) {
-        attn32_load_tile<D>(sK + w * 32 * LDQ, base + p.C, C3, kv0 + w * 32, p.N, tid, 256);
-        attn32_load_tile<D>(sV + w * 32 * LDQ, base + 2 * p.C, C3, kv0 + w * 32, p.N, tid, 256);
+    for (int w = 0; w < NW; ++w) {
+        attn32_load_tile<D>(sK + w * 32 * LDQ, base + p.C, C3, kv0 + w * 32, p.N, tid, NT);
+        attn32_load_tile<D>(sV + w * 32 * LDQ, base + 2 * p.C, C3, kv0 + w * 32, p.N, tid, NT);
     }
     const int ki = kv0 + wave * 32 + fr; const bool kok = ki < p.N;
     f32x16 dk[DT], dv[DT];
@@ -334,8 +336,8 @@ __global__ __launch_bounds__(256) void attn32_bwd_dkv_kernel(const Attn32BwdPara
         for (int r = 0; r < 16; ++r) { dk[t][r] = 0.f; dv[t][r] = 0.f; }
     for (int q0 = 0; q0 < p.N; q0 += 32) {
         __syncthreads();
-        attn32_load_tile<D>(sQ, base, C3, q0, p.N, tid, 256);
-        attn32_load_tile<D>(sO, dob, p.C, q0, p.N, tid, 256);
+        attn32_load_tile<D>(sQ, base, C3, q0, p.N, tid, NT);
+        attn32_load_tile<D>(sO, dob, p.C, q0, p.N, tid, NT);
         if (tid < 32) {
             int qi = q0 + tid; const bool ok = qi < p.N; if (!ok) qi = p.N - 1;
             sL[tid] = ok ? p.lse[((size_t)b * p.heads + head) * p.N + qi] : INFINITY;           // exp(s - inf) = 0 masks the row
@@ -384,27 +386,30 @@ __global__ __launch_bounds__(256) void attn32_bwd_dkv_kernel(const Attn32BwdPara
                 make_float4(dv[t][4 * g], dv[t][4 * g + 1], dv[t][4 * g + 2], dv[t][4 * g + 3]);
         }
 }
-template <int DT>
+template <int DT, int NW>
 static hipError_t launch_attn32_bwd_d(const Attn32BwdParams& p, hipStream_t s) {
-    constexpr int D = DT * 32;
-    constexpr int LDS_DQ = (2 * 128 + 2 * 32) * (D + 1) * 4, LDS_DKV = (2 * 128 + 2 * 32) * (D + 1) * 4 + 64 * 4;
+    constexpr int D = DT * 32, ROWS = 32 * NW;
+    constexpr int LDS_DQ = (2 * ROWS + 2 * 32) * (D + 1) * 4, LDS_DKV = (2 * ROWS + 2 * 32) * (D + 1) * 4 + 64 * 4;
+    static_assert(LDS_DKV <= 160 * 1024, "LDS budget");
     static bool once = false;
     if (!once) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn32_bwd_dq_kernel<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DQ);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn32_bwd_dkv_kernel<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DKV);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn32_bwd_dq_kernel<DT, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DQ);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn32_bwd_dkv_kernel<DT, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DKV);
         if (e != hipSuccess) return e;
         once = true;
     }
     const long dthreads = (long)p.B * p.N * p.heads * (D / 4);
     hipLaunchKernelGGL(attn32_delta_kernel, dim3((unsigned)((dthreads + 255) / 256)), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(attn32_bwd_dq_kernel<DT>, dim3((p.N + 127) / 128, p.heads, p.B), dim3(256), LDS_DQ, s, p);
-    hipLaunchKernelGGL(attn32_bwd_dkv_kernel<DT>, dim3((p.N + 127) / 128, p.heads, p.B), dim3(256), LDS_DKV, s, p);
+    hipLaunchKernelGGL((attn32_bwd_dq_kernel<DT, NW>), dim3((p.N + ROWS - 1) / ROWS, p.heads, p.B), dim3(64 * NW), LDS_DQ, s, p);
+    hipLaunchKernelGGL((attn32_bwd_dkv_kernel<DT, NW>), dim3((p.N + ROWS - 1) / ROWS, p.heads, p.B), dim3(64 * NW), LDS_DKV, s, p);
     return hipGetLastError();
 }
 static hipError_t launch_attn32_bwd(const Attn32BwdParams& p, hipStream_t s) {
     switch (p.d) {
-        case 32: return launch_attn32_bwd_d<1>(p, s);
-        case 64: return launch_attn32_bwd_d<2>(p, s);        // d = 128 / 256 (AutoencoderKL blocks) would need > 160 KiB of LDS in this form
+        case 32: return launch_attn32_bwd_d<1, 4>(p, s);
+        case 64: return launch_attn32_bwd_d<2, 4>(p, s);
+        case 128: return launch_attn32_bwd_d<4, 2>(p, s);        // the AutoencoderKL's single-head blocks (d = C)
+        case 256: return launch_attn32_bwd_d<8, 1>(p, s);
     }
     return hipErrorInvalidValue;
 }

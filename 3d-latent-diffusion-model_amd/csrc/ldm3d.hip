@@ -750,7 +750,6 @@ struct Builder {
         at.i[0] = x.N; at.i[1] = x.D * x.H * x.W; at.i[2] = C; at.i[3] = C / head_ch; at.i[4] = head_ch; at.f[0] = 1.0f / sqrtf((float)head_ch);
         size_t lse_off = 0;
         if (train) {
-            if (head_ch > 64) { err = "fp32 precision: the attention backward handles head dimensions 32 and 64 (" + p + ")"; return Act(); }
             lse_off = pool.alloc((size_t)x.N * (C / head_ch) * at.i[1] * 4); at.r[2] = ws_ref(lse_off);
         }
         plan->ops.push_back(at);
@@ -1049,7 +1048,7 @@ struct Builder {
         Op o{}; o.kind = OP_VAE_HEADS_BWD;
         o.r[0] = ws_ref(dz.off); o.r[1] = ws_ref(vae_ml_off); o.r[2] = ws_ref(vae_z_off); o.r[3] = io_ref(1); o.r[6] = io_ref(2);
         o.r[7] = ws_ref(dout_heads.off);
-        o.i[0] = dz.N; o.i[1] = vae_L; o.i[2] = cs; o.i[3] = dz.D * dz.H * dz.W; o.i[4] = dz.C;
+        o.i[0] = dz.N; o.i[1] = vae_L; o.i[2] = cs; o.i[3] = dz.D * dz.H * dz.W; o.i[4] = dz.C; o.i[5] = hp ? 1 : 0;
         plan->ops.push_back(o);
         return true;
     }
@@ -1505,12 +1504,12 @@ static int vae_build_decode(ldm_model* m, int B, int d, int h_, int w, Plan* pla
 // AutoencoderKL.forward with the tape + backward (stage-1 trainer, 3d_ldm/train_autoencoder.py:366-451):
 //   forward  I/O: 0 = x, 1 = eps, 2 = z_mu, 3 = z_sigma, 5 = reconstruction
 //   backward I/O: 0 = d recon, 1 = d z_mu (or null), 2 = d z_sigma (or null), 4 = flat parameter gradients
-static int vae_build_train(ldm_model* m, int B, int D, int H, int W, Plan* plan) {
+static int vae_build_train(ldm_model* m, int B, int D, int H, int W, Plan* plan, bool hp = false) {
     const ldm_vae_cfg& c = m->vcfg;
-    Builder b; b.m = m; b.plan = plan; b.train = true; b.recording = true;
+    Builder b; b.m = m; b.plan = plan; b.train = true; b.recording = true; b.hp = hp;
     const int cs = rup(c.in_channels, 32), L = c.latent_channels, ls = rup(L, 32);
     Act xin = b.new_act(B, D, H, W, cs);
-    { Op o{}; o.kind = OP_PACK; o.r[0] = io_ref(0); o.r[1] = Ref(); o.r[2] = ws_ref(xin.off);
+    { Op o{}; o.kind = hp ? OP_PACK32 : OP_PACK; o.r[0] = io_ref(0); o.r[1] = Ref(); o.r[2] = ws_ref(xin.off);
       o.i[0] = B; o.i[1] = c.in_channels; o.i[2] = cs; o.i[3] = D * H * W; o.i[4] = 1; plan->ops.push_back(o); }
     const size_t t0 = b.tape.size();
     Act h;
@@ -1525,7 +1524,7 @@ static int vae_build_train(ldm_model* m, int B, int D, int H, int W, Plan* plan)
     { Op o{}; o.kind = OP_VAE_HEADS; o.r[0] = ws_ref(ml_off); o.r[1] = io_ref(1); o.r[2] = io_ref(2); o.r[3] = io_ref(3); o.r[4] = ws_ref(z_off);
       o.i[0] = B; o.i[1] = L; o.i[2] = dhw; plan->ops.push_back(o); }
     Act zin = b.new_act(B, h.D, h.H, h.W, ls);
-    { Op o{}; o.kind = OP_PACK; o.r[0] = ws_ref(z_off); o.r[1] = Ref(); o.r[2] = ws_ref(zin.off);
+    { Op o{}; o.kind = hp ? OP_PACK32 : OP_PACK; o.r[0] = ws_ref(z_off); o.r[1] = Ref(); o.r[2] = ws_ref(zin.off);
       o.i[0] = B; o.i[1] = L; o.i[2] = ls; o.i[3] = dhw; o.i[4] = 1; plan->ops.push_back(o); }
     Builder::ConvArgs pq; pq.xa = zin; pq.w = &m->convs.at("post_quant_conv"); pq.k = 1; pq.pad = 0; pq.Do = h.D; pq.Ho = h.H; pq.Wo = h.W;
     Act z2 = b.conv(pq, "post_quant_conv");
@@ -1536,10 +1535,10 @@ static int vae_build_train(ldm_model* m, int B, int D, int H, int W, Plan* plan)
     plan->train = true; plan->bwd_begin = plan->ops.size();
     b.recording = false;
     b.vae_zin = zin; b.vae_ml_off = ml_off; b.vae_z_off = z_off; b.vae_L = L;
-    { Op o{}; o.kind = OP_WT_BATCH; plan->ops.push_back(o); }
+    { Op o{}; o.kind = OP_WT_BATCH; o.i[0] = hp ? 1 : 0; plan->ops.push_back(o); }
     const int cos_ = rup(c.out_channels, 32);
     Act dout = b.new_act(B, D, H, W, cos_);
-    { Op o{}; o.kind = OP_PACK; o.r[0] = io_ref(0); o.r[1] = Ref(); o.r[2] = ws_ref(dout.off);
+    { Op o{}; o.kind = hp ? OP_PACK32 : OP_PACK; o.r[0] = io_ref(0); o.r[1] = Ref(); o.r[2] = ws_ref(dout.off);
       o.i[0] = B; o.i[1] = c.out_channels; o.i[2] = cos_; o.i[3] = D * H * W; o.i[4] = 1; plan->ops.push_back(o); }
     b.bucket_hi = b.done_from = m->flat_total;
     if (!b.backward_all(dout)) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
@@ -2086,9 +2085,12 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                 break; }
             case OP_VAE_HEADS_BWD: {
                 const long total = (long)i[0] * i[3] * i[2];
-                hipLaunchKernelGGL(vae_heads_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)rp(bs, o.r[0]), i[4],
-                                   (const float*)rp(bs, o.r[1]), (const float*)rp(bs, o.r[2]), (const float*)rp(bs, o.r[3]),
-                                   (const float*)rp(bs, o.r[6]), (bf16_t*)rp(bs, o.r[7]), i[0], i[1], i[2], i[3]);
+                if (i[5]) hipLaunchKernelGGL(vae_heads_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)rp(bs, o.r[0]), i[4],
+                                             (const float*)rp(bs, o.r[1]), (const float*)rp(bs, o.r[2]), (const float*)rp(bs, o.r[3]),
+                                             (const float*)rp(bs, o.r[6]), (float*)rp(bs, o.r[7]), i[0], i[1], i[2], i[3]);
+                else hipLaunchKernelGGL(vae_heads_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)rp(bs, o.r[0]), i[4],
+                                        (const float*)rp(bs, o.r[1]), (const float*)rp(bs, o.r[2]), (const float*)rp(bs, o.r[3]),
+                                        (const float*)rp(bs, o.r[6]), (bf16_t*)rp(bs, o.r[7]), i[0], i[1], i[2], i[3]);
                 break; }
             case OP_LIN_DW:         // i: B, I, O, dy_stride, x_stride, silu, fp32 precision
                 if (i[6]) { hipLaunchKernelGGL(linear_bwd_dw_f32_kernel, dim3(grid_for((long)i[2] * i[1], 256, 1 << 24)), dim3(256), 0, s,
@@ -2267,14 +2269,12 @@ static int get_plan(ldm_model* m, const char* kind, int B, int D, int H, int W, 
     if (B < 1 || D < 1 || H < 1 || W < 1 || D > 255 * 8 || H > 255 * 8 || W > 255 * 8) return fail(LDM_ERR_BAD_ARG, "bad shape");
     const bool train = kind[0] == 't';
     const bool hp = m->precision == 1;
-    if (train && hp && m->type != 0)
-        return fail(LDM_ERR_UNSUPPORTED, "the fp32 precision mode trains the DiffusionModelUNet only (the AutoencoderKL training plans are bf16; its inference plans have both)");
     char key[96]; snprintf(key, sizeof key, "%s:%d:%d:%d:%d:p%d:t%d", kind, B, D, H, W, hp ? 1 : 0, tap_mode);
     auto it = m->plans.find(key);
     if (it != m->plans.end()) { *out = it->second; return 0; }
     std::shared_ptr<Plan> p(new Plan());
     if (m->type == 0) LDM_TRY(unet_build(m, B, D, H, W, p.get(), train, hp, tap_mode));
-    else if (train) LDM_TRY(vae_build_train(m, B, D, H, W, p.get()));
+    else if (train) LDM_TRY(vae_build_train(m, B, D, H, W, p.get(), hp));
     else if (kind[0] == 'e') LDM_TRY(vae_build_encode(m, B, D, H, W, p.get(), hp, tap_mode));
     else LDM_TRY(vae_build_decode(m, B, D, H, W, p.get(), hp, tap_mode));
     m->plans[key] = p; *out = p;

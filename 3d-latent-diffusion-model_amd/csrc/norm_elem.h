@@ -1360,9 +1360,10 @@ __global__ __launch_bounds__(256) void weight_flip_transpose_batched_kernel(cons
 // Given dz (bf16 NDHWC [M][Ls], from the decoder), g_mu / g_sigma (fp32 NCDHW, from the KL term; may be null):
 //   d_mu = dz + g_mu;   d_lv = (dz * (z - mu) + g_sigma * sigma) * 0.5  inside the clamp, 0 outside.
 // Output: gradient of the fused 1x1 heads conv, bf16 NDHWC [M][Cs] with channels (d_mu | d_lv | 0 padding).
-__global__ __launch_bounds__(256) void vae_heads_bwd_kernel(const bf16_t* __restrict__ dz, int Ls, const float* __restrict__ ml,
+template <typename T>                                     // activation storage: bf16_t, or float in the fp32 precision mode
+__global__ __launch_bounds__(256) void vae_heads_bwd_kernel(const T* __restrict__ dz, int Ls, const float* __restrict__ ml,
                                                             const float* __restrict__ z, const float* __restrict__ g_mu,
-                                                            const float* __restrict__ g_sigma, bf16_t* __restrict__ dy,
+                                                            const float* __restrict__ g_sigma, T* __restrict__ dy,
                                                             int N, int L, int Cs, int DHW) {
     const long total = (long)N * DHW * Cs;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -1373,7 +1374,8 @@ __global__ __launch_bounds__(256) void vae_heads_bwd_kernel(const bf16_t* __rest
         float g = 0.f;
         if (c < 2 * L) {
             const int l = c < L ? c : c - L;
-            const float gz = bf2f(dz[row * Ls + l]);
+            float gz;
+            if constexpr (sizeof(T) == 4) gz = dz[row * Ls + l]; else gz = bf2f(dz[row * Ls + l]);
             const size_t j = ((size_t)n * L + l) * DHW + sp;
             if (c < L) g = gz + (g_mu ? g_mu[j] : 0.f);
             else {
@@ -1385,7 +1387,7 @@ __global__ __launch_bounds__(256) void vae_heads_bwd_kernel(const bf16_t* __rest
                 }
             }
         }
-        dy[i] = f2bf(g);
+        if constexpr (sizeof(T) == 4) dy[i] = g; else dy[i] = f2bf(g);
     }
 }
 

@@ -40,8 +40,12 @@ def parse_cli():
     ap.add_argument("--chains", type=int, default=1, help="independent chains advanced concurrently on this GPU (own stream + module instance each)")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from the host instead of replaying the UNet's HIP graph")
     ap.add_argument("--condition", default=None, help="NPZ pair whose low-count volume conditions the sampling (mode='concat')")
+    ap.add_argument("--precision", default=None, choices=["bf16", "fp32"],
+                        help="arithmetic of the networks: bf16 (default, the fast path) or fp32 (the reference's own arithmetic, 1e-5 from its CPU path; also LDM_PRECISION)")
     ap.add_argument("--scale-factor", type=float, default=None, help="latent scale (default: model_dir/scale_factor.json, else 1.0)")
     ns = ap.parse_args()
+    if ns.precision:
+        os.environ["LDM_PRECISION"] = ns.precision     # read by every network at construction (networks.py)
     for path in (ns.environment_file, ns.config_file):           # both JSON files land on the namespace, config last
         with open(path) as fh:
             vars(ns).update(json.load(fh))

@@ -25,6 +25,10 @@ SCHED = dict(num_train_timesteps=1000, schedule="scaled_linear_beta", beta_start
 VAE_TINY_ATTN = dict(spatial_dims=3, in_channels=1, out_channels=1, latent_channels=8, channels=[32, 64, 64],
                      num_res_blocks=[1, 2, 2], norm_num_groups=16, norm_eps=1e-6, attention_levels=[False, False, True],
                      with_encoder_nonlocal_attn=True, with_decoder_nonlocal_attn=True)
+# d = 128 (two waves per workgroup in the fp32 attention backward)
+VAE_MID_ATTN = dict(spatial_dims=3, in_channels=1, out_channels=1, latent_channels=8, channels=[32, 64, 128],
+                    num_res_blocks=[1, 1, 1], norm_num_groups=16, norm_eps=1e-6, attention_levels=[False, False, True],
+                    with_encoder_nonlocal_attn=True, with_decoder_nonlocal_attn=False)
 # the full-width one: channels [64, 128, 256], single-head attention at 256 channels (d = 256)
 VAE_FULL_ATTN = dict(spatial_dims=3, in_channels=1, out_channels=1, latent_channels=16, channels=[64, 128, 256],
                      num_res_blocks=[1, 2, 2], norm_num_groups=32, norm_eps=1e-6, attention_levels=[False, False, True],

@@ -54,6 +54,23 @@ def test_train_then_conditional_sampling(tmp_path):
     assert dim[1] == dim[2] == dim[3] and dim[1] % 4 == 0 and dim[1] >= 64
 
 
+def test_entry_points_in_the_fp32_precision_mode(tmp_path):
+    """--precision fp32 (the reference's arithmetic, train_autoencoder.py / train_diffusion.py without --amp): stage 1 (the warm-up
+    phase: reconstruction + KL), stage 2 and sampling run end to end on the fp32 kernels."""
+    env = {"npz_dir": str(tmp_path / "pairs"), "val_fraction": 0.25, "model_dir": str(tmp_path / "ckpt"),
+           "tfevent_path": str(tmp_path / "tfevent"), "output_dir": str(tmp_path / "out"), "resume_ckpt": False, "seed": 0}
+    env_file = str(tmp_path / "environment.json")
+    with open(env_file, "w") as fh:
+        json.dump(env, fh)
+    log = _run("train_autoencoder.py", env_file, "--random-init", "--synthetic", "8", "--max-steps", "3", "--precision", "fp32")
+    assert os.path.exists(tmp_path / "ckpt" / "autoencoder.pt") and "nan" not in log.lower()
+    log = _run("train_diffusion.py", env_file, "--random-init", "--max-steps", "3", "--precision", "fp32")
+    assert os.path.exists(tmp_path / "ckpt" / "diffusion_unet.pt") and "nan" not in log.lower()
+    pair = sorted(glob.glob(str(tmp_path / "pairs" / "*.npz")))[0]
+    _run("inference.py", env_file, "-n", "1", "--steps", "3", "--condition", pair, "--precision", "fp32")
+    assert len(glob.glob(str(tmp_path / "out" / "*.nii"))) == 1
+
+
 @pytest.mark.parametrize("shape,b", [((37, 41, 29), 2), ((64, 64, 64), 1), ((144, 176, 112), 1)])
 def test_percentile_scaling_on_device_matches_the_host_transform(cuda, shape, b):
     """ScaleIntensityRangePercentiles(0, 99.5 -> 0, 1) (3d_ldm/utils.py:94-107) on the device against the numpy restatement of

@@ -111,7 +111,8 @@ def test_unit_gain_gradients_sit_on_the_bf16_floor(cuda):
 
 
 @pytest.mark.parametrize("name,dims,b,cond", [("UNET_TINY", (8, 8, 8), 2, 0), ("UNET_TINY_ALT", (6, 10, 8), 1, 0),
-                                              ("UNET_TINY_COND", (8, 12, 4), 2, 4), ("UNET_TINY_HEAD32", (8, 8, 8), 1, 0)])
+                                              ("UNET_TINY_COND", (8, 12, 4), 2, 4), ("UNET_TINY_HEAD32", (8, 8, 8), 1, 0),
+                                              ("UNET_FULL", (8, 8, 8), 1, 0)])
 def test_fp32_mode_gradients_match_the_fp32_reference_at_unit_gain(cuda, name, dims, b, cond):
     """The reference trains in fp32 (3d_ldm/train_diffusion.py:177: autocast off).  set_precision("fp32") runs the training plans on
     fp32 activations / weights and the fp32 matrix instruction (csrc/f32_train.h): at UNIT weight gain, where the bf16 plans sit on a
@@ -356,6 +357,47 @@ def test_autoencoder_parameter_gradients_match_oracle_autograd(cuda, name, dims,
             fl = rel_l2(_cat(gbf, sel), _cat(g32, sel))
             e = rel_l2(_cat(got, sel), _cat(g32, sel))
             assert e <= 2.5 * fl + 1e-2, (fam, e, fl)
+
+
+@pytest.mark.parametrize("name,dims,b", [("VAE_TINY", (16, 16, 16), 2), ("VAE_TINY_ATTN", (16, 16, 16), 1), ("VAE_FULL", (16, 16, 16), 1),
+                                         ("VAE_MID_ATTN", (16, 24, 16), 1), ("VAE_FULL_ATTN", (32, 32, 32), 1)])
+def test_autoencoder_fp32_mode_gradients_match_the_fp32_reference(cuda, name, dims, b):
+    """Stage 1 in the reference's arithmetic (train_autoencoder.py:366-451 runs fp32 unless --amp): set_precision("fp32") runs the
+    AutoencoderKL training plans on the fp32 kernels (csrc/f32_train.h; the single-head d = C attention backward at d = 128 / 256
+    included) and every parameter gradient of L1 + KL agrees with torch autograd through the fp32 CPU oracle to 1e-3 at UNIT gain."""
+    from ldm3d.networks import AutoencoderKL
+    from oracle import autoencoder as oa
+    from oracle.unet import init_state_dict
+    cfg = getattr(cfgs, name)
+    sd = init_state_dict(oa.ae_param_shapes(cfg), 17, gain=1.0)
+    g = torch.Generator().manual_seed(18)
+    x = torch.rand((b, cfg["in_channels"], *dims), generator=g)
+    f = 2 ** (len(cfg["channels"]) - 1)
+    eps = torch.randn((b, cfg["latent_channels"], *[d // f for d in dims]), generator=g)
+    klw = 1e-3
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    recon32, mu32, sigma32 = oa.forward(leaves, cfg, x, eps, emulate_bf16=False)
+    loss32 = F.l1_loss(recon32, x) + klw * oa.kl_loss(mu32, sigma32).mean()
+    loss32.backward()
+    g32 = {k: v.grad for k, v in leaves.items()}
+    m = AutoencoderKL(**cfg)
+    m.load_state_dict(sd)
+    m = m.to(cuda).train().set_precision("fp32")
+    recon, mu, sigma = m(x.to(cuda), eps=eps.to(cuda))
+    loss = F.l1_loss(recon, x.to(cuda)) + klw * oa.kl_loss(mu, sigma).mean()
+    loss.backward()
+    torch.cuda.synchronize()
+    names = list(sd.keys())
+    got = {k: p.grad for k, p in m.named_parameters()}
+    assert all(got[n] is not None and torch.isfinite(got[n]).all() for n in names)
+    e_out = rel_l2(recon.detach().cpu(), recon32.detach())
+    e_all = rel_l2(_cat(got, names), _cat(g32, names))
+    total = _cat(g32, names).norm()
+    worst = max(((rel_l2(got[n].cpu(), g32[n]), n) for n in names if g32[n].norm() > 1e-4 * total), default=(0.0, ""))
+    print(f"{name} {dims} fp32 mode, unit gain: loss {float(loss.detach()):.6f} / oracle {float(loss32.detach()):.6f}; recon {e_out:.2e}; gradients vs fp32 autograd "
+          f"{e_all:.2e}, worst tensor {worst[0]:.2e} ({worst[1]})")
+    assert e_out <= 1e-4 and abs(float(loss.detach()) - float(loss32.detach())) <= 1e-5 * abs(float(loss32.detach()))
+    assert e_all <= 1e-3 and worst[0] <= 2e-3, (e_all, worst)    # L1's sign(recon - x) flips where |recon - x| is at the 1e-6 noise level
 
 
 def test_autoencoder_full_size_backward_runs(cuda):

@@ -34,8 +34,12 @@ def main():
     parser.add_argument("--local_rank", type=int, default=0)
     parser.add_argument("--random-init", action="store_true")
     parser.add_argument("--synthetic", type=int, default=0)
+    parser.add_argument("--precision", default=None, choices=["bf16", "fp32"],
+                        help="arithmetic of the networks: bf16 (default, the fast path) or fp32 (the reference's own arithmetic, 1e-5 from its CPU path; also LDM_PRECISION)")
     parser.add_argument("--max-steps", type=int, default=0)
     args = parser.parse_args()
+    if args.precision:
+        os.environ["LDM_PRECISION"] = args.precision     # read by every network at construction (networks.py)
 
     import torch
     from ldm3d import parallel

@@ -33,9 +33,13 @@ def main():
     parser.add_argument("--reference-rng-order", action="store_true")
     parser.add_argument("--gpu-transforms", action="store_true",
                         help="percentile intensity scaling on the GPU (ldm_op_scale_intensity_percentiles) instead of in the host loader")
+    parser.add_argument("--precision", default=None, choices=["bf16", "fp32"],
+                        help="arithmetic of the networks: bf16 (default, the fast path) or fp32 (the reference's own arithmetic, 1e-5 from its CPU path; also LDM_PRECISION)")
     parser.add_argument("--grad-allreduce-dtype", default="fp32", choices=["fp32", "bf16"],
                         help="wire format of the data-parallel gradient all-reduce (the reference's DDP uses fp32)")
     args = parser.parse_args()
+    if args.precision:
+        os.environ["LDM_PRECISION"] = args.precision     # read by every network at construction (networks.py)
 
     import torch
     from ldm3d import parallel
