@@ -34,11 +34,10 @@ struct Conv32Params {
 // 64 voxels x BN / 2 couts = 2 x NI MFMA tiles of 32 x 32 (A = weights, B = voxels: a lane ends with 4 consecutive couts per register
 // quad of one voxel).  K step = 16 input channels of one tap.
 template <int BN>
-__global__ __launch_bounds__(256, 2) void conv_f32_kernel(const Conv32Params p) {
+__global__ __launch_bounds__(256, 3) void conv_f32_kernel(const Conv32Params p) {
     constexpr int BM = 128, BK = 16, LDR = BK + 4, NI = BN / 64;   // LDS row stride 80 B: conflict-free ds_read_b128
     __shared__ __attribute__((aligned(16))) float sA[2][BN * LDR];  // weights (rows 64 .. 127 unused when BN == 64)
     __shared__ __attribute__((aligned(16))) float sB[2][BM * LDR];  // voxels
-    __shared__ int tapv[27 * BM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
     int lid = xcd_remap(blockIdx.x, gridDim.x);
@@ -49,39 +48,37 @@ __global__ __launch_bounds__(256, 2) void conv_f32_kernel(const Conv32Params p) 
     const int s_begin = split * p.steps_per_split;
     int s_end = s_begin + p.steps_per_split; if (s_end > p.steps) s_end = p.steps;
     const int DHWo = p.Dout * p.Hout * p.Wout, HWo = p.Hout * p.Wout;
-    const int taps = p.ksize * p.ksize * p.ksize;
     const int cin = p.ca + p.cb;
-    {   // (tap, row) -> source voxel, -1 = zero padding / beyond M
-        const int DinU = p.Din << p.ups, HinU = p.Hin << p.ups, WinU = p.Win << p.ups;
-        for (int e = tid; e < taps * BM; e += 256) {
-            const int tap = e / BM, row = e - tap * BM;
-            const int m = m0 + row;
-            int v = -1;
-            if (m < p.M) {
-                const int n = m / DHWo; int r = m - n * DHWo; const int od = r / HWo; r -= od * HWo; const int oh = r / p.Wout, ow = r - oh * p.Wout;
-                int kd = 0, kh = 0, kw = 0;
-                if (p.ksize == 3) { kd = tap / 9; kh = (tap - kd * 9) / 3; kw = tap - kd * 9 - kh * 3; }
-                const int id = od * p.stride + kd - p.pad, ih = oh * p.stride + kh - p.pad, iw = ow * p.stride + kw - p.pad;
-                const bool ok = ((unsigned)id < (unsigned)DinU) & ((unsigned)ih < (unsigned)HinU) & ((unsigned)iw < (unsigned)WinU) &
-                                !(p.exact & (id | ih | iw) & 1);
-                if (ok) v = n * p.Din * p.Hin * p.Win + ((id >> p.ups) * p.Hin + (ih >> p.ups)) * p.Win + (iw >> p.ups);
-            }
-            tapv[e] = v;
-        }
-    }
-    __syncthreads();
+    const int DinU = p.Din << p.ups, HinU = p.Hin << p.ups, WinU = p.Win << p.ups;
 
     const int lc = tid & 3, lr = tid >> 2;              // loader: 16-byte chunk of the 16-channel row, rows lr and lr + 64
+    // output coordinates of the loader's two voxel rows (the (tap, row) -> source voxel map is computed per step from these: a table
+    // in LDS would cost 13.5 KiB and the third workgroup per CU)
+    int r_n[2], r_d[2], r_h[2], r_w[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int m = m0 + lr + 64 * j;
+        r_n[j] = -1; r_d[j] = r_h[j] = r_w[j] = 0;
+        if (m < p.M) {
+            const int n = m / DHWo; int r = m - n * DHWo; const int od = r / HWo; r -= od * HWo; const int oh = r / p.Wout;
+            r_n[j] = n; r_d[j] = od * p.stride - p.pad; r_h[j] = oh * p.stride - p.pad; r_w[j] = (r - oh * p.Wout) * p.stride - p.pad;
+        }
+    }
     float4 ra[NI], rb[2];
     auto load_step = [&](int s) {
         const int tap = s / p.nchunk, ch = (s - tap * p.nchunk) * BK;
+        int kd = 0, kh = 0, kw = 0;
+        if (p.ksize == 3) { kd = tap / 9; kh = (tap - kd * 9) / 3; kw = tap - kd * 9 - kh * 3; }
         const bool second = ch >= p.ca;
         const float* src = second ? p.xb : p.xa;
         const int cs = second ? p.cb : p.ca, cc = (second ? ch - p.ca : ch) + lc * 4;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int row = lr + 64 * j;
-            const int v = tapv[tap * BM + row];
+            const int id = r_d[j] + kd, ih = r_h[j] + kh, iw = r_w[j] + kw;
+            const bool ok = (r_n[j] >= 0) & ((unsigned)id < (unsigned)DinU) & ((unsigned)ih < (unsigned)HinU) & ((unsigned)iw < (unsigned)WinU) &
+                            !(p.exact & (id | ih | iw) & 1);
+            const int v = ok ? ((r_n[j] * p.Din + (id >> p.ups)) * p.Hin + (ih >> p.ups)) * p.Win + (iw >> p.ups) : -1;
             rb[j] = (v >= 0) ? *reinterpret_cast<const float4*>(src + (size_t)v * cs + cc) : make_float4(0.f, 0.f, 0.f, 0.f);
             if (j < NI) {
                 const int co = n0 + row;

@@ -144,7 +144,8 @@ def test_fp32_mode_gradients_match_the_fp32_reference_at_unit_gain(cuda, name, d
     got = {k: p.grad.clone() for k, p in m.named_parameters()}
     assert rel_l2(out.detach().cpu(), out32) <= 1e-4 and abs(float(loss) - loss32) <= 1e-5 * abs(loss32)
     e_all = rel_l2(_cat(got, names), _cat(g32, names))
-    worst = max(((rel_l2(got[n], g32[n]), n) for n in names if g32[n].norm() > 1e-4 * _cat(g32, names).norm()), default=(0.0, ""))
+    total = _cat(g32, names).norm()
+    worst = max(((rel_l2(got[n], g32[n]), n) for n in names if g32[n].norm() > 1e-4 * total), default=(0.0, ""))
     print(f"{name} fp32 mode, unit gain: loss {float(loss):.6f} / oracle {loss32:.6f}; gradients vs fp32 autograd {e_all:.2e}, "
           f"worst tensor {worst[0]:.2e} ({worst[1]})")
     assert e_all <= 1e-3 and worst[0] <= 1e-3
