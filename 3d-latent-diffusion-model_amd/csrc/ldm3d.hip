@@ -361,7 +361,9 @@ struct Builder {
     bool temb_pending = false;
     // measured (MI355X, ROCm 7.2): 14 fork / join pairs per step cost more than the overlapped work saves: 2.36 vs 2.17 ms per
     // step under graph replay, 2.29 ms eager.  Kept as an opt-in experiment (LDM_SIDE_LANE=1).
-    static bool side_lane_enabled() { const char* e = getenv("LDM_SIDE_LANE"); return e ? atoi(e) != 0 : false; }
+    // second stream of the inference plans: bit 0 = the time-embedding chain (runs beside pack / conv_in), bit 1 = the 1x1 skip projections
+    static int side_lane_mode() { const char* e = getenv("LDM_SIDE_LANE"); return e ? atoi(e) : 0; }
+    static bool side_lane_enabled() { return (side_lane_mode() & 2) != 0; }
     static bool phase_enabled() { const char* e = getenv("LDM_CONV_PHASE"); return e ? atoi(e) != 0 : true; }
     // halo_n > 0: the conv is eligible for conv3_halo_kernel (3^3, stride 1, pad 1, single source, BK 64); halo_n = N
     // and halo_dhw = voxels per sample (its 126-row tiles never straddle samples).
@@ -1194,7 +1196,7 @@ static int unet_build(ldm_model* m, int B, int D, int H, int W, Plan* plan, bool
     b.tproj_stride = m->tproj_rows;
     b.temb_all_off = b.pool.alloc(((size_t)B * m->tproj_rows + 256) * 4);
     // inference: the whole time-embedding chain runs on the side lane, beside pack / conv_in / the first GroupNorm
-    const int tlane = (!train && Builder::side_lane_enabled()) ? 1 : 0;
+    const int tlane = (!train && !hp && (Builder::side_lane_mode() & 1)) ? 1 : 0;
     { Op o{}; o.kind = OP_SINUSOID; o.r[0] = io_ref(2); o.r[1] = ws_ref(sin_off); o.i[0] = B; o.i[1] = ch[0]; o.lane = tlane; o.sync = tlane != 0;
       plan->ops.push_back(o); }
     auto gemv = [&](size_t w_off, size_t b_off, size_t x_off, size_t y_off, int I, int O, int xs, int ys, int silu) {
