@@ -228,3 +228,23 @@ def test_headline_plan_launch_count(built_lib, monkeypatch):
     assert counts[None] == counts["0"] and counts["0"][1] == 0 and counts["1"][1] >= 20
     assert counts["0"][0] - counts["1"][0] == counts["1"][1]
     assert counts["0"][0] <= 155 and counts["1"][0] <= 130, counts
+
+
+def test_shapes_the_networks_cannot_take_fail_loudly(built_lib):
+    """The reference crops / pads every volume to a multiple of 2^(levels-1) (utils.py:87-95 `size_divisible`, DivisiblePadd) because
+    MONAI's skip concatenation fails on odd sizes; here the planner refuses them with a message instead of a size mismatch deep inside."""
+    import ctypes as C
+    from ldm3d import _lib
+    from ldm3d.networks import AutoencoderKL, DiffusionModelUNet
+    L = _lib.lib()
+    f = C.c_int(0)
+    unet = DiffusionModelUNet(**cfgs.UNET_TINY)
+    for dims in ((7, 8, 8), (8, 8, 6), (2, 2, 2), (1, 4, 4)):
+        assert L.ldm_model_plan_launches(unet._h, b"unet", 1, *dims, C.byref(f)) == -2, dims     # LDM_ERR_UNSUPPORTED
+        assert b"odd spatial size" in L.ldm_last_error()
+    assert L.ldm_model_plan_launches(unet._h, b"unet", 1, 4, 4, 4, C.byref(f)) > 0               # the smallest legal latent
+    assert L.ldm_model_plan_launches(unet._h, b"unet", 0, 8, 8, 8, C.byref(f)) == -1             # empty batch: LDM_ERR_BAD_ARG
+    vae = AutoencoderKL(**cfgs.VAE_TINY)
+    for dims in ((7, 8, 8), (2, 2, 2), (16, 16, 18)):
+        assert L.ldm_model_plan_launches(vae._h, b"enc", 1, *dims, C.byref(f)) == -2, dims
+    assert L.ldm_model_plan_launches(vae._h, b"enc", 1, 4, 4, 4, C.byref(f)) > 0
