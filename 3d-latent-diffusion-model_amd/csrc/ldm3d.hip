@@ -2038,8 +2038,17 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                 float* flat = (float*)bs.p[BASE_IO4];
                 if (!flat) return fail(LDM_ERR_BAD_ARG, "backward without a gradient buffer");
                 hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(i[6], i[4]), dim3(256), 0, s, p);
-                hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(i[2], i[4]), dim3(256), 0, s, p);
-                hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid_for((long)i[4] * i[3] * (C / 8), 256, 2048)), dim3(256), 0, s, p);
+                static const bool gnb_fold = [] { const char* e = getenv("LDM_GNB_FOLD"); return e ? atoi(e) != 0 : true; }();
+                if (gnb_fold && C / i[2] <= 64 && i[6] <= 512) {       // passes 2 + 3 in one launch (gn_bwd_fold_apply_kernel)
+                    const int slices = (C + 63) / 64;
+                    int chunks = std::max(1, std::min(256 / (slices * i[4]), (i[3] + 31) / 32));
+                    p.rows_per_block = rup((i[3] + chunks - 1) / chunks, 32);
+                    chunks = (i[3] + p.rows_per_block - 1) / p.rows_per_block;
+                    hipLaunchKernelGGL(gn_bwd_fold_apply_kernel, dim3(chunks, slices, i[4]), dim3(256), 0, s, p);
+                } else {
+                    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(i[2], i[4]), dim3(256), 0, s, p);
+                    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid_for((long)i[4] * i[3] * (C / 8), 256, 2048)), dim3(256), 0, s, p);
+                }
                 if (i[4] > 1) {
                     hipLaunchKernelGGL(rowsum_n_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)p.dgamma_n, flat + i[8], i[4], C);
                     hipLaunchKernelGGL(rowsum_n_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)p.dbeta_n, flat + i[9], i[4], C);

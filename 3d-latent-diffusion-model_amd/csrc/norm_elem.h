@@ -240,16 +240,12 @@ struct GnFusedParams {
     float* ab; float* mr;                              // optional (training): [N][C][2] scale/shift, [N][G][2] mean/rstd
 };
 
-// Slab fold of gn_fused_apply_kernel / fin_gn_kernel: sums the partial (sum, sum of squares) rows of the channels that cover the block's
-// 64-channel slice `by` of sample n and leaves mean / rstd of those groups in gstat[g - g_lo].  Fixed summation order (reproducible).
-__device__ __forceinline__ void gn_fused_fold(const GnFusedParams& p, const int n, const int by, const bool first_block,
-                                              float (*part)[96][4], double (*csum)[2], float (*gstat)[2]) {
+// Channel fold shared by the GroupNorm kernels that read per-row-block partial slabs [N * nrb][c][2] of two channel-concatenated sources:
+// leaves the totals of channel cov_lo + k (k < ncov <= 192) in csum[k][0..1].  Fixed summation order (reproducible).
+struct GnFoldSrc { const float* sa; const float* sb; int ca, cb, nrb_a, nrb_b; };
+__device__ __forceinline__ void gn_fold_cover(const GnFoldSrc p, const int n, const int cpg, const int cov_lo, const int ncov,
+                                              float (*part)[96][4], double (*csum)[2]) {
     const int tid = threadIdx.x;
-    const int C = p.ca + p.cb, cpg = C / p.groups;
-    const int c0 = by * 64;
-    int c1 = c0 + 64; if (c1 > C) c1 = C;
-    const int g_lo = c0 / cpg, g_hi = (c1 + cpg - 1) / cpg;
-    const int cov_lo = g_lo * cpg, ncov = g_hi * cpg - cov_lo;           // <= 64 + 2 * 63
     if (((cpg | p.ca) & 1) == 0) {
         // thread = (channel pair of the cover, one of 8 slab lanes); 16 slab rows in flight per thread
         const int bl = tid >> 5;
@@ -306,6 +302,19 @@ __device__ __forceinline__ void gn_fused_fold(const GnFusedParams& p, const int 
             csum[tid][0] = s; csum[tid][1] = q;
         }
     }
+}
+
+// Slab fold of gn_fused_apply_kernel / fin_gn_kernel: sums the partial (sum, sum of squares) rows of the channels that cover the block's
+// 64-channel slice `by` of sample n and leaves mean / rstd of those groups in gstat[g - g_lo].
+__device__ __forceinline__ void gn_fused_fold(const GnFusedParams& p, const int n, const int by, const bool first_block,
+                                              float (*part)[96][4], double (*csum)[2], float (*gstat)[2]) {
+    const int tid = threadIdx.x;
+    const int C = p.ca + p.cb, cpg = C / p.groups;
+    const int c0 = by * 64;
+    int c1 = c0 + 64; if (c1 > C) c1 = C;
+    const int g_lo = c0 / cpg, g_hi = (c1 + cpg - 1) / cpg;
+    const int cov_lo = g_lo * cpg, ncov = g_hi * cpg - cov_lo;           // <= 64 + 2 * 63
+    gn_fold_cover(GnFoldSrc{p.sa, p.sb, p.ca, p.cb, p.nrb_a, p.nrb_b}, n, cpg, cov_lo, ncov, part, csum);
     __syncthreads();
     if (tid < g_hi - g_lo) {
         double s = 0.0, q = 0.0;
@@ -805,6 +814,7 @@ struct GnBwdParams {
     float* dgamma_n; float* dbeta_n;               // [N][C] per-sample parameter gradients (summed over N by the caller)
     const bf16_t* acc_a; const bf16_t* acc_b;      // optional gradients to add to dx (residual / skip paths), same split
     bf16_t* dxa; bf16_t* dxb;                      // outputs [N*DHW][ca], [N*DHW][cb]
+    int rows_per_block;                            // gn_bwd_fold_apply_kernel: rows per block of the apply grid (a multiple of 32)
 };
 
 // activation code of the GroupNorm kernels (fields named `silu`): 0 = none, 1 = SiLU, 2 = LeakyReLU(0.2) (PatchDiscriminator)
@@ -957,6 +967,78 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GnBwdParams p) 
 #pragma unroll
         for (int k = 0; k < 4; ++k) o[k] = pack2bf(out[2 * k], out[2 * k + 1]);
         *reinterpret_cast<u32x4*>((second ? p.dxb : p.dxa) + row * cs + cc) = o;
+    }
+}
+
+// Passes 2 + 3 in one launch (training plans, bf16): every block folds the partial rows of the channels that cover its 64-channel slice
+// (gn_fold_cover, as the forward's one-launch GroupNorm does), derives the two group means, and applies to its row chunk; the blocks
+// of row chunk 0 write dgamma / dbeta of their slice.  Replaces gn_bwd_finalize + gn_bwd_apply wherever channels per group <= 64 and
+// the partial rows per sample are few (<= 512): one launch floor less per GroupNorm.  grid = (row chunks, ceil(C / 64), N), 256 threads.
+__global__ __launch_bounds__(256) void gn_bwd_fold_apply_kernel(const GnBwdParams p) {
+    __shared__ __attribute__((aligned(16))) float part[8][96][4];
+    __shared__ double csum[192][2];
+    __shared__ float gstat[64][2];
+    const int tid = threadIdx.x, n = blockIdx.z;
+    const int C = p.ca + p.cb, cpg = C / p.groups;
+    const int c0 = blockIdx.y * 64;
+    int c1 = c0 + 64; if (c1 > C) c1 = C;
+    const int g_lo = c0 / cpg, g_hi = (c1 + cpg - 1) / cpg;
+    const int cov_lo = g_lo * cpg, ncov = g_hi * cpg - cov_lo;
+    gn_fold_cover(GnFoldSrc{p.partial, nullptr, C, 0, p.nslab, 0}, n, cpg, cov_lo, ncov, part, csum);
+    __syncthreads();
+    if (blockIdx.x == 0 && tid < c1 - c0) {
+        p.dbeta_n[(size_t)n * C + c0 + tid] = (float)csum[c0 - cov_lo + tid][0];
+        p.dgamma_n[(size_t)n * C + c0 + tid] = (float)csum[c0 - cov_lo + tid][1];
+    }
+    if (tid < g_hi - g_lo) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = 0; k < cpg; ++k) {
+            const double gm = (double)p.gamma[cov_lo + tid * cpg + k];
+            s1 += gm * csum[tid * cpg + k][0]; s2 += gm * csum[tid * cpg + k][1];
+        }
+        const double cnt = (double)cpg * (double)p.DHW;
+        gstat[tid][0] = (float)(s1 / cnt); gstat[tid][1] = (float)(s2 / cnt);
+    }
+    __syncthreads();
+    const int vec = tid & 7, rl = tid >> 3;
+    const int c = c0 + vec * 8;
+    if (c >= C) return;
+    const bool second = c >= p.ca;
+    const int cs = second ? p.cb : p.ca, cc = second ? c - p.ca : c;
+    const bf16_t* xs = second ? p.xb : p.xa;
+    const bf16_t* accp = second ? p.acc_b : p.acc_a;
+    bf16_t* dxs = second ? p.dxb : p.dxa;
+    float a[8], b[8], mean[8], rstd[8], m1[8], m2[8], gam[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        a[k] = p.ab[((size_t)n * C + c + k) * 2]; b[k] = p.ab[((size_t)n * C + c + k) * 2 + 1];
+        const int g = (c + k) / cpg;
+        mean[k] = p.mr[((size_t)n * p.groups + g) * 2]; rstd[k] = p.mr[((size_t)n * p.groups + g) * 2 + 1];
+        m1[k] = gstat[g - g_lo][0]; m2[k] = gstat[g - g_lo][1];
+        gam[k] = p.gamma[c + k];
+    }
+    const int r0 = blockIdx.x * p.rows_per_block;          // row chunk of this block (host: a multiple of 32 rows)
+    int r1 = r0 + p.rows_per_block; if (r1 > p.DHW) r1 = p.DHW;
+    for (int r = r0 + rl; r < r1; r += 32) {
+        const size_t row = (size_t)n * p.DHW + r;
+        const u32x4 xv = *reinterpret_cast<const u32x4*>(xs + row * cs + cc);
+        const u32x4 dv = *reinterpret_cast<const u32x4*>(p.dy + row * C + c);
+        u32x4 av = {0u, 0u, 0u, 0u};
+        if (accp) av = *reinterpret_cast<const u32x4*>(accp + row * cs + cc);
+        float out[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float x = __uint_as_float((k & 1) ? (xv[k >> 1] & 0xffff0000u) : (xv[k >> 1] << 16));
+            const float dy = __uint_as_float((k & 1) ? (dv[k >> 1] & 0xffff0000u) : (dv[k >> 1] << 16));
+            const float ac = __uint_as_float((k & 1) ? (av[k >> 1] & 0xffff0000u) : (av[k >> 1] << 16));
+            const float gg = gn_bwd_g(dy, a[k] * x + b[k], p.silu);
+            const float xh = (x - mean[k]) * rstd[k];
+            out[k] = rstd[k] * (gam[k] * gg - m1[k] - xh * m2[k]) + ac;
+        }
+        u32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = pack2bf(out[2 * k], out[2 * k + 1]);
+        *reinterpret_cast<u32x4*>(dxs + row * cs + cc) = o;
     }
 }
 
