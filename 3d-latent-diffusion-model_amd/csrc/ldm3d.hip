@@ -69,6 +69,7 @@ struct Act {                                         // NDHWC bf16 activation li
     size_t stats_off = 0; bool has_stats = false;   // GroupNorm partials [blocks][C][2] written by the producer
     int stats_nrb = 0;                               // blocks per sample (0: one per 32 rows of the whole tensor)
     int esz = 2;                                     // bytes per element: 2 = bf16, 4 = fp32 (LDM_PREC_FP32 plans)
+    size_t cs_off = 0; int cs_rows = 0;              // gradient tensors: column-sum partials [N][cs_rows][C][2] left by the GroupNorm backward that wrote it
     size_t bytes() const { return (size_t)N * D * H * W * C * esz; }
     long rows() const { return (long)N * D * H * W; }
 };
@@ -841,6 +842,14 @@ struct Builder {
         const int cvec = C / 8, rows_par = std::max(1, 256 / cvec);
         int nslab = std::min((DHW + rows_par - 1) / rows_par, std::max(1, 512 / N));
         const int rps = (DHW + nslab - 1) / nslab; nslab = (DHW + rps - 1) / rps;
+        if (g.cs_off && colsum_batched() && out.base == BASE_WS) {       // the GroupNorm backward that wrote g left its column sums
+            ColsumDesc d{}; d.partial_off = (long)g.cs_off; d.out_off = (long)out.off; d.N = N; d.nslab = g.cs_rows; d.C = C;
+            d.accumulate_over_n = per_sample ? 0 : 1; d.count = count; d.out_stride = out_stride; d.gx = (count + 15) / 16;
+            const int nb = d.gx * (per_sample ? N : 1);
+            for (int b = 0; b < nb; ++b) cs_map.push_back(make_int2((int)cs_descs.size(), b));
+            cs_descs.push_back(d);
+            return;
+        }
         Op st{}; st.kind = hp ? OP_GN_STATS32 : OP_GN_STATS; st.r[0] = ws_ref(g.off);
         st.i[0] = C; st.i[1] = 0; st.i[2] = DHW; st.i[3] = nslab; st.i[4] = rps; st.i[5] = N;
         if (colsum_batched() && out.base == BASE_WS) {
@@ -862,6 +871,7 @@ struct Builder {
         gnpart_fixups.push_back(plan->ops.size()); plan->ops.push_back(cs);
     }
     std::vector<ColsumDesc> cs_descs; std::vector<int2> cs_map;
+    static bool gnb_fold_enabled() { const char* e = getenv("LDM_GNB_FOLD"); return e ? atoi(e) != 0 : true; }
     static bool colsum_batched() { const char* e = getenv("LDM_COLSUM_BATCH"); return e ? atoi(e) != 0 : true; }
     size_t cs_flushed = 0, exp_flushed = 0;              // blocks of cs_map / exp_map already launched by an earlier flush
     void flush_colsums() {
@@ -1003,6 +1013,23 @@ struct Builder {
         Op o{}; o.kind = OP_GNB;
         o.r[0] = ws_ref(dy.off); o.r[1] = ws_ref(xa.off); o.r[2] = xb.valid ? ws_ref(xb.off) : Ref(); o.r[3] = ws_ref(t.ab_off);
         o.r[5] = ws_ref(t.mr_off); o.r[6] = w_ref(t.g->g_off); o.r[7] = ws_ref(gsum); o.r[8] = ws_ref(dgn); o.r[9] = ws_ref(dbn);
+        // passes 2 + 3 in one launch (gn_bwd_fold_apply_kernel) where the forward's one-launch form applies too; its blocks also leave the
+        // column sums of dx per row chunk, which are the bias / time-embedding gradients of the convs that produced xa / xb (emit_colsum)
+        o.i[11] = 0; o.i[12] = 0;
+        if (!hp && gnb_fold_enabled() && C / t.groups <= 64 && nslab <= 512) {
+            const int slices = (C + 63) / 64;
+            int chunks = std::max(1, std::min(256 / (slices * N), (DHW + 31) / 32));
+            const int rpb = rup((DHW + chunks - 1) / chunks, 32);
+            chunks = (DHW + rpb - 1) / rpb;
+            o.i[11] = rpb; o.i[12] = chunks;
+            if (colsum_batched()) {
+                const size_t cs = pool.alloc((size_t)N * chunks * C * 2 * 4);       // kept to the end of the plan, like every batched column-sum partial
+                o.r[7] = ws_ref(cs);                                               // (the group-sum scratch is not used by this form)
+                dxa.cs_off = cs; dxa.cs_rows = chunks;
+                if (xb.valid) { dxb.cs_off = cs + (size_t)N * chunks * xa.C * 2 * 4; dxb.cs_rows = chunks; }
+                o.i[13] = 1;
+            }
+        }
         o.r[10] = acc_a.valid ? ws_ref(acc_a.off) : Ref(); o.r[11] = acc_b.valid ? ws_ref(acc_b.off) : Ref();
         o.r[12] = ws_ref(dxa.off); o.r[13] = xb.valid ? ws_ref(dxb.off) : Ref();
         int* i = o.i;
@@ -2038,13 +2065,10 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                 float* flat = (float*)bs.p[BASE_IO4];
                 if (!flat) return fail(LDM_ERR_BAD_ARG, "backward without a gradient buffer");
                 hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(i[6], i[4]), dim3(256), 0, s, p);
-                static const bool gnb_fold = [] { const char* e = getenv("LDM_GNB_FOLD"); return e ? atoi(e) != 0 : true; }();
-                if (gnb_fold && C / i[2] <= 64 && i[6] <= 512) {       // passes 2 + 3 in one launch (gn_bwd_fold_apply_kernel)
-                    const int slices = (C + 63) / 64;
-                    int chunks = std::max(1, std::min(256 / (slices * i[4]), (i[3] + 31) / 32));
-                    p.rows_per_block = rup((i[3] + chunks - 1) / chunks, 32);
-                    chunks = (i[3] + p.rows_per_block - 1) / p.rows_per_block;
-                    hipLaunchKernelGGL(gn_bwd_fold_apply_kernel, dim3(chunks, slices, i[4]), dim3(256), 0, s, p);
+                if (i[11]) {                             // passes 2 + 3 in one launch (Builder::backward_gn decided)
+                    p.rows_per_block = i[11];
+                    p.cs = i[13] ? (float*)rp(bs, o.r[7]) : nullptr;
+                    hipLaunchKernelGGL(gn_bwd_fold_apply_kernel, dim3(i[12], (C + 63) / 64, i[4]), dim3(256), 0, s, p);
                 } else {
                     hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(i[2], i[4]), dim3(256), 0, s, p);
                     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid_for((long)i[4] * i[3] * (C / 8), 256, 2048)), dim3(256), 0, s, p);

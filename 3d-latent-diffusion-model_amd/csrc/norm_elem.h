@@ -815,6 +815,8 @@ struct GnBwdParams {
     const bf16_t* acc_a; const bf16_t* acc_b;      // optional gradients to add to dx (residual / skip paths), same split
     bf16_t* dxa; bf16_t* dxb;                      // outputs [N*DHW][ca], [N*DHW][cb]
     int rows_per_block;                            // gn_bwd_fold_apply_kernel: rows per block of the apply grid (a multiple of 32)
+    float* cs;                                     // optional: column sums of dx per row chunk, [N][chunks][ca][2] then [N][chunks][cb][2] (pair = (sum, 0)):
+                                                   // the bias / time-embedding gradient of the conv that produced x (Builder::emit_colsum)
 };
 
 // activation code of the GroupNorm kernels (fields named `silu`): 0 = none, 1 = SiLU, 2 = LeakyReLU(0.2) (PatchDiscriminator)
@@ -1002,43 +1004,69 @@ __global__ __launch_bounds__(256) void gn_bwd_fold_apply_kernel(const GnBwdParam
     __syncthreads();
     const int vec = tid & 7, rl = tid >> 3;
     const int c = c0 + vec * 8;
-    if (c >= C) return;
+    const bool active = c < C;
     const bool second = c >= p.ca;
     const int cs = second ? p.cb : p.ca, cc = second ? c - p.ca : c;
     const bf16_t* xs = second ? p.xb : p.xa;
     const bf16_t* accp = second ? p.acc_b : p.acc_a;
     bf16_t* dxs = second ? p.dxb : p.dxa;
-    float a[8], b[8], mean[8], rstd[8], m1[8], m2[8], gam[8];
+    float colsum[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        a[k] = p.ab[((size_t)n * C + c + k) * 2]; b[k] = p.ab[((size_t)n * C + c + k) * 2 + 1];
-        const int g = (c + k) / cpg;
-        mean[k] = p.mr[((size_t)n * p.groups + g) * 2]; rstd[k] = p.mr[((size_t)n * p.groups + g) * 2 + 1];
-        m1[k] = gstat[g - g_lo][0]; m2[k] = gstat[g - g_lo][1];
-        gam[k] = p.gamma[c + k];
-    }
-    const int r0 = blockIdx.x * p.rows_per_block;          // row chunk of this block (host: a multiple of 32 rows)
-    int r1 = r0 + p.rows_per_block; if (r1 > p.DHW) r1 = p.DHW;
-    for (int r = r0 + rl; r < r1; r += 32) {
-        const size_t row = (size_t)n * p.DHW + r;
-        const u32x4 xv = *reinterpret_cast<const u32x4*>(xs + row * cs + cc);
-        const u32x4 dv = *reinterpret_cast<const u32x4*>(p.dy + row * C + c);
-        u32x4 av = {0u, 0u, 0u, 0u};
-        if (accp) av = *reinterpret_cast<const u32x4*>(accp + row * cs + cc);
-        float out[8];
+    for (int k = 0; k < 8; ++k) colsum[k] = 0.f;
+    if (active) {
+        float a[8], b[8], mean[8], rstd[8], m1[8], m2[8], gam[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const float x = __uint_as_float((k & 1) ? (xv[k >> 1] & 0xffff0000u) : (xv[k >> 1] << 16));
-            const float dy = __uint_as_float((k & 1) ? (dv[k >> 1] & 0xffff0000u) : (dv[k >> 1] << 16));
-            const float ac = __uint_as_float((k & 1) ? (av[k >> 1] & 0xffff0000u) : (av[k >> 1] << 16));
-            const float gg = gn_bwd_g(dy, a[k] * x + b[k], p.silu);
-            const float xh = (x - mean[k]) * rstd[k];
-            out[k] = rstd[k] * (gam[k] * gg - m1[k] - xh * m2[k]) + ac;
+            a[k] = p.ab[((size_t)n * C + c + k) * 2]; b[k] = p.ab[((size_t)n * C + c + k) * 2 + 1];
+            const int g = (c + k) / cpg;
+            mean[k] = p.mr[((size_t)n * p.groups + g) * 2]; rstd[k] = p.mr[((size_t)n * p.groups + g) * 2 + 1];
+            m1[k] = gstat[g - g_lo][0]; m2[k] = gstat[g - g_lo][1];
+            gam[k] = p.gamma[c + k];
         }
-        u32x4 o;
+        const int r0 = blockIdx.x * p.rows_per_block;          // row chunk of this block (host: a multiple of 32 rows)
+        int r1 = r0 + p.rows_per_block; if (r1 > p.DHW) r1 = p.DHW;
+        for (int r = r0 + rl; r < r1; r += 32) {
+            const size_t row = (size_t)n * p.DHW + r;
+            const u32x4 xv = *reinterpret_cast<const u32x4*>(xs + row * cs + cc);
+            const u32x4 dv = *reinterpret_cast<const u32x4*>(p.dy + row * C + c);
+            u32x4 av = {0u, 0u, 0u, 0u};
+            if (accp) av = *reinterpret_cast<const u32x4*>(accp + row * cs + cc);
+            float out[8];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) o[k] = pack2bf(out[2 * k], out[2 * k + 1]);
-        *reinterpret_cast<u32x4*>(dxs + row * cs + cc) = o;
+            for (int k = 0; k < 8; ++k) {
+                const float x = __uint_as_float((k & 1) ? (xv[k >> 1] & 0xffff0000u) : (xv[k >> 1] << 16));
+                const float dy = __uint_as_float((k & 1) ? (dv[k >> 1] & 0xffff0000u) : (dv[k >> 1] << 16));
+                const float ac = __uint_as_float((k & 1) ? (av[k >> 1] & 0xffff0000u) : (av[k >> 1] << 16));
+                const float gg = gn_bwd_g(dy, a[k] * x + b[k], p.silu);
+                const float xh = (x - mean[k]) * rstd[k];
+                out[k] = rstd[k] * (gam[k] * gg - m1[k] - xh * m2[k]) + ac;
+            }
+            u32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                o[k] = pack2bf(out[2 * k], out[2 * k + 1]);
+                colsum[2 * k] += __uint_as_float(o[k] << 16); colsum[2 * k + 1] += __uint_as_float(o[k] & 0xffff0000u);   // of the STORED values
+            }
+            *reinterpret_cast<u32x4*>(dxs + row * cs + cc) = o;
+        }
+    }
+    if (p.cs == nullptr) return;
+    // column sums of this block's rows: 32 row lanes through LDS (fixed order), one (sum, 0) pair per channel
+    float* red = &part[0][0][0];                           // 32 x 64 floats (the fold is done with it)
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[rl * 64 + vec * 8 + k] = colsum[k];
+    __syncthreads();
+    if (tid < 64 && c0 + tid < C) {
+        float t = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) t += red[k * 64 + tid];
+        const int ch = c0 + tid;
+        const bool sec = ch >= p.ca;
+        const int chunks = gridDim.x;
+        float* dst = sec ? p.cs + (size_t)p.N * chunks * p.ca * 2 + (((size_t)n * chunks + blockIdx.x) * p.cb + (ch - p.ca)) * 2
+                         : p.cs + (((size_t)n * chunks + blockIdx.x) * p.ca + ch) * 2;
+        dst[0] = t; dst[1] = 0.f;
     }
 }
 
