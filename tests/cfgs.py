@@ -36,6 +36,9 @@ VAE_FULL_ATTN = dict(spatial_dims=3, in_channels=1, out_channels=1, latent_chann
 # num_head_channels 32 (diffusion_def of config_train_stable.json:39-48), reduced channels
 UNET_TINY_HEAD32 = dict(spatial_dims=3, in_channels=4, out_channels=4, channels=[64, 64, 128],
                         attention_levels=[False, False, True], num_head_channels=[0, 0, 32], num_res_blocks=2, norm_num_groups=32)
+# 96 channels in 32 groups: THREE channels per group (the odd-group paths of the GroupNorm folds), 3 heads of 32
+UNET_TINY_ODD = dict(spatial_dims=3, in_channels=4, out_channels=4, channels=[96, 96],
+                     attention_levels=[False, True], num_head_channels=[0, 32], num_res_blocks=1, norm_num_groups=32)
 
 # kwargs of autoencoder_def / diffusion_def of the five shipped reference configs (3d_ldm/config/*.json, "@" / "$@" references
 # resolved) with the patch sizes of their autoencoder_train / diffusion_train sections: the shapes the reference's own entry scripts run

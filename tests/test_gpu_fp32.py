@@ -46,7 +46,7 @@ def gate(got, ref, what, tol=TOL):
 
 
 @pytest.mark.parametrize("name,dims,b", [("UNET_TINY", (8, 8, 8), 1), ("UNET_TINY", (8, 12, 4), 2), ("UNET_TINY_ALT", (6, 10, 8), 2),
-                                         ("UNET_TINY_COND", (8, 8, 8), 2), ("UNET_TINY_HEAD32", (8, 8, 8), 1)])
+                                         ("UNET_TINY_COND", (8, 8, 8), 2), ("UNET_TINY_HEAD32", (8, 8, 8), 1), ("UNET_TINY_ODD", (8, 8, 8), 2)])
 def test_unet_tiny_fp32_meets_1e3(cuda, name, dims, b):
     from oracle import unet as ou
     cfg = getattr(cfgs, name)

@@ -60,7 +60,7 @@ def _faults(m):
 
 
 @pytest.mark.parametrize("name,dims,b", [("UNET_FULL", (24, 24, 24), 1), ("UNET_FULL", (16, 16, 16), 2), ("UNET_TINY", (8, 8, 8), 2),
-                                         ("UNET_TINY_ALT", (6, 10, 8), 1), ("UNET_TINY_COND", (8, 8, 8), 1)])
+                                         ("UNET_TINY_ALT", (6, 10, 8), 1), ("UNET_TINY_COND", (8, 8, 8), 1), ("UNET_TINY_ODD", (8, 8, 8), 2)])
 def test_fused_finalize_groupnorm_is_bit_identical(cuda, name, dims, b):
     cfg = getattr(cfgs, name)
     fused, plain = _pair(cfg, 21, cuda)

@@ -42,7 +42,7 @@ def _unet_pair(cfg, seed, cuda):
 
 
 @pytest.mark.parametrize("name,dims,b", [("UNET_TINY", (8, 8, 8), 1), ("UNET_TINY", (8, 12, 4), 2), ("UNET_TINY_ALT", (6, 10, 8), 2),
-                                         ("UNET_TINY_HEAD32", (8, 8, 8), 2)])
+                                         ("UNET_TINY_HEAD32", (8, 8, 8), 2), ("UNET_TINY_ODD", (8, 8, 8), 2)])
 def test_unet_tiny_matches_oracle(cuda, name, dims, b):
     from oracle import unet as ou
     cfg = getattr(cfgs, name)

@@ -48,7 +48,7 @@ def _check_blocks(got, ref, tol, what, attn=()):
 
 
 @pytest.mark.parametrize("name,dims,b", [("UNET_TINY", (8, 8, 8), 2), ("UNET_TINY_ALT", (6, 10, 8), 1), ("UNET_FULL", (16, 16, 16), 1),
-                                         ("UNET_TINY_HEAD32", (8, 8, 8), 1)])
+                                         ("UNET_TINY_HEAD32", (8, 8, 8), 1), ("UNET_TINY_ODD", (8, 8, 8), 2)])
 def test_unet_blocks_teacher_forced(cuda, name, dims, b):
     from oracle import unet as ou
     cfg = getattr(cfgs, name)

@@ -31,7 +31,7 @@ def _cat(gd, names):
 
 
 @pytest.mark.parametrize("name,dims,b,cond", [("UNET_TINY", (8, 8, 8), 2, 0), ("UNET_TINY_ALT", (6, 10, 8), 1, 0),
-                                              ("UNET_TINY_COND", (8, 12, 4), 1, 4), ("UNET_TINY_HEAD32", (8, 8, 8), 2, 0)])
+                                              ("UNET_TINY_COND", (8, 12, 4), 1, 4), ("UNET_TINY_HEAD32", (8, 8, 8), 2, 0), ("UNET_TINY_ODD", (8, 8, 8), 2, 0)])
 def test_unet_parameter_gradients_match_oracle_autograd(cuda, name, dims, b, cond):
     from ldm3d.networks import DiffusionModelUNet
     from oracle import unet as ou
