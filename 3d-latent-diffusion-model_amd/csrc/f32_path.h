@@ -165,6 +165,159 @@ __global__ __launch_bounds__(256, 3) void conv_f32_kernel(const Conv32Params p) 
     }
 }
 
+// ---- the same convolution on the bf16 matrix cores with fp32-class accuracy ("3 x bf16"): every fp32 operand is split on its way into
+// LDS into hi = bf16(x) and lo = bf16(x - hi), so x = hi + lo to 2^-18 relative, and every product is three MFMAs,
+// hi*hi + hi*lo + lo*hi (the dropped lo*lo term is <= 2^-18 of the product), accumulated in fp32.  v_mfma_f32_16x16x32_bf16 runs at
+// 16x the rate of v_mfma_f32_32x32x2_f32 (2.5 vs 0.157 PFLOP/s), so three of them per product are still ~5x faster than one fp32 MFMA; per-product
+// error ~1e-5 relative, i.e. the same order as fp32 accumulation-order noise over K = 27 * Cin.  Same tile, grid, split-K and epilogue as
+// conv_f32_kernel; K step = 32 input channels of one tap (Cin % 32 == 0, checked by the planner).  LDM_F32_X3=0 plans the plain fp32 kernel.
+__device__ __forceinline__ void split_bf16x4(const float4 v, uint2& hi, uint2& lo) {
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        h[k] = f2bf(x[k]);
+        l[k] = f2bf(x[k] - __uint_as_float(h[k] << 16));
+    }
+    hi = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+    lo = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+}
+
+template <int BN>
+__global__ __launch_bounds__(256, 2) void conv_x3_kernel(const Conv32Params p) {
+    constexpr int BM = 128, BK = 32, LDB = (BK + 8) * 2, NI = BN / 32;   // LDS row stride 80 B (bf16): conflict-free ds_read_b128; NI cout tiles of 16 per wave
+    // [buffer][hi | lo][rows][80 B]
+    __shared__ __attribute__((aligned(16))) char sA[2][2][BN * LDB];   // weights
+    __shared__ __attribute__((aligned(16))) char sB[2][2][BM * LDB];   // voxels
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int mtile = lid % p.mtiles; lid /= p.mtiles;
+    const int ntile = lid % p.ntiles;
+    const int split = lid / p.ntiles;
+    const int m0 = mtile * BM, n0 = ntile * BN;
+    const int s_begin = split * p.steps_per_split;
+    int s_end = s_begin + p.steps_per_split; if (s_end > p.steps) s_end = p.steps;
+    const int DHWo = p.Dout * p.Hout * p.Wout, HWo = p.Hout * p.Wout;
+    const int cin = p.ca + p.cb;
+    const int DinU = p.Din << p.ups, HinU = p.Hin << p.ups, WinU = p.Win << p.ups;
+
+    // loader: thread = (16-byte fp32 chunk lc of the 32-channel row, rows lr + 32 j)
+    const int lc = tid & 7, lr = tid >> 3;
+    constexpr int RJ = BM / 32, WJ = BN / 32;
+    int r_n[RJ], r_d[RJ], r_h[RJ], r_w[RJ];
+#pragma unroll
+    for (int j = 0; j < RJ; ++j) {
+        const int m = m0 + lr + 32 * j;
+        r_n[j] = -1; r_d[j] = r_h[j] = r_w[j] = 0;
+        if (m < p.M) {
+            const int n = m / DHWo; int r = m - n * DHWo; const int od = r / HWo; r -= od * HWo; const int oh = r / p.Wout;
+            r_n[j] = n; r_d[j] = od * p.stride - p.pad; r_h[j] = oh * p.stride - p.pad; r_w[j] = (r - oh * p.Wout) * p.stride - p.pad;
+        }
+    }
+    float4 ra[WJ], rb[RJ];
+    auto load_step = [&](int s) {
+        const int tap = s / p.nchunk, ch = (s - tap * p.nchunk) * BK;
+        int kd = 0, kh = 0, kw = 0;
+        if (p.ksize == 3) { kd = tap / 9; kh = (tap - kd * 9) / 3; kw = tap - kd * 9 - kh * 3; }
+        const bool second = ch >= p.ca;
+        const float* src = second ? p.xb : p.xa;
+        const int cs = second ? p.cb : p.ca, cc = (second ? ch - p.ca : ch) + lc * 4;
+#pragma unroll
+        for (int j = 0; j < RJ; ++j) {
+            const int id = r_d[j] + kd, ih = r_h[j] + kh, iw = r_w[j] + kw;
+            const bool ok = (r_n[j] >= 0) & ((unsigned)id < (unsigned)DinU) & ((unsigned)ih < (unsigned)HinU) & ((unsigned)iw < (unsigned)WinU) &
+                            !(p.exact & (id | ih | iw) & 1);
+            const int v = ok ? ((r_n[j] * p.Din + (id >> p.ups)) * p.Hin + (ih >> p.ups)) * p.Win + (iw >> p.ups) : -1;
+            rb[j] = (v >= 0) ? *reinterpret_cast<const float4*>(src + (size_t)v * cs + cc) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < WJ; ++j) {
+            const int co = n0 + lr + 32 * j;
+            ra[j] = (co < p.CoutPad) ? *reinterpret_cast<const float4*>(p.w + ((size_t)tap * p.CoutPad + co) * cin + ch + lc * 4)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_step = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < RJ; ++j) {
+            uint2 hi, lo; split_bf16x4(rb[j], hi, lo);
+            *reinterpret_cast<uint2*>(&sB[buf][0][(lr + 32 * j) * LDB + lc * 8]) = hi;
+            *reinterpret_cast<uint2*>(&sB[buf][1][(lr + 32 * j) * LDB + lc * 8]) = lo;
+        }
+#pragma unroll
+        for (int j = 0; j < WJ; ++j) {
+            uint2 hi, lo; split_bf16x4(ra[j], hi, lo);
+            *reinterpret_cast<uint2*>(&sA[buf][0][(lr + 32 * j) * LDB + lc * 8]) = hi;
+            *reinterpret_cast<uint2*>(&sA[buf][1][(lr + 32 * j) * LDB + lc * 8]) = lo;
+        }
+    };
+
+    f32x4 acc[NI][4];                                   // [cout tile of 16][voxel tile of 16]: wave tile = (BN / 2) couts x 64 voxels
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fg = lane >> 4;           // fragment row, 8-deep k slice
+    if (s_begin < s_end) { load_step(s_begin); store_step(0); }
+    __syncthreads();
+    for (int s = s_begin; s < s_end; ++s) {
+        const int buf = (s - s_begin) & 1;
+        if (s + 1 < s_end) load_step(s + 1);
+        bf16x8 ah[NI], al[NI], bh[4], bl[4];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int off = (wn * (BN / 2) + i * 16 + fr) * LDB + fg * 16;
+            ah[i] = *reinterpret_cast<const bf16x8*>(&sA[buf][0][off]); al[i] = *reinterpret_cast<const bf16x8*>(&sA[buf][1][off]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int off = (wm * 64 + j * 16 + fr) * LDB + fg * 16;
+            bh[j] = *reinterpret_cast<const bf16x8*>(&sB[buf][0][off]); bl[j] = *reinterpret_cast<const bf16x8*>(&sB[buf][1][off]);
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);   // the small terms first
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+            }
+        if (s + 1 < s_end) store_step(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: accumulator register r of tile (i, j) = cout 16 i + 4 fg + r of voxel 16 j + fr
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + wm * 64 + j * 16 + fr;
+        if (m >= p.M) continue;
+        const int n = m / DHWo, sp = m - n * DHWo;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int c = n0 + wn * (BN / 2) + i * 16 + 4 * fg;
+            float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            if (p.splitk > 1) {
+                if (c < p.CoutPad) *reinterpret_cast<float4*>(p.partial + ((size_t)split * p.M + m) * p.CoutPad + c) = v;
+                continue;
+            }
+            if (c >= p.CoutPad) continue;
+            if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + c); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+            if (p.temb) { const float4 b = *reinterpret_cast<const float4*>(p.temb + (size_t)n * p.temb_stride + c); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+            if (p.out_ncdhw) {
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (c + r < p.CoutReal) p.out_ncdhw[((size_t)n * p.CoutReal + c + r) * DHWo + sp] = vv[r];
+                continue;
+            }
+            if (c >= p.CoutS) continue;
+            if (p.residual) { const float4 b = *reinterpret_cast<const float4*>(p.residual + (size_t)m * p.CoutS + c); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+            *reinterpret_cast<float4*>(p.out + (size_t)m * p.CoutS + c) = v;
+        }
+    }
+}
+
 // split-K slabs -> epilogue (slabs summed in order: bitwise reproducible).  thread = one row x 4 channels.
 __global__ __launch_bounds__(256) void finalize_f32_kernel(const Conv32Params p) {
     const int DHWo = p.Dout * p.Hout * p.Wout;

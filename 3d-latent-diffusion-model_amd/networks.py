@@ -216,9 +216,10 @@ class _LdmModule(nn.Module):
     def set_precision(self, precision: str = "bf16"):
         """``"bf16"`` (default): bf16 storage / bf16 MFMA / fp32 accumulate, the headline path.  ``"fp32"``: the
         reference's own arithmetic (autocast is off at 3d_ldm/train_diffusion.py:177 and absent from inference.py:91-99):
-        fp32 activations and weights on the fp32 matrix instruction, ~1e-5 rel-L2 from the CPU path at about a quarter of
-        the bf16 throughput.  Inference plans only; training always runs the bf16 plans.  Environment default:
-        ``LDM_PRECISION=fp32``."""
+        fp32 activations and weights; inference convolutions as three bf16 MFMAs per product on hi / lo splits of the fp32 operands
+        (fp32-class accuracy, ~5e-5 rel-L2 from the CPU path, about 0.3 of the bf16 throughput), everything else and every
+        training plan on the exact fp32 matrix instruction (gradients ~1e-5 from fp32 autograd).  Inference and training plans
+        of both networks.  Environment default: ``LDM_PRECISION=fp32``."""
         code = {"bf16": 0, "fp32": 1}.get(str(precision).lower())
         if code is None:
             raise ValueError(f"precision must be 'bf16' or 'fp32', got {precision!r}")

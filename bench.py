@@ -258,9 +258,10 @@ def main():
             d32 = time.perf_counter() - t32
             fp32_leg = {"steps_per_s": n32 / d32, "ms_per_step": d32 / n32 * 1e3, "steps": n32,
                         "unet_step_tflops": UNET_STEP_GFLOP / (d32 / n32 * 1e3),
-                        "frac_of_fp32_mfma_peak_157TF": UNET_STEP_GFLOP / (d32 / n32 * 1e3) / 157.3,
-                        "what": "set_precision('fp32'): fp32 activations / weights on v_mfma_f32_32x32x2_f32 (csrc/f32_path.h), "
-                                "same step, same graph replay; rel-L2 vs the fp32 CPU oracle ~1e-5 (bf16 path: ~3e-2)"}
+                        "what": "set_precision('fp32'): fp32 activations / weights; convolutions as 3 x bf16 MFMA (every fp32 operand split into "
+                                "hi + lo bf16 on its way into LDS, hi*hi + hi*lo + lo*hi accumulated in fp32: csrc/f32_path.h conv_x3_kernel), "
+                                "attention / GroupNorm / linears in fp32; same step, same graph replay; rel-L2 vs the fp32 CPU oracle ~5e-5 "
+                                "(bf16 path: ~3e-2; LDM_F32_X3=0 = exact fp32 MFMA everywhere: ~1e-5 at 84 steps/s)"}
             unet.set_precision("bf16")
     assert torch.isfinite(x).all()
 

@@ -142,7 +142,8 @@ int ldm_model_set_graph_mode(ldm_model* m, int on);
 
 /* ---- precision of the inference AND training plans of both networks.  The reference computes in fp32 (autocast off: 3d_ldm/train_diffusion.py:177,237;
  *      3d_ldm/inference.py:91-99 has no autocast): LDM_PREC_FP32 runs the same plans on fp32 activations / weights with the
- *      fp32 matrix instruction (v_mfma_f32_32x32x2_f32) and stays within ~1e-5 rel-L2 of the CPU path; LDM_PREC_BF16 (default)
+ *      fp32 matrix instruction (v_mfma_f32_32x32x2_f32; the convolutions of the inference plans as three bf16 MFMAs per product on
+ *      hi / lo splits of the fp32 operands, fp32-class accuracy) and stays within ~5e-5 rel-L2 of the CPU path; LDM_PREC_BF16 (default)
  *      is the bf16-MFMA headline path (~3e-2 at the benchmark depth, its own rounding floor).  After switching to fp32 upload the
  *      parameters again (the unrounded copies are made at upload time). ------------------------------------------------- */
 #define LDM_PREC_BF16 0
