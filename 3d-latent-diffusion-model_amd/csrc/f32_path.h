@@ -403,6 +403,58 @@ __global__ __launch_bounds__(256) void gn_apply_f32_kernel(const Gn32Params p) {
     }
 }
 
+// Statistics fold + apply in one launch (inference plans): every block folds the partial rows of the channels that cover its 64-channel
+// slice (gn_fold_cover, norm_elem.h: the forward one-launch GroupNorm's fold, fp64 totals), derives mean / rstd of those groups and
+// normalises its row chunk.  Replaces gn_finalize_kernel + gn_apply_f32_kernel.  grid = (row chunks, ceil(C / 64), N), 256 threads.
+struct Gn32FusedParams {
+    const float* xa; const float* xb; int ca, cb, DHW, N, nslab, groups, silu, rows_per_block; float eps;
+    const float* partial; const float* gamma; const float* beta; float* out;
+};
+__global__ __launch_bounds__(256) void gn32_fold_apply_kernel(const Gn32FusedParams p) {
+    __shared__ __attribute__((aligned(16))) float part[8][96][4];
+    __shared__ double csum[192][2];
+    __shared__ float gstat[64][2];
+    const int tid = threadIdx.x, n = blockIdx.z;
+    const int C = p.ca + p.cb, cpg = C / p.groups;
+    const int c0 = blockIdx.y * 64;
+    int c1 = c0 + 64; if (c1 > C) c1 = C;
+    const int g_lo = c0 / cpg, g_hi = (c1 + cpg - 1) / cpg;
+    const int cov_lo = g_lo * cpg, ncov = g_hi * cpg - cov_lo;
+    gn_fold_cover(GnFoldSrc{p.partial, nullptr, C, 0, p.nslab, 0}, n, cpg, cov_lo, ncov, part, csum);
+    __syncthreads();
+    if (tid < g_hi - g_lo) {
+        double s = 0.0, q = 0.0;
+        for (int k = 0; k < cpg; ++k) { s += csum[tid * cpg + k][0]; q += csum[tid * cpg + k][1]; }
+        const double cnt = (double)cpg * (double)p.DHW;
+        const double mean = s / cnt;
+        double var = q / cnt - mean * mean; if (var < 0.0) var = 0.0;
+        gstat[tid][0] = (float)mean; gstat[tid][1] = (float)(1.0 / sqrt(var + (double)p.eps));
+    }
+    __syncthreads();
+    const int vec = tid & 15, rl = tid >> 4;               // 16 float4 per 64-channel slice x 16 row lanes
+    const int c = c0 + vec * 4;
+    if (c >= C) return;
+    const bool second = c >= p.ca;
+    const float* src = second ? p.xb : p.xa;
+    const int cs = second ? p.cb : p.ca, cc = second ? c - p.ca : c;
+    float a[4], b[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int g = (c + k) / cpg - g_lo;
+        a[k] = p.gamma[c + k] * gstat[g][1];
+        b[k] = p.beta[c + k] - gstat[g][0] * a[k];
+    }
+    const int r0 = blockIdx.x * p.rows_per_block;
+    int r1 = r0 + p.rows_per_block; if (r1 > p.DHW) r1 = p.DHW;
+    for (int r = r0 + rl; r < r1; r += 16) {
+        const size_t row = (size_t)n * p.DHW + r;
+        const float4 v = *reinterpret_cast<const float4*>(src + row * cs + cc);
+        float4 y = make_float4(v.x * a[0] + b[0], v.y * a[1] + b[1], v.z * a[2] + b[2], v.w * a[3] + b[3]);
+        if (p.silu) { y.x = y.x / (1.0f + expf(-y.x)); y.y = y.y / (1.0f + expf(-y.y)); y.z = y.z / (1.0f + expf(-y.z)); y.w = y.w / (1.0f + expf(-y.w)); }
+        *reinterpret_cast<float4*>(p.out + row * C + c) = y;
+    }
+}
+
 // ---- self-attention on fp32 q|k|v rows [B*N][3C] (q | k | v, heads of d channels each), flash style, fp32 MFMA.
 // A wave owns 32 queries; per 32-key tile  S^T = K Q^T  (32x32x2 MFMA over d) lands with the query on the lane and 16 of the 32 keys
 // in the lane's registers (the other 16 in lane ^ 32), so the softmax needs one cross-lane exchange per row statistic and P feeds

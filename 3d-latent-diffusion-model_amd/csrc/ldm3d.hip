@@ -652,7 +652,10 @@ struct Builder {
         } else {
             const int cvec = C / 8;
             const int rows_par = std::max(1, 256 / cvec);
-            int nslab = std::min((DHW + rows_par - 1) / rows_par, std::max(1, 512 / N));
+            // fp32 inference plans: statistics fold + apply in one launch (gn32_fold_apply_kernel); one partial row per CU keeps the fold short
+            static const bool gn32_fold = [] { const char* e = getenv("LDM_GN32_FOLD"); return e ? atoi(e) != 0 : true; }();
+            const bool fold32 = hp && !train && gn32_fold && C / groups <= 64;
+            int nslab = std::min((DHW + rows_par - 1) / rows_par, std::max(1, (fold32 ? 256 : 512) / N));
             int rps = (DHW + nslab - 1) / nslab;
             nslab = (DHW + rps - 1) / rps;
             gnpart_bytes = std::max(gnpart_bytes, (size_t)N * nslab * C * 2 * 4);
@@ -660,6 +663,20 @@ struct Builder {
             st.r[0] = ws_ref(xa.off); st.r[1] = xb.valid ? ws_ref(xb.off) : Ref();
             st.i[0] = xa.C; st.i[1] = xb.valid ? xb.C : 0; st.i[2] = DHW; st.i[3] = nslab; st.i[4] = rps; st.i[5] = N;
             gnpart_fixups.push_back(plan->ops.size()); plan->ops.push_back(st);
+            if (fold32) {
+                Act out = new_act(N, xa.D, xa.H, xa.W, C);
+                const int slices = (C + 63) / 64;
+                int chunks = std::max(1, std::min(256 / (slices * N), (DHW + 15) / 16));
+                const int rpb = rup((DHW + chunks - 1) / chunks, 16);
+                chunks = (DHW + rpb - 1) / rpb;
+                Op ap{}; ap.kind = OP_GN_APPLY32;
+                ap.r[0] = ws_ref(xa.off); ap.r[1] = xb.valid ? ws_ref(xb.off) : Ref(); ap.r[3] = ws_ref(out.off);
+                ap.r[6] = w_ref(g.g_off); ap.r[7] = w_ref(g.b_off);
+                ap.i[0] = xa.C; ap.i[1] = xb.valid ? xb.C : 0; ap.i[2] = DHW; ap.i[3] = N; ap.i[4] = silu ? 1 : 0;
+                ap.i[5] = nslab; ap.i[6] = groups; ap.i[7] = rpb; ap.i[8] = chunks; ap.f[0] = eps;
+                gnpart_fixups.push_back(plan->ops.size()); plan->ops.push_back(ap);
+                return out;
+            }
             Op f{}; f.kind = OP_GN_FINALIZE;
             f.r[1] = w_ref(g.g_off); f.r[2] = w_ref(g.b_off);
             f.i[0] = nslab; f.i[1] = C; f.i[2] = groups; f.i[3] = DHW; f.i[4] = N; f.f[0] = eps;
@@ -1829,6 +1846,11 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                 if (o.kind == OP_GN_STATS32) {
                     p.DHW = i[2]; p.nslab = i[3]; p.rows_per_slab = i[4]; p.N = i[5]; p.partial = (float*)rp(bs, o.r[4]);
                     hipLaunchKernelGGL(gn_stats_f32_kernel, dim3(i[3], i[5]), dim3(256), 0, s, p);
+                } else if (i[5] > 0) {       // statistics fold + apply in one launch (inference plans)
+                    Gn32FusedParams q{}; q.xa = p.xa; q.xb = p.xb; q.ca = p.ca; q.cb = p.cb; q.DHW = i[2]; q.N = i[3]; q.silu = i[4];
+                    q.nslab = i[5]; q.groups = i[6]; q.rows_per_block = i[7]; q.eps = o.f[0]; q.partial = (const float*)rp(bs, o.r[4]);
+                    q.gamma = (const float*)rp(bs, o.r[6]); q.beta = (const float*)rp(bs, o.r[7]); q.out = (float*)rp(bs, o.r[3]);
+                    hipLaunchKernelGGL(gn32_fold_apply_kernel, dim3(i[8], (p.ca + p.cb + 63) / 64, i[3]), dim3(256), 0, s, q);
                 } else {
                     p.DHW = i[2]; p.N = i[3]; p.silu = i[4]; p.ab = (const float*)rp(bs, o.r[5]); p.out = (float*)rp(bs, o.r[3]);
                     hipLaunchKernelGGL(gn_apply_f32_kernel, dim3(grid_for((long)i[3] * i[2] * ((i[0] + i[1]) / 4), 256, 4096)), dim3(256), 0, s, p);
