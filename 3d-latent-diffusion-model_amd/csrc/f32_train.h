@@ -114,6 +114,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const Wgrad32Params p
         }
 }
 
+// (A 3 x bf16 form of this kernel -- operands split into hi + lo bf16 by a transposing loader, as conv_x3_kernel does for the forward --
+// was built and measured in round 2: gradients stayed at 2e-6 ... 7e-5 from fp32 autograd, since an error in dW is not amplified by
+// anything downstream, but it ran 20 % SLOWER than this kernel (250 vs 208 us per launch on average; 820 vs 690 us for the 24^3 256-channel
+// shapes) at every split setting: with one or two workgroups per CU and a one-step register prefetch the loop is bound by the latency
+// of its 32 KiB of operand loads per step, not by the matrix pipe, so making the MFMAs 5x cheaper buys nothing.  Removed.)
+
 // ---- GroupNorm (+SiLU) backward on fp32 tensors: partial sums per slab, fold (gn_bwd_finalize_kernel, type agnostic), apply ----
 struct Gnb32Params {
     const float* dy; const float* xa; const float* xb; int ca, cb;

@@ -293,7 +293,7 @@ struct ldm_model {
 };
 
 // ================================================================================================ builder
-static int wgrad_ksplit(long M, int taps, int cout, int cin);
+static int wgrad_ksplit(long M, int taps, int cout, int cin, bool hp = false);
 static bool wgrad3_enabled();
 static int wgrad3_ksplit(long KP, int cout, int cin);
 
@@ -985,7 +985,7 @@ struct Builder {
         // weights
         cur_w3 = (!hp && a.k == 3 && a.stride == 1 && a.pad == 1 && a.ups == 0 && wgrad3_enabled()) ? 1 : 0;
         cur_ksplit = cur_w3 ? wgrad3_ksplit((long)dout.N * dout.D * dout.H * (dout.W + 2), w.cout, cin_real)
-                            : wgrad_ksplit(dout.rows(), a.k * a.k * a.k, w.cout, cin_real);
+                            : wgrad_ksplit(dout.rows(), a.k * a.k * a.k, w.cout, cin_real, hp);
         cur_rows_total = w.cout;
         dw_off = pool.alloc((size_t)cur_ksplit * a.k * a.k * a.k * w.cout * cin_real * 4);
         if (a.xb.valid) {
@@ -996,7 +996,7 @@ struct Builder {
         if (a.w1) {
             const int c1 = a.g1a.C + (a.g1b.valid ? a.g1b.C : 0);
             cur_w3 = 0;
-            cur_ksplit = wgrad_ksplit(dout.rows(), 1, a.w1->cout, c1); cur_rows_total = a.w1->cout;
+            cur_ksplit = wgrad_ksplit(dout.rows(), 1, a.w1->cout, c1, hp); cur_rows_total = a.w1->cout;
             dw_off = pool.alloc((size_t)cur_ksplit * a.w1->cout * c1 * 4);
             emit_wgrad(dout, a.g1a, a.w1->cout, a.g1a.C, c1, 0, 1, 1, 0, 0);
             if (a.g1b.valid) emit_wgrad(dout, a.g1b, a.w1->cout, a.g1b.C, c1, a.g1a.C, 1, 1, 0, 0);
@@ -1690,11 +1690,11 @@ static inline int grid_for(long total, int per_block = 256, int cap = 4096) {
 }
 
 // voxel-range split of the weight-gradient GEMM: enough workgroups for 2 waves of 256 CUs, at least 16 K steps each
-static int wgrad_ksplit(long M, int taps, int cout, int cin) {
+static int wgrad_ksplit(long M, int taps, int cout, int cin, bool hp) {
     const long wgs = (long)taps * ((cout + 127) / 128) * ((cin + 127) / 128);
     const long steps = (M + 63) / 64;
-    const char* e = getenv("LDM_WGRAD_WGS");                 // tuning knob: workgroups aimed at (default: one round of 256 CUs)
-    const long target = e ? atol(e) : 256;
+    const char* e = getenv("LDM_WGRAD_WGS");                 // tuning knob: workgroups aimed at (default: one round of 256 CUs;
+    const long target = e ? atol(e) : (hp ? 768 : 256);      // the fp32 kernel, latency bound on its operand loads, wants three per CU: 49.3 -> 46.6 ms per step)
     long k = (target + wgs / 2) / wgs;                       // nearest count of whole rounds
     if (k > steps / 16) k = steps / 16;
     if (k > 16) k = 16;
