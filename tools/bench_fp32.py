@@ -1,7 +1,7 @@
 """fp32 precision mode of the headline step (UNet forward on 1x4x24^3 + DDPM step, graph replay), alone: ms per step and the share
-of the fp32 MFMA peak.  Used for the tiling sweeps of csrc/f32_path.h (LDM_F32_BN, LDM_F32_WGS are read when the library plans).
+of the fp32 MFMA peak.  Used for the sweeps of csrc/f32_path.h (LDM_F32_X3, LDM_F32_BN, LDM_F32_WGS, LDM_GN32_FOLD are read when the library plans).
 
-    python tools/bench_fp32.py [--steps 30] [--trace]      # --trace: per-kind totals through LDM_PLAN_TRACE-free HIP events"""
+    python tools/bench_fp32.py [--steps 30]"""
 import argparse
 import json
 import os
@@ -37,7 +37,7 @@ def main():
     assert torch.isfinite(y).all()
     print(json.dumps({"fp32_forward_ms": dt * 1e3, "forwards_per_s": 1.0 / dt, "tflops": bench.UNET_STEP_GFLOP / (dt * 1e3),
                       "frac_of_157TF": bench.UNET_STEP_GFLOP / (dt * 1e3) / 157.3,
-                      "knobs": {k: os.environ.get(k) for k in ("LDM_F32_BN", "LDM_F32_WGS")}}))
+                      "knobs": {k: os.environ.get(k) for k in ("LDM_F32_X3", "LDM_F32_BN", "LDM_F32_WGS", "LDM_GN32_FOLD")}}))
 
 
 if __name__ == "__main__":
