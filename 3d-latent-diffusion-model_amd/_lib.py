@@ -123,6 +123,7 @@ SIGNATURES = {
     "ldm_model_plan_conv_cfgs": (C.c_int, [_P, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]),
     "ldm_comm_unique_id": (C.c_int, [C.c_char_p]),
     "ldm_comm_init": (C.c_int, [C.c_int, C.c_int, C.c_char_p, C.POINTER(_P)]),
+    "ldm_comm_init_custom": (C.c_int, [C.c_int, C.c_int, _P, _P, C.POINTER(_P)]),
     "ldm_comm_allreduce": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int, _P]),
     "ldm_comm_broadcast": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int, _P]),
     "ldm_comm_barrier": (C.c_int, [_P, _P]),
@@ -133,7 +134,11 @@ SIGNATURES = {
     "ldm_model_plan_launches": (C.c_int, [_P, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "ldm_model_sync_faults": (C.c_int, [_P]),
     "ldm_model_grad_sync_trace": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]),
+    "ldm_model_grad_schedule": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64),
+                                          C.POINTER(C.c_int64), C.POINTER(C.c_int), C.c_int]),
 }
+# ldm_allreduce_fn (include/ldm3d.h): int fn(void* user, void* buf, int64_t count, int dtype, int op, void* stream)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, _P, _P, C.c_int64, C.c_int, C.c_int, _P)
 
 _lib = None
 _lock = threading.Lock()

@@ -15,6 +15,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <map>
 #include <memory>
 #include <string>
@@ -137,13 +138,20 @@ struct Pool {                                        // plan-time workspace allo
 // Descriptor table of a batched kernel: device copy of the descriptors + (descriptor, local block) per launched block.
 struct DevTable {
     void* descs = nullptr; int2* map = nullptr; int nblocks = 0;
+    std::vector<char> h_descs, h_map;                // staged at plan-build time (no device needed), uploaded on first use (ready)
     ~DevTable() { if (descs) (void)hipFree(descs); if (map) (void)hipFree(map); }
     template <class D> int upload(const std::vector<D>& d, const std::vector<int2>& m) {
         if (d.empty()) return 0;
-        if (hipMalloc(&descs, d.size() * sizeof(D)) != hipSuccess || hipMalloc((void**)&map, m.size() * sizeof(int2)) != hipSuccess) return -1;
-        if (hipMemcpy(descs, d.data(), d.size() * sizeof(D), hipMemcpyHostToDevice) != hipSuccess) return -1;
-        if (hipMemcpy(map, m.data(), m.size() * sizeof(int2), hipMemcpyHostToDevice) != hipSuccess) return -1;
+        h_descs.assign((const char*)d.data(), (const char*)(d.data() + d.size()));
+        h_map.assign((const char*)m.data(), (const char*)(m.data() + m.size()));
         nblocks = (int)m.size();
+        return 0;
+    }
+    int ready() {
+        if (descs || h_descs.empty()) return 0;
+        if (hipMalloc(&descs, h_descs.size()) != hipSuccess || hipMalloc((void**)&map, h_map.size()) != hipSuccess) return -1;
+        if (hipMemcpy(descs, h_descs.data(), h_descs.size(), hipMemcpyHostToDevice) != hipSuccess) return -1;
+        if (hipMemcpy(map, h_map.data(), h_map.size(), hipMemcpyHostToDevice) != hipSuccess) return -1;
         return 0;
     }
 };
@@ -156,7 +164,7 @@ struct Plan {
     size_t ws_bytes = 0;
     size_t bwd_begin = 0;                            // training plans: ops [0, bwd_begin) = forward, the rest = backward
     bool train = false;
-    DevTable wt_tab, exp_tab, cs_tab;                // training plans: all weight transposes / gradient exports / column-sum finalizes in one launch each
+    mutable DevTable wt_tab, exp_tab, cs_tab;                // training plans: all weight transposes / gradient exports / column-sum finalizes in one launch each
 };
 
 // ================================================================================================ parameters
@@ -203,7 +211,9 @@ struct ldm_model {
     // HIP-graph replay of the forward plan (ldm_model_set_graph_mode): one hipGraphLaunch instead of ~150 kernel launches
     // per step on the host.  A graph is instantiated per (plan, pointer set) the second time that set is seen.
     int graph_mode = 0;
-    struct GraphEntry { const Plan* plan; const void* ptr[8]; int rt[2]; int seen; hipGraphExec_t exec; };
+    // sampler_uid: the captured sampler kernel bakes the sampler's seed / step table / state pointers in by value, and a freed
+    // ldm_sampler's address is readily handed out again: the key carries the sampler's never-reused id, not only its address
+    struct GraphEntry { const Plan* plan; const void* ptr[8]; int rt[2]; uint64_t sampler_uid; int seen; hipGraphExec_t exec; };
     std::vector<GraphEntry> graphs;
     hipStream_t side_stream = nullptr; std::vector<hipEvent_t> lane_events;     // side lane of the inference plans (run_plan)
     hipStream_t cap_stream = nullptr;        // capture happens on a private stream (the caller's may be the null stream, which cannot capture)
@@ -2355,6 +2365,7 @@ static int check_ready(ldm_model* m, const void* ws, size_t ws_bytes, const Plan
     }
     if (!ws || ws_bytes < p.ws_bytes) return fail(LDM_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", p.ws_bytes, ws_bytes);
     if (((uintptr_t)ws) & 255) return fail(LDM_ERR_BAD_ARG, "workspace must be 256-byte aligned");
+    if (p.wt_tab.ready() || p.exp_tab.ready() || p.cs_tab.ready()) return fail(LDM_ERR_HIP, "descriptor table upload failed");
     return 0;
 }
 
@@ -2365,8 +2376,10 @@ size_t ldm_unet_workspace_bytes(ldm_model* m, int B, int D, int H, int W) {
 }
 
 // ---- device-resident sampler (fused scheduler step with in-kernel Philox noise) ----------------------------------------------
+static std::atomic<uint64_t> g_sampler_uid{0};
 struct ldm_sampler {
     float* coef = nullptr; SamplerState* st = nullptr; int n_steps = 0, kind = 0, clip = 1; unsigned seed_lo = 0, seed_hi = 0;
+    uint64_t uid = ++g_sampler_uid;                  // never reused (graph-replay cache key)
 };
 static int sampler_launch(ldm_sampler* sp, const float* eps, float* x, float* x0_out, int64_t n, float* tbuf, int B, hipStream_t s) {
     SamplerParams p{}; p.coef = sp->coef; p.st = sp->st; p.n_steps = sp->n_steps; p.kind = sp->kind; p.clip = sp->clip;
@@ -2399,15 +2412,23 @@ static int unet_forward_impl(ldm_model* m, const float* x, int x_channels, const
     if (!m->graph_mode || g_prof.on) return run_all((hipStream_t)stream);
     // ---- graph replay: same launches, recorded once per pointer set
     const void* key[8] = {x, cond, timesteps, out, workspace, stream, sp, x_inout};
+    const uint64_t suid = sp ? sp->uid : 0;
     ldm_model::GraphEntry* ge = nullptr;
+    for (size_t k = 0; k < m->graphs.size();) {          // entries recorded for a sampler that has since been destroyed at this address
+        auto& g = m->graphs[k];
+        if (sp && g.ptr[6] == (const void*)sp && g.sampler_uid != suid) {
+            if (g.exec) (void)hipGraphExecDestroy(g.exec);
+            m->graphs.erase(m->graphs.begin() + k);
+        } else ++k;
+    }
     for (auto& g : m->graphs)
-        if (g.plan == p.get() && !memcmp(g.ptr, key, sizeof key) && g.rt[0] == rt[0] && g.rt[1] == rt[1]) { ge = &g; break; }
+        if (g.plan == p.get() && !memcmp(g.ptr, key, sizeof key) && g.rt[0] == rt[0] && g.rt[1] == rt[1] && g.sampler_uid == suid) { ge = &g; break; }
     if (!ge) {
         if (m->graphs.size() >= 16) {                    // bounded cache: drop the oldest entry
             if (m->graphs.front().exec) (void)hipGraphExecDestroy(m->graphs.front().exec);
             m->graphs.erase(m->graphs.begin());
         }
-        ldm_model::GraphEntry g{}; g.plan = p.get(); memcpy(g.ptr, key, sizeof key); g.rt[0] = rt[0]; g.rt[1] = rt[1];
+        ldm_model::GraphEntry g{}; g.plan = p.get(); memcpy(g.ptr, key, sizeof key); g.rt[0] = rt[0]; g.rt[1] = rt[1]; g.sampler_uid = suid;
         m->graphs.push_back(g); ge = &m->graphs.back();
     }
     if (ge->exec) { HIP_TRY(hipGraphLaunch(ge->exec, (hipStream_t)stream)); return 0; }
@@ -2616,7 +2637,7 @@ static int ensure_pack_tab(ldm_model* m) {
             for (int b = 0; b < nb; ++b) map.push_back(make_int2((int)descs.size(), b));
             descs.push_back(e);
         }
-        if (m->pack_tab.upload(descs, map)) return fail(LDM_ERR_HIP, "descriptor table upload failed");
+        if (m->pack_tab.upload(descs, map) || m->pack_tab.ready()) return fail(LDM_ERR_HIP, "descriptor table upload failed");
     }
     return 0;
 }
@@ -2754,14 +2775,28 @@ int ldm_model_adam_step(ldm_model* m, float* params_flat, const float* grads_fla
 
 static int vae_factor(const ldm_model* m) { return 1 << (m->vcfg.num_levels - 1); }
 
+// The samples of an inference batch are independent (GroupNorm and attention are per sample), and the kernels address a tensor through
+// buffer descriptors with 32-bit byte offsets: a batch whose largest activation would pass 4 GiB (4 x 64 ch x 160x224x160 in the fp32
+// mode: 5.9 GB) runs as several sub-batches of the largest size that divides B and fits, one after the other on the same stream and
+// in the same workspace.  Returns that sub-batch size and its plan.
+static int vae_fit_batch(ldm_model* m, const char* kind, int B, int D, int H, int W, std::shared_ptr<Plan>* p, int* chunk) {
+    int rc = 0;
+    for (int c = B; c >= 1; --c) {
+        if (B % c) continue;
+        rc = get_plan(m, kind, c, D, H, W, p);
+        if (rc == 0) { *chunk = c; return 0; }
+        if (rc != LDM_ERR_UNSUPPORTED) break;
+    }
+    return rc;
+}
 size_t ldm_vae_encode_workspace_bytes(ldm_model* m, int B, int D, int H, int W) {
     if (!m || m->type != 1) { fail(LDM_ERR_BAD_ARG, "not an AutoencoderKL handle"); return 0; }
-    std::shared_ptr<Plan> p; if (get_plan(m, "enc", B, D, H, W, &p)) return 0;
+    std::shared_ptr<Plan> p; int chunk = 0; if (vae_fit_batch(m, "enc", B, D, H, W, &p, &chunk)) return 0;
     return p->ws_bytes;
 }
 size_t ldm_vae_decode_workspace_bytes(ldm_model* m, int B, int d, int h, int w) {
     if (!m || m->type != 1) { fail(LDM_ERR_BAD_ARG, "not an AutoencoderKL handle"); return 0; }
-    std::shared_ptr<Plan> p; if (get_plan(m, "dec", B, d, h, w, &p)) return 0;
+    std::shared_ptr<Plan> p; int chunk = 0; if (vae_fit_batch(m, "dec", B, d, h, w, &p, &chunk)) return 0;
     return p->ws_bytes;
 }
 
@@ -2772,14 +2807,21 @@ static int vae_encode_impl(ldm_model* m, const float* x, const float* eps, float
     if (!x) return fail(LDM_ERR_BAD_ARG, "null tensor argument");
     const int f = vae_factor(m);
     if (D % f || H % f || W % f) return fail(LDM_ERR_UNSUPPORTED, "image size must be a multiple of %d", f);
-    std::shared_ptr<Plan> p; LDM_TRY(get_plan(m, "enc", B, D, H, W, &p, tap_mode));
+    std::shared_ptr<Plan> p; int chunk = B;
+    if (tap_mode) LDM_TRY(get_plan(m, "enc", B, D, H, W, &p, tap_mode)); else LDM_TRY(vae_fit_batch(m, "enc", B, D, H, W, &p, &chunk));
     LDM_TRY(check_ready(m, workspace, workspace_bytes, *p));
-    Bases bs{}; bs.p[BASE_WS] = (char*)workspace; bs.p[BASE_W] = m->arena; bs.p[BASE_W32] = m->arena32;
-    bs.p[BASE_IO0] = (char*)x; bs.p[BASE_IO1] = (char*)eps; bs.p[BASE_IO2] = (char*)z_mu; bs.p[BASE_IO3] = (char*)z_sigma; bs.p[BASE_IO4] = (char*)z;
-    bs.p[BASE_TAPO] = (char*)taps_out; bs.p[BASE_TAPI] = (char*)taps_in;
-    const int rt[2] = {m->vcfg.in_channels, 0};
     LDM_TRY(ensure_derived(m, (hipStream_t)stream));
-    return run_plan(*p, bs, rt, (hipStream_t)stream);
+    const size_t in_n = (size_t)m->vcfg.in_channels * D * H * W, lat_n = (size_t)m->vcfg.latent_channels * (D / f) * (H / f) * (W / f);
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+        Bases bs{}; bs.p[BASE_WS] = (char*)workspace; bs.p[BASE_W] = m->arena; bs.p[BASE_W32] = m->arena32;
+        auto at = [&](const float* q, size_t per) { return q ? (char*)(q + (size_t)b0 * per) : nullptr; };
+        bs.p[BASE_IO0] = at(x, in_n); bs.p[BASE_IO1] = at(eps, lat_n); bs.p[BASE_IO2] = at(z_mu, lat_n); bs.p[BASE_IO3] = at(z_sigma, lat_n);
+        bs.p[BASE_IO4] = at(z, lat_n);
+        bs.p[BASE_TAPO] = (char*)taps_out; bs.p[BASE_TAPI] = (char*)taps_in;
+        const int rt[2] = {m->vcfg.in_channels, 0};
+        LDM_TRY(run_plan(*p, bs, rt, (hipStream_t)stream));
+    }
+    return 0;
 }
 int ldm_vae_encode(ldm_model* m, const float* x, const float* eps, float* z_mu, float* z_sigma, float* z,
                    int B, int D, int H, int W, void* workspace, size_t workspace_bytes, void* stream) {
@@ -2797,14 +2839,20 @@ static int vae_decode_impl(ldm_model* m, const float* z, float* out, int B, int 
                            int tap_mode, void* workspace, size_t workspace_bytes, void* stream) {
     if (!m || m->type != 1) return fail(LDM_ERR_BAD_ARG, "not an AutoencoderKL handle");
     if (!z || !out) return fail(LDM_ERR_BAD_ARG, "null tensor argument");
-    std::shared_ptr<Plan> p; LDM_TRY(get_plan(m, "dec", B, d, h, w, &p, tap_mode));
+    std::shared_ptr<Plan> p; int chunk = B;
+    if (tap_mode) LDM_TRY(get_plan(m, "dec", B, d, h, w, &p, tap_mode)); else LDM_TRY(vae_fit_batch(m, "dec", B, d, h, w, &p, &chunk));
     LDM_TRY(check_ready(m, workspace, workspace_bytes, *p));
-    Bases bs{}; bs.p[BASE_WS] = (char*)workspace; bs.p[BASE_W] = m->arena; bs.p[BASE_W32] = m->arena32;
-    bs.p[BASE_IO0] = (char*)z; bs.p[BASE_IO1] = (char*)out;
-    bs.p[BASE_TAPO] = (char*)taps_out; bs.p[BASE_TAPI] = (char*)taps_in;
-    const int rt[2] = {m->vcfg.latent_channels, 0};
     LDM_TRY(ensure_derived(m, (hipStream_t)stream));
-    return run_plan(*p, bs, rt, (hipStream_t)stream);
+    const int f = vae_factor(m);
+    const size_t lat_n = (size_t)m->vcfg.latent_channels * d * h * w, out_n = (size_t)m->vcfg.out_channels * d * h * w * f * f * f;
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+        Bases bs{}; bs.p[BASE_WS] = (char*)workspace; bs.p[BASE_W] = m->arena; bs.p[BASE_W32] = m->arena32;
+        bs.p[BASE_IO0] = (char*)(z + (size_t)b0 * lat_n); bs.p[BASE_IO1] = (char*)(out + (size_t)b0 * out_n);
+        bs.p[BASE_TAPO] = (char*)taps_out; bs.p[BASE_TAPI] = (char*)taps_in;
+        const int rt[2] = {m->vcfg.latent_channels, 0};
+        LDM_TRY(run_plan(*p, bs, rt, (hipStream_t)stream));
+    }
+    return 0;
 }
 int ldm_vae_decode(ldm_model* m, const float* z, float* out, int B, int d, int h, int w,
                    void* workspace, size_t workspace_bytes, void* stream) {
@@ -3302,7 +3350,11 @@ struct RcclApi {
 static RcclApi g_rccl;
 static int rccl_load() {
     if (g_rccl.lib) return 0;
-    void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    // the copy the process has already loaded (torch links its own librccl) comes first: two different RCCL builds in one process
+    // would each bring their own kernels and IPC state
+    void* h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!h) return fail(LDM_ERR_RCCL, "cannot load librccl.so: %s", dlerror());
@@ -3320,7 +3372,8 @@ static int rccl_load() {
 #define RCCL_TRY(x) do { int r_ = (x); if (r_ != 0) return fail(LDM_ERR_RCCL, "%s failed: %s", #x, \
     g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "?"); } while (0)
 
-struct ldm_comm { rccl_comm_t comm = nullptr; int rank = 0, world = 1; float* token = nullptr; };
+struct ldm_comm { rccl_comm_t comm = nullptr; int rank = 0, world = 1; float* token = nullptr;
+                  ldm_allreduce_fn fn = nullptr; void* user = nullptr; };   // fn: caller-supplied transport (ldm_comm_init_custom)
 
 int ldm_comm_unique_id(char id[128]) {
     if (!id) return fail(LDM_ERR_BAD_ARG, "null id");
@@ -3340,19 +3393,36 @@ int ldm_comm_init(int rank, int world, const char id[128], ldm_comm** out) {
     *out = c.release();
     return 0;
 }
+/* A communicator whose all-reduce is the caller's function instead of RCCL: fn(user, buf, count, dtype, op, stream) must leave the
+ * reduction over the `world` ranks in buf, ordered on `stream` (dtype / op as for ldm_comm_allreduce; non-zero return = failure).
+ * Everything above the transport -- which ranges of the gradient buffer are handed over, when, on which stream, with which op, and
+ * the join in front of the optimizer -- is the same code as with RCCL, so a test can stand in for the peers of a world > 1 job on one
+ * GPU.  ldm_comm_broadcast is not available on such a communicator. */
+int ldm_comm_init_custom(int rank, int world, ldm_allreduce_fn fn, void* user, ldm_comm** out) {
+    if (!fn || !out || world < 1 || rank < 0 || rank >= world) return fail(LDM_ERR_BAD_ARG, "bad argument");
+    std::unique_ptr<ldm_comm> c(new ldm_comm()); c->rank = rank; c->world = world; c->fn = fn; c->user = user;
+    *out = c.release();
+    return 0;
+}
 // ncclDataType: float32 = 7, bfloat16 = 9; ncclRedOp: sum = 0, avg = 4
 int ldm_comm_allreduce(ldm_comm* c, void* buf, int64_t count, int dtype, int op, void* stream) {
     if (!c || !buf || count < 0 || dtype < 0 || dtype > 1 || op < 0 || op > 1) return fail(LDM_ERR_BAD_ARG, "bad argument");
+    if (c->fn) {
+        const int r = c->fn(c->user, buf, count, dtype, op, stream);
+        return r ? fail(LDM_ERR_RCCL, "custom all-reduce returned %d", r) : 0;
+    }
     RCCL_TRY(g_rccl.AllReduce(buf, buf, (size_t)count, dtype == 0 ? 7 : 9, op == 0 ? 0 : 4, c->comm, (hipStream_t)stream));
     return 0;
 }
 int ldm_comm_broadcast(ldm_comm* c, void* buf, int64_t count, int dtype, int root, void* stream) {
     if (!c || !buf || count < 0 || dtype < 0 || dtype > 1 || root < 0 || root >= c->world) return fail(LDM_ERR_BAD_ARG, "bad argument");
+    if (c->fn) return fail(LDM_ERR_UNSUPPORTED, "broadcast on a custom-transport communicator");
     RCCL_TRY(g_rccl.Broadcast(buf, buf, (size_t)count, dtype == 0 ? 7 : 9, root, c->comm, (hipStream_t)stream));
     return 0;
 }
 int ldm_comm_barrier(ldm_comm* c, void* stream) {
     if (!c) return fail(LDM_ERR_BAD_ARG, "null comm");
+    if (c->fn) { HIP_TRY(hipStreamSynchronize((hipStream_t)stream)); return 0; }
     RCCL_TRY(g_rccl.AllReduce(c->token, c->token, 1, 7, 0, c->comm, (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return 0;
@@ -3395,6 +3465,43 @@ int ldm_model_grad_sync_trace(ldm_model* m, double* issue_ms, double* done_ms, i
     }
     if (max > n) { float e = 0.f; HIP_TRY(hipEventElapsedTime(&e, g.ev[0], g.ev[1])); issue_ms[n] = done_ms[n] = e; elems[n] = 0; }
     return n;
+}
+
+/* The gradient-exchange schedule of a training plan, readable without a GPU (plans are built on the host): one event per entry, in
+ * launch order.  kind[k]: 0 = an op writes flat_grads[lo, lo + n) (final values), 1 = bucket: [lo, lo + n) is handed to the
+ * communicator here, 2 = join (the launch stream waits for every bucket; the optimizer may follow), 3 = a write the dump does not
+ * understand (a test failure).  op[k] = index of the launch-plan op.  Returns the number of events (may exceed max; only max are
+ * written).  tests/test_grad_schedule_cpu.py checks: buckets tile [0, total) exactly once, no write into a range after its bucket
+ * was issued, every element written before its bucket, join last. */
+int ldm_model_grad_schedule(ldm_model* m, int B, int D, int H, int W, int* kind, int64_t* lo, int64_t* n, int* op, int max) {
+    if (!m || max < 0 || (max > 0 && (!kind || !lo || !n || !op))) return fail(LDM_ERR_BAD_ARG, "bad argument");
+    std::shared_ptr<Plan> p; LDM_TRY(get_plan(m, "train", B, D, H, W, &p));
+    int cnt = 0;
+    auto put = [&](int k, int64_t a, int64_t c, size_t oi) { if (cnt < max) { kind[cnt] = k; lo[cnt] = a; n[cnt] = c; op[cnt] = (int)oi; } ++cnt; };
+    const ExportDesc* ed = (const ExportDesc*)p->exp_tab.h_descs.data(); const int2* em = (const int2*)p->exp_tab.h_map.data();
+    for (size_t oi = p->bwd_begin; oi < p->ops.size(); ++oi) {
+        const Op& o = p->ops[oi];
+        switch (o.kind) {
+            case OP_EXPORT_BATCH: {
+                int last = -1;
+                for (int b = o.i[0]; b < o.i[1]; ++b) if (em[b].x != last) {
+                    last = em[b].x; const ExportDesc& e = ed[last];
+                    put(0, e.dst_off, (int64_t)e.taps * e.cout * e.cin, oi);
+                }
+                break;
+            }
+            case OP_GNB: put(0, o.i[8], o.i[0] + o.i[1], oi); put(0, o.i[9], o.i[0] + o.i[1], oi); break;
+            case OP_LIN_DW:
+                if (o.r[2].base == BASE_IO4) put(0, (int64_t)(o.r[2].off / 4), (int64_t)o.i[1] * o.i[2], oi);
+                if (o.r[3].base == BASE_IO4) put(0, (int64_t)(o.r[3].off / 4), o.i[2], oi);
+                break;
+            case OP_BUCKET: put(1, o.i[0], o.i[1], oi); break;
+            case OP_BUCKET_JOIN: put(2, 0, 0, oi); break;
+            default:
+                for (const Ref& r : o.r) if (r.base == BASE_IO4) put(3, (int64_t)(r.off / 4), 0, oi);
+        }
+    }
+    return cnt;
 }
 
 }  // extern "C"

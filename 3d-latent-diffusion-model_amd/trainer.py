@@ -36,30 +36,61 @@ class GradSync:
         self._avg = self.on and dist.get_backend() == "nccl"
         self.grad_dtype = grad_dtype
 
-    def attach(self, module, force_single: bool = False) -> bool:
+    def attach(self, module, force_single: bool = False, transport=None, world: Optional[int] = None, rank: int = 0) -> bool:
         """Route the gradient exchange of ``module`` through the library's own RCCL communicator (``ldm_comm_*``) and overlap it
         with backward: ``loss.backward()`` then all-reduces (mean, fp32) the flat gradient buffer bucket by bucket on a comm
         stream while the backward plan is still running (``ldm_model_set_grad_sync``; DistributedDataParallel's bucketed hooks,
         3d_ldm/train_diffusion.py:147-149), and ``mean_`` becomes a no-op for that module.  The 128-byte RCCL unique id is made
         on rank 0 and broadcast over the existing torch.distributed group.  Only with the "nccl" backend on GPUs and fp32
-        gradients; ``force_single`` builds a world-size-1 communicator without torch.distributed (tests, single-GPU traces)."""
+        gradients; ``force_single`` builds a world-size-1 communicator without torch.distributed (tests, single-GPU traces).
+
+        ``transport(buf_ptr, count, dtype, op, stream_ptr) -> int`` (with ``world`` / ``rank``) replaces RCCL by a caller-supplied
+        all-reduce (``ldm_comm_init_custom``): the test seam that lets one GPU play a rank of a world > 1 job.
+
+        Every rank must build the same buckets, so rank 0's ``LDM_GRAD_BUCKET_MB`` is broadcast and written into this process's
+        environment before any training plan exists.  If the communicator cannot be created (no librccl, a failing
+        ``ncclCommInitRank``) the ranks agree on that and fall back together to ``mean_`` after backward instead of raising."""
         import ctypes as C
+        import os
+        import warnings
         from . import _lib
-        single = force_single and not self.on
-        if not single and not (self.on and dist.get_backend() == "nccl" and self.grad_dtype == torch.float32):
-            return False
         L = _lib.lib()
-        rank = 0 if single else dist.get_rank()
-        world = 1 if single else self.world
-        uid = C.create_string_buffer(128)
-        if rank == 0:
-            _lib.check(L.ldm_comm_unique_id(uid))
-        if not single:
-            t = torch.tensor(list(uid.raw), dtype=torch.uint8, device="cuda")
-            dist.broadcast(t, src=0)
-            uid = C.create_string_buffer(bytes(t.cpu().tolist()), 128)
         comm = C.c_void_p()
-        _lib.check(L.ldm_comm_init(rank, world, uid, C.byref(comm)))
+        if transport is not None:
+            fn = _lib.ALLREDUCE_FN(lambda user, buf, count, dtype, op, stream: int(transport(buf, count, dtype, op, stream) or 0))
+            _lib.check(L.ldm_comm_init_custom(int(rank), int(world or 1), C.cast(fn, C.c_void_p), None, C.byref(comm)))
+            module._grad_transport = fn                      # the C function pointer must outlive the communicator
+        else:
+            single = force_single and not self.on
+            if not single and not (self.on and dist.get_backend() == "nccl" and self.grad_dtype == torch.float32):
+                return False
+            rank = 0 if single else dist.get_rank()
+            world = 1 if single else self.world
+            uid = C.create_string_buffer(128)
+            ok = 1
+            if rank == 0 and L.ldm_comm_unique_id(uid) != 0:
+                ok = 0
+            if not single:
+                mb = int(os.environ.get("LDM_GRAD_BUCKET_MB", "48") or 48)
+                t = torch.tensor(list(uid.raw) + [ok, mb & 0xFF, (mb >> 8) & 0xFF], dtype=torch.uint8, device="cuda")
+                dist.broadcast(t, src=0)
+                raw = bytes(t.cpu().tolist())
+                uid = C.create_string_buffer(raw[:128], 128)
+                ok = raw[128]
+                os.environ["LDM_GRAD_BUCKET_MB"] = str(raw[129] | (raw[130] << 8))
+            if ok and L.ldm_comm_init(rank, world, uid, C.byref(comm)) != 0:
+                ok = 0
+            if not single:                                   # all ranks or none
+                flag = torch.tensor([float(ok)], device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok = int(flag.item())
+            if not ok:
+                msg = L.ldm_last_error()
+                warnings.warn("in-library RCCL gradient exchange unavailable (%s): falling back to one all-reduce after backward "
+                              "over torch.distributed" % (msg.decode() if msg else "?"))
+                if comm:
+                    L.ldm_comm_destroy(comm)
+                return False
         _lib.check(L.ldm_model_set_grad_sync(module._h, comm))
         module._grad_comm = comm                         # keeps the handle alive as long as the module
         self._attached = getattr(self, "_attached", set()) | {id(module)}

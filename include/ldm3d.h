@@ -293,6 +293,12 @@ int ldm_model_sync_faults(ldm_model* m);
 typedef struct ldm_comm ldm_comm;
 int ldm_comm_unique_id(char id[128]);
 int ldm_comm_init(int rank, int world, const char id[128], ldm_comm** out);
+/* Same communicator object over a caller-supplied transport instead of RCCL: fn must leave the reduction (op) over the `world`
+ * ranks in buf, ordered on `stream`; non-zero return = failure.  What the library does around the transport (bucket ranges, issue
+ * points, streams, op = avg, the join in front of the optimizer) is identical, which is what lets tests/test_gpu_comm.py play the
+ * second rank of a 2-rank job on one GPU.  No reference counterpart (test seam). */
+typedef int (*ldm_allreduce_fn)(void* user, void* buf, int64_t count, int dtype, int op, void* stream);
+int ldm_comm_init_custom(int rank, int world, ldm_allreduce_fn fn, void* user, ldm_comm** out);
 int ldm_comm_allreduce(ldm_comm* c, void* buf, int64_t count, int dtype, int op, void* stream);
 int ldm_comm_broadcast(ldm_comm* c, void* buf, int64_t count, int dtype, int root, void* stream);
 int ldm_comm_barrier(ldm_comm* c, void* stream);
@@ -306,6 +312,10 @@ int ldm_comm_world(const ldm_comm* c);
  * ldm_model_grad_sync_trace returns the bucket timeline of the last backward call (n buckets; entry n = end of the call). */
 int ldm_model_set_grad_sync(ldm_model* m, ldm_comm* comm);
 int ldm_model_grad_sync_trace(ldm_model* m, double* issue_ms, double* done_ms, int64_t* elems, int max);
+/* The exchange schedule of the training plan for this shape, built on the host (no GPU needed): events in launch order with
+ * kind 0 = an op leaves final values in flat_grads[lo, lo + n), 1 = bucket [lo, lo + n) handed to the communicator, 2 = join,
+ * 3 = unclassified write; op = index of the launch-plan op.  Returns the event count (only `max` are written). */
+int ldm_model_grad_schedule(ldm_model* m, int B, int D, int H, int W, int* kind, int64_t* lo, int64_t* n, int* op, int max);
 
 #ifdef __cplusplus
 }

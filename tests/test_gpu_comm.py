@@ -1,9 +1,10 @@
 """RCCL through the library's C ABI and the bucketed, backward-overlapped gradient exchange (-m gpu, one GPU).
 
-A one-GPU box can only run a world-size-1 communicator, which still exercises every entry point (unique id, init, all-reduce
+A one-GPU box can only run a world-size-1 RCCL communicator, which still exercises every entry point (unique id, init, all-reduce
 SUM / AVG in fp32 and bf16, broadcast, barrier, destroy), the bucket plumbing of the backward plans (events, comm stream, join) and
-its timeline.  The N > 1 arithmetic (mean of shard gradients == full-batch gradient) is covered by the gloo tests in
-tests/test_dist_cpu.py; the 8-GPU run is the driver's.
+its timeline.  The N > 1 behaviour of the in-library path runs here against a fake second rank (ldm_comm_init_custom: the
+transport is the only thing replaced); tests/test_grad_schedule_cpu.py checks the bucket schedule itself without a GPU; the gloo tests in
+tests/test_dist_cpu.py cover the torch.distributed fallback; the 8-GPU run is the driver's.
 """
 import ctypes as C
 
@@ -120,3 +121,139 @@ def test_autoencoder_backward_buckets_tile_the_buffer(cuda, monkeypatch):
     issue, done, elems = (C.c_double * 64)(), (C.c_double * 64)(), (C.c_int64 * 64)()
     n = L.ldm_model_grad_sync_trace(m._h, issue, done, elems, 64)
     assert n >= 5 and sum(elems[k] for k in range(n)) == int(L.ldm_model_param_numel_total(m._h))
+
+
+class FakePeer:
+    """Stands in for rank 1 of a 2-rank job on one GPU: the transport handed to ``ldm_comm_init_custom``.  It receives exactly what
+    ncclAllReduce would (buffer, count, dtype, op, stream) and leaves op(own, peer) in the buffer ON THAT STREAM, with the peer's
+    gradients taken from a tensor computed beforehand.  Everything else -- which ranges are handed over, when, with which op, the
+    join in front of the optimizer -- is the library's production code."""
+
+    def __init__(self, flat: torch.Tensor, peer: torch.Tensor):
+        self.flat, self.peer, self.calls = flat, peer, []
+
+    def __call__(self, buf, count, dtype, op, stream):
+        off = (buf - self.flat.data_ptr()) // 4
+        self.calls.append((off, count, dtype, op))
+        if not (0 <= off and off + count <= self.flat.numel()):
+            return 1
+        with torch.cuda.stream(torch.cuda.ExternalStream(stream)):
+            view = self.flat[off:off + count]
+            view.add_(self.peer[off:off + count])
+            if op == 1:
+                view.mul_(0.5)
+        return 0
+
+
+def test_bucketed_exchange_with_a_fake_second_rank_gives_the_mean(cuda, monkeypatch):
+    """World size 2 through the in-library path (3d_ldm/train_diffusion.py:147-149,214: DDP averages the ranks' gradients inside
+    backward).  Rank 0 (this process) differentiates sample A, the fake peer contributes the gradients of sample B: the buffer must end
+    up as (gA + gB) / 2 bit for bit -- a bucket issued before its gradients were final, a range reduced twice or never, a sum instead
+    of a mean, or an optimizer step that does not wait for the comm stream would all show here (none of them can at world size 1)."""
+    from ldm3d import _lib
+    from ldm3d.networks import DiffusionModelUNet
+    from ldm3d.optim import FlatAdam
+    from ldm3d.trainer import GradSync
+    from oracle import unet as ou
+    monkeypatch.setenv("LDM_GRAD_BUCKET_MB", "1")
+    cfg = cfgs.UNET_TINY
+    sd = ou.init_state_dict(ou.unet_param_shapes(cfg), 3, gain=0.5)
+
+    def fresh():
+        m = DiffusionModelUNet(**cfg)
+        m.load_state_dict(sd)
+        m = m.to(cuda).train()
+        m.flatten_parameters()
+        return m
+    m = fresh()
+    g = torch.Generator().manual_seed(7)
+    xs = torch.randn((2, 4, 8, 8, 8), generator=g).to(cuda)
+    tg = torch.randn((2, 4, 8, 8, 8), generator=g).to(cuda)
+    ts = torch.tensor([17.0, 803.0], device=cuda)
+    gA = _train_once(m, xs[:1], ts[:1], tg[:1])
+    gB = _train_once(m, xs[1:], ts[1:], tg[1:])
+    assert not torch.equal(gA, gB)
+    peer = FakePeer(m.flat_grads, gB)
+    sync = GradSync()
+    assert sync.attach(m, transport=peer, world=2, rank=0) and sync.attached(m)
+    L = _lib.lib()
+    assert L.ldm_comm_world(m._grad_comm) == 2 and L.ldm_comm_rank(m._grad_comm) == 0
+    m.flat_grads.fill_(float("nan"))
+    synced = _train_once(m, xs[:1], ts[:1], tg[:1])
+    total = m.flat_grads.numel()
+    assert torch.equal(synced, (gA + gB) * 0.5)
+    # what the transport saw: fp32, op = mean, ranges that tile the buffer back to front exactly once
+    assert len(peer.calls) >= 4 and all(d == 0 and op == 1 for _, _, d, op in peer.calls)
+    assert peer.calls[0][0] + peer.calls[0][1] == total and peer.calls[-1][0] == 0
+    assert all(a[0] == b[0] + b[1] for a, b in zip(peer.calls, peer.calls[1:]))
+    # the B = 2 gradient of the same two samples (mse mean over the batch) is that mean, up to bf16 summation order
+    gAB = _train_once(fresh(), xs, ts, tg)
+    r = float((gAB - synced).norm() / gAB.norm())
+    print(f"mean of the two ranks' gradients vs the B = 2 gradient: rel-L2 {r:.2e}")
+    assert r <= 2e-2
+    # and the optimizer waits for the exchange: the same step with a peer that is slow to answer updates the parameters identically
+    def step_with(peer_delay):
+        mm = fresh()
+        opt = FlatAdam(mm, lr=1e-3, max_grad_norm=1.0)
+        pr = FakePeer(mm.flat_grads, gB)
+        if peer_delay:
+            inner = pr.__call__
+
+            def slow(buf, count, dtype, op, stream):
+                with torch.cuda.stream(torch.cuda.ExternalStream(stream)):
+                    torch.cuda._sleep(20_000_000)              # ~10 ms on the comm stream in front of every bucket
+                return inner(buf, count, dtype, op, stream)
+            tr = slow
+        else:
+            tr = pr
+        assert GradSync().attach(mm, transport=tr, world=2, rank=0)
+        out = mm(x=xs[:1], timesteps=ts[:1])
+        F.mse_loss(out.float(), tg[:1]).backward()
+        opt.step()
+        torch.cuda.synchronize()
+        return mm.flat_params.clone()
+    assert torch.equal(step_with(False), step_with(True))
+
+
+def test_fake_second_rank_on_the_benchmark_unet_and_the_autoencoder(cuda, monkeypatch):
+    """The same check at full width (191 M gradients, default 48 MB buckets) and for the AutoencoderKL backward plan."""
+    from ldm3d.networks import AutoencoderKL, DiffusionModelUNet
+    from ldm3d.trainer import GradSync
+    from oracle import autoencoder as oa
+    from oracle import unet as ou
+    cfg = cfgs.UNET_FULL
+    m = DiffusionModelUNet(**cfg)
+    m.load_state_dict(ou.init_state_dict(ou.unet_param_shapes(cfg), 3, gain=0.5))
+    m = m.to(cuda).train()
+    m.flatten_parameters()
+    g = torch.Generator().manual_seed(5)
+    xs = torch.randn((2, 4, 16, 16, 16), generator=g).to(cuda)
+    tg = torch.randn((2, 4, 16, 16, 16), generator=g).to(cuda)
+    ts = torch.tensor([400.0, 91.0], device=cuda)
+    gA = _train_once(m, xs[:1], ts[:1], tg[:1])
+    gB = _train_once(m, xs[1:], ts[1:], tg[1:])
+    peer = FakePeer(m.flat_grads, gB)
+    assert GradSync().attach(m, transport=peer, world=2)
+    m.flat_grads.fill_(float("nan"))
+    assert torch.equal(_train_once(m, xs[:1], ts[:1], tg[:1]), (gA + gB) * 0.5)
+    assert sum(c for _, c, _, _ in peer.calls) == m.flat_grads.numel()
+    del m, gA, gB, peer
+    monkeypatch.setenv("LDM_GRAD_BUCKET_MB", "2")
+    vcfg = cfgs.VAE_TINY_ATTN
+    v = AutoencoderKL(**vcfg)
+    v.load_state_dict(ou.init_state_dict(oa.ae_param_shapes(vcfg), 3))
+    v = v.to(cuda).train()
+    v.flatten_parameters()
+    imgs = torch.rand((2, 1, 16, 16, 16), device=cuda)
+    eps = torch.randn((2, 8, 4, 4, 4), device=cuda)
+
+    def once(k):
+        rec, mu, sigma = v(imgs[k:k + 1], eps=eps[k:k + 1])
+        (F.l1_loss(rec, imgs[k:k + 1]) + 1e-6 * oa.kl_loss(mu, sigma).mean()).backward()
+        torch.cuda.synchronize()
+        return v.flat_grads.clone()
+    vA, vB = once(0), once(1)
+    vpeer = FakePeer(v.flat_grads, vB)
+    assert GradSync().attach(v, transport=vpeer, world=2)
+    v.flat_grads.fill_(float("nan"))
+    assert torch.equal(once(0), (vA + vB) * 0.5)

@@ -122,3 +122,34 @@ def test_inferer_sample_with_fused_seed(cuda):
     plain = inf.sample(noise, None, m)                       # DDIM (eta = 0) draws no noise: the two loops must agree exactly
     assert rel_l2(fused, plain) <= 1e-5
     assert torch.isfinite(fused).all()
+
+
+def test_graph_replay_never_reuses_a_graph_recorded_for_a_destroyed_sampler(cuda):
+    """``inferer.sample(fused_seed=...)`` builds a new DeviceSampler per call and frees the old one; malloc readily hands the new
+    ldm_sampler (and torch the new x / tbuf) the old addresses.  The captured sampler kernel bakes seed, step table and state pointers
+    in by value, so the replay cache must be keyed on the sampler's identity, not its address: a second chain with another seed and
+    another schedule (DDPM: the seed matters) must equal its own eager run, not replay the first chain's graph."""
+    import gc
+    from ldm3d.inferer import LatentDiffusionInferer
+    from ldm3d.networks import DiffusionModelUNet
+    from ldm3d.schedulers import DDPMScheduler
+    from oracle import unet as ou
+    cfg = cfgs.UNET_TINY
+    m = DiffusionModelUNet(**cfg)
+    m.load_state_dict(ou.init_state_dict(ou.unet_param_shapes(cfg), 1))
+    m = m.to(cuda).eval()
+    noise = torch.randn((1, 4, 8, 8, 8), device=cuda)
+
+    def chain(seed, n_train, graph):
+        sch = DDPMScheduler(**dict(cfgs.SCHED, num_train_timesteps=n_train))
+        m.enable_graph_replay(graph)
+        out = LatentDiffusionInferer(sch).sample(noise, None, m, fused_seed=seed, verbose=False).clone()
+        gc.collect()                                        # the DeviceSampler of this call is destroyed here
+        return out
+    eager_a, eager_b = chain(11, 12, False), chain(12, 9, False)
+    assert not torch.equal(eager_a, eager_b)
+    ga = chain(11, 12, True)
+    gb = chain(12, 9, True)                                 # same model, same staging tensors, recycled sampler address
+    ga2 = chain(11, 12, True)
+    m.enable_graph_replay(False)
+    assert torch.equal(ga, eager_a) and torch.equal(gb, eager_b) and torch.equal(ga2, eager_a)
