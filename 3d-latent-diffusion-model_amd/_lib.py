@@ -120,6 +120,7 @@ SIGNATURES = {
     "ldm_profile_start": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "ldm_profile_detail": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]),
     "ldm_profile_stop": (C.c_int, [C.POINTER(C.c_double)]),
+    "ldm_set_plan_trace": (C.c_int, [C.c_char_p]),
     "ldm_model_plan_conv_cfgs": (C.c_int, [_P, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]),
     "ldm_comm_unique_id": (C.c_int, [C.c_char_p]),
     "ldm_comm_init": (C.c_int, [C.c_int, C.c_int, C.c_char_p, C.POINTER(_P)]),
@@ -131,8 +132,7 @@ SIGNATURES = {
     "ldm_comm_rank": (C.c_int, [_P]),
     "ldm_comm_world": (C.c_int, [_P]),
     "ldm_model_set_grad_sync": (C.c_int, [_P, _P]),
-    "ldm_model_plan_launches": (C.c_int, [_P, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
-    "ldm_model_sync_faults": (C.c_int, [_P]),
+    "ldm_model_plan_launches": (C.c_int, [_P, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "ldm_model_grad_sync_trace": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]),
     "ldm_model_grad_schedule": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64),
                                           C.POINTER(C.c_int64), C.POINTER(C.c_int), C.c_int]),

@@ -639,7 +639,7 @@ struct FinalizeParams {
     bf16_t* out; float* out_f32; float* stats;
 };
 
-// The body is shared with fin_gn_kernel (fin_gn.h: slab fold + GroupNorm in one launch): bx / by = the block's 32-row granule and
+// bx / by = the block's 32-row granule and
 // 64-channel slice; o_keep returns the thread's packed bf16 output (row bx * 32 + tid / 8, channels by * 64 + (tid & 7) * 8 ...).
 template <bool WT>
 __device__ __forceinline__ void splitk_finalize_body(const FinalizeParams& p, const int bx, const int by, float (*red)[8][16], u32x4& o_keep) {

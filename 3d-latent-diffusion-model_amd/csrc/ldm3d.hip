@@ -28,7 +28,6 @@
 #include "gemm_light.h"
 #include "conv_wgrad.h"
 #include "norm_elem.h"
-#include "fin_gn.h"
 #include "f32_path.h"
 #include "f32_train.h"
 
@@ -85,8 +84,7 @@ enum OpKind { OP_PACK, OP_CONV, OP_FINALIZE, OP_GN_STATS, OP_GN_FINALIZE, OP_GN_
               // fp32 precision mode (f32_path.h)
               OP_PACK32, OP_CONV32, OP_FIN32, OP_GN_STATS32, OP_GN_APPLY32, OP_ATTN32, OP_GEMV32,
               OP_TAP,                              // debug tap: export an activation as fp32 NCDHW and / or overwrite it (teacher forcing)
-              OP_BUCKET, OP_BUCKET_JOIN,           // training plans: a tail range of the flat gradient buffer is final (all-reduce it now) / wait for every bucket
-              OP_FIN_GN };                         // split-K finalize + one-launch GroupNorm of the folded tensor in one launch (fin_gn.h)
+              OP_BUCKET, OP_BUCKET_JOIN };         // training plans: a tail range of the flat gradient buffer is final (all-reduce it now) / wait for every bucket
 
 struct ConvCfg { int wgm, wgn, bk, splitk; int halo = 0, mtps = 0, qps = 0; };   // halo: conv3_halo_kernel (126-row tiles)
 
@@ -199,8 +197,7 @@ struct ldm_model {
     ldm_unet_cfg ucfg{}; ldm_vae_cfg vcfg{};
     std::vector<ParamDesc> params;
     std::map<std::string, int> pindex;
-    size_t arena_bytes = 8192 + 256;                 // first 8 KiB: the zero page (one padded input row, C <= 4096); then the grid-barrier state
-    static constexpr size_t sync_off = 8192;         // {arrivals, generation, faults} of fin_gn_kernel's barrier (zero from ensure_arena on)
+    size_t arena_bytes = 8192 + 256;                 // first 8 KiB: the zero page (one padded input row, C <= 4096)
     char* arena = nullptr;
     // fp32 precision mode (ldm_model_set_precision): unrounded copies of every matrix, allocated on first use
     int precision = 0; char* arena32 = nullptr;
@@ -613,27 +610,6 @@ struct Builder {
         const int nrb_tot = fused ? blocks_of(xa) + (xb.valid ? blocks_of(xb) : 0) : 0;
         if (fused && C / groups <= 64 && nrb_tot <= 512) {   // few slab rows: ONE launch folds them per block and applies
             Act out = new_act(N, xa.D, xa.H, xa.W, C);
-            // the producer was a split-K conv whose finalize is the op in front of this one: fold + normalise in one launch (fin_gn.h)
-            if (fin_gn_enabled() && !plan->ops.empty()) {
-                Op& fz = plan->ops.back();
-                const Ref xr = ws_ref(xa.off);
-                const long grid = (((long)N * DHW + 31) / 32) * ((C + 63) / 64);
-                if (fz.kind == OP_FINALIZE && fz.r[10].base == xr.base && fz.r[10].off == xr.off && fz.i[22] == 0 && fz.lane == 0 &&
-                    xa.stats_nrb == 0 && fz.i[16] == xa.C && (N == 1 || DHW % 32 == 0) && (!xb.valid || xa.C % 64 == 0) &&
-                    grid <= FIN_GN_MAX_BLOCKS) {
-                    fz.kind = OP_FIN_GN;                   // r[6..12], i[4..22], cc stay the finalize's; the conv-input slots carry the GroupNorm
-                    fz.r[0] = w_ref(g.g_off); fz.r[1] = xb.valid ? ws_ref(xb.off) : Ref(); fz.r[2] = w_ref(g.b_off);
-                    fz.r[3] = xb.valid ? ws_ref(xb.stats_off) : Ref(); fz.r[4] = ws_ref(out.off);
-                    fz.r[5] = train ? ws_ref(ab_off) : Ref(); fz.r[13] = train ? ws_ref(mr_off) : Ref();
-                    fz.i[0] = xb.valid ? xb.C : 0; fz.i[1] = xb.valid ? blocks_of(xb) : 0; fz.i[2] = groups; fz.i[3] = silu ? 1 : 0;
-                    fz.f[0] = eps;
-                    if (recording) {
-                        Tape t; t.kind = 1; t.g = &g; t.xa = xa; t.xb = xb; t.out = out; t.ab_off = ab_off; t.mr_off = mr_off;
-                        t.groups = groups; t.silu = silu; tape.push_back(t);
-                    }
-                    return out;
-                }
-            }
             const int slices = (C + 63) / 64;
             static const int gn_blocks = [] { const char* e = getenv("LDM_GN_BLOCKS"); return e ? atoi(e) : 256; }();   // tuning knob
             int chunks = std::max(1, std::min(gn_blocks / (slices * N), (DHW + 31) / 32));   // one round of the 256 CUs: the slab fold is per block
@@ -706,7 +682,6 @@ struct Builder {
 
     // first conv of a network as im2col + light GEMM (inference plans; the training tape keeps the 3^3 form): r0 / r1 = the fp32
     // NCDHW inputs (x | cond).  Returns an invalid Act when the model has no derived weights for it.
-    static bool fin_gn_enabled() { const char* e = getenv("LDM_FIN_GN"); return e ? atoi(e) != 0 : false; }   // opt-in: measured slower (fin_gn.h)
     static bool im2col_enabled() { const char* e = getenv("LDM_CONV_IM2COL"); return e ? atoi(e) != 0 : true; }
     Act conv_in_im2col(const std::string& name, Ref r0, Ref r1, int N, int D, int H, int W, int cin, bool internal) {
         auto it = m->convs.find(name + ".im2col");
@@ -1752,13 +1727,16 @@ static int launch_wgrad(const WgradParams& p, hipStream_t s) {
 
 static bool wt_stores() { static const int v = [] { const char* e = getenv("LDM_WT_STORES"); return e ? atoi(e) : 1; }(); return v != 0; }   // GroupNorm / finalize outputs written through (sc1): -24 us per step
 
+// per-op timeline of every launch plan that runs while it is on (ldm_set_plan_trace; initial state from LDM_PLAN_TRACE)
+struct PlanTrace { bool on = false; std::string path; PlanTrace() { const char* e = getenv("LDM_PLAN_TRACE"); if (e && *e) { on = true; path = e; } } };
+static PlanTrace g_plan_trace;
 struct LaneCtx { hipStream_t side = nullptr; std::vector<hipEvent_t>* events = nullptr; GradSyncState* sync = nullptr; };
 
 static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_t s, size_t begin = 0, size_t end = (size_t)-1,
                     LaneCtx lanes = LaneCtx()) {
     if (end > plan.ops.size()) end = plan.ops.size();
     // LDM_PLAN_TRACE=<file>: measurement aid (tools/plan_trace.py) -- a HIP event before every op, one CSV row per op appended
-    static const char* trace_path = getenv("LDM_PLAN_TRACE");
+    const char* trace_path = g_plan_trace.on ? g_plan_trace.path.c_str() : nullptr;
     std::vector<hipEvent_t> tev;
     if (trace_path) { tev.resize(end - begin + 1); for (auto& e : tev) HIP_TRY(hipEventCreate(&e)); }
     struct TraceDone {
@@ -1890,7 +1868,7 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                     else hipLaunchKernelGGL(pack2_ncdhw_kernel, dim3(grid_for(tot2)), dim3(256), 0, s, src, i[1], (const float*)nullptr, 0, (bf16_t*)rp(bs, o.r[0]), i[0], i[2], i[3]);
                 }
                 break; }
-            case OP_CONV: case OP_FINALIZE: case OP_FIN_GN: {
+            case OP_CONV: case OP_FINALIZE: {
                 ConvParams p{};
                 p.x0a = (const bf16_t*)rp(bs, o.r[0]); p.x0b = (const bf16_t*)rp(bs, o.r[1]); p.c0a = i[0]; p.c0b = i[1];
                 p.w0 = (const bf16_t*)rp(bs, o.r[2]);
@@ -1914,25 +1892,6 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                 p.partial = (float*)rp(bs, o.r[11]);
                 p.stats = (float*)rp(bs, o.r[12]);
                 if (o.kind == OP_CONV) { LDM_TRY(launch_conv(p, o.cc, s)); }
-                else if (o.kind == OP_FIN_GN) {         // r[0..5], r[13], i[0..3], f[0]: the GroupNorm that follows (Builder::gn_apply)
-                    FinGnParams q{};
-                    FinalizeParams& f = q.f; f.partial = p.partial; f.splitk = p.splitk; f.M = p.M; f.CoutPad = p.CoutPad;
-                    f.CoutS = p.CoutS; f.CoutReal = p.CoutReal; f.DHWo = p.Dout * p.Hout * p.Wout;
-                    f.bias = p.bias; f.bias2 = p.bias2; f.temb = p.temb; f.temb_stride = p.temb_stride; f.residual = p.residual;
-                    f.out = p.out; f.out_f32 = nullptr; f.stats = p.stats;
-                    GnFusedParams& g = q.g; g.xa = p.out; g.xb = (const bf16_t*)rp(bs, o.r[1]); g.ca = p.CoutS; g.cb = i[0];
-                    g.sa = p.stats; g.sb = (const float*)rp(bs, o.r[3]); g.nrb_a = (f.DHWo + 31) / 32; g.nrb_b = i[1];
-                    g.groups = i[2]; g.DHW = f.DHWo; g.N = p.N; g.silu = i[3]; g.rows_per_block = 32; g.eps = o.f[0];
-                    g.gamma = (const float*)rp(bs, o.r[0]); g.beta = (const float*)rp(bs, o.r[2]); g.out = (bf16_t*)rp(bs, o.r[4]);
-                    g.ab = (float*)rp(bs, o.r[5]); g.mr = (float*)rp(bs, o.r[13]);
-                    q.sync = (unsigned*)(bs.p[BASE_W] + ldm_model::sync_off);
-                    const dim3 grid((p.M + 31) / 32, (g.ca + g.cb + 63) / 64);
-                    q.nblocks = grid.x * grid.y;
-                    { static const int dbg = [] { const char* e = getenv("LDM_FIN_GN_DBG"); return e ? atoi(e) : 0; }(); q.dbg = dbg; }
-                    if (!f.partial || !f.out || !f.stats || q.nblocks > (unsigned)FIN_GN_MAX_BLOCKS) return fail(LDM_ERR_BAD_ARG, "fin_gn: bad operands");
-                    if (wt_stores()) hipLaunchKernelGGL(fin_gn_kernel<true>, grid, dim3(256), 0, s, q);
-                    else hipLaunchKernelGGL(fin_gn_kernel<false>, grid, dim3(256), 0, s, q);
-                }
                 else {
                     FinalizeParams f{}; f.partial = p.partial; f.splitk = p.splitk; f.M = p.M; f.CoutPad = p.CoutPad;
                     f.CoutS = p.CoutS; f.CoutReal = p.CoutReal; f.DHWo = p.Dout * p.Hout * p.Wout;
@@ -2409,7 +2368,7 @@ static int unet_forward_impl(ldm_model* m, const float* x, int x_channels, const
         if (sp) LDM_TRY(sampler_launch(sp, out, x_inout, nullptr, n_out, (float*)timesteps, B, s));
         return 0;
     };
-    if (!m->graph_mode || g_prof.on) return run_all((hipStream_t)stream);
+    if (!m->graph_mode || g_prof.on || g_plan_trace.on) return run_all((hipStream_t)stream);
     // ---- graph replay: same launches, recorded once per pointer set
     const void* key[8] = {x, cond, timesteps, out, workspace, stream, sp, x_inout};
     const uint64_t suid = sp ? sp->uid : 0;
@@ -2508,6 +2467,16 @@ int ldm_unet_denoise_step(ldm_model* m, ldm_sampler* sp, float* x, int x_channel
     if (!sp) return fail(LDM_ERR_BAD_ARG, "null sampler");
     if (m && m->type == 0 && x_channels != m->ucfg.out_channels) return fail(LDM_ERR_BAD_ARG, "x must have the UNet's out_channels (%d)", m->ucfg.out_channels);
     return unet_forward_impl(m, x, x_channels, cond, cond_channels, tbuf, eps_scratch, B, D, H, W, workspace, workspace_bytes, stream, sp, x);
+}
+
+/* Per-op timeline of every launch plan that runs from now on: a HIP event in front of every op, one CSV row per op appended to
+ * `path` when the call returns (ops of the plan, op index, op kind, microseconds, shape); NULL or "" switches it off.  Tracing
+ * synchronises at the end of every call and bypasses graph replay: a measurement aid, the hook behind the harness's --profile
+ * (3d_ldm/train_autoencoder.py:81,312-329 wraps a few steps in torch.profiler).  Initial state: the LDM_PLAN_TRACE environment variable. */
+int ldm_set_plan_trace(const char* path) {
+    g_plan_trace.on = path && *path;
+    g_plan_trace.path = g_plan_trace.on ? path : "";
+    return 0;
 }
 
 /* on != 0: ldm_unet_forward replays a HIP graph of its launch plan whenever it sees the same (x, cond, timesteps, out,
@@ -2946,24 +2915,13 @@ int ldm_model_plan_conv_cfgs(ldm_model* m, const char* kind, int B, int D, int H
     return n;
 }
 
-/* Launches of a cached inference plan: returns the number of ops; *fused_fin_gn receives how many of them are the one-launch
- * split-K finalize + GroupNorm (fin_gn.h).  ldm_model_sync_faults: grid-barrier timeouts of those launches since the model was
- * created (0 in a healthy run; synchronises the device). */
-int ldm_model_plan_launches(ldm_model* m, const char* kind, int B, int D, int H, int W, int* fused_fin_gn) {
+/* Launches of a cached inference plan ("unet" | "enc" | "dec"; builds it if needed): the number of ops. */
+int ldm_model_plan_launches(ldm_model* m, const char* kind, int B, int D, int H, int W) {
     if (!m || !kind) return fail(LDM_ERR_BAD_ARG, "null argument");
     std::shared_ptr<Plan> p; LDM_TRY(get_plan(m, kind, B, D, H, W, &p));
-    int n = 0, f = 0;
-    for (const Op& o : p->ops) { if (o.kind != OP_TAP) ++n; if (o.kind == OP_FIN_GN) ++f; }
-    if (fused_fin_gn) *fused_fin_gn = f;
+    int n = 0;
+    for (const Op& o : p->ops) if (o.kind != OP_TAP) ++n;
     return n;
-}
-int ldm_model_sync_faults(ldm_model* m) {
-    if (!m) return fail(LDM_ERR_BAD_ARG, "null model");
-    if (!m->arena) return 0;
-    unsigned st[3] = {0, 0, 0};
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(st, m->arena + ldm_model::sync_off, sizeof(st), hipMemcpyDeviceToHost));
-    return (int)st[2];
 }
 
 // ---- operator-level entry points (the same kernels the plans launch; used by per-kernel parity tests and

@@ -304,7 +304,7 @@ __device__ __forceinline__ void gn_fold_cover(const GnFoldSrc p, const int n, co
     }
 }
 
-// Slab fold of gn_fused_apply_kernel / fin_gn_kernel: sums the partial (sum, sum of squares) rows of the channels that cover the block's
+// Slab fold of gn_fused_apply_kernel: sums the partial (sum, sum of squares) rows of the channels that cover the block's
 // 64-channel slice `by` of sample n and leaves mean / rstd of those groups in gstat[g - g_lo].
 __device__ __forceinline__ void gn_fused_fold(const GnFusedParams& p, const int n, const int by, const bool first_block,
                                               float (*part)[96][4], double (*csum)[2], float (*gstat)[2]) {

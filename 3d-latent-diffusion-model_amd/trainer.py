@@ -246,6 +246,7 @@ class AutoencoderTrainer:
                  discriminator=None):
         from .discriminator import PatchAdversarialLoss, PatchDiscriminator
         from .optim import FlatAdam, FlatModuleAdam
+        self.perceptual_dropped = bool(perceptual_weight)     # logged by train_autoencoder.py (scalars + perceptual_term.json)
         if perceptual_weight:
             # the reference's PerceptualLoss downloads a pretrained SqueezeNet (train_autoencoder.py:236): no weights, no network here.
             # Every shipped config sets a (small: 1e-5 .. 1e-3) weight, so warn once and train without the term instead of refusing.

@@ -243,6 +243,11 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
 
+    # RCCL prints a version banner on stdout whenever a communicator is created (torch's process group, the library's own): stdout is
+    # kept for the ONE JSON line, everything else of this process goes to stderr
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -356,16 +361,7 @@ def main():
     if not args.no_ddp_train:
         del unet
         torch.cuda.empty_cache()
-        # RCCL prints a version banner on stdout when a communicator is created: keep stdout for the ONE JSON line
-        sys.stdout.flush()
-        saved_stdout = os.dup(1)
-        os.dup2(2, 1)
-        try:
-            ddp = ddp_train_leg(dev, rank, world, dist, rehearsal)
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved_stdout, 1)
-            os.close(saved_stdout)
+        ddp = ddp_train_leg(dev, rank, world, dist, rehearsal)
 
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -423,7 +419,7 @@ def main():
         out["ddp_train"] = ddp
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline()
-    print(json.dumps(out), flush=True)
+    print(json.dumps(out), file=json_out, flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

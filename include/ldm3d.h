@@ -279,12 +279,12 @@ int ldm_op_attention_bwd(const void* qkv, const void* o, const void* d_o, const 
 int ldm_profile_start(int wgm, int wgn, int bk, int max_launches);
 int ldm_profile_detail(double* flops, double* ms, int max);   /* per instrumented launch; call before ldm_profile_stop; returns their number */
 int ldm_profile_stop(double out[5]);
+/* Per-op timeline (HIP events around every op of every launch plan that runs while it is on) appended as CSV rows to `path`; NULL or
+ * "" = off.  Replaces the torch.profiler window of 3d_ldm/train_autoencoder.py:312-329 (--profile).  Initially: $LDM_PLAN_TRACE. */
+int ldm_set_plan_trace(const char* path);
 int ldm_model_plan_conv_cfgs(ldm_model* m, const char* kind, int B, int D, int H, int W, int* cfgs, int max_convs);
-/* launches of a cached plan ("unet"|"enc"|"dec"; builds it if needed) and how many of them are the one-launch split-K finalize +
- * GroupNorm (csrc/fin_gn.h; LDM_FIN_GN=0 plans them as two launches); sync_faults = grid-barrier timeouts of those launches since
- * the model was created (0 in a healthy run; synchronises the device). */
-int ldm_model_plan_launches(ldm_model* m, const char* kind, int B, int D, int H, int W, int* fused_fin_gn);
-int ldm_model_sync_faults(ldm_model* m);
+/* launches of a cached inference plan ("unet"|"enc"|"dec"; builds it if needed) */
+int ldm_model_plan_launches(ldm_model* m, const char* kind, int B, int D, int H, int W);
 
 /* ---- data-parallel collectives (replaces init_process_group("nccl") + DDP all-reduce,
  *      3d_ldm/utils.py:55-63, 3d_ldm/train_diffusion.py:121-123,147-149,281-283): RCCL over xGMI.

@@ -207,27 +207,13 @@ def test_state_dict_emits_monai_core_names_and_loads_legacy_checkpoints(built_li
             m.load_state_dict({k.replace("norm1", "norm_one"): v for k, v in sd.items()})
 
 
-def test_headline_plan_launch_count(built_lib, monkeypatch):
-    """Plans are host-side objects: the launch count of the headline step (BASELINE configs[2]) is checked without a GPU.  With
-    LDM_FIN_GN=1 every split-K conv that a GroupNorm directly follows folds and normalises in one launch (csrc/fin_gn.h: an experiment
-    that measured slower than the two launches and is therefore opt-in)."""
-    import ctypes as C
+def test_headline_plan_launch_count(built_lib):
+    """Plans are host-side objects: the launch count of the headline step (BASELINE configs[2]) is checked without a GPU."""
     from ldm3d import _lib
     from ldm3d.networks import DiffusionModelUNet
-    L = _lib.lib()
-    counts = {}
-    for knob in ("1", "0", None):
-        if knob is None:
-            monkeypatch.delenv("LDM_FIN_GN", raising=False)
-        else:
-            monkeypatch.setenv("LDM_FIN_GN", knob)
-        m = DiffusionModelUNet(**cfgs.UNET_FULL)
-        f = C.c_int(0)
-        n = L.ldm_model_plan_launches(m._h, b"unet", 1, 24, 24, 24, C.byref(f))
-        counts[knob] = (n, f.value)
-    assert counts[None] == counts["0"] and counts["0"][1] == 0 and counts["1"][1] >= 20
-    assert counts["0"][0] - counts["1"][0] == counts["1"][1]
-    assert counts["0"][0] <= 155 and counts["1"][0] <= 130, counts
+    m = DiffusionModelUNet(**cfgs.UNET_FULL)
+    n = _lib.lib().ldm_model_plan_launches(m._h, b"unet", 1, 24, 24, 24)
+    assert 100 <= n <= 155, n
 
 
 def test_shapes_the_networks_cannot_take_fail_loudly(built_lib):
@@ -237,14 +223,13 @@ def test_shapes_the_networks_cannot_take_fail_loudly(built_lib):
     from ldm3d import _lib
     from ldm3d.networks import AutoencoderKL, DiffusionModelUNet
     L = _lib.lib()
-    f = C.c_int(0)
     unet = DiffusionModelUNet(**cfgs.UNET_TINY)
     for dims in ((7, 8, 8), (8, 8, 6), (2, 2, 2), (1, 4, 4)):
-        assert L.ldm_model_plan_launches(unet._h, b"unet", 1, *dims, C.byref(f)) == -2, dims     # LDM_ERR_UNSUPPORTED
+        assert L.ldm_model_plan_launches(unet._h, b"unet", 1, *dims) == -2, dims     # LDM_ERR_UNSUPPORTED
         assert b"odd spatial size" in L.ldm_last_error()
-    assert L.ldm_model_plan_launches(unet._h, b"unet", 1, 4, 4, 4, C.byref(f)) > 0               # the smallest legal latent
-    assert L.ldm_model_plan_launches(unet._h, b"unet", 0, 8, 8, 8, C.byref(f)) == -1             # empty batch: LDM_ERR_BAD_ARG
+    assert L.ldm_model_plan_launches(unet._h, b"unet", 1, 4, 4, 4) > 0               # the smallest legal latent
+    assert L.ldm_model_plan_launches(unet._h, b"unet", 0, 8, 8, 8) == -1             # empty batch: LDM_ERR_BAD_ARG
     vae = AutoencoderKL(**cfgs.VAE_TINY)
     for dims in ((7, 8, 8), (2, 2, 2), (16, 16, 18)):
-        assert L.ldm_model_plan_launches(vae._h, b"enc", 1, *dims, C.byref(f)) == -2, dims
-    assert L.ldm_model_plan_launches(vae._h, b"enc", 1, 4, 4, 4, C.byref(f)) > 0
+        assert L.ldm_model_plan_launches(vae._h, b"enc", 1, *dims) == -2, dims
+    assert L.ldm_model_plan_launches(vae._h, b"enc", 1, 4, 4, 4) > 0

@@ -32,8 +32,14 @@ def test_train_then_conditional_sampling(tmp_path):
         json.dump(env, fh)
     _run("train_autoencoder.py", env_file, "--random-init", "--synthetic", "8", "--max-steps", "4")
     assert os.path.exists(tmp_path / "ckpt" / "autoencoder.pt")
-    log = _run("train_diffusion.py", env_file, "--random-init", "--max-steps", "6", "--gpu-transforms")
+    log = _run("train_diffusion.py", env_file, "--random-init", "--max-steps", "6", "--gpu-transforms", "--sample-steps", "5")
     assert "scale_factor" in log and os.path.exists(tmp_path / "ckpt" / "diffusion_unet.pt")
+    # the periodic rank-0 conditional sample of 3d_ldm/train_diffusion.py:306-359 (epoch 0 is a multiple of 2 * val_interval)
+    import numpy as np
+    smp = np.load(tmp_path / "tfevent" / "diffusion" / "samples" / "epoch_0.npz")
+    assert sorted(smp.files) == sorted(f"{n}_{a}" for n in ("val_lowcount_input", "val_highcount_gt", "val_denoised_cond") for a in range(3))
+    assert all(np.isfinite(smp[k]).all() and smp[k].ndim == 2 for k in smp.files)
+    assert smp["val_denoised_cond_0"].shape == smp["val_highcount_gt_0"].shape and "conditional sample (5 steps" in log
     sf = json.load(open(tmp_path / "ckpt" / "scale_factor.json"))["scale_factor"]
     assert sf > 0
     pair = sorted(glob.glob(str(tmp_path / "pairs" / "*.npz")))[0]

@@ -8,8 +8,10 @@
 The PatchDiscriminator / LSGAN adversarial phase after 5 warm-up epochs (:150-158,407-424,454-494) runs on the same HIP kernels
 (ldm3d/discriminator.py); checkpoints discriminator.pt / discriminator_last.pt as the reference (:183-186).  NOT reproduced: the
 perceptual loss needs a downloaded pretrained SqueezeNet: a non-zero `autoencoder_train.perceptual_weight` (every shipped config
-has one) is reported once and the term is left out.  --amp / --compile / --profile / --no-images are accepted
-and ignored (compute is bf16 on fp32 master weights; there is no tracing compiler on this path).
+has one) is reported once, recorded in the scalars log and the checkpoint directory (perceptual_term.json), and the term is left out.
+--profile (:81,312-329) traces the launch plans of a few steps with the reference's schedule (wait 1, warm-up 1, active 3, repeat 2)
+into ./profiler_logs (ldm3d/profiling.py on ldm_set_plan_trace).  --amp / --compile / --no-images are accepted and ignored (compute
+is bf16 on fp32 master weights, or fp32 with --precision fp32; there is no tracing compiler on this path).
 Opt-in extras: --random-init, --synthetic N, --max-steps K (as train_diffusion.py)."""
 import argparse
 import json
@@ -92,6 +94,17 @@ def main():
             log.write(json.dumps({"tag": tag, "value": float(value), "step": int(step), "time": time.time()}) + "\n")
             log.flush()
 
+    profiler = None
+    if args.profile and rank == 0:                          # 3d_ldm/train_autoencoder.py:312-329
+        from ldm3d.profiling import PlanProfiler
+        profiler = PlanProfiler("./profiler_logs")
+        print("Profiler started")
+    if rank == 0 and trainer.perceptual_dropped:
+        scalar("perceptual_term_dropped", 1.0, 0)
+        with open(os.path.join(args.model_dir, "perceptual_term.json"), "w") as fh:
+            json.dump({"perceptual_term": "dropped", "perceptual_weight": tcfg.get("perceptual_weight", 0.0),
+                       "reason": "pretrained SqueezeNet / LPIPS weights are not available offline"}, fh)
+        print(f"perceptual_term: dropped (autoencoder_train.perceptual_weight = {tcfg.get('perceptual_weight', 0.0)}; no pretrained weights offline)")
     total_step, best_val, done = 0, 100.0, False
     for epoch in range(tcfg["max_epochs"]):
         if ddp:
@@ -100,6 +113,8 @@ def main():
         t0, sums, nb = time.perf_counter(), {}, 0
         for step, batch in enumerate(train_loader):
             losses, skipped = trainer.train_step(batch["image"].to(device), epoch)
+            if profiler is not None:
+                profiler.step()
             if skipped:
                 print(f"Warning: non-finite input or loss at epoch {epoch}, step {step}: skipped on every rank")
                 continue
@@ -131,6 +146,8 @@ def main():
                     print("Got best val recon loss. Saved", best_path)
         if done:
             break
+    if profiler is not None:
+        profiler.stop()
     if log:
         log.close()
     if ddp:

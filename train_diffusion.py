@@ -9,8 +9,10 @@ MI355X-native path.
 
 Opt-in extras (never on by default): --random-init (no autoencoder checkpoint: smoke / benchmark runs),
 --synthetic N (write N synthetic NPZ pairs into npz_dir first), --max-steps K (stop after K optimizer steps),
---reference-rng-order (also run the label encode the reference uses only to learn the latent shape).
-Scalars go to <tfevent_path>/diffusion/scalars.jsonl (tensorboard is not a dependency here)."""
+--reference-rng-order (also run the label encode the reference uses only to learn the latent shape),
+--sample-steps N (reverse-diffusion steps of the periodic validation sample; 0 = the scheduler's full chain as in the reference).
+Scalars go to <tfevent_path>/diffusion/scalars.jsonl (tensorboard is not a dependency here); the periodic conditional sample of
+:308-359 (every 2 * val_interval epochs on rank 0) goes to <tfevent_path>/diffusion/samples/epoch_<n>.npz as centre slices."""
 import argparse
 import json
 import os
@@ -20,6 +22,59 @@ from pathlib import Path
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+
+def centre_slices(vol):
+    """The three centre slices of a [D, H, W] volume (visualize_one_slice_in_3d_image of 3d_ldm/utils.py at the centre of each axis)."""
+    d, h, w = vol.shape
+    return [vol[d // 2].float().cpu().numpy(), vol[:, h // 2].float().cpu().numpy(), vol[:, :, w // 2].float().cpu().numpy()]
+
+
+def sample_validation_volume(trainer, val_loader, device, out_dir, epoch, sample_steps, scalar, schedule_args=None):
+    """3d_ldm/train_diffusion.py:306-359: noise in the shape of the label latents (:309-310), image latents of the first sample of the
+    last validation batch (:324), ``inferer.sample(input_noise, autoencoder, unet, scheduler, conditioning=image_latents,
+    mode="concat")`` (:326-333), then the centre slices of low-count input, high-count ground truth and the conditional sample
+    (:335-359) -- written as one NPZ per epoch instead of TensorBoard images.  The chain runs on the device-resident sampler (one HIP
+    graph launch per step) seeded from torch's RNG; ``--sample-steps N`` (an extra) replaces the full DDPM chain by N DDIM steps
+    over the same beta schedule."""
+    import numpy as np
+    import torch
+    from ldm3d.schedulers import DDIMScheduler
+    batch = None
+    for batch in val_loader:                                  # the reference uses whatever batch the validation loop ended on
+        pass
+    if batch is None:
+        return None
+    images, labels = batch["image"].to(device).float(), batch["label"].to(device).float()
+    unet, autoencoder, inferer = trainer.unet, trainer.autoencoder, trainer.inferer
+    was_training = unet.training
+    unet.eval()
+    with torch.no_grad():
+        shape = autoencoder.encode_stage_2_inputs(labels[0:1]).shape
+        test_noise = torch.randn(shape, dtype=torch.float32).to(device)
+        image_latents = autoencoder.encode_stage_2_inputs(images[0:1])
+        sch = inferer.scheduler
+        if sample_steps and sample_steps < sch.num_train_timesteps and schedule_args:
+            sch = DDIMScheduler(**schedule_args)
+            sch.set_timesteps(sample_steps)
+        t0 = time.perf_counter()
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+        sample = inferer.sample(input_noise=test_noise, autoencoder_model=autoencoder, diffusion_model=unet, scheduler=sch,
+                                conditioning=image_latents, mode="concat", fused_seed=seed)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    unet.train(was_training)
+    os.makedirs(out_dir, exist_ok=True)
+    path = os.path.join(out_dir, f"epoch_{epoch}.npz")
+    arrays = {}
+    for name, vol in (("val_lowcount_input", images[0, 0]), ("val_highcount_gt", labels[0, 0]), ("val_denoised_cond", sample[0, 0])):
+        for axis, sl in enumerate(centre_slices(vol)):
+            arrays[f"{name}_{axis}"] = sl
+    np.savez_compressed(path, **arrays)
+    err = float((sample[0, 0] - labels[0, 0]).abs().mean())
+    scalar("val_denoised_cond_l1", err, epoch)
+    print(f"Epoch {epoch}: conditional sample ({len(sch.timesteps)} steps, {dt:.2f} s) -> {path}, L1 vs ground truth {err:.4f}")
+    return path
 
 
 def main():
@@ -35,6 +90,8 @@ def main():
                         help="percentile intensity scaling on the GPU (ldm_op_scale_intensity_percentiles) instead of in the host loader")
     parser.add_argument("--precision", default=None, choices=["bf16", "fp32"],
                         help="arithmetic of the networks: bf16 (default, the fast path) or fp32 (the reference's own arithmetic, 1e-5 from its CPU path; also LDM_PRECISION)")
+    parser.add_argument("--sample-steps", type=int, default=0,
+                        help="steps of the periodic validation sample (0 = all num_train_timesteps, as 3d_ldm/train_diffusion.py:326-333)")
     parser.add_argument("--grad-allreduce-dtype", default="fp32", choices=["fp32", "bf16"],
                         help="wire format of the data-parallel gradient all-reduce (the reference's DDP uses fp32)")
     args = parser.parse_args()
@@ -164,6 +221,13 @@ def main():
                     best_val = val
                     torch.save(unet.state_dict(), best_path)
                     print("Got best val noise pred loss. Saved", best_path)
+                # "Test denoising capability" (3d_ldm/train_diffusion.py:306-359): every 2 * val_interval epochs rank 0 samples one
+                # high-count volume conditioned on the low-count latents of the last validation batch (mode="concat") and logs the
+                # centre slices of input / ground truth / sample along the three axes
+                if epoch % (2 * tcfg["val_interval"]) == 0:
+                    sample_validation_volume(trainer, val_loader, device, os.path.join(tb, "samples"), epoch, args.sample_steps, scalar,
+                                             dict(num_train_timesteps=ns["num_train_timesteps"], schedule="scaled_linear_beta",
+                                                  beta_start=ns["beta_start"], beta_end=ns["beta_end"]))
         if done:
             break
     if log:
