@@ -47,9 +47,12 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
 
     const int nwg = gridDim.x;
     int lid = xcd_remap(blockIdx.x, nwg);
-    const int mtile = lid % p.mtiles; lid /= p.mtiles;
-    const int ntile = lid % p.ntiles;
-    const int split = lid / p.ntiles;
+    int mtile, ntile, split;
+    if (p.tile_order == 1) {                                   // cout tiles fastest: every XCD gets a contiguous range of M tiles with ALL their cout tiles
+        ntile = lid % p.ntiles; lid /= p.ntiles; mtile = lid % p.mtiles; split = lid / p.mtiles;
+    } else {                                                   // M tiles fastest: every XCD streams one weight panel (one cout tile)
+        mtile = lid % p.mtiles; lid /= p.mtiles; ntile = lid % p.ntiles; split = lid / p.ntiles;
+    }
     const int n0 = ntile * BN;
     const int DHW = p.Dout * p.Hout * p.Wout, HW = p.Hout * p.Wout;
     const int smp = mtile / p.halo_mtps, tin = mtile - smp * p.halo_mtps;

@@ -42,6 +42,7 @@ struct ConvParams {
     int splitk, steps_per_split;
     int mtiles, ntiles;
     int halo_mtps, q_per_split;       // conv3_halo_kernel only: 126-row tiles per sample, (kd,kh,chunk) macro steps per K split
+    int tile_order;                   // conv3_halo_kernel only: 0 = M tiles fastest over the (XCD-contiguous) block order, 1 = cout tiles fastest
     // phase mode (nearest x2 upsample + 3^3 conv, pad 1, as eight 2^3 convolutions on the LOW-resolution grid, one per output
     // parity (pd, ph, pw): 8 taps instead of 27.  ksize = 2, w0 = [parity][tap][CoutPad][cin] with the 3^3 taps that land on
     // the same source voxel pre-summed (phase_weights_kernel).  Tiles are [sample][parity][mtiles_pp] over the source voxels;

@@ -1638,7 +1638,10 @@ static int launch_conv(const ConvParams& p, const ConvCfg& cc, hipStream_t s) {
     return 0;
 }
 
-static int launch_conv_halo(const ConvParams& p, hipStream_t s, bool tall = false) {
+// LDM_HALO_ORDER (tuning knob): block -> tile order of conv3_halo_kernel, see ConvParams::tile_order
+static int halo_tile_order() { static const int v = [] { const char* e = getenv("LDM_HALO_ORDER"); return e ? atoi(e) : 0; }(); return v; }
+static int launch_conv_halo(const ConvParams& p_in, hipStream_t s, bool tall = false) {
+    ConvParams p = p_in; p.tile_order = halo_tile_order();
     constexpr int LDS = 6 * 16384 + 3 * 16384 + 9 * 128 * 4;
     constexpr int LDS_TALL = 6 * 8192 + 3 * 32768 + 9 * 256 * 4;
     static bool attr_set = false;
