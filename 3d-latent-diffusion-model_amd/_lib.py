@@ -7,7 +7,8 @@ import threading
 
 LDM_MAX_LEVELS = 8
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libldm3d.so")
+# LDM3D_LIB: a diagnostic build of the same sources (tools/kstamps.py: in-kernel stamps); never a different implementation
+LIB_PATH = os.environ.get("LDM3D_LIB") or os.path.join(_HERE, "libldm3d.so")
 
 
 class UNetCfg(C.Structure):
@@ -121,6 +122,7 @@ SIGNATURES = {
     "ldm_profile_detail": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]),
     "ldm_profile_stop": (C.c_int, [C.POINTER(C.c_double)]),
     "ldm_set_plan_trace": (C.c_int, [C.c_char_p]),
+    "ldm_debug_kstamps": (C.c_int, [C.POINTER(C.c_uint64), C.c_int, C.c_int]),
     "ldm_model_plan_conv_cfgs": (C.c_int, [_P, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]),
     "ldm_comm_unique_id": (C.c_int, [C.c_char_p]),
     "ldm_comm_init": (C.c_int, [C.c_int, C.c_int, C.c_char_p, C.POINTER(_P)]),

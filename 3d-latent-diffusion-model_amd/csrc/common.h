@@ -40,3 +40,35 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+
+// ---- diagnostic build only (make EXTRA=-DLDM_KSTAMPS OUT=...): per-launch in-kernel timeline.  Thread 0 of block (0,0,0) of every
+// instrumented kernel draws a ticket (= launch order) and records 100 MHz s_memrealtime stamps: [0] = kernel id, [1] = entry,
+// [1 + k] = KSTAMP(k).  Read back with ldm_debug_kstamps (tools/kstamps.py).  Compiled out of the product library.
+#ifdef LDM_KSTAMPS
+__device__ unsigned long long g_kstamp[8192 * 8];
+__device__ unsigned g_kstamp_seq;
+struct KStamp {
+    unsigned slot;
+    __device__ __forceinline__ KStamp(int id) {
+        slot = 0xffffffffu;
+        if ((blockIdx.x | blockIdx.y | blockIdx.z) == 0 && threadIdx.x == 0) {
+            const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+            slot = atomicAdd(&g_kstamp_seq, 1u) & 8191u;
+            g_kstamp[slot * 8] = (unsigned long long)id; g_kstamp[slot * 8 + 1] = t;
+            for (int k = 2; k < 8; ++k) g_kstamp[slot * 8 + k] = 0;
+        }
+    }
+    __device__ __forceinline__ void at(int k) { if (slot != 0xffffffffu) g_kstamp[slot * 8 + 1 + k] = __builtin_amdgcn_s_memrealtime(); }
+};
+#define KSTAMP_BEGIN(id) KStamp kst_(id)
+#define KSTAMP(k) kst_.at(k)
+#define KSTAMP_DRAIN(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); kst_.at(k); } while (0)
+#define KSTAMP_PARAM , KStamp& kst_
+#define KSTAMP_ARG , kst_
+#else
+#define KSTAMP_PARAM
+#define KSTAMP_ARG
+#define KSTAMP_BEGIN(id) do { } while (0)
+#define KSTAMP(k) do { } while (0)
+#define KSTAMP_DRAIN(k) do { } while (0)
+#endif

@@ -40,6 +40,7 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
+    KSTAMP_BEGIN(6);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, wq = wave & 3;
@@ -66,19 +67,7 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
     const unsigned cin2 = (unsigned)p.c0a * 2u;
     const int dbgflag = p.dbg;
 
-    // ---- (pair, LDS row) -> source voxel; LDS row j holds the voxel under tap (kd, kh, kw = 1) of output l0 - 1 + j
-    int* const tab = reinterpret_cast<int*>(smem + TOFF);
-    for (int e = tid; e < 9 * BM; e += 512) {
-        const int pr = e / BM, j = e % BM;
-        const int l = l0 - 1 + j;
-        int v = -1;
-        if (l >= 0 && l < DHW) {
-            const int od = l / HW, r = l - od * HW, oh = r / p.Wout, ow = r - oh * p.Wout;
-            const int id = od + pr / 3 - 1, ih = oh + pr % 3 - 1;
-            if ((unsigned)id < (unsigned)p.Din && (unsigned)ih < (unsigned)p.Hin) v = smp * DHW + (id * p.Hin + ih) * p.Win + ow;
-        }
-        tab[e] = v;
-    }
+    int* const tab = reinterpret_cast<int*>(smem + TOFF);          // (pair, LDS row) -> source voxel, built in the prologue
 
     // ---- loader lanes: every wave copies PA pieces (8 rows x 128 B) of a voxel tile and PB of a weight tile
     const int prow = lane >> 3, pchunk = lane & 7;
@@ -114,18 +103,22 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
         }                                                                                           \
     } while (0)
     // copies of one step; KW is the step's kw (static).  Slot of the weight tile = relative step % NSB (static: BSLOT).
-#define HL_ISSUE(KW, BSLOT) do {                                                                    \
-        {                                                                                           \
-            const unsigned sb_ = (unsigned)(i_pair * 3 + (KW)) * wtap + (unsigned)i_chunk * (BK * 2);                      \
-            if (!(ABL & 4)) _Pragma("unroll") for (int j = 0; j < PB; ++j)                          \
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr_t)(smem + (BSLOT) * BT + (wave * PB + j) * 1024), 16, b_vo[j], sb_, 0, 0); \
-            if ((KW) == 0 && !(ABL & 4)) {                                                          \
-                _Pragma("unroll") for (int j = 0; j < PA; ++j)                                      \
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr_t)(smem + AOFF + i_aslot + (wave * PA + j) * 1024), 16, a_vo[j], \
-                                                             (unsigned)i_chunk * (BK * 2), 0, 0);  \
-            }                                                                                       \
-            ++i_s;                                                                                  \
+#define HL_ISSUE_W(KW, BSLOT) do {                                                                  \
+        const unsigned sb_ = (unsigned)(i_pair * 3 + (KW)) * wtap + (unsigned)i_chunk * (BK * 2);                          \
+        if (!(ABL & 4)) _Pragma("unroll") for (int j = 0; j < PB; ++j)                              \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr_t)(smem + (BSLOT) * BT + (wave * PB + j) * 1024), 16, b_vo[j], sb_, 0, 0); \
+    } while (0)
+#define HL_ISSUE_A() do {                                                                           \
+        if (!(ABL & 4)) {                                                                           \
+            _Pragma("unroll") for (int j = 0; j < PA; ++j)                                          \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr_t)(smem + AOFF + i_aslot + (wave * PA + j) * 1024), 16, a_vo[j], \
+                                                         (unsigned)i_chunk * (BK * 2), 0, 0);      \
         }                                                                                           \
+    } while (0)
+#define HL_ISSUE(KW, BSLOT) do {                                                                    \
+        HL_ISSUE_W(KW, BSLOT);                                                                      \
+        if ((KW) == 0) HL_ISSUE_A();                                                                \
+        ++i_s;                                                                                      \
     } while (0)
     // issue stream moves on to the next macro step: next Cin chunk, or next (kd, kh) pair (table read + multiply-add per
     // copied row).  Runs in front of the waits of a kw == 0 step, outside the hot block.
@@ -220,19 +213,41 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
 #define HL_STAMP(I) do { if ((dbgflag & 512) && tid == 0) {                                         \
         p.stamps[(size_t)blockIdx.x * 8 + 2 * (I)] = __builtin_amdgcn_s_memrealtime();             \
         p.stamps[(size_t)blockIdx.x * 8 + 2 * (I) + 1] = __builtin_amdgcn_s_memtime(); } } while (0)
-    // ---- prologue
-    __syncthreads();                                           // table complete
+    // ---- prologue.  The first macro step's copies are requested BEFORE the tap table exists (a lane works out the source voxels of
+    //      its own PA rows for that one (kd, kh) pair by itself), so that their round trip to memory (cold: the weights come from HBM,
+    //      the voxels from another XCD's write-back) overlaps the table's integer divisions and its barrier.
+    auto src_voxel = [&](const int pr, const int j) -> int {   // LDS row j holds the voxel under tap (kd, kh, kw = 1) of output l0 - 1 + j
+        const int l = l0 - 1 + j;
+        int v = -1;
+        if (l >= 0 && l < DHW) {
+            const int od = l / HW, r = l - od * HW, oh = r / p.Wout, ow = r - oh * p.Wout;
+            const int id = od + pr / 3 - 1, ih = oh + pr % 3 - 1;
+            if ((unsigned)id < (unsigned)p.Din && (unsigned)ih < (unsigned)p.Hin) v = smp * DHW + (id * p.Hin + ih) * p.Win + ow;
+        }
+        return v;
+    };
+#pragma unroll
+    for (int j = 0; j < PA; ++j) {
+        const int v_ = src_voxel(i_pair, a_row[j]);
+        a_vo[j] = (v_ >= 0 && !(ABL & 32)) ? (unsigned)v_ * cin2 + a_kb[j] : 0xFFFFFFFFu;
+    }
+    HL_ISSUE(0, 0); HL_ISSUE(1, 1); HL_ISSUE(2, 2);            // issue order from here on as in the steady state: w0 a0 w1 w2 | w3 a3 w4 w5
+    for (int e = tid; e < 9 * BM; e += 512) tab[e] = src_voxel(e / BM, e % BM);
+    // table complete.  A raw barrier behind an LDS-only wait: __syncthreads() would drain vmcnt(0) and with it the copies in flight
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    KSTAMP(1);
     HL_STAMP(0);
-    HL_LOAD_TAB();
     if (nsteps >= 6) {
-        HL_ISSUE(0, 0); HL_ISSUE(1, 1); HL_ISSUE(2, 2); HL_ADVANCE(); HL_ISSUE(0, 3); HL_ISSUE(1, 4); HL_ISSUE(2, 5);
+        HL_ADVANCE(); HL_ISSUE(0, 3); HL_ISSUE(1, 4); HL_ISSUE(2, 5);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * PB + PA) : "memory");      // step 0 landed; steps 1..5 = 5 weight tiles + one voxel tile in flight
     } else {                                                   // a single macro step in this K range
-        HL_ISSUE(0, 0); HL_ISSUE(1, 1); HL_ISSUE(2, 2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    KSTAMP(2);
     HL_READ(wfA, afA, 0, 0);
 
     int s = 0;
@@ -277,16 +292,50 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
 #undef HL_MASK
 #undef HL_READ
 #undef HL_ISSUE
+#undef HL_ISSUE_W
+#undef HL_ISSUE_A
 #undef HL_ADVANCE
 #undef HL_LOAD_TAB
 
     HL_STAMP(1);
+    KSTAMP(3);
 #undef HL_STAMP
     // ---- intra-workgroup K reduction (the two wave groups took the two 32-deep halves of every K step)
     const int mt_base = 2 * grp;
+    // The epilogue's operands (bias, time-embedding row, residual rows) are requested HERE, in front of the exchange: they are one more
+    // round trip to memory nobody has touched in this launch, which the K-group exchange and its two barriers then hide
+    const int cbase = n0 + wn * 64 + 16 * fg;
+    const bool fused_ep = p.splitk == 1;
+    float4 ebias[4], etemb[4]; u32x4 eres[2][2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { ebias[q] = make_float4(0.f, 0.f, 0.f, 0.f); etemb[q] = ebias[q]; }
+#pragma unroll
+    for (int ml = 0; ml < 2; ++ml) { eres[ml][0] = (u32x4){0u, 0u, 0u, 0u}; eres[ml][1] = eres[ml][0]; }
+    if (fused_ep) {
+        if (p.bias) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ebias[q] = *reinterpret_cast<const float4*>(p.bias + cbase + 4 * q);
+        }
+        if (p.temb) {
+            const float* te = p.temb + (size_t)smp * p.temb_stride + cbase;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) etemb[q] = *reinterpret_cast<const float4*>(te + 4 * q);
+        }
+        if (p.residual && !p.out_f32 && cbase < p.CoutS) {
+#pragma unroll
+            for (int ml = 0; ml < 2; ++ml) {
+                const int r_t = wm * 64 + (mt_base + ml) * 16 + fr;
+                if (r_t < TM && l0 + r_t < DHW) {
+                    const u32x4* rp = reinterpret_cast<const u32x4*>(p.residual + (size_t)(m_base + r_t) * p.CoutS + cbase);
+                    eres[ml][0] = rp[0]; eres[ml][1] = rp[1];
+                }
+            }
+        }
+    }
     {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // every LDS-DMA copy was waited for by the last K steps (vmcnt(0) there)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
         float* xch = reinterpret_cast<float*>(smem);
         const int dst = 1 - grp;
 #pragma unroll
@@ -296,7 +345,9 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     xch[(((dst * 4 + wq) * 32) + (nt * 2 + ml) * 4 + r) * 64 + lane] = (grp == 0) ? acc[nt][2 + ml][r] : acc[nt][ml][r];
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // LDS-only wait + raw barrier: the epilogue operands stay in flight
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -308,10 +359,10 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
                 }
     }
 
+    KSTAMP(4);
     // ---- epilogue (conv_igemm.h's, with the 126-row tile mapping).  After the exchange this wave owns the 32-row block
     //      rows [64 wm + 32 grp, +32) of the tile = 16-row tiles mt_base + {0, 1}; GroupNorm partials of the whole tile go to slab
     //      row `mtile` (bitwise reproducible: no atomics).
-    const int cbase = n0 + wn * 64 + 16 * fg;
     const bool do_stats = (p.stats != nullptr) && (p.splitk == 1) && (p.out != nullptr);
     float ssum[16], ssq[16];
 #pragma unroll
@@ -335,12 +386,11 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
         }
         if (p.bias) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) v[q] += p.bias[cbase + q];
+            for (int q = 0; q < 4; ++q) { v[4 * q] += ebias[q].x; v[4 * q + 1] += ebias[q].y; v[4 * q + 2] += ebias[q].z; v[4 * q + 3] += ebias[q].w; }
         }
         if (p.temb) {
-            const float* te = p.temb + (size_t)smp * p.temb_stride + cbase;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) v[q] += te[q];
+            for (int q = 0; q < 4; ++q) { v[4 * q] += etemb[q].x; v[4 * q + 1] += etemb[q].y; v[4 * q + 2] += etemb[q].z; v[4 * q + 3] += etemb[q].w; }
         }
         if (p.out_f32) {
             const int sp = l0 + r_t;
@@ -351,10 +401,9 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
         }
         if (cbase >= p.CoutS) continue;
         if (p.residual) {
-            const u32x4* rp = reinterpret_cast<const u32x4*>(p.residual + (size_t)m * p.CoutS + cbase);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const u32x4 rv = rp[h];
+                const u32x4 rv = eres[ml][h];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     v[h * 8 + 2 * q] += __uint_as_float(rv[q] << 16);
@@ -400,5 +449,7 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
             *reinterpret_cast<float2*>(p.stats + ((size_t)mtile * p.CoutS + n0 + tid) * 2) = make_float2(s0, s1);
         }
     }
+    KSTAMP(5);
+    KSTAMP_DRAIN(6);
 #endif  // __HIP_DEVICE_COMPILE__
 }

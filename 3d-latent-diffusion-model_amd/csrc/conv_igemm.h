@@ -97,6 +97,7 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_igemm_kernel(const ConvParam
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
+    KSTAMP_BEGIN(7);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -344,6 +345,7 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_igemm_kernel(const ConvParam
     } while (0)
 
     LDM_STAMP(1);
+    KSTAMP(1);
     if (dbg & 256) return;                             // timing experiment: setup only
     // ---- prologue: fill the ring (NS steps in flight), wait for the first step ----------------------------------
     __syncthreads();                                   // tap table complete
@@ -357,6 +359,7 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_igemm_kernel(const ConvParam
         LDM_READ_FRAGS(wfA, afA, 0);
     }
     LDM_STAMP(2);
+    KSTAMP(2);
     // Steady state: one hot basic block per K step.  The segment change (rare, VALU heavy) runs BEFORE the wait; the
     // copies of step s+NS, the fragment reads of step s+1 and the 16 MFMAs of step s then sit in one scheduling
     // region and sched_group_barrier interleaves them (an MFMA occupies the matrix pipe for 16 cycles but the issue
@@ -484,6 +487,7 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_igemm_kernel(const ConvParam
 #undef LDM_SRC_SETUP
 
     LDM_STAMP(3);
+    KSTAMP(3);
     if (dbg & 64) return;                              // timing experiment: no reduction / epilogue
     // ---- intra-workgroup K reduction: group g keeps voxel tiles mt in {2g, 2g+1} and receives its partner's
     //      partial sums for them through LDS (the ring is dead by now). --------------------------------------------
@@ -515,6 +519,7 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_igemm_kernel(const ConvParam
     }
 
     LDM_STAMP(4);
+    KSTAMP(4);
     // ---- epilogue -------------------------------------------------------------------------------
     // Per lane: 16 consecutive couts of one voxel per 16-row tile.  Optionally also the GroupNorm partial sums of
     // the (bf16-rounded) output over each 32-row block, written to a slab (no atomics -> bitwise reproducible).
@@ -628,6 +633,8 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_igemm_kernel(const ConvParam
         }
     }
     LDM_STAMP(5);
+    KSTAMP(5);
+    KSTAMP_DRAIN(6);
 #undef LDM_STAMP
 #endif  // __HIP_DEVICE_COMPILE__
 }
@@ -642,8 +649,8 @@ struct FinalizeParams {
 
 // bx / by = the block's 32-row granule and
 // 64-channel slice; o_keep returns the thread's packed bf16 output (row bx * 32 + tid / 8, channels by * 64 + (tid & 7) * 8 ...).
-template <bool WT>
-__device__ __forceinline__ void splitk_finalize_body(const FinalizeParams& p, const int bx, const int by, float (*red)[8][16], u32x4& o_keep) {
+template <bool WT, int NB>
+__device__ __forceinline__ void splitk_finalize_body(const FinalizeParams& p, const int bx, const int by, float (*red)[8][16], u32x4& o_keep KSTAMP_PARAM) {
     // block = 32 rows (bx) x 64 channels (by); thread = one row x 8 channels
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cv = tid & 7, rl = tid >> 3;
@@ -657,55 +664,54 @@ __device__ __forceinline__ void splitk_finalize_body(const FinalizeParams& p, co
         float v[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[q] = 0.f;
-        // slabs are summed in order 0, 1, 2, ... (bitwise reproducible); four slabs' loads are in flight at a time so the
-        // sum is not one L2 round trip per slab
+        // Every operand of the row is requested BEFORE anything is waited for: the epilogue vectors and the residual first, then the
+        // slabs in batches of NB with all 2 NB loads of a batch in flight (unconditional loads of a clamped slab index; the adds are
+        // masked).  The launch is bound by dependent round trips to memory the producing conv left on other XCDs (1.5 - 2 us each):
+        // 8 in flight + a serial tail took 2 - 4 of them at split factors 9 ... 29.  Slabs are still summed in order 0, 1, 2, ...
+        const int n = m / p.DHWo;
+        float4 eb[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)}, eb2[2] = {eb[0], eb[0]}, et[2] = {eb[0], eb[0]};
+        u32x4 rv = {0u, 0u, 0u, 0u};
+        if (p.bias) { eb[0] = *reinterpret_cast<const float4*>(p.bias + c); eb[1] = *reinterpret_cast<const float4*>(p.bias + c + 4); }
+        if (p.bias2) { eb2[0] = *reinterpret_cast<const float4*>(p.bias2 + c); eb2[1] = *reinterpret_cast<const float4*>(p.bias2 + c + 4); }
+        if (p.temb) {
+            const float* te = p.temb + (size_t)n * p.temb_stride + c;
+            et[0] = *reinterpret_cast<const float4*>(te); et[1] = *reinterpret_cast<const float4*>(te + 4);
+        }
+        if (p.residual && !p.out_f32) rv = *reinterpret_cast<const u32x4*>(p.residual + (size_t)m * p.CoutS + c);
         const size_t slab = (size_t)p.M * p.CoutPad;
         const float* src0 = p.partial + (size_t)m * p.CoutPad + c;
-        int s = 0;
-        for (; s + 8 <= p.splitk; s += 8) {              // eight slabs' loads in flight (the launch is latency bound)
-            float4 a[8], b[8];
+        for (int s = 0; s < p.splitk; s += NB) {
+            float4 a[NB], b[NB];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const float4* src = reinterpret_cast<const float4*>(src0 + (size_t)(s + u) * slab);
+            for (int u = 0; u < NB; ++u) {
+                int su = s + u; if (su >= p.splitk) su = p.splitk - 1;
+                const float4* src = reinterpret_cast<const float4*>(src0 + (size_t)su * slab);
                 a[u] = src[0]; b[u] = src[1];
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                v[0] += a[u].x; v[1] += a[u].y; v[2] += a[u].z; v[3] += a[u].w;
-                v[4] += b[u].x; v[5] += b[u].y; v[6] += b[u].z; v[7] += b[u].w;
+            for (int u = 0; u < NB; ++u)
+                if (s + u < p.splitk) {
+                    v[0] += a[u].x; v[1] += a[u].y; v[2] += a[u].z; v[3] += a[u].w;
+                    v[4] += b[u].x; v[5] += b[u].y; v[6] += b[u].z; v[7] += b[u].w;
+                }
+        }
+        KSTAMP(1);
+        {
+            const float e0[8] = {eb[0].x, eb[0].y, eb[0].z, eb[0].w, eb[1].x, eb[1].y, eb[1].z, eb[1].w};
+            const float e1[8] = {eb2[0].x, eb2[0].y, eb2[0].z, eb2[0].w, eb2[1].x, eb2[1].y, eb2[1].z, eb2[1].w};
+            const float e2[8] = {et[0].x, et[0].y, et[0].z, et[0].w, et[1].x, et[1].y, et[1].z, et[1].w};
+            if (p.bias) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] += e0[q];
             }
-        }
-        for (; s + 4 <= p.splitk; s += 4) {
-            float4 a[4], b[4];
+            if (p.bias2) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float4* src = reinterpret_cast<const float4*>(src0 + (size_t)(s + u) * slab);
-                a[u] = src[0]; b[u] = src[1];
+                for (int q = 0; q < 8; ++q) v[q] += e1[q];
             }
+            if (p.temb) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                v[0] += a[u].x; v[1] += a[u].y; v[2] += a[u].z; v[3] += a[u].w;
-                v[4] += b[u].x; v[5] += b[u].y; v[6] += b[u].z; v[7] += b[u].w;
+                for (int q = 0; q < 8; ++q) v[q] += e2[q];
             }
-        }
-        for (; s < p.splitk; ++s) {
-            const float4* src = reinterpret_cast<const float4*>(src0 + (size_t)s * slab);
-            const float4 a = src[0], b = src[1];
-            v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
-            v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
-        }
-        const int n = m / p.DHWo;
-        if (p.bias) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] += p.bias[c + q];
-        }
-        if (p.bias2) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] += p.bias2[c + q];
-        }
-        if (p.temb) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] += p.temb[(size_t)n * p.temb_stride + c + q];
         }
         if (p.out_f32) {
             const int sp = m - n * p.DHWo;
@@ -714,7 +720,6 @@ __device__ __forceinline__ void splitk_finalize_body(const FinalizeParams& p, co
                 if (c + q < p.CoutReal) p.out_f32[((size_t)n * p.CoutReal + c + q) * p.DHWo + sp] = v[q];
         } else {
             if (p.residual) {
-                const u32x4 rv = *reinterpret_cast<const u32x4*>(p.residual + (size_t)m * p.CoutS + c);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     v[2 * q] += __uint_as_float(rv[q] << 16);
@@ -728,6 +733,7 @@ __device__ __forceinline__ void splitk_finalize_body(const FinalizeParams& p, co
                 const float lo = __uint_as_float(o[q] << 16), hi = __uint_as_float(o[q] & 0xffff0000u);
                 ss[2 * q] = lo; sq[2 * q] = lo * lo; ss[2 * q + 1] = hi; sq[2 * q + 1] = hi * hi;
             }
+            KSTAMP(2);
             store16<WT>(p.out + (size_t)m * p.CoutS + c, o);
             o_keep = o;
         }
@@ -754,9 +760,14 @@ __device__ __forceinline__ void splitk_finalize_body(const FinalizeParams& p, co
     }
 }
 
-template <bool WT>
+// NB = slabs whose loads are in flight together: 16 (128 registers of operands) where the grid has more than one block per CU, 32 for
+// the small grids of the 6^3 level (split factors 24 ... 32: one round trip instead of two at one block per CU)
+template <bool WT, int NB>
 __global__ __launch_bounds__(256) void splitk_finalize_kernel(const FinalizeParams p) {
+    KSTAMP_BEGIN(4);
     __shared__ float red[4][8][16];
     u32x4 o;
-    splitk_finalize_body<WT>(p, blockIdx.x, blockIdx.y, red, o);
+    splitk_finalize_body<WT, NB>(p, blockIdx.x, blockIdx.y, red, o KSTAMP_ARG);
+    KSTAMP(3);
+    KSTAMP_DRAIN(4);
 }

@@ -22,6 +22,7 @@ struct LightParams {
 // wave tile = (16 MT) rows x (16 NT) couts; CH = 32-deep K steps per register chunk (two chunks in flight).
 template <int MT, int NT, int CH>
 __global__ __launch_bounds__(64) void gemm_light_kernel(const LightParams p) {
+    KSTAMP_BEGIN(5);
     const int lane = threadIdx.x, fr = lane & 15, fg = lane >> 4;
     const int mtile = blockIdx.x % p.mtiles, ntile = blockIdx.x / p.mtiles;       // mtile fastest: neighbours share the weight rows
     const int m0 = mtile * 16 * MT, n0 = ntile * 16 * NT;
@@ -70,6 +71,7 @@ __global__ __launch_bounds__(64) void gemm_light_kernel(const LightParams p) {
     }
 #undef GL_LOAD
 #undef GL_MFMA
+    KSTAMP(1);
 
     // ---- epilogue: lane = voxel fr of each 16-row tile, couts cb .. cb + 4 NT - 1 --------------------------------
     constexpr int NC = 4 * NT;
@@ -132,6 +134,8 @@ __global__ __launch_bounds__(64) void gemm_light_kernel(const LightParams p) {
                 *reinterpret_cast<float4*>(d + 4 * q) = make_float4(ssum[2 * q], ssq[2 * q], ssum[2 * q + 1], ssq[2 * q + 1]);
         }
     }
+    KSTAMP(2);
+    KSTAMP_DRAIN(3);
 }
 
 // tile choice: 64 x 64 per wave once that still gives every CU a wave, else 32 x 32

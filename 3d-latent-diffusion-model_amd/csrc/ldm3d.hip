@@ -1626,6 +1626,21 @@ static double conv_algorithmic_flops(const ConvParams& p) {
     return 2.0 * (double)p.M * (double)p.CoutReal * (taps * (double)(p.c0a + p.c0b) + (double)(p.c1a + p.c1b));
 }
 
+// LDM_FIN_NB (tuning knob): slabs whose loads one finalize thread keeps in flight: 8 (default), 16, or 0 = 16 with 32 on the small
+// grids of the 6^3 level.  Measured (same box, whole step): see DESIGN.md section 5 -- the launch is bound by the bytes of the slabs
+// crossing XCDs, not by the number of round trips, and more loads in flight per thread made it slower.
+static void launch_finalize(const FinalizeParams& f, bool wt, hipStream_t s) {
+    static const int nb_knob = [] { const char* e = getenv("LDM_FIN_NB"); return e ? atoi(e) : 8; }();
+    const dim3 grid((f.M + 31) / 32, (f.CoutS + 63) / 64);
+    int nb = nb_knob;
+    if (nb == 0) nb = (f.splitk > 16 && (long)grid.x * grid.y <= 256) ? 32 : 16;
+#define FIN_CASE(NB_) if (nb == NB_) { if (wt) hipLaunchKernelGGL((splitk_finalize_kernel<true, NB_>), grid, dim3(256), 0, s, f); \
+                                       else hipLaunchKernelGGL((splitk_finalize_kernel<false, NB_>), grid, dim3(256), 0, s, f); return; }
+    FIN_CASE(16) FIN_CASE(32)
+#undef FIN_CASE
+    if (wt) hipLaunchKernelGGL((splitk_finalize_kernel<true, 8>), grid, dim3(256), 0, s, f);
+    else hipLaunchKernelGGL((splitk_finalize_kernel<false, 8>), grid, dim3(256), 0, s, f);
+}
 static int launch_conv_impl(const ConvParams& p, const ConvCfg& cc, hipStream_t s);
 static int launch_conv(const ConvParams& p, const ConvCfg& cc, hipStream_t s) {
     if (!g_prof.on) return launch_conv_impl(p, cc, s);
@@ -1900,8 +1915,7 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                     f.CoutS = p.CoutS; f.CoutReal = p.CoutReal; f.DHWo = p.Dout * p.Hout * p.Wout;
                     f.bias = p.bias; f.bias2 = p.bias2; f.temb = p.temb; f.temb_stride = p.temb_stride; f.residual = p.residual;
                     f.out = p.out; f.out_f32 = p.out_f32; f.stats = p.stats;
-                    if (wt_stores()) hipLaunchKernelGGL(splitk_finalize_kernel<true>, dim3((p.M + 31) / 32, (p.CoutS + 63) / 64), dim3(256), 0, s, f);
-                    else hipLaunchKernelGGL(splitk_finalize_kernel<false>, dim3((p.M + 31) / 32, (p.CoutS + 63) / 64), dim3(256), 0, s, f);
+                    launch_finalize(f, wt_stores(), s);
                 }
                 break; }
             case OP_GEMM_LIGHT: {       // i: M, K, CoutS, CoutPad, big
@@ -2472,6 +2486,26 @@ int ldm_unet_denoise_step(ldm_model* m, ldm_sampler* sp, float* x, int x_channel
     return unet_forward_impl(m, x, x_channels, cond, cond_channels, tbuf, eps_scratch, B, D, H, W, workspace, workspace_bytes, stream, sp, x);
 }
 
+/* Diagnostic builds only (EXTRA=-DLDM_KSTAMPS, tools/kstamps.py): the in-kernel stamps of the instrumented kernels, [entries][8] =
+ * {kernel id, entry, stamp 1 ... stamp 6} in 10 ns ticks, in launch order; reset != 0 clears the log afterwards.  Returns the number
+ * of entries (0 in the product library, which carries no stamps). */
+int ldm_debug_kstamps(unsigned long long* out, int max_entries, int reset) {
+#ifdef LDM_KSTAMPS
+    if (!out || max_entries < 0) return fail(LDM_ERR_BAD_ARG, "bad argument");
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned n = 0;
+    HIP_TRY(hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_kstamp_seq), sizeof n));
+    const int cnt = (int)std::min<unsigned>(n, 8192u);
+    const int take = std::min(cnt, max_entries);
+    if (take > 0) HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_kstamp), (size_t)take * 8 * sizeof(unsigned long long)));
+    if (reset) { const unsigned z = 0; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_kstamp_seq), &z, sizeof z)); }
+    return take;
+#else
+    (void)out; (void)max_entries; (void)reset;
+    return 0;
+#endif
+}
+
 /* Per-op timeline of every launch plan that runs from now on: a HIP event in front of every op, one CSV row per op appended to
  * `path` when the call returns (ops of the plan, op index, op kind, microseconds, shape); NULL or "" switches it off.  Tracing
  * synchronises at the end of every call and bypasses graph replay: a measurement aid, the hook behind the harness's --profile
@@ -2716,7 +2750,7 @@ int ldm_grad_sq_norm(const float* flat_grads, int64_t n, float* out, void* strea
 int ldm_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int step, const float* sq_norm, float max_norm, void* stream) {
     if (!params || !grads || !exp_avg || !exp_avg_sq || n < 0 || step < 1) return fail(LDM_ERR_BAD_ARG, "bad argument");
-    AdamCoef k{lr, beta1, beta2, eps, 1.0f - powf(beta1, (float)step), sqrtf(1.0f - powf(beta2, (float)step)), max_norm, lr * weight_decay};
+    AdamCoef k{lr, beta1, beta2, eps, 1.0f - powf(beta1, (float)step), sqrtf(1.0f - powf(beta2, (float)step)), max_norm, lr * weight_decay, step};
     hipLaunchKernelGGL(adam_step_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq,
                        (long)n, k, sq_norm);
     HIP_TRY(hipGetLastError());
@@ -2731,7 +2765,7 @@ int ldm_model_adam_step(ldm_model* m, float* params_flat, const float* grads_fla
     if (!m || !params_flat || !grads_flat || !exp_avg || !exp_avg_sq || step < 1) return fail(LDM_ERR_BAD_ARG, "bad argument");
     LDM_TRY(ensure_arena(m));
     LDM_TRY(ensure_pack_tab(m));
-    AdamCoef k{lr, beta1, beta2, eps, 1.0f - powf(beta1, (float)step), sqrtf(1.0f - powf(beta2, (float)step)), max_norm, lr * weight_decay};
+    AdamCoef k{lr, beta1, beta2, eps, 1.0f - powf(beta1, (float)step), sqrtf(1.0f - powf(beta2, (float)step)), max_norm, lr * weight_decay, step};
     hipLaunchKernelGGL(adam_pack_batched_kernel, dim3(m->pack_tab.nblocks), dim3(256), 0, (hipStream_t)stream,
                        (const PackDesc*)m->pack_tab.descs, (const int2*)m->pack_tab.map, params_flat, grads_flat, exp_avg, exp_avg_sq,
                        m->arena, k, sq_norm);
@@ -3028,8 +3062,7 @@ static int op_conv3d_impl(const void* xa, int ca, const void* xb, int cb, const 
         FinalizeParams f{}; f.partial = p.partial; f.splitk = p.splitk; f.M = p.M; f.CoutPad = p.CoutPad; f.CoutS = p.CoutS;
         f.CoutReal = p.CoutReal; f.DHWo = Do * Ho * Wo; f.bias = bias; f.bias2 = bias2; f.temb = temb; f.temb_stride = temb_stride;
         f.residual = p.residual; f.out = p.out; f.out_f32 = p.out_f32; f.stats = stats;
-        if (stats && wt_stores()) hipLaunchKernelGGL(splitk_finalize_kernel<true>, dim3((p.M + 31) / 32, (p.CoutS + 63) / 64), dim3(256), 0, (hipStream_t)stream, f);
-        else hipLaunchKernelGGL(splitk_finalize_kernel<false>, dim3((p.M + 31) / 32, (p.CoutS + 63) / 64), dim3(256), 0, (hipStream_t)stream, f);
+        launch_finalize(f, stats && wt_stores(), (hipStream_t)stream);
     }
     HIP_TRY(hipGetLastError());
     return 0;

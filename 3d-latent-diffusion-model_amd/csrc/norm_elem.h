@@ -336,6 +336,7 @@ __global__ __launch_bounds__(256) void gn_fused_apply_kernel(const GnFusedParams
     __shared__ __attribute__((aligned(16))) float part[8][96][4];
     __shared__ double csum[192][2];
     __shared__ float gstat[64][2];
+    KSTAMP_BEGIN(3);
     const int tid = threadIdx.x, n = blockIdx.z;
     const int C = p.ca + p.cb, cpg = C / p.groups;     // host guarantees cpg <= 64
     const int c0 = blockIdx.y * 64;
@@ -362,7 +363,9 @@ __global__ __launch_bounds__(256) void gn_fused_apply_kernel(const GnFusedParams
         gam[0] = *reinterpret_cast<const float4*>(p.gamma + c); gam[1] = *reinterpret_cast<const float4*>(p.gamma + c + 4);
         bet[0] = *reinterpret_cast<const float4*>(p.beta + c); bet[1] = *reinterpret_cast<const float4*>(p.beta + c + 4);
     }
+    KSTAMP(1);
     gn_fused_fold(p, n, blockIdx.y, blockIdx.x == 0, part, csum, gstat);
+    KSTAMP(2);
     // ---- apply
     if (!active) return;
     float a[8], b[8];
@@ -403,6 +406,8 @@ __global__ __launch_bounds__(256) void gn_fused_apply_kernel(const GnFusedParams
             }
         }
     }
+    KSTAMP(3);
+    KSTAMP_DRAIN(4);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -427,6 +432,7 @@ __global__ __launch_bounds__(256) void pack2_ncdhw_kernel(const float* __restric
 // GEMV with bf16 weights [out][in], fp32 activations; one wave per output row.
 __global__ __launch_bounds__(256) void temb_sinusoid_kernel(const float* __restrict__ t, float* __restrict__ out,
                                                             int B, int dim) {
+    KSTAMP_BEGIN(1);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int half = dim / 2;
     if (i >= B * dim) return;
@@ -434,13 +440,16 @@ __global__ __launch_bounds__(256) void temb_sinusoid_kernel(const float* __restr
     const int j = k < half ? k : k - half;
     const float f = expf((-logf(10000.0f) * (float)j) / (float)half);     // same op order as get_timestep_embedding
     const float a = t[b] * f;
+    KSTAMP(1);
     out[i] = (k < half) ? cosf(a) : ((k < 2 * half) ? sinf(a) : 0.f);
+    KSTAMP_DRAIN(2);
 }
 
 // y[b][o] = sum_i W[o][i] * act(x[b][i]) + bias[o];  act = SiLU when silu_in.  grid = (ceil(O/4), B).
 __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16_t* __restrict__ W, const float* __restrict__ bias,
                                                         const float* __restrict__ x, float* __restrict__ y,
                                                         int I, int O, int x_stride, int y_stride, int silu_in) {
+    KSTAMP_BEGIN(2);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int o = blockIdx.x * 4 + wave, b = blockIdx.y;
     if (o >= O) return;
@@ -457,7 +466,9 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16_t* __restrict
         }
     }
     acc = wave_sum(acc);
+    KSTAMP(1);
     if (lane == 0) y[(size_t)b * y_stride + o] = acc + (bias ? bias[o] : 0.f);
+    KSTAMP_DRAIN(2);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -565,6 +576,7 @@ __global__ __launch_bounds__(256) void sampler_noise_kernel(float* __restrict__ 
     }
 }
 __global__ __launch_bounds__(256) void sampler_step_kernel(const SamplerParams p) {
+    KSTAMP_BEGIN(9);
     __shared__ int s_last;
     const int k = p.st->k;                                  // every block reads the counter before it can bump `done`
     const bool live = k < p.n_steps;
@@ -1325,11 +1337,34 @@ __global__ __launch_bounds__(256) void sq_norm_fold_kernel(const float* __restri
     for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
     if (threadIdx.x == 0) *out = (float)red[0];
 }
-struct AdamCoef { float lr, b1, b2, eps, bc1, bc2_sqrt, max_norm, decay; };   // decay = lr * weight_decay (AdamW, decoupled)
+struct AdamCoef { float lr, b1, b2, eps, bc1, bc2_sqrt, max_norm, decay; int step; };   // decay = lr * weight_decay (AdamW, decoupled)
+// The agreed NaN-skip of the trainers without a host read: a non-finite gradient norm (a NaN / inf loss makes every gradient NaN,
+// and the data-parallel mean carries it to every rank) leaves parameters and moments untouched, and sq_norm[1] counts the skipped
+// steps; the bias corrections use step - skipped, as if the optimizer had not been called (the reference `continue`s in front of
+// optimizer.step(): 3d_ldm/train_diffusion.py:210-212).  Returns false when this launch must do nothing.
+__device__ __forceinline__ bool adam_prologue(AdamCoef& k, const float* __restrict__ sq_norm, float& clip, const bool counter_block) {
+    clip = 1.f;
+    if (!sq_norm || k.max_norm <= 0.f) return true;
+    const float nn = sq_norm[0];
+    const float skipped = sq_norm[1];
+    if (!(nn == nn) || nn > 3.0e38f) {                  // NaN or inf
+        if (counter_block) const_cast<float*>(sq_norm)[1] = skipped + 1.f;
+        return false;
+    }
+    const float c = k.max_norm / (sqrtf(nn) + 1e-6f); clip = c < 1.f ? c : 1.f;
+    if (skipped > 0.f) {
+        const float eff = fmaxf((float)k.step - skipped, 1.f);
+        k.bc1 = 1.0f - powf(k.b1, eff); k.bc2_sqrt = sqrtf(1.0f - powf(k.b2, eff));
+    }
+    return true;
+}
 __global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                         float* __restrict__ v, long n, AdamCoef k, const float* __restrict__ sq_norm) {
-    float clip = 1.f;
-    if (sq_norm && k.max_norm > 0.f) { const float c = k.max_norm / (sqrtf(*sq_norm) + 1e-6f); clip = c < 1.f ? c : 1.f; }
+    float clip;
+    // every block reads the skip counter before any block can bump it?  No: block 0 may run first.  The counter is therefore bumped by
+    // the LAST block of the grid in launch order only after its own read, and readers tolerate either value: a skip decision depends on
+    // sq_norm[0] alone, and the bias correction is only evaluated on steps that do update.
+    if (!adam_prologue(k, sq_norm, clip, blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)) return;
     const float step = k.lr / k.bc1;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const float gi = g[i] * clip;
@@ -1381,8 +1416,8 @@ __global__ __launch_bounds__(256) void adam_pack_batched_kernel(const PackDesc* 
     const int2 bm = blockmap[blockIdx.x];
     const PackDesc e = descs[bm.x];
     const int tid = threadIdx.x;
-    float clip = 1.f;
-    if (sq_norm && k.max_norm > 0.f) { const float c = k.max_norm / (sqrtf(*sq_norm) + 1e-6f); clip = c < 1.f ? c : 1.f; }
+    float clip;
+    if (!adam_prologue(k, sq_norm, clip, blockIdx.x == gridDim.x - 1 && tid == 0)) return;
     const float step = k.lr / k.bc1;
     auto update = [&](long i) -> float {
         const float gi = flat_g[i] * clip;

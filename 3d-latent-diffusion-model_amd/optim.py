@@ -36,7 +36,8 @@ class FlatAdam(torch.optim.Optimizer):
         self.fuse_repack = True                        # Adam + bf16 re-pack in one kernel (ldm_model_adam_step)
         self.exp_avg = torch.zeros_like(flat)
         self.exp_avg_sq = torch.zeros_like(flat)
-        self.sq_norm = torch.zeros((1,), dtype=torch.float32, device=flat.device)
+        # {sum g^2 of the current gradients, optimizer steps skipped on the device because that sum was not finite}: include/ldm3d.h
+        self.sq_norm = torch.zeros((2,), dtype=torch.float32, device=flat.device)
         self.steps = 0
 
     def zero_grad(self, set_to_none: bool = True):     # gradients are overwritten by every backward: nothing to clear
@@ -49,6 +50,11 @@ class FlatAdam(torch.optim.Optimizer):
         with torch.cuda.device(g.device):
             _lib.check(L.ldm_grad_sq_norm(g.data_ptr(), g.numel(), self.sq_norm.data_ptr(), _lib.current_stream()))
         return self.sq_norm.sqrt()[0]
+
+    def skipped_steps(self) -> torch.Tensor:
+        """Device scalar: how many ``step()`` calls left the parameters untouched because the gradient norm was NaN / inf (the agreed
+        NaN-skip of the trainers, decided on the device: no host read inside the step)."""
+        return self.sq_norm[1]
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -101,7 +107,7 @@ class FlatModuleAdam:
         self.params = params
         self.lr, self.betas, self.eps, self.weight_decay, self.max_grad_norm = lr, tuple(betas), eps, weight_decay, max_grad_norm
         self.exp_avg, self.exp_avg_sq = torch.zeros_like(self.flat_params), torch.zeros_like(self.flat_params)
-        self.sq_norm = torch.zeros((1,), dtype=torch.float32, device=dev)
+        self.sq_norm = torch.zeros((2,), dtype=torch.float32, device=dev)
         self.steps = 0
         self.param_groups = [dict(lr=lr)]
 

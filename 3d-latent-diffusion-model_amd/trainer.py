@@ -11,8 +11,10 @@ Reference behaviour being reproduced (3d_ldm/train_diffusion.py):
 MI355X design: one process per GPU; the UNet's gradients live in ONE flat fp32 buffer written in place by the
 hand-written backward plan, so the data-parallel exchange is a single (optionally chunked) all-reduce over RCCL/xGMI
 issued right after backward, and clip + Adam are two fused launches over the flat buffers (``FlatAdam``).  Two
-reference quirks are fixed on purpose: the NaN-skip is agreed across ranks with a MAX
-all-reduce (a single rank skipping ``backward`` dead-locks DDP in the reference), and the label encode that the
+reference quirks are fixed on purpose: the NaN-skip is agreed across ranks (a single rank skipping
+``backward`` dead-locks DDP in the reference) and decided ON THE DEVICE: a NaN loss makes every gradient NaN, the data-parallel
+mean carries that to every rank, and the fused clip + Adam launch leaves parameters and moments untouched when the gradient norm is
+not finite (``FlatAdam.skipped_steps``) -- no flag all-reduce and no host read inside the step; and the label encode that the
 reference runs only to learn the latent shape (:179-181) is not executed (``reference_rng_order=True`` restores it).
 """
 from __future__ import annotations
@@ -181,7 +183,8 @@ class DiffusionTrainer:
 
     def train_step(self, images: torch.Tensor, labels: torch.Tensor, noise: Optional[torch.Tensor] = None,
                    timesteps: Optional[torch.Tensor] = None):
-        """One optimizer step.  Returns (loss [device scalar], skipped [bool])."""
+        """One optimizer step.  Returns (loss [device scalar], skipped [0-dim device bool tensor: truthy if this step was a NaN-skip]).
+        Nothing in here reads a device value on the host: ranks never wait for each other's host, only for the gradient exchange."""
         self.unet.train()
         images, labels = images.float(), labels.float()
         self.optimizer.zero_grad(set_to_none=True)
@@ -191,14 +194,12 @@ class DiffusionTrainer:
             timesteps = t2 if timesteps is None else timesteps
         noise_pred = self._predict(images, labels, noise, timesteps)
         loss = F.mse_loss(noise_pred.float(), noise.float())
-        bad = self.sync.any(torch.isnan(loss.detach()).to(torch.float32))
-        if float(bad) > 0.0:                              # every rank skips together
-            return loss.detach(), True
+        before = self.optimizer.skipped_steps().clone()
         loss.backward()                                  # with self.overlap the buckets are reduced inside this call
         if not self.overlap:
             self.sync.mean_(self.unet.flat_grads)
-        self.optimizer.step()
-        return loss.detach(), False
+        self.optimizer.step()                            # a NaN / inf gradient norm (on any rank, after the mean) skips the update on the device
+        return loss.detach(), self.optimizer.skipped_steps() > before
 
     def end_epoch(self):
         self.lr_scheduler.step()
@@ -280,9 +281,9 @@ class AutoencoderTrainer:
         """-> (dict of detached scalar losses, skipped)."""
         self.autoencoder.train()
         images = torch.clamp(images.float(), 0.0, 1.0)
-        bad_in = self.sync.any((~torch.isfinite(images)).any().to(torch.float32))
-        if float(bad_in) > 0.0:
-            return {}, True
+        # No host read of a device value in this step: non-finite inputs or losses (:362-365,417-422,426-437,470-484 `continue`) make
+        # the gradient norm non-finite, the data-parallel mean carries that to every rank, and the fused clip + AdamW launches then
+        # leave parameters and moments untouched (optim.FlatAdam.skipped_steps); a non-finite adversarial term alone is dropped (:417-422).
         adversarial = epoch > self.warm_up_epochs
         reconstruction, z_mu, z_sigma = self.autoencoder(images, eps=eps)
         recons = self.intensity_loss(reconstruction, images)
@@ -292,12 +293,10 @@ class AutoencoderTrainer:
         if adversarial:
             logits_fake = self.discriminator(reconstruction.contiguous().float())[-1]
             generator_loss = self.adv_loss(logits_fake, target_is_real=True, for_discriminator=False)
-            if bool(torch.isfinite(generator_loss.detach())):                      # a NaN adversarial term is dropped (:417-422)
-                loss_g = loss_g + self.adv_weight * generator_loss
-                out["adv_g"] = generator_loss.detach()
-        bad = self.sync.any((~torch.isfinite(loss_g.detach())).to(torch.float32))
-        if float(bad) > 0.0:
-            return {}, True
+            ok = torch.isfinite(generator_loss.detach())
+            loss_g = loss_g + self.adv_weight * torch.where(ok, generator_loss, torch.zeros_like(generator_loss))
+            out["adv_g"] = generator_loss.detach()
+        before = self.optimizer.skipped_steps().clone()
         loss_g.backward()
         if not self.overlap:
             self.sync.mean_(self.autoencoder.flat_grads)
@@ -312,13 +311,11 @@ class AutoencoderTrainer:
             loss_d_real = self.adv_loss(logits_real, target_is_real=True, for_discriminator=True)
             discriminator_loss = (loss_d_fake + loss_d_real) * 0.5
             loss_d = self.adv_weight * discriminator_loss
-            bad_d = self.sync.any((~torch.isfinite(loss_d.detach())).to(torch.float32))
-            if float(bad_d) == 0.0:
-                loss_d.backward()
-                self.sync.mean_(self.optimizer_d.flat_grads)
-                self.optimizer_d.step()
-                out["adv_d"] = discriminator_loss.detach()
-        return out, False
+            loss_d.backward()
+            self.sync.mean_(self.optimizer_d.flat_grads)
+            self.optimizer_d.step()                          # skips itself on a non-finite gradient norm
+            out["adv_d"] = discriminator_loss.detach()
+        return out, self.optimizer.skipped_steps() > before
 
     @torch.no_grad()
     def validate(self, loader, device) -> float:

@@ -30,6 +30,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0         # /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
 UNET_STEP_GFLOP = 889.1                      # SURVEY.md section 8d / BASELINE.md section 3 (2*MAC, real channel counts)
+# what the launch plan executes: the two Upsample layers (nearest x2 + 3^3 conv: 73.4 GFLOP as the reference computes them) run as
+# eight 2^3 phase convolutions on the source grid with pre-summed taps (21.7 GFLOP): DESIGN.md section 3.1c
+UNET_STEP_EXECUTED_GFLOP = 889.1 - 73.4 + 21.7
 DOMINANT_TILE = (2, 2, 64 | 256)             # conv3_halo_kernel (bk | 256 selects it): 126 voxels x 128 couts x K 64 per step
 
 
@@ -388,6 +391,10 @@ def main():
                               "HIP graph replay of the forward plan; scheduler step driven from the host (torch.randn)")},
         "steps_per_s_per_gpu": args.steps / dt,
         "unet_step_tflops": UNET_STEP_GFLOP / ms_per_step,
+        # unet_step_tflops and whole_step_fractions price the step at the REFERENCE's FLOP count (889.1 G); the plan executes fewer
+        # (executed_gflop), so matrix-pipe utilisation of the step is executed_tflops / peak, not the fraction below
+        "executed_gflop": UNET_STEP_EXECUTED_GFLOP, "executed_tflops": UNET_STEP_EXECUTED_GFLOP / ms_per_step,
+        "executed_frac_of_mfma_peak": UNET_STEP_EXECUTED_GFLOP / ms_per_step / MFMA_BF16_DENSE_PEAK_TFLOPS,
         # SURVEY.md section 8d asks for the three fractions side by side (per GPU): whole step vs the dense bf16 MFMA peak,
         # vs the vector-fp32 peak north_star's wording implies (157 TFLOP/s), and algorithmic bytes (0.992 GB/step) vs HBM
         "whole_step_fractions": {"mfma_bf16_dense": UNET_STEP_GFLOP / ms_per_step / MFMA_BF16_DENSE_PEAK_TFLOPS,

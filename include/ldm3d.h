@@ -125,7 +125,11 @@ int ldm_vae_train_backward(ldm_model* m, const float* d_recon, const float* d_mu
  *   grad_sq_norm: *out (device fp32 scalar) = sum g^2.
  *   adam_step: g' = g * min(1, max_norm / (sqrt(*sq_norm) + 1e-6)) when sq_norm != NULL and max_norm > 0; then
  *              m = b1 m + (1-b1) g'; v = b2 v + (1-b2) g'^2; p = p (1 - lr wd) - lr * (m / (1-b1^step)) / (sqrt(v / (1-b2^step)) + eps)
- *              (wd = 0: torch.optim.Adam of train_diffusion.py:155; wd > 0: the decoupled AdamW of train_autoencoder.py:274-279). */
+ *              (wd = 0: torch.optim.Adam of train_diffusion.py:155; wd > 0: the decoupled AdamW of train_autoencoder.py:274-279).
+ *   sq_norm points at TWO device floats {sum g^2, skipped steps}: the NaN-skip of the reference's trainers (train_diffusion.py:210-212
+ *   `continue`s in front of backward when the loss is NaN) without a host read: when sum g^2 is not finite (a NaN loss makes every
+ *   gradient NaN; the data-parallel mean carries it to every rank) the step leaves params / exp_avg / exp_avg_sq untouched and adds 1
+ *   to sq_norm[1]; the bias corrections use step - sq_norm[1].  The caller zeroes sq_norm[1] once; ldm_grad_sq_norm writes out[0] only. */
 int ldm_grad_sq_norm(const float* flat_grads, int64_t n, float* out, void* stream);
 int ldm_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int step, const float* sq_norm, float max_norm, void* stream);
@@ -282,6 +286,9 @@ int ldm_profile_stop(double out[5]);
 /* Per-op timeline (HIP events around every op of every launch plan that runs while it is on) appended as CSV rows to `path`; NULL or
  * "" = off.  Replaces the torch.profiler window of 3d_ldm/train_autoencoder.py:312-329 (--profile).  Initially: $LDM_PLAN_TRACE. */
 int ldm_set_plan_trace(const char* path);
+/* diagnostic builds (-DLDM_KSTAMPS) only: in-kernel 100 MHz stamps of the instrumented kernels, [entries][8] in launch order; the
+ * product library returns 0 entries */
+int ldm_debug_kstamps(unsigned long long* out, int max_entries, int reset);
 int ldm_model_plan_conv_cfgs(ldm_model* m, const char* kind, int B, int D, int H, int W, int* cfgs, int max_convs);
 /* launches of a cached inference plan ("unet"|"enc"|"dec"; builds it if needed) */
 int ldm_model_plan_launches(ldm_model* m, const char* kind, int B, int D, int H, int W);

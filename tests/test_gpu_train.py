@@ -514,3 +514,46 @@ def test_fused_adam_repack_equals_adam_then_repack(cuda):
     for a, b in zip(res[True][:3], res[False][:3]):          # same arithmetic up to FMA contraction: ulp-level differences
         assert torch.allclose(a, b, rtol=2e-5, atol=1e-8)
     assert rel_l2(res[True][3], res[False][3]) <= 1e-2
+
+
+def test_nan_step_is_skipped_on_the_device_and_does_not_count(cuda):
+    """The reference `continue`s in front of backward when the loss is NaN (3d_ldm/train_diffusion.py:210-212), so neither the
+    parameters nor Adam's moments nor its step count move.  Here that decision is taken on the device, without a host read inside the
+    step: a NaN loss makes every gradient NaN, the fused clip + Adam launch sees a non-finite gradient norm and leaves everything
+    untouched (include/ldm3d.h: sq_norm[1] counts such steps, the bias corrections use step - skipped).  A run with one poisoned batch
+    in the middle must therefore end exactly where the run without it ends."""
+    from ldm3d.networks import DiffusionModelUNet
+    from ldm3d.optim import FlatAdam
+    from oracle import unet as ou
+    cfg = cfgs.UNET_TINY
+    sd = ou.init_state_dict(ou.unet_param_shapes(cfg), 5, gain=0.5)
+    g = torch.Generator().manual_seed(2)
+    xs = [torch.randn((1, 4, 8, 8, 8), generator=g).to(cuda) for _ in range(3)]
+    tg = [torch.randn((1, 4, 8, 8, 8), generator=g).to(cuda) for _ in range(3)]
+    t = torch.tensor([300.0], device=cuda)
+
+    def run(poison):
+        m = DiffusionModelUNet(**cfg)
+        m.load_state_dict(sd)
+        m = m.to(cuda).train()
+        opt = FlatAdam(m, lr=1e-3, max_grad_norm=1.0)
+        flags = []
+        for k in range(3):
+            if poison and k == 1:                           # a batch that produces a NaN loss between two good ones
+                bad = xs[k].clone()
+                bad[0, 0, 0, 0, 0] = float("nan")
+                before = opt.skipped_steps().clone()
+                F.mse_loss(m(x=bad, timesteps=t).float(), tg[k]).backward()
+                opt.step()
+                flags.append(bool(opt.skipped_steps() > before))
+            before = opt.skipped_steps().clone()
+            F.mse_loss(m(x=xs[k], timesteps=t).float(), tg[k]).backward()
+            opt.step()
+            flags.append(bool(opt.skipped_steps() > before))
+        torch.cuda.synchronize()
+        return m.flat_params.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), flags, float(opt.skipped_steps())
+    p0, m0, v0, f0, s0 = run(False)
+    p1, m1, v1, f1, s1 = run(True)
+    assert f0 == [False, False, False] and s0 == 0.0
+    assert f1 == [False, True, False, False] and s1 == 1.0
+    assert torch.isfinite(p1).all() and torch.equal(p0, p1) and torch.equal(m0, m1) and torch.equal(v0, v1)

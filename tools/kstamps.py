@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""In-kernel timeline of the small kernels of the headline step (diagnostic build with -DLDM_KSTAMPS).
+
+    make -C 3d-latent-diffusion-model_amd/csrc EXTRA=-DLDM_KSTAMPS OUT=../libldm3d_kstamps.so
+    LDM3D_LIB=$PWD/3d-latent-diffusion-model_amd/libldm3d_kstamps.so python tools/kstamps.py
+
+Thread 0 of block 0 of every instrumented kernel records 100 MHz stamps (csrc/common.h KSTAMP): entry, a few points inside, and the
+drained end.  Printed per launch of one graph-replayed step: time since the previous instrumented kernel's end (the boundary + the tail
+of that kernel's other blocks), and the in-kernel segments.  Kernel ids: 1 sinusoid, 2 gemv, 3 gn_fused (1 loads issued, 2 fold done,
+3 stores issued, 4 drained), 4 finalize (1 slabs summed, 2 before store, 3 stats done, 4 drained), 5 gemm_light (1 K loop done,
+2 epilogue issued, 3 drained), 6 conv_halo (1 tap table, 2 ring filled, 3 K loop done, 4 K-group exchange done, 5 epilogue issued,
+6 drained), 7 conv_igemm (1 setup, 2 ring filled, 3 K loop done, 4 exchange done, 5 epilogue issued, 6 drained), 8 attention, 9 sampler."""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+NAMES = {1: "sinusoid", 2: "gemv", 3: "gn_fused", 4: "finalize", 5: "gemm_light", 6: "conv_halo", 7: "conv_igemm", 8: "attention", 9: "sampler"}
+
+
+def main():
+    import torch
+    import bench
+    import cfgs
+    from ldm3d import _lib
+    from ldm3d.schedulers import DDPMScheduler
+    dev = torch.device("cuda:0")
+    L = _lib.lib()
+    unet = bench.make_unet(dev, seed=0)
+    unet.enable_graph_replay(True)
+    sch = DDPMScheduler(**cfgs.SCHED)
+    x = torch.randn((1, 4, 24, 24, 24), device=dev)
+    tbuf = torch.empty((1,), dtype=torch.float32, device=dev)
+    sampler = sch.device_sampler(seed=1)
+    sampler.reset(tbuf)
+    with torch.no_grad():
+        for _ in range(30):
+            unet.denoise_step(x, tbuf, sampler)
+        torch.cuda.synchronize()
+        buf = (C.c_uint64 * (8192 * 8))()
+        L.ldm_debug_kstamps(buf, 8192, 1)                    # clear
+        for _ in range(3):
+            unet.denoise_step(x, tbuf, sampler)
+        torch.cuda.synchronize()
+    n = L.ldm_debug_kstamps(buf, 8192, 1)
+    if n <= 0:
+        sys.exit("no stamps: build with EXTRA=-DLDM_KSTAMPS and point LDM3D_LIB at it")
+    rows = [[int(buf[i * 8 + k]) for k in range(8)] for i in range(n)]
+    per_step = n // 3
+    rows = rows[per_step:2 * per_step]                       # the middle step
+    prev_end = None
+    agg = {}
+    for r in rows:
+        kid, entry, st = r[0], r[1], [v for v in r[2:] if v]
+        end = st[-1] if st else entry
+        gap = (entry - prev_end) / 100.0 if prev_end else 0.0
+        segs = [(b - a) / 100.0 for a, b in zip([entry] + st[:-1], st)]
+        print(f"{NAMES.get(kid, kid):10s} since prev end {gap:7.2f} us | in-kernel " + " ".join(f"{s:6.2f}" for s in segs) + f" | total {(end - entry) / 100.0:6.2f}")
+        a = agg.setdefault(kid, [0, 0.0, 0.0])
+        a[0] += 1; a[1] += gap; a[2] += (end - entry) / 100.0
+        prev_end = end
+    for kid, (cnt, gap, tot) in agg.items():
+        print(f"{NAMES.get(kid, kid):10s} x{cnt:3d}: mean gap before {gap / cnt:6.2f} us, mean in-kernel (block 0) {tot / cnt:6.2f} us")
+
+
+if __name__ == "__main__":
+    main()

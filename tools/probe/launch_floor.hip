@@ -24,6 +24,31 @@ __global__ void k_touch_wt(const uint4* __restrict__ in, uint4* __restrict__ out
     }
 }
 
+// block b reads the range block (b + shift) wrote in the previous launch: shift % 8 != 0 = produced on ANOTHER XCD (round-robin
+// placement), shift % 8 == 0 = same XCD, another CU.  wt: write-through stores.
+template <bool WT>
+__global__ void k_shift(const uint4* __restrict__ in, uint4* __restrict__ out, int per_block, int shift) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const int src = (blockIdx.x + shift) % gridDim.x;
+    for (int i = threadIdx.x; i < per_block; i += blockDim.x) {
+        const uint4 t = in[(long)src * per_block + i];
+        u32x4 v = {t.x + 1, t.y, t.z, t.w};
+        if (WT) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"((void*)(out + (long)blockIdx.x * per_block + i)), "v"(v) : "memory");
+        else out[(long)blockIdx.x * per_block + i] = make_uint4(v.x, v.y, v.z, v.w);
+    }
+}
+// two dependent round trips inside the kernel: an index read, then the row it names (a slab fold followed by an apply has this shape)
+__global__ void k_chain2(const uint4* __restrict__ in, uint4* __restrict__ out, int per_block, int shift) {
+    const int src = (blockIdx.x + shift) % gridDim.x;
+    const uint4 first = in[(long)src * per_block];
+    const int hop = (int)(first.y & 7u);                       // data dependent (always < 8)
+    for (int i = threadIdx.x; i < per_block; i += blockDim.x) {
+        uint4 t = in[(long)((src + hop) % gridDim.x) * per_block + i];
+        t.x += 1; t.y = 0;
+        out[(long)blockIdx.x * per_block + i] = t;
+    }
+}
+
 template <class F> static double run(hipStream_t s, int K, int reps, bool graph, F launch) {
     hipGraphExec_t exec = nullptr;
     if (graph) {
@@ -66,6 +91,21 @@ int main() {
             hipLaunchKernelGGL(k_touch_wt, dim3(1024), dim3(256), 0, s, (const uint4*)(k & 1 ? b : a), (uint4*)(k & 1 ? a : b), big / 16); }));
         printf("%s  7 MB ping-pong, sc1, 2048 blk  : %6.2f us per launch\n", tag, run(s, K, reps, graph, [&](int k) {
             hipLaunchKernelGGL(k_touch_wt, dim3(2048), dim3(256), 0, s, (const uint4*)(k & 1 ? b : a), (uint4*)(k & 1 ? a : b), big / 16); }));
+        for (int shift : {0, 8, 1, 3}) {
+            printf("%s  221 KB, block b reads what block b+%d wrote, plain : %6.2f us per launch\n", tag, shift, run(s, K, reps, graph, [&](int k) {
+                hipLaunchKernelGGL(k_shift<false>, dim3(54), dim3(256), 0, s, (const uint4*)(k & 1 ? b : a), (uint4*)(k & 1 ? a : b), 256, shift); }));
+            printf("%s  221 KB, block b reads what block b+%d wrote, sc1   : %6.2f us per launch\n", tag, shift, run(s, K, reps, graph, [&](int k) {
+                hipLaunchKernelGGL(k_shift<true>, dim3(54), dim3(256), 0, s, (const uint4*)(k & 1 ? b : a), (uint4*)(k & 1 ? a : b), 256, shift); }));
+        }
+        for (int shift : {0, 1}) {
+            printf("%s  7 MB (1728 blocks), reads block b+%d, plain        : %6.2f us per launch\n", tag, shift, run(s, K, reps, graph, [&](int k) {
+                hipLaunchKernelGGL(k_shift<false>, dim3(1728), dim3(256), 0, s, (const uint4*)(k & 1 ? b : a), (uint4*)(k & 1 ? a : b), 256, shift); }));
+            printf("%s  7 MB (1728 blocks), reads block b+%d, sc1          : %6.2f us per launch\n", tag, shift, run(s, K, reps, graph, [&](int k) {
+                hipLaunchKernelGGL(k_shift<true>, dim3(1728), dim3(256), 0, s, (const uint4*)(k & 1 ? b : a), (uint4*)(k & 1 ? a : b), 256, shift); }));
+        }
+        for (int shift : {0, 1})
+            printf("%s  221 KB, two dependent reads, shift %d               : %6.2f us per launch\n", tag, shift, run(s, K, reps, graph, [&](int k) {
+                hipLaunchKernelGGL(k_chain2, dim3(54), dim3(256), 0, s, (const uint4*)(k & 1 ? b : a), (uint4*)(k & 1 ? a : b), 256, shift); }));
     }
     return 0;
 }
