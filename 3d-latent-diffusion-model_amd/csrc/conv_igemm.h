@@ -42,7 +42,9 @@ struct ConvParams {
     int splitk, steps_per_split;
     int mtiles, ntiles;
     int halo_mtps, q_per_split;       // conv3_halo_kernel only: 126-row tiles per sample, (kd,kh,chunk) macro steps per K split
-    int tile_order;                   // conv3_halo_kernel only: 0 = M tiles fastest over the (XCD-contiguous) block order, 1 = cout tiles fastest
+    int tile_order;                   // 0 = M tiles fastest over the (XCD-contiguous) block order: an XCD streams one weight panel; 1 = cout
+                                      // tiles fastest: an XCD owns a contiguous range of output rows (all couts), like the GroupNorm blocks
+                                      // that read them next (GnFusedParams::xcd_rows)
     // phase mode (nearest x2 upsample + 3^3 conv, pad 1, as eight 2^3 convolutions on the LOW-resolution grid, one per output
     // parity (pd, ph, pw): 8 taps instead of 27.  ksize = 2, w0 = [parity][tap][CoutPad][cin] with the 3^3 taps that land on
     // the same source voxel pre-summed (phase_weights_kernel).  Tiles are [sample][parity][mtiles_pp] over the source voxels;
@@ -108,9 +110,12 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_igemm_kernel(const ConvParam
     // ---- block -> (split, ntile, mtile); mtile fastest so one XCD streams one weight panel
     const int nwg = gridDim.x;
     int lid = xcd_remap(blockIdx.x, nwg);
-    const int mtile = lid % p.mtiles; lid /= p.mtiles;
-    const int ntile = lid % p.ntiles;
-    const int split = lid / p.ntiles;
+    int mtile, ntile, split;
+    if (p.tile_order == 1) {                           // cout tiles fastest: an XCD gets a contiguous range of M tiles with all their cout tiles
+        ntile = lid % p.ntiles; lid /= p.ntiles; mtile = lid % p.mtiles; split = lid / p.mtiles;
+    } else {
+        mtile = lid % p.mtiles; lid /= p.mtiles; ntile = lid % p.ntiles; split = lid / p.ntiles;
+    }
     int m0 = mtile * BM; const int n0 = ntile * BN;
     int Mloc = p.M;                                    // rows addressed by m0 + row
     int ph_n = 0, ph_d = 0, ph_h = 0, ph_w = 0;        // phase mode: sample and output parity of this tile

@@ -95,9 +95,6 @@ struct Op {
     int i[24];
     float f[2];
     ConvCfg cc;
-    // inference plans: lane 1 = the side stream (work off the critical path: time embedding, 1x1 skip GEMMs); sync = before
-    // this op its lane waits for everything issued so far on the other lane
-    int lane = 0; bool sync = false;
 };
 
 struct Pool {                                        // plan-time workspace allocator (first fit + coalescing)
@@ -212,7 +209,6 @@ struct ldm_model {
     // ldm_sampler's address is readily handed out again: the key carries the sampler's never-reused id, not only its address
     struct GraphEntry { const Plan* plan; const void* ptr[8]; int rt[2]; uint64_t sampler_uid; int seen; hipGraphExec_t exec; };
     std::vector<GraphEntry> graphs;
-    hipStream_t side_stream = nullptr; std::vector<hipEvent_t> lane_events;     // side lane of the inference plans (run_plan)
     hipStream_t cap_stream = nullptr;        // capture happens on a private stream (the caller's may be the null stream, which cannot capture)
     GradSyncState gsync;                     // ldm_model_set_grad_sync
     // UNet: stacked time_emb_proj GEMV
@@ -351,7 +347,6 @@ struct Builder {
         // backward-pass uses of the same kernel (data gradients)
         Ref w_over; bool no_bias = false; int exact = 0;   // weights from the workspace; zero-insertion upsample
         int temb_row = -1;                            // first row of this ResBlock in the stacked time projection
-        int lane = 0; bool sync = false;              // Op::lane / Op::sync of the emitted (first) op
         int f32_tag = 0;                              // which externally supplied gradient an fp32-output conv receives (0 final, 1 VAE heads)
     };
     struct Tape {                                    // one differentiable forward op, recorded in training plans
@@ -366,12 +361,6 @@ struct Builder {
     // LDM_HALO_TALL: 0 = never, 1 = wherever the cost model prefers it, 2 (default) = only for Cout % 128 != 0
     static int tall_mode() { const char* e = getenv("LDM_HALO_TALL"); return e ? atoi(e) : 2; }
     static bool light_enabled() { const char* e = getenv("LDM_GEMM_LIGHT"); return e ? atoi(e) != 0 : true; }
-    bool temb_pending = false;
-    // measured (MI355X, ROCm 7.2): 14 fork / join pairs per step cost more than the overlapped work saves: 2.36 vs 2.17 ms per
-    // step under graph replay, 2.29 ms eager.  Kept as an opt-in experiment (LDM_SIDE_LANE=1).
-    // second stream of the inference plans: bit 0 = the time-embedding chain (runs beside pack / conv_in), bit 1 = the 1x1 skip projections
-    static int side_lane_mode() { const char* e = getenv("LDM_SIDE_LANE"); return e ? atoi(e) : 0; }
-    static bool side_lane_enabled() { return (side_lane_mode() & 2) != 0; }
     static bool phase_enabled() { const char* e = getenv("LDM_CONV_PHASE"); return e ? atoi(e) != 0 : true; }
     // halo_n > 0: the conv is eligible for conv3_halo_kernel (3^3, stride 1, pad 1, single source, BK 64); halo_n = N
     // and halo_dhw = voxels per sample (its 126-row tiles never straddle samples).
@@ -525,7 +514,7 @@ struct Builder {
             op.r[0] = ws_ref(a.xa.off); op.r[1] = a.xb.valid ? ws_ref(a.xb.off) : Ref();
             op.r[2] = a.w_over.base != BASE_NULL ? a.w_over : w_ref(w.w_off);
             op.r[6] = a.no_bias ? Ref() : w_ref(w.b_off); op.r[9] = a.residual.valid ? ws_ref(a.residual.off) : Ref();
-            op.i[5] = a.xa.C; op.lane = a.lane; op.sync = a.sync;
+            op.i[5] = a.xa.C;
             op.r[10] = ws_ref(out.off); op.r[12] = out.has_stats ? ws_ref(out.stats_off) : Ref();
             op.i[0] = (int)M; op.i[1] = cin0; op.i[2] = couts_l; op.i[3] = w.cout_pad; op.i[4] = big;
             plan->ops.push_back(op);
@@ -559,7 +548,7 @@ struct Builder {
                 }
             }
         }
-        Op op{}; op.kind = OP_CONV; op.cc = cc; op.lane = a.lane; op.sync = a.sync;
+        Op op{}; op.kind = OP_CONV; op.cc = cc;
         op.r[0] = ws_ref(a.xa.off); op.r[1] = a.xb.valid ? ws_ref(a.xb.off) : Ref();
         op.r[2] = a.w_over.base != BASE_NULL ? a.w_over : w_ref(phase ? w.wp_off : w.w_off);
         op.r[3] = a.w1 ? ws_ref(a.g1a.off) : Ref(); op.r[4] = (a.w1 && a.g1b.valid) ? ws_ref(a.g1b.off) : Ref();
@@ -584,7 +573,7 @@ struct Builder {
         (void)bn;
         plan->ops.push_back(op);
         if (cc.splitk > 1) {
-            Op f = op; f.kind = OP_FINALIZE; f.sync = false;
+            Op f = op; f.kind = OP_FINALIZE;
             partial_fixups.push_back(plan->ops.size());
             plan->ops.push_back(f);
         }
@@ -711,15 +700,15 @@ struct Builder {
     Act resblock(const std::string& p, const Act& xa, const Act& xb, int cout, int groups, float eps,
                  const std::string& skip_name, bool with_temb) {
         const int cin = xa.C + (xb.valid ? xb.C : 0);
-        // inference: the 1x1 skip projection runs as a light GEMM on the side lane, concurrently with norm1 / conv1 / norm2, and
-        // enters conv2 as its residual: conv2 stays a single-source 3^3 conv (halo kernel) instead of the fused two-group form
+        // fp32 precision: the 1x1 skip projection runs as its own conv and enters conv2 as its residual (the bf16 plans fuse it
+        // into conv2 as extra K steps).  A second stream for it (and for the time-embedding chain) was measured and removed: one
+        // fork / join pair per step costs 5 % of the step under graph replay, fourteen cost 8 %
         Act sk;
-        if (cin != cout && ((hp) || (!train && side_lane_enabled() && cin % 128 == 0))) {
+        if (cin != cout && hp) {
             ConvArgs cs; cs.xa = xa; cs.xb = xb; cs.w = &m->convs.at(p + skip_name); cs.k = 1; cs.pad = 0;
-            cs.Do = xa.D; cs.Ho = xa.H; cs.Wo = xa.W; cs.want_stats = false; cs.lane = hp ? 0 : 1; cs.sync = !hp;
+            cs.Do = xa.D; cs.Ho = xa.H; cs.Wo = xa.W; cs.want_stats = false;
             sk = conv(cs, p + skip_name);
             if (!sk.valid) return Act();
-            if (!hp && plan->ops.back().kind != OP_GEMM_LIGHT) { err = "resblock: side-lane skip needs the light GEMM"; return Act(); }
         }
         Act h0 = gn_apply(m->gns.at(p + ".norm1"), xa, xb, groups, eps, true);
         if (!h0.valid) return Act();
@@ -727,7 +716,6 @@ struct Builder {
         if (with_temb) {
             c1.temb = ws_ref(temb_all_off + (size_t)m->tproj_row.at(p) * 4); c1.temb_stride = tproj_stride;
             c1.temb_row = m->tproj_row.at(p);
-            if (temb_pending) { c1.sync = true; temb_pending = false; }      // first consumer joins the side lane
         }
         Act h1 = conv(c1, p + ".conv1");
         free_act(h0);
@@ -736,7 +724,7 @@ struct Builder {
         free_act(h1);
         if (!h2.valid) return Act();
         ConvArgs c2; c2.xa = h2; c2.w = &m->convs.at(p + ".conv2"); c2.Do = xa.D; c2.Ho = xa.H; c2.Wo = xa.W;
-        if (sk.valid) { c2.residual = sk; c2.sync = !hp; }
+        if (sk.valid) c2.residual = sk;
         else if (cin != cout) { c2.g1a = xa; c2.g1b = xb; c2.w1 = &m->convs.at(p + skip_name); }
         else { if (xb.valid) { err = "resblock: identity skip with concat input"; return Act(); } c2.residual = xa; }
         Act out = conv(c2, p + ".conv2");
@@ -1231,15 +1219,12 @@ static int unet_build(ldm_model* m, int B, int D, int H, int W, Plan* plan, bool
     const size_t e2_off = b.pool.alloc((size_t)B * temb * 4);
     b.tproj_stride = m->tproj_rows;
     b.temb_all_off = b.pool.alloc(((size_t)B * m->tproj_rows + 256) * 4);
-    // inference: the whole time-embedding chain runs on the side lane, beside pack / conv_in / the first GroupNorm
-    const int tlane = (!train && !hp && (Builder::side_lane_mode() & 1)) ? 1 : 0;
-    { Op o{}; o.kind = OP_SINUSOID; o.r[0] = io_ref(2); o.r[1] = ws_ref(sin_off); o.i[0] = B; o.i[1] = ch[0]; o.lane = tlane; o.sync = tlane != 0;
+    { Op o{}; o.kind = OP_SINUSOID; o.r[0] = io_ref(2); o.r[1] = ws_ref(sin_off); o.i[0] = B; o.i[1] = ch[0];
       plan->ops.push_back(o); }
     auto gemv = [&](size_t w_off, size_t b_off, size_t x_off, size_t y_off, int I, int O, int xs, int ys, int silu) {
         Op o{}; o.kind = hp ? OP_GEMV32 : OP_GEMV; o.r[0] = hp ? w32_ref(w_off) : w_ref(w_off); o.r[1] = w_ref(b_off); o.r[2] = ws_ref(x_off); o.r[3] = ws_ref(y_off);
-        o.i[0] = I; o.i[1] = O; o.i[2] = xs; o.i[3] = ys; o.i[4] = silu; o.i[5] = B; o.lane = tlane; plan->ops.push_back(o);
+        o.i[0] = I; o.i[1] = O; o.i[2] = xs; o.i[3] = ys; o.i[4] = silu; o.i[5] = B; plan->ops.push_back(o);
     };
-    b.temb_pending = tlane != 0;
     const LinW& l0 = m->lins.at("time_embed.0"); const LinW& l2 = m->lins.at("time_embed.2");
     gemv(l0.w_off, l0.b_off, sin_off, e1_off, ch[0], temb, ch[0], temb, 0);
     gemv(l2.w_off, l2.b_off, e1_off, e2_off, temb, temb, temb, temb, 1);
@@ -1593,8 +1578,15 @@ static int vae_build_train(ldm_model* m, int B, int D, int H, int W, Plan* plan,
 struct Bases { char* p[BASE_COUNT]; };
 static inline char* rp(const Bases& b, const Ref& r) { return r.base == BASE_NULL ? nullptr : (b.p[r.base] ? b.p[r.base] + r.off : nullptr); }
 
+// LDM_XCD_ROWS (tuning knob, default 0: measured 0.4 % SLOWER over the step, with and without write-through stores: DESIGN.md section 5): unsplit convolutions and the GroupNorm launches deal contiguous ROW ranges to the XCDs
+// (ConvParams::tile_order 1, GnFusedParams::xcd_rows), so that a tensor is produced and consumed by the same XCD where the order of
+// the work allows it; 0 = the round-2 orders (an XCD streams one weight panel; GroupNorm blocks in launch order)
+static int xcd_rows_mode() { static const int v = [] { const char* e = getenv("LDM_XCD_ROWS"); return e ? atoi(e) : 0; }(); return v; }
+static inline int conv_tile_order(const ConvParams& p) { return (xcd_rows_mode() && p.splitk == 1 && !p.phase_mode) ? 1 : 0; }
+
 template <int WGM, int WGN, int BK>
-static int launch_conv_t(const ConvParams& p, hipStream_t s) {
+static int launch_conv_t(const ConvParams& p_in, hipStream_t s) {
+    ConvParams p = p_in; p.tile_order = conv_tile_order(p);
     // 128 KiB-class LDS ring; BK = 64 tiles run 8 waves (two per SIMD, intra-workgroup K split)
     constexpr int STAGE = (64 * WGM + 64 * WGN) * BK * 2;
     constexpr int NG = (BK == 64) ? 2 : 1;
@@ -1653,10 +1645,8 @@ static int launch_conv(const ConvParams& p, const ConvCfg& cc, hipStream_t s) {
     return 0;
 }
 
-// LDM_HALO_ORDER (tuning knob): block -> tile order of conv3_halo_kernel, see ConvParams::tile_order
-static int halo_tile_order() { static const int v = [] { const char* e = getenv("LDM_HALO_ORDER"); return e ? atoi(e) : 0; }(); return v; }
 static int launch_conv_halo(const ConvParams& p_in, hipStream_t s, bool tall = false) {
-    ConvParams p = p_in; p.tile_order = halo_tile_order();
+    ConvParams p = p_in; p.tile_order = conv_tile_order(p);
     constexpr int LDS = 6 * 16384 + 3 * 16384 + 9 * 128 * 4;
     constexpr int LDS_TALL = 6 * 8192 + 3 * 32768 + 9 * 256 * 4;
     static bool attr_set = false;
@@ -1748,7 +1738,7 @@ static bool wt_stores() { static const int v = [] { const char* e = getenv("LDM_
 // per-op timeline of every launch plan that runs while it is on (ldm_set_plan_trace; initial state from LDM_PLAN_TRACE)
 struct PlanTrace { bool on = false; std::string path; PlanTrace() { const char* e = getenv("LDM_PLAN_TRACE"); if (e && *e) { on = true; path = e; } } };
 static PlanTrace g_plan_trace;
-struct LaneCtx { hipStream_t side = nullptr; std::vector<hipEvent_t>* events = nullptr; GradSyncState* sync = nullptr; };
+struct LaneCtx { GradSyncState* sync = nullptr; };   // the gradient exchange of the backward plans (comm stream, events)
 
 static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_t s, size_t begin = 0, size_t end = (size_t)-1,
                     LaneCtx lanes = LaneCtx()) {
@@ -1776,32 +1766,10 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
             for (auto e : ev) (void)hipEventDestroy(e);
         }
     } trace_done{plan, begin, end, tev, s, trace_path};
-    // lanes: ops tagged lane 1 go to the side stream; Op::sync makes the op's lane wait (event) for what the other lane has
-    // been given so far.  Without a side stream (training, tracing, profiling) everything runs in plan order on s.
-    const hipStream_t s_main = s;
-    const bool use_side = lanes.side != nullptr && lanes.events != nullptr && !trace_path && !g_prof.on;
-    size_t ev_i = 0; bool side_dirty = false;
-    auto cross = [&](hipStream_t from, hipStream_t to) -> int {
-        if (ev_i >= lanes.events->size()) { hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); lanes.events->push_back(e); }
-        hipEvent_t e = (*lanes.events)[ev_i++];
-        HIP_TRY(hipEventRecord(e, from)); HIP_TRY(hipStreamWaitEvent(to, e, 0));
-        return 0;
-    };
-    struct JoinAtExit {                                 // every return path leaves the side lane joined to s (stream capture needs it)
-        bool& dirty; decltype(cross)& x; hipStream_t side, main;
-        ~JoinAtExit() { if (dirty) (void)x(side, main); }
-    } join_at_exit{side_dirty, cross, lanes.side, s_main};
     for (size_t oi = begin; oi < end; ++oi) {
         const Op& o = plan.ops[oi];
         const int* i = o.i;
-        if (trace_path) HIP_TRY(hipEventRecord(tev[oi - begin], s_main));
-        const bool on_side = use_side && o.lane == 1;
-        if (use_side && o.sync) {
-            if (on_side) LDM_TRY(cross(s_main, lanes.side));
-            else if (side_dirty) { LDM_TRY(cross(lanes.side, s_main)); side_dirty = false; }
-        }
-        if (on_side) side_dirty = true;
-        const hipStream_t s = on_side ? lanes.side : s_main;
+        if (trace_path) HIP_TRY(hipEventRecord(tev[oi - begin], s));
         switch (o.kind) {
             case OP_PACK: {
                 // two fp32 NCDHW sources (x | cond) -> one zero-padded NDHWC bf16 tensor
@@ -1946,7 +1914,7 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                 p.sa = (const float*)rp(bs, o.r[7]); p.sb = (const float*)rp(bs, o.r[8]); p.nrb_a = i[2]; p.nrb_b = i[3];
                 p.groups = i[4]; p.DHW = i[5]; p.N = i[6]; p.silu = i[7]; p.rows_per_block = i[8]; p.eps = o.f[0];
                 p.gamma = (const float*)rp(bs, o.r[2]); p.beta = (const float*)rp(bs, o.r[3]); p.out = (bf16_t*)rp(bs, o.r[9]);
-                p.ab = (float*)rp(bs, o.r[5]); p.mr = (float*)rp(bs, o.r[6]);
+                p.ab = (float*)rp(bs, o.r[5]); p.mr = (float*)rp(bs, o.r[6]); p.xcd_rows = xcd_rows_mode();
                 if (wt_stores()) hipLaunchKernelGGL(gn_fused_apply_kernel<true>, dim3(i[9], (i[0] + i[1] + 63) / 64, i[6]), dim3(256), 0, s, p);
                 else hipLaunchKernelGGL(gn_fused_apply_kernel<false>, dim3(i[9], (i[0] + i[1] + 63) / 64, i[6]), dim3(256), 0, s, p);
                 break; }
@@ -2201,10 +2169,8 @@ void ldm_model_destroy(ldm_model* m) {
     if (!m) return;
     for (auto& g : m->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
     if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
-    if (m->side_stream) (void)hipStreamDestroy(m->side_stream);
     if (m->gsync.stream) (void)hipStreamDestroy(m->gsync.stream);
     for (auto e : m->gsync.ev) (void)hipEventDestroy(e);
-    for (auto e : m->lane_events) (void)hipEventDestroy(e);
     if (m->arena) (void)hipFree(m->arena);
     if (m->arena32) (void)hipFree(m->arena32);
     delete m;
@@ -2376,8 +2342,7 @@ static int unet_forward_impl(ldm_model* m, const float* x, int x_channels, const
     bs.p[BASE_IO0] = (char*)x; bs.p[BASE_IO1] = (char*)cond; bs.p[BASE_IO2] = (char*)timesteps; bs.p[BASE_IO3] = (char*)out;
     const int rt[2] = {x_channels, cond_channels};
     LDM_TRY(ensure_derived(m, (hipStream_t)stream));
-    if (!m->side_stream) HIP_TRY(hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking));
-    LaneCtx lanes; lanes.side = m->side_stream; lanes.events = &m->lane_events;
+    LaneCtx lanes;
     const int64_t n_out = (int64_t)B * m->ucfg.out_channels * D * H * W;
     // one denoising step = the forward plan, then (with a sampler) the fused scheduler step on the same stream
     auto run_all = [&](hipStream_t s) -> int {

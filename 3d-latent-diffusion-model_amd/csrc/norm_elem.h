@@ -238,6 +238,7 @@ struct GnFusedParams {
     int groups, DHW, N, silu, rows_per_block; float eps;
     const float* gamma; const float* beta; bf16_t* out;
     float* ab; float* mr;                              // optional (training): [N][C][2] scale/shift, [N][G][2] mean/rstd
+    int xcd_rows;                                      // block order: 1 = every XCD gets a contiguous range of row chunks (all channel slices)
 };
 
 // Channel fold shared by the GroupNorm kernels that read per-row-block partial slabs [N * nrb][c][2] of two channel-concatenated sources:
@@ -337,9 +338,20 @@ __global__ __launch_bounds__(256) void gn_fused_apply_kernel(const GnFusedParams
     __shared__ double csum[192][2];
     __shared__ float gstat[64][2];
     KSTAMP_BEGIN(3);
-    const int tid = threadIdx.x, n = blockIdx.z;
+    const int tid = threadIdx.x;
+    // Block order.  xcd_rows: blocks b, b + 8, ... share an XCD (observed round-robin dispatch; speed only, never correctness), so the
+    // bijective remap of the convolutions hands every XCD one contiguous range of (sample, row chunk) units with all their channel
+    // slices: the rows a conv's workgroups left in that XCD's L2 (ConvParams::tile_order 1) are normalised by blocks of the same XCD,
+    // and the conv that follows finds most of its voxel rows there too.  A hand-off between XCDs runs at about a third of that rate.
+    int bx = blockIdx.x, by = blockIdx.y, n = blockIdx.z;
+    if (p.xcd_rows) {
+        const int per_n = gridDim.x * gridDim.y;
+        int lid = xcd_remap((int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)), per_n * (int)gridDim.z);
+        n = lid / per_n; lid -= n * per_n;
+        bx = lid / (int)gridDim.y; by = lid - bx * (int)gridDim.y;
+    }
     const int C = p.ca + p.cb, cpg = C / p.groups;     // host guarantees cpg <= 64
-    const int c0 = blockIdx.y * 64;
+    const int c0 = by * 64;
     const int g_lo = c0 / cpg;
     // ---- the block's first rows are requested before the fold, so that their latency overlaps it
     //      apply mapping: thread = (8-channel vector of the slice, row lane)
@@ -350,7 +362,7 @@ __global__ __launch_bounds__(256) void gn_fused_apply_kernel(const GnFusedParams
     const bool second_x = c >= p.ca;
     const bf16_t* src = second_x ? p.xb : p.xa;
     const int xcs = second_x ? p.cb : p.ca, xcl = second_x ? c - p.ca : c;
-    const int r0 = blockIdx.x * p.rows_per_block;
+    const int r0 = bx * p.rows_per_block;
     int r1 = r0 + p.rows_per_block; if (r1 > p.DHW) r1 = p.DHW;
     u32x4 v[PF];
     float4 gam[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)}, bet[2] = {gam[0], gam[0]};
@@ -364,7 +376,7 @@ __global__ __launch_bounds__(256) void gn_fused_apply_kernel(const GnFusedParams
         bet[0] = *reinterpret_cast<const float4*>(p.beta + c); bet[1] = *reinterpret_cast<const float4*>(p.beta + c + 4);
     }
     KSTAMP(1);
-    gn_fused_fold(p, n, blockIdx.y, blockIdx.x == 0, part, csum, gstat);
+    gn_fused_fold(p, n, by, bx == 0, part, csum, gstat);
     KSTAMP(2);
     // ---- apply
     if (!active) return;
@@ -377,7 +389,7 @@ __global__ __launch_bounds__(256) void gn_fused_apply_kernel(const GnFusedParams
         a[k] = gk[k] * gstat[g][1];
         b[k] = bk[k] - gstat[g][0] * a[k];
     }
-    if (p.ab && blockIdx.x == 0 && rl == 0) {
+    if (p.ab && bx == 0 && rl == 0) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) { p.ab[((size_t)n * C + c + k) * 2] = a[k]; p.ab[((size_t)n * C + c + k) * 2 + 1] = b[k]; }
     }
