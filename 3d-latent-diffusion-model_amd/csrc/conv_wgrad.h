@@ -431,11 +431,16 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad3_kernel(const Wgrad3Params 
             F[t] = (bf16x8){l_[0], l_[1], l_[2], l_[3], h_[0], h_[1], h_[2], h_[3]};                \
         }                                                                                           \
     } while (0)
+    // The 192 accumulator registers live in the ACCUMULATOR half of the unified register file for the whole loop: the MFMAs are inline
+    // asm with "+a" operands.  Through the builtin hipcc (ROCm 7.2) split them between VGPRs and AGPRs at this size and moved them back
+    // and forth around every MFMA (128 v_accvgpr_read + 128 v_accvgpr_write per K step: the MFMAs alone took 1.33 us per step instead of
+    // 0.8).  Each accumulator is touched once per 48 MFMAs, so no dependent-MFMA wait states are needed inside the loop; the read-out
+    // after the loop sits behind explicit s_nops (the hazard recognizer cannot see into asm).
 #define W3_MFMA(KW, AF, BF) do {                                                                    \
         if (ABL & 8) break;                                                                         \
         _Pragma("unroll") for (int a = 0; a < 4; ++a)                                               \
             _Pragma("unroll") for (int b = 0; b < 4; ++b)                                           \
-                acc[KW][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[a], BF[b], acc[KW][a][b], 0, 0, 0); \
+                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[KW][a][b]) : "v"(AF[a]), "v"(BF[b])); \
     } while (0)
 
     // ---- table protocol: publish #k (offsets of step k) goes to table parity k & 1.  The issue of step k reads it after a
@@ -495,6 +500,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad3_kernel(const Wgrad3Params 
 #undef W3_PUBLISH
 
     // ---- store: accumulator col = lane & 15 -> cin, row = 4 fg + r -> cout
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // last MFMA results -> v_accvgpr_read (see W3_MFMA)
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw) {
         const int tap = pair * 3 + kw;
