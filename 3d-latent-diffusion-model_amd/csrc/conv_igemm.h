@@ -654,7 +654,7 @@ struct FinalizeParams {
 
 // bx / by = the block's 32-row granule and
 // 64-channel slice; o_keep returns the thread's packed bf16 output (row bx * 32 + tid / 8, channels by * 64 + (tid & 7) * 8 ...).
-template <bool WT, int NB>
+template <bool WT>
 __device__ __forceinline__ void splitk_finalize_body(const FinalizeParams& p, const int bx, const int by, float (*red)[8][16], u32x4& o_keep KSTAMP_PARAM) {
     // block = 32 rows (bx) x 64 channels (by); thread = one row x 8 channels
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -669,54 +669,59 @@ __device__ __forceinline__ void splitk_finalize_body(const FinalizeParams& p, co
         float v[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[q] = 0.f;
-        // Every operand of the row is requested BEFORE anything is waited for: the epilogue vectors and the residual first, then the
-        // slabs in batches of NB with all 2 NB loads of a batch in flight (unconditional loads of a clamped slab index; the adds are
-        // masked).  The launch is bound by dependent round trips to memory the producing conv left on other XCDs (1.5 - 2 us each):
-        // 8 in flight + a serial tail took 2 - 4 of them at split factors 9 ... 29.  Slabs are still summed in order 0, 1, 2, ...
-        const int n = m / p.DHWo;
-        float4 eb[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)}, eb2[2] = {eb[0], eb[0]}, et[2] = {eb[0], eb[0]};
-        u32x4 rv = {0u, 0u, 0u, 0u};
-        if (p.bias) { eb[0] = *reinterpret_cast<const float4*>(p.bias + c); eb[1] = *reinterpret_cast<const float4*>(p.bias + c + 4); }
-        if (p.bias2) { eb2[0] = *reinterpret_cast<const float4*>(p.bias2 + c); eb2[1] = *reinterpret_cast<const float4*>(p.bias2 + c + 4); }
-        if (p.temb) {
-            const float* te = p.temb + (size_t)n * p.temb_stride + c;
-            et[0] = *reinterpret_cast<const float4*>(te); et[1] = *reinterpret_cast<const float4*>(te + 4);
-        }
-        if (p.residual && !p.out_f32) rv = *reinterpret_cast<const u32x4*>(p.residual + (size_t)m * p.CoutS + c);
+        // Round 3 measured the alternatives on the whole step (same box): all operands requested up front with 16 or 32 slabs in flight
+        // per thread is 1 - 1.3 % SLOWER, and unconditional clamped batches of 8 (no 4-batch, no serial tail) 1.6 % slower (a split
+        // factor of 9 then loads 16 slabs): the launch is bound by the slab bytes crossing XCDs, not by its round trips.
+        // slabs are summed in order 0, 1, 2, ... (bitwise reproducible); four slabs' loads are in flight at a time so the
+        // sum is not one L2 round trip per slab
         const size_t slab = (size_t)p.M * p.CoutPad;
         const float* src0 = p.partial + (size_t)m * p.CoutPad + c;
-        for (int s = 0; s < p.splitk; s += NB) {
-            float4 a[NB], b[NB];
+        int s = 0;
+        for (; s + 8 <= p.splitk; s += 8) {              // eight slabs' loads in flight (the launch is latency bound)
+            float4 a[8], b[8];
 #pragma unroll
-            for (int u = 0; u < NB; ++u) {
-                int su = s + u; if (su >= p.splitk) su = p.splitk - 1;
-                const float4* src = reinterpret_cast<const float4*>(src0 + (size_t)su * slab);
+            for (int u = 0; u < 8; ++u) {
+                const float4* src = reinterpret_cast<const float4*>(src0 + (size_t)(s + u) * slab);
                 a[u] = src[0]; b[u] = src[1];
             }
 #pragma unroll
-            for (int u = 0; u < NB; ++u)
-                if (s + u < p.splitk) {
-                    v[0] += a[u].x; v[1] += a[u].y; v[2] += a[u].z; v[3] += a[u].w;
-                    v[4] += b[u].x; v[5] += b[u].y; v[6] += b[u].z; v[7] += b[u].w;
-                }
+            for (int u = 0; u < 8; ++u) {
+                v[0] += a[u].x; v[1] += a[u].y; v[2] += a[u].z; v[3] += a[u].w;
+                v[4] += b[u].x; v[5] += b[u].y; v[6] += b[u].z; v[7] += b[u].w;
+            }
         }
+        for (; s + 4 <= p.splitk; s += 4) {
+            float4 a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4* src = reinterpret_cast<const float4*>(src0 + (size_t)(s + u) * slab);
+                a[u] = src[0]; b[u] = src[1];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                v[0] += a[u].x; v[1] += a[u].y; v[2] += a[u].z; v[3] += a[u].w;
+                v[4] += b[u].x; v[5] += b[u].y; v[6] += b[u].z; v[7] += b[u].w;
+            }
+        }
+        for (; s < p.splitk; ++s) {
+            const float4* src = reinterpret_cast<const float4*>(src0 + (size_t)s * slab);
+            const float4 a = src[0], b = src[1];
+            v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+            v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+        }
+        const int n = m / p.DHWo;
         KSTAMP(1);
-        {
-            const float e0[8] = {eb[0].x, eb[0].y, eb[0].z, eb[0].w, eb[1].x, eb[1].y, eb[1].z, eb[1].w};
-            const float e1[8] = {eb2[0].x, eb2[0].y, eb2[0].z, eb2[0].w, eb2[1].x, eb2[1].y, eb2[1].z, eb2[1].w};
-            const float e2[8] = {et[0].x, et[0].y, et[0].z, et[0].w, et[1].x, et[1].y, et[1].z, et[1].w};
-            if (p.bias) {
+        if (p.bias) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] += e0[q];
-            }
-            if (p.bias2) {
+            for (int q = 0; q < 8; ++q) v[q] += p.bias[c + q];
+        }
+        if (p.bias2) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] += e1[q];
-            }
-            if (p.temb) {
+            for (int q = 0; q < 8; ++q) v[q] += p.bias2[c + q];
+        }
+        if (p.temb) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] += e2[q];
-            }
+            for (int q = 0; q < 8; ++q) v[q] += p.temb[(size_t)n * p.temb_stride + c + q];
         }
         if (p.out_f32) {
             const int sp = m - n * p.DHWo;
@@ -725,6 +730,7 @@ __device__ __forceinline__ void splitk_finalize_body(const FinalizeParams& p, co
                 if (c + q < p.CoutReal) p.out_f32[((size_t)n * p.CoutReal + c + q) * p.DHWo + sp] = v[q];
         } else {
             if (p.residual) {
+                const u32x4 rv = *reinterpret_cast<const u32x4*>(p.residual + (size_t)m * p.CoutS + c);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     v[2 * q] += __uint_as_float(rv[q] << 16);
@@ -765,14 +771,12 @@ __device__ __forceinline__ void splitk_finalize_body(const FinalizeParams& p, co
     }
 }
 
-// NB = slabs whose loads are in flight together: 16 (128 registers of operands) where the grid has more than one block per CU, 32 for
-// the small grids of the 6^3 level (split factors 24 ... 32: one round trip instead of two at one block per CU)
-template <bool WT, int NB>
+template <bool WT>
 __global__ __launch_bounds__(256) void splitk_finalize_kernel(const FinalizeParams p) {
     KSTAMP_BEGIN(4);
     __shared__ float red[4][8][16];
     u32x4 o;
-    splitk_finalize_body<WT, NB>(p, blockIdx.x, blockIdx.y, red, o KSTAMP_ARG);
+    splitk_finalize_body<WT>(p, blockIdx.x, blockIdx.y, red, o KSTAMP_ARG);
     KSTAMP(3);
     KSTAMP_DRAIN(4);
 }

@@ -600,7 +600,7 @@ struct Builder {
         if (fused && C / groups <= 64 && nrb_tot <= 512) {   // few slab rows: ONE launch folds them per block and applies
             Act out = new_act(N, xa.D, xa.H, xa.W, C);
             const int slices = (C + 63) / 64;
-            static const int gn_blocks = [] { const char* e = getenv("LDM_GN_BLOCKS"); return e ? atoi(e) : 256; }();   // tuning knob
+            static const int gn_blocks = [] { const char* e = getenv("LDM_GN_BLOCKS"); return e ? atoi(e) : 512; }();   // tuning knob: 512 = two blocks per CU at 24^3 (the apply is VALU-latency bound at one wave per SIMD: +0.3 % over the step; 1024: -1 %, every block folds the slabs again)
             int chunks = std::max(1, std::min(gn_blocks / (slices * N), (DHW + 31) / 32));   // one round of the 256 CUs: the slab fold is per block
             int rpb = rup((DHW + chunks - 1) / chunks, 32);
             chunks = (DHW + rpb - 1) / rpb;
@@ -1618,20 +1618,10 @@ static double conv_algorithmic_flops(const ConvParams& p) {
     return 2.0 * (double)p.M * (double)p.CoutReal * (taps * (double)(p.c0a + p.c0b) + (double)(p.c1a + p.c1b));
 }
 
-// LDM_FIN_NB (tuning knob): slabs whose loads one finalize thread keeps in flight: 8 (default), 16, or 0 = 16 with 32 on the small
-// grids of the 6^3 level.  Measured (same box, whole step): see DESIGN.md section 5 -- the launch is bound by the bytes of the slabs
-// crossing XCDs, not by the number of round trips, and more loads in flight per thread made it slower.
 static void launch_finalize(const FinalizeParams& f, bool wt, hipStream_t s) {
-    static const int nb_knob = [] { const char* e = getenv("LDM_FIN_NB"); return e ? atoi(e) : 8; }();
     const dim3 grid((f.M + 31) / 32, (f.CoutS + 63) / 64);
-    int nb = nb_knob;
-    if (nb == 0) nb = (f.splitk > 16 && (long)grid.x * grid.y <= 256) ? 32 : 16;
-#define FIN_CASE(NB_) if (nb == NB_) { if (wt) hipLaunchKernelGGL((splitk_finalize_kernel<true, NB_>), grid, dim3(256), 0, s, f); \
-                                       else hipLaunchKernelGGL((splitk_finalize_kernel<false, NB_>), grid, dim3(256), 0, s, f); return; }
-    FIN_CASE(16) FIN_CASE(32)
-#undef FIN_CASE
-    if (wt) hipLaunchKernelGGL((splitk_finalize_kernel<true, 8>), grid, dim3(256), 0, s, f);
-    else hipLaunchKernelGGL((splitk_finalize_kernel<false, 8>), grid, dim3(256), 0, s, f);
+    if (wt) hipLaunchKernelGGL(splitk_finalize_kernel<true>, grid, dim3(256), 0, s, f);
+    else hipLaunchKernelGGL(splitk_finalize_kernel<false>, grid, dim3(256), 0, s, f);
 }
 static int launch_conv_impl(const ConvParams& p, const ConvCfg& cc, hipStream_t s);
 static int launch_conv(const ConvParams& p, const ConvCfg& cc, hipStream_t s) {

@@ -521,7 +521,8 @@ def test_nan_step_is_skipped_on_the_device_and_does_not_count(cuda):
     parameters nor Adam's moments nor its step count move.  Here that decision is taken on the device, without a host read inside the
     step: a NaN loss makes every gradient NaN, the fused clip + Adam launch sees a non-finite gradient norm and leaves everything
     untouched (include/ldm3d.h: sq_norm[1] counts such steps, the bias corrections use step - skipped).  A run with one poisoned batch
-    in the middle must therefore end exactly where the run without it ends."""
+    in the middle must therefore end where the run without it ends (to the last ulp of the bias corrections: after a skip they are
+    evaluated with the device's powf instead of the host's)."""
     from ldm3d.networks import DiffusionModelUNet
     from ldm3d.optim import FlatAdam
     from oracle import unet as ou
@@ -556,4 +557,5 @@ def test_nan_step_is_skipped_on_the_device_and_does_not_count(cuda):
     p1, m1, v1, f1, s1 = run(True)
     assert f0 == [False, False, False] and s0 == 0.0
     assert f1 == [False, True, False, False] and s1 == 1.0
-    assert torch.isfinite(p1).all() and torch.equal(p0, p1) and torch.equal(m0, m1) and torch.equal(v0, v1)
+    assert torch.isfinite(p1).all() and torch.equal(m0, m1) and torch.equal(v0, v1)
+    assert float((p0 - p1).abs().max()) <= 1e-6 * float(p0.abs().max())

@@ -97,7 +97,7 @@ int main() {
             printf("%s  221 KB, block b reads what block b+%d wrote, sc1   : %6.2f us per launch\n", tag, shift, run(s, K, reps, graph, [&](int k) {
                 hipLaunchKernelGGL(k_shift<true>, dim3(54), dim3(256), 0, s, (const uint4*)(k & 1 ? b : a), (uint4*)(k & 1 ? a : b), 256, shift); }));
         }
-        for (int shift : {0, 1}) {
+        for (int shift : {0, 8, 256, 1}) {
             printf("%s  7 MB (1728 blocks), reads block b+%d, plain        : %6.2f us per launch\n", tag, shift, run(s, K, reps, graph, [&](int k) {
                 hipLaunchKernelGGL(k_shift<false>, dim3(1728), dim3(256), 0, s, (const uint4*)(k & 1 ? b : a), (uint4*)(k & 1 ? a : b), 256, shift); }));
             printf("%s  7 MB (1728 blocks), reads block b+%d, sc1          : %6.2f us per launch\n", tag, shift, run(s, K, reps, graph, [&](int k) {
