@@ -298,6 +298,7 @@ struct ldm_model {
 // ================================================================================================ builder
 static int wgrad_ksplit(long M, int taps, int cout, int cin, bool hp = false);
 static bool wgrad3_enabled();
+static int wgrad3_mode();
 static int wgrad3_ksplit(long KP, int cout, int cin);
 
 struct Builder {
@@ -1686,7 +1687,9 @@ static int wgrad_ksplit(long M, int taps, int cout, int cin, bool hp) {
 // conv_wgrad3_kernel (kw-triplet weight gradient) is correct but not yet faster than conv_wgrad_kernel: with 192 accumulator
 // registers per lane hipcc shuttles accumulators between VGPRs and AGPRs around every MFMA, so it is
 // opt-in (LDM_WGRAD3=1) until its inner loop is register-allocated by hand.
-static bool wgrad3_enabled() { const char* e = getenv("LDM_WGRAD3"); return e ? atoi(e) != 0 : false; }
+// LDM_WGRAD3: 0 = one tap per workgroup (conv_wgrad_kernel), 1 = kw triplet on four waves, 2 = kw triplet on eight waves
+static int wgrad3_mode() { const char* e = getenv("LDM_WGRAD3"); return e ? atoi(e) : 0; }
+static bool wgrad3_enabled() { return wgrad3_mode() != 0; }
 // kw-triplet kernel: 9 (kd, kh) pairs x tiles x ksplit workgroups
 static int wgrad3_ksplit(long KP, int cout, int cin) {
     const long wgs = 9L * ((cout + 127) / 128) * ((cin + 127) / 128);
@@ -1705,6 +1708,13 @@ static int launch_wgrad3(const Wgrad3Params& p, hipStream_t s) {
           hipLaunchKernelGGL(conv_wgrad3_kernel<A>, dim3(9 * p.co_tiles * p.ci_tiles * p.ksplit), dim3(256), LDS, s, p); return 0; }
       W3_ABL(4) W3_ABL(8) W3_ABL(16) W3_ABL(32) W3_ABL(12) W3_ABL(20) W3_ABL(24) W3_ABL(28)
 #undef W3_ABL
+    }
+    if (wgrad3_mode() == 2) {                               // eight waves, two per SIMD (conv_wgrad3b_kernel)
+        constexpr int LDSB = LDS + 1024;                    // + the KiB the dummy copy pieces zero-fill
+        static bool attr_b = false;
+        if (!attr_b) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad3b_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB)); attr_b = true; }
+        hipLaunchKernelGGL(conv_wgrad3b_kernel<0>, dim3(9 * p.co_tiles * p.ci_tiles * p.ksplit), dim3(512), LDSB, s, p);
+        return 0;
     }
     hipLaunchKernelGGL(conv_wgrad3_kernel<0>, dim3(9 * p.co_tiles * p.ci_tiles * p.ksplit), dim3(256), LDS, s, p);
     return 0;
