@@ -957,9 +957,26 @@ struct Builder {
         if (a.w1) export_bias(*a.w1);
         if (a.temb_row >= 0) emit_colsum(dout, true, ws_ref(dtemb_off + (size_t)a.temb_row * 4), w.cout, tproj_stride);
         // weights
-        cur_w3 = (!hp && a.k == 3 && a.stride == 1 && a.pad == 1 && a.ups == 0 && wgrad3_enabled()) ? 1 : 0;
-        cur_ksplit = cur_w3 ? wgrad3_ksplit((long)dout.N * dout.D * dout.H * (dout.W + 2), w.cout, cin_real)
-                            : wgrad_ksplit(dout.rows(), a.k * a.k * a.k, w.cout, cin_real, hp);
+        // which weight-gradient kernel (OP_WGRAD i[20]): 0 = one tap per workgroup, 1 / 2 = kw triplet on four / eight waves
+        cur_w3 = 0; cur_ksplit = 0;
+        if (!hp && a.k == 3 && a.stride == 1 && a.pad == 1 && a.ups == 0) {
+            const long KP = (long)dout.N * dout.D * dout.H * (dout.W + 2);
+            const int mode = wgrad3_mode();
+            if (mode == 1 || mode == 2) { cur_w3 = mode; cur_ksplit = wgrad3_ksplit(KP, w.cout, cin_real); }
+            else if (mode == 3) {
+                // auto (measured per shape, tools/bench_wgrad.py): the eight-wave triplet where a workgroup gets a long voxel range
+                // (24^3 and larger: 62 vs 81 us at 256 -> 256, 123 vs 156 us at 512 -> 256, voxel split chosen for ONE round of the
+                // CUs) and at 6^3 (one short K range per workgroup, three taps per pass over it: 16 vs 21 us); the one-tap kernel
+                // in between (12^3: 18 vs 20 us)
+                const long steps = (KP + 63) / 64;
+                const long wgs = 9L * ((w.cout + 127) / 128) * ((cin_real + 127) / 128);
+                if (steps >= 96) {
+                    long k = (256 + wgs / 2) / wgs; if (k > steps / 12) k = steps / 12; if (k < 1) k = 1; if (k > 32) k = 32;
+                    cur_w3 = 2; cur_ksplit = (int)k;
+                } else if (steps <= 8) { cur_w3 = 2; cur_ksplit = 1; }
+            }
+        }
+        if (!cur_w3) cur_ksplit = wgrad_ksplit(dout.rows(), a.k * a.k * a.k, w.cout, cin_real, hp);
         cur_rows_total = w.cout;
         dw_off = pool.alloc((size_t)cur_ksplit * a.k * a.k * a.k * w.cout * cin_real * 4);
         if (a.xb.valid) {
@@ -1699,7 +1716,7 @@ static int wgrad3_ksplit(long KP, int cout, int cin) {
     if (k > 32) k = 32;
     return (int)(k < 1 ? 1 : k);
 }
-static int launch_wgrad3(const Wgrad3Params& p, hipStream_t s) {
+static int launch_wgrad3(const Wgrad3Params& p, hipStream_t s, int variant = 0) {   // variant 0: by LDM_WGRAD3; 1 / 2: four / eight waves
     constexpr int LDS = 4 * (64 + 80) * 256 + 2 * (64 + 80) * 4;   // ring + double-buffered source-offset table
     static bool attr_set = false;
     if (!attr_set) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad3_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr_set = true; }
@@ -1709,7 +1726,7 @@ static int launch_wgrad3(const Wgrad3Params& p, hipStream_t s) {
       W3_ABL(4) W3_ABL(8) W3_ABL(16) W3_ABL(32) W3_ABL(12) W3_ABL(20) W3_ABL(24) W3_ABL(28)
 #undef W3_ABL
     }
-    if (wgrad3_mode() == 2) {                               // eight waves, two per SIMD (conv_wgrad3b_kernel)
+    if (variant == 2 || (variant == 0 && wgrad3_mode() >= 2)) {   // eight waves, two per SIMD (conv_wgrad3b_kernel)
         constexpr int LDSB = LDS + 1024;                    // + the KiB the dummy copy pieces zero-fill
         static bool attr_b = false;
         if (!attr_b) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad3b_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB)); attr_b = true; }
@@ -2000,7 +2017,7 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                     q.co_tiles = p.co_tiles; q.ci_tiles = p.ci_tiles; q.ksplit = p.ksplit; q.slab_stride = p.slab_stride;
                     if ((long)p.M * p.cdy * 2 >= (1L << 32) || (long)p.M * p.cx * 2 >= (1L << 32))
                         return fail(LDM_ERR_UNSUPPORTED, "weight gradient: tensor exceeds 4 GiB");
-                    LDM_TRY(launch_wgrad3(q, s));
+                    LDM_TRY(launch_wgrad3(q, s, i[20]));
                     break;
                 }
                 if ((long)p.M * p.cdy * 2 >= (1L << 32) || (long)p.N * p.Din * p.Hin * p.Win * p.cx * 2 >= (1L << 32))
