@@ -57,6 +57,7 @@ SIGNATURES = {
     "ldm_vae_train_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_size_t, _P]),
     "ldm_vae_train_backward": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_size_t, _P]),
     "ldm_grad_sq_norm": (C.c_int, [_P, C.c_int64, _P, _P]),
+    "ldm_op_mse_loss": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P]),
     "ldm_adam_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, _P,
                                 C.c_float, _P]),
     "ldm_model_adam_step": (C.c_int, [_P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, _P,

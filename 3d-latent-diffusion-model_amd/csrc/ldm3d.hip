@@ -2718,6 +2718,19 @@ int ldm_vae_train_backward(ldm_model* m, const float* d_recon, const float* d_mu
     return run_plan(*p, bs, rt, (hipStream_t)stream, p->bwd_begin, p->ops.size(), lanes);
 }
 
+/* loss_out[0] = mean((pred - target)^2) over n fp32 elements; grad_out (optional, n elements) = 2 (pred - target) / n: the loss of
+ * 3d_ldm/train_diffusion.py:207 and the gradient autograd hands to the network's backward (:214), in two launches. */
+static float* g_mse_parts = nullptr;
+int ldm_op_mse_loss(const float* pred, const float* target, int64_t n, float* loss_out, float* grad_out, void* stream) {
+    if (!pred || !target || !loss_out || n < 1) return fail(LDM_ERR_BAD_ARG, "bad argument");
+    if (!g_mse_parts) HIP_TRY(hipMalloc((void**)&g_mse_parts, 1024 * 4));
+    const int nb = grid_for(n, 256 * 4, 1024);
+    hipLaunchKernelGGL(mse_part_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, pred, target, (long)n, grad_out, g_mse_parts);
+    hipLaunchKernelGGL(mse_fold_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)g_mse_parts, nb, (long)n, loss_out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 static float* g_norm_parts = nullptr;
 int ldm_grad_sq_norm(const float* flat_grads, int64_t n, float* out, void* stream) {
     if (!flat_grads || !out || n < 0) return fail(LDM_ERR_BAD_ARG, "bad argument");

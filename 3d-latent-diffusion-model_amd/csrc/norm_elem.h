@@ -1349,6 +1349,32 @@ __global__ __launch_bounds__(256) void sq_norm_fold_kernel(const float* __restri
     for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
     if (threadIdx.x == 0) *out = (float)red[0];
 }
+// mean((pred - target)^2) and its gradient 2 (pred - target) / n in one pass (F.mse_loss + the first step of loss.backward(),
+// 3d_ldm/train_diffusion.py:207,214): partial sums per block, folded by mse_fold_kernel (deterministic two-stage reduction)
+__global__ __launch_bounds__(256) void mse_part_kernel(const float* __restrict__ pred, const float* __restrict__ target, long n,
+                                                       float* __restrict__ grad, float* __restrict__ part) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    const float gs = 2.0f / (float)n;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float d = pred[i] - target[i];
+        acc += d * d;
+        if (grad) grad[i] = gs * d;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(256) void mse_fold_kernel(const float* __restrict__ part, int nparts, long n, float* __restrict__ out) {
+    __shared__ double red[256];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) acc += (double)part[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) *out = (float)(red[0] / (double)n);
+}
 struct AdamCoef { float lr, b1, b2, eps, bc1, bc2_sqrt, max_norm, decay; int step; };   // decay = lr * weight_decay (AdamW, decoupled)
 // The agreed NaN-skip of the trainers without a host read: a non-finite gradient norm (a NaN / inf loss makes every gradient NaN,
 // and the data-parallel mean carries it to every rank) leaves parameters and moments untouched, and sq_norm[1] counts the skipped

@@ -25,6 +25,8 @@ import torch
 import torch.distributed as dist
 import torch.nn.functional as F
 
+from .optim import mse_loss
+
 
 class GradSync:
     """Collectives of the data-parallel trainer over torch.distributed ("nccl" = RCCL on ROCm; "gloo" in CPU tests)."""
@@ -193,7 +195,7 @@ class DiffusionTrainer:
             noise = n2 if noise is None else noise
             timesteps = t2 if timesteps is None else timesteps
         noise_pred = self._predict(images, labels, noise, timesteps)
-        loss = F.mse_loss(noise_pred.float(), noise.float())
+        loss = mse_loss(noise_pred, noise)               # F.mse_loss (:207) + its gradient in two HIP launches
         before = self.optimizer.skipped_steps().clone()
         loss.backward()                                  # with self.overlap the buckets are reduced inside this call
         if not self.overlap:

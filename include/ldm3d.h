@@ -131,6 +131,9 @@ int ldm_vae_train_backward(ldm_model* m, const float* d_recon, const float* d_mu
  *   gradient NaN; the data-parallel mean carries it to every rank) the step leaves params / exp_avg / exp_avg_sq untouched and adds 1
  *   to sq_norm[1]; the bias corrections use step - sq_norm[1].  The caller zeroes sq_norm[1] once; ldm_grad_sq_norm writes out[0] only. */
 int ldm_grad_sq_norm(const float* flat_grads, int64_t n, float* out, void* stream);
+/* F.mse_loss(noise_pred, noise) of 3d_ldm/train_diffusion.py:207 together with the gradient loss.backward() (:214) hands to the network:
+ * loss_out[0] = mean((pred - target)^2), grad_out (optional) = 2 (pred - target) / n; fp32 device buffers of n elements. */
+int ldm_op_mse_loss(const float* pred, const float* target, int64_t n, float* loss_out, float* grad_out, void* stream);
 int ldm_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int step, const float* sq_norm, float max_norm, void* stream);
 /* Adam(W) over a model's flat fp32 parameter buffer (layout of ldm_model_param_offset) that re-packs the library's bf16 weight

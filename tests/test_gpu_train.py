@@ -559,3 +559,34 @@ def test_nan_step_is_skipped_on_the_device_and_does_not_count(cuda):
     assert f1 == [False, True, False, False] and s1 == 1.0
     assert torch.isfinite(p1).all() and torch.equal(m0, m1) and torch.equal(v0, v1)
     assert float((p0 - p1).abs().max()) <= 1e-6 * float(p0.abs().max())
+
+
+def test_fused_mse_loss_and_gradient(cuda):
+    """``optim.mse_loss`` = F.mse_loss(pred, target) of 3d_ldm/train_diffusion.py:207 with the gradient autograd needs at :214, in two
+    HIP launches: value and d loss / d pred against torch at ragged sizes (not a multiple of the block size), under an upstream
+    gradient, and through a DiffusionTrainer-shaped use (loss.backward() fills the network's gradients)."""
+    from ldm3d.networks import DiffusionModelUNet
+    from ldm3d.optim import mse_loss
+    g = torch.Generator().manual_seed(3)
+    for shape in ((1, 4, 8, 8, 8), (2, 4, 9, 7, 5), (3, 1, 1, 1, 1)):
+        p = torch.randn(shape, generator=g).to(cuda).requires_grad_(True)
+        t = torch.randn(shape, generator=g).to(cuda)
+        pr = p.detach().clone().requires_grad_(True)
+        (3.0 * mse_loss(p, t)).backward()
+        (3.0 * F.mse_loss(pr, t)).backward()
+        assert abs(float(mse_loss(p, t)) - float(F.mse_loss(pr, t))) <= 1e-6 * float(F.mse_loss(pr, t))
+        assert torch.allclose(p.grad, pr.grad, rtol=1e-6, atol=1e-9)
+    m = DiffusionModelUNet(**cfgs.UNET_TINY).to(cuda).train()
+    with torch.no_grad():
+        for q in m.parameters():
+            q.add_(0.01 * torch.randn_like(q))
+    x = torch.randn((1, 4, 8, 8, 8), device=cuda)
+    tt = torch.tensor([400.0], device=cuda)
+    tgt = torch.randn((1, 4, 8, 8, 8), device=cuda)
+    mse_loss(m(x=x, timesteps=tt), tgt).backward()
+    ga = torch.cat([q.grad.reshape(-1) for q in m.parameters()]).clone()
+    for q in m.parameters():
+        q.grad = None
+    F.mse_loss(m(x=x, timesteps=tt).float(), tgt).backward()
+    gb = torch.cat([q.grad.reshape(-1) for q in m.parameters()])
+    assert torch.isfinite(ga).all() and float((ga - gb).norm()) <= 1e-6 * float(gb.norm())
