@@ -246,11 +246,18 @@ class AutoencoderTrainer:
 
     def __init__(self, autoencoder, lr: float, kl_weight: float, recon_loss: str = "l1", perceptual_weight: float = 0.0,
                  max_grad_norm: float = 0.5, weight_decay: float = 1e-5, warm_up_epochs: int = 5, adv_weight: float = 0.01,
-                 discriminator=None):
+                 discriminator=None, perceptual_weights: Optional[str] = None):
         from .discriminator import PatchAdversarialLoss, PatchDiscriminator
         from .optim import FlatAdam, FlatModuleAdam
-        self.perceptual_dropped = bool(perceptual_weight)     # logged by train_autoencoder.py (scalars + perceptual_term.json)
-        if perceptual_weight:
+        # the perceptual term (:236,386,406) needs LPIPS / SqueezeNet weights: from a user-supplied file, else dropped and recorded
+        self.perceptual_weight, self.loss_perceptual = float(perceptual_weight or 0.0), None
+        if perceptual_weight and perceptual_weights:
+            from .perceptual import PerceptualLoss
+            self.loss_perceptual = PerceptualLoss.from_file(perceptual_weights).to(autoencoder.flat_params.device
+                                                                                  if getattr(autoencoder, "flat_params", None) is not None
+                                                                                  else next(autoencoder.parameters()).device)
+        self.perceptual_dropped = bool(perceptual_weight) and self.loss_perceptual is None   # logged by train_autoencoder.py
+        if self.perceptual_dropped:
             # the reference's PerceptualLoss downloads a pretrained SqueezeNet (train_autoencoder.py:236): no weights, no network here.
             # Every shipped config sets a (small: 1e-5 .. 1e-3) weight, so warn once and train without the term instead of refusing.
             import warnings
@@ -292,6 +299,10 @@ class AutoencoderTrainer:
         kl = kl_loss(z_mu, z_sigma).mean()
         loss_g = recons + self.kl_weight * kl
         out = {"recons": recons.detach(), "kl": kl.detach()}
+        if self.loss_perceptual is not None:                                       # :386,406
+            p_loss = self.loss_perceptual(reconstruction.float(), images.float())
+            loss_g = loss_g + self.perceptual_weight * p_loss
+            out["perceptual"] = p_loss.detach()
         if adversarial:
             logits_fake = self.discriminator(reconstruction.contiguous().float())[-1]
             generator_loss = self.adv_loss(logits_fake, target_is_real=True, for_discriminator=False)

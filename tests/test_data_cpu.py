@@ -67,3 +67,39 @@ def test_trainer_kl_loss_matches_oracle_and_closed_form():
     mu, sigma = torch.randn((2, 3, 4, 4, 4), generator=g), torch.rand((2, 3, 4, 4, 4), generator=g) + 0.1
     assert torch.allclose(kl_loss(mu, sigma), oa.kl_loss(mu, sigma))
     assert float(kl_loss(torch.zeros(1, 1, 2, 2, 2), torch.ones(1, 1, 2, 2, 2)).abs().max()) < 1e-6      # KL(N(0,1) || N(0,1)) = 0
+
+
+def test_perceptual_loss_from_a_weights_file(tmp_path):
+    """--perceptual-weights (3d_ldm/train_autoencoder.py:236,386,406: PerceptualLoss(squeeze, fake 3-D 0.2)): host-side structure of the
+    restated LPIPS-squeeze network from a synthetic weights file: 57 tensors with the shapes of lpips.LPIPS(net='squeeze'), zero for equal
+    volumes, symmetric, positive, differentiable, 20 % of the slices of each axis, and loud errors for a wrong file.  The arithmetic
+    itself is unpinned (neither MONAI nor lpips can be installed here): ldm3d/perceptual.py states so."""
+    import pytest
+    import torch
+    from ldm3d.perceptual import PerceptualLoss, expected_keys
+    g = torch.Generator().manual_seed(0)
+    keys = expected_keys()
+    assert len(keys) == 57 and keys["net.slice1.0.weight"] == (64, 3, 3, 3) and keys["lin6.model.1.weight"] == (1, 512, 1, 1)
+    sd = {k: (torch.rand(s, generator=g) if k.startswith("lin") else 0.1 * torch.randn(s, generator=g)) for k, s in keys.items()}
+    path = str(tmp_path / "lpips_squeeze.pt")
+    torch.save(sd, path)
+    pl = PerceptualLoss.from_file(path)
+    x = torch.rand((1, 1, 40, 40, 40), generator=g).requires_grad_(True)
+    y = torch.rand((1, 1, 40, 40, 40), generator=g)
+    torch.manual_seed(1)
+    loss = pl(x, y)
+    loss.backward()
+    torch.manual_seed(1)
+    assert float(pl(y, x.detach())) == pytest.approx(float(loss.detach()), rel=1e-6)
+    assert float(loss.detach()) > 0 and float(pl(y, y)) == 0.0 and float(x.grad.abs().sum()) > 0
+    picked = []
+    pl.net.forward = lambda a, b, orig=pl.net.forward: (picked.append(a.shape[0]), orig(a, b))[1]
+    pl(x.detach(), y)
+    assert picked == [8, 8, 8]                                # int(40 * 0.2) slices per axis
+    bad = dict(sd)
+    bad.pop("lin3.model.1.weight")
+    with pytest.raises(KeyError):
+        PerceptualLoss(bad)
+    bad = dict(sd, **{"net.slice2.3.squeeze.weight": torch.zeros(16, 64, 3, 3)})
+    with pytest.raises(ValueError):
+        PerceptualLoss(bad)

@@ -141,3 +141,42 @@ def test_discriminator_layers_match_torch_on_identical_inputs(cuda, cin, cout, d
         e_v, e_u = rel_l2(vk.detach().cpu(), v.detach()), rel_l2(ud.grad.cpu(), gu)
         print(f"instance norm + leaky relu C={c}: y {e_v:.2e} dx {e_u:.2e}")
         assert e_v <= 4e-3 and e_u <= 6e-3
+
+
+def test_perceptual_term_from_user_weights_reaches_the_autoencoder(cuda, tmp_path):
+    """AutoencoderTrainer(perceptual_weight > 0, perceptual_weights=file): the term of 3d_ldm/train_autoencoder.py:236,386,406 from a
+    user-supplied LPIPS-squeeze state_dict (synthetic here): it is reported, finite, and its gradient reaches the AutoencoderKL through
+    ``reconstruction`` and the HIP backward plan (the gradients differ from the step without it); without a file the term is dropped
+    and flagged."""
+    from ldm3d.networks import AutoencoderKL
+    from ldm3d.perceptual import expected_keys
+    from ldm3d.trainer import AutoencoderTrainer
+    from oracle import autoencoder as oa
+    from oracle.unet import init_state_dict
+    g = torch.Generator().manual_seed(0)
+    sd = {k: (torch.rand(s, generator=g) if k.startswith("lin") else 0.1 * torch.randn(s, generator=g)) for k, s in expected_keys().items()}
+    path = str(tmp_path / "lpips_squeeze.pt")
+    torch.save(sd, path)
+    cfg = cfgs.VAE_TINY
+    x = torch.rand((1, 2, 32, 32, 32), generator=g).to(cuda)
+    eps = torch.randn((1, 8, 8, 8, 8), generator=g).to(cuda)
+
+    def one(weights_file):
+        ae = AutoencoderKL(**cfg)
+        ae.load_state_dict(init_state_dict(oa.ae_param_shapes(cfg), 3, gain=0.7))
+        ae = ae.to(cuda)
+        torch.manual_seed(0)
+        if weights_file is None:
+            with pytest.warns(UserWarning, match="perceptual"):
+                tr = AutoencoderTrainer(ae, lr=1e-4, kl_weight=1e-6, perceptual_weight=0.5)
+        else:
+            tr = AutoencoderTrainer(ae, lr=1e-4, kl_weight=1e-6, perceptual_weight=0.5, perceptual_weights=weights_file)
+        torch.manual_seed(4)                                 # the slice draw of the fake 3-D evaluation
+        out, skipped = tr.train_step(x, epoch=0, eps=eps)
+        return tr, out, bool(skipped), ae.flat_grads.clone()
+    tr0, out0, s0, g0 = one(None)
+    tr1, out1, s1, g1 = one(path)
+    assert tr0.perceptual_dropped and "perceptual" not in out0 and not s0
+    assert not tr1.perceptual_dropped and not s1 and bool(torch.isfinite(out1["perceptual"])) and float(out1["perceptual"]) > 0
+    assert torch.isfinite(g1).all() and not torch.equal(g0, g1)
+    assert abs(float(out1["loss_g"]) - (float(out1["recons"]) + 1e-6 * float(out1["kl"]) + 0.5 * float(out1["perceptual"]))) <= 1e-5

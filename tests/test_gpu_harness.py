@@ -30,8 +30,12 @@ def test_train_then_conditional_sampling(tmp_path):
     env_file = str(tmp_path / "environment.json")
     with open(env_file, "w") as fh:
         json.dump(env, fh)
-    _run("train_autoencoder.py", env_file, "--random-init", "--synthetic", "8", "--max-steps", "4")
+    log_ae = _run("train_autoencoder.py", env_file, "--random-init", "--synthetic", "8", "--max-steps", "4", "--profile")
     assert os.path.exists(tmp_path / "ckpt" / "autoencoder.pt")
+    # every shipped config sets a perceptual weight; without --perceptual-weights the term is dropped AND recorded (not only warned)
+    assert "perceptual_term: dropped" in log_ae and json.load(open(tmp_path / "ckpt" / "perceptual_term.json"))["perceptual_term"] == "dropped"
+    # --profile (3d_ldm/train_autoencoder.py:81,312-329): per-op timelines of the traced steps
+    assert "Profiler started" in log_ae and "[profile]" in log_ae and glob.glob(os.path.join(ROOT, "profiler_logs", "plan_trace_cycle*.csv"))
     log = _run("train_diffusion.py", env_file, "--random-init", "--max-steps", "6", "--gpu-transforms", "--sample-steps", "5")
     assert "scale_factor" in log and os.path.exists(tmp_path / "ckpt" / "diffusion_unet.pt")
     # the periodic rank-0 conditional sample of 3d_ldm/train_diffusion.py:306-359 (epoch 0 is a multiple of 2 * val_interval)

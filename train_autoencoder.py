@@ -7,8 +7,9 @@
 
 The PatchDiscriminator / LSGAN adversarial phase after 5 warm-up epochs (:150-158,407-424,454-494) runs on the same HIP kernels
 (ldm3d/discriminator.py); checkpoints discriminator.pt / discriminator_last.pt as the reference (:183-186).  NOT reproduced: the
-perceptual loss needs a downloaded pretrained SqueezeNet: a non-zero `autoencoder_train.perceptual_weight` (every shipped config
-has one) is reported once, recorded in the scalars log and the checkpoint directory (perceptual_term.json), and the term is left out.
+perceptual loss as MONAI builds it (it downloads a pretrained LPIPS / SqueezeNet): `--perceptual-weights file.pt` supplies those weights
+(ldm3d/perceptual.py); without the flag a non-zero `autoencoder_train.perceptual_weight` (every shipped config has one) is reported once,
+recorded in the scalars log and the checkpoint directory (perceptual_term.json), and the term is left out.
 --profile (:81,312-329) traces the launch plans of a few steps with the reference's schedule (wait 1, warm-up 1, active 3, repeat 2)
 into ./profiler_logs (ldm3d/profiling.py on ldm_set_plan_trace).  --amp / --compile / --no-images are accepted and ignored (compute
 is bf16 on fp32 master weights, or fp32 with --precision fp32; there is no tracing compiler on this path).
@@ -39,6 +40,9 @@ def main():
     parser.add_argument("--precision", default=None, choices=["bf16", "fp32"],
                         help="arithmetic of the networks: bf16 (default, the fast path) or fp32 (the reference's own arithmetic, 1e-5 from its CPU path; also LDM_PRECISION)")
     parser.add_argument("--max-steps", type=int, default=0)
+    parser.add_argument("--perceptual-weights", default=None,
+                        help="state_dict of lpips.LPIPS(net='squeeze') (torch.save): enables the perceptual term of :236,406; "
+                             "without it the term is dropped and recorded (no download is possible offline)")
     args = parser.parse_args()
     if args.precision:
         os.environ["LDM_PRECISION"] = args.precision     # read by every network at construction (networks.py)
@@ -77,7 +81,7 @@ def main():
         print(f"Rank {rank}: loaded {best_path}")
     autoencoder = autoencoder.to(device)
     trainer = AutoencoderTrainer(autoencoder, lr=tcfg["lr"], kl_weight=tcfg["kl_weight"], recon_loss=tcfg.get("recon_loss", "l1"),
-                                 perceptual_weight=tcfg.get("perceptual_weight", 0.0),
+                                 perceptual_weight=tcfg.get("perceptual_weight", 0.0), perceptual_weights=args.perceptual_weights,
                                  warm_up_epochs=int(tcfg.get("warm_up_epochs", 5)))      # 5 in the reference (:304); the key is an extension
     d_best = os.path.join(args.model_dir, "discriminator.pt")
     if getattr(args, "resume_ckpt", False) and os.path.exists(d_best):
