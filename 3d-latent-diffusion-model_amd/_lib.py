@@ -123,6 +123,17 @@ SIGNATURES = {
     "ldm_profile_detail": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]),
     "ldm_profile_stop": (C.c_int, [C.POINTER(C.c_double)]),
     "ldm_set_plan_trace": (C.c_int, [C.c_char_p]),
+    "ldm_op_pack_ncdhw_f32": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int64, _P]),
+    "ldm_op_unpack_ndhwc_f32": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int64, _P]),
+    "ldm_op_im2col_f32": (C.c_int, [_P, _P] + [C.c_int] * 10 + [_P]),
+    "ldm_op_col2im_f32": (C.c_int, [_P, _P] + [C.c_int] * 10 + [_P]),
+    "ldm_op_leaky_relu_f32": (C.c_int, [_P, _P, C.c_int64, C.c_float, _P]),
+    "ldm_op_leaky_relu_bwd_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_float, _P]),
+    "ldm_op_gemm_f32": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, _P]),
+    "ldm_op_gemm_wgrad_f32": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, C.c_int, C.c_int64, C.c_int, _P]),
+    "ldm_op_group_norm_f32_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "ldm_op_group_norm_f32": (C.c_int, [_P, C.c_int, _P, _P, C.c_int, C.c_float, C.c_int, _P, C.c_int, C.c_int, _P, C.c_size_t, _P]),
+    "ldm_op_group_norm_bwd_f32": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, C.c_float, C.c_int, _P, _P, _P, C.c_int, C.c_int, _P, C.c_size_t, _P]),
     "ldm_debug_kstamps": (C.c_int, [C.POINTER(C.c_uint64), C.c_int, C.c_int]),
     "ldm_model_plan_conv_cfgs": (C.c_int, [_P, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]),
     "ldm_comm_unique_id": (C.c_int, [C.c_char_p]),

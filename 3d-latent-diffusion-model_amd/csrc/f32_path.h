@@ -398,7 +398,10 @@ __global__ __launch_bounds__(256) void gn_apply_f32_kernel(const Gn32Params p) {
         const float4* abp = reinterpret_cast<const float4*>(p.ab + ((size_t)n * C + c) * 2);
         const float4 ab0 = abp[0], ab1 = abp[1];
         float4 y = make_float4(v.x * ab0.x + ab0.y, v.y * ab0.z + ab0.w, v.z * ab1.x + ab1.y, v.w * ab1.z + ab1.w);
-        if (p.silu) { y.x = y.x / (1.0f + expf(-y.x)); y.y = y.y / (1.0f + expf(-y.y)); y.z = y.z / (1.0f + expf(-y.z)); y.w = y.w / (1.0f + expf(-y.w)); }
+        if (p.silu == 1) { y.x = y.x / (1.0f + expf(-y.x)); y.y = y.y / (1.0f + expf(-y.y)); y.z = y.z / (1.0f + expf(-y.z)); y.w = y.w / (1.0f + expf(-y.w)); }
+        else if (p.silu == 2) {                           // LeakyReLU(0.2) (InstanceNorm + LeakyReLU of the PatchDiscriminator)
+            y.x = y.x > 0.f ? y.x : 0.2f * y.x; y.y = y.y > 0.f ? y.y : 0.2f * y.y; y.z = y.z > 0.f ? y.z : 0.2f * y.z; y.w = y.w > 0.f ? y.w : 0.2f * y.w;
+        }
         *reinterpret_cast<float4*>(p.out + row * C + c) = y;
     }
 }
@@ -450,7 +453,10 @@ __global__ __launch_bounds__(256) void gn32_fold_apply_kernel(const Gn32FusedPar
         const size_t row = (size_t)n * p.DHW + r;
         const float4 v = *reinterpret_cast<const float4*>(src + row * cs + cc);
         float4 y = make_float4(v.x * a[0] + b[0], v.y * a[1] + b[1], v.z * a[2] + b[2], v.w * a[3] + b[3]);
-        if (p.silu) { y.x = y.x / (1.0f + expf(-y.x)); y.y = y.y / (1.0f + expf(-y.y)); y.z = y.z / (1.0f + expf(-y.z)); y.w = y.w / (1.0f + expf(-y.w)); }
+        if (p.silu == 1) { y.x = y.x / (1.0f + expf(-y.x)); y.y = y.y / (1.0f + expf(-y.y)); y.z = y.z / (1.0f + expf(-y.z)); y.w = y.w / (1.0f + expf(-y.w)); }
+        else if (p.silu == 2) {                           // LeakyReLU(0.2) (InstanceNorm + LeakyReLU of the PatchDiscriminator)
+            y.x = y.x > 0.f ? y.x : 0.2f * y.x; y.y = y.y > 0.f ? y.y : 0.2f * y.y; y.z = y.z > 0.f ? y.z : 0.2f * y.z; y.w = y.w > 0.f ? y.w : 0.2f * y.w;
+        }
         *reinterpret_cast<float4*>(p.out + row * C + c) = y;
     }
 }

@@ -3141,33 +3141,43 @@ int ldm_op_group_norm(const void* xa, int ca, const void* xb, int cb, const floa
 }
 
 /* ---- PatchDiscriminator building blocks (stage-1 GAN tail): generic-kernel-size convs as im2col + the 1x1 GEMM kernels ---- */
-int ldm_op_im2col(const void* x, void* col, int N, int D, int H, int W, int Cs, int C, int k, int stride, int pad, int Kp, void* stream) {
-    if (!x || !col || N < 1 || C < 1 || C > Cs || k < 1 || stride < 1 || pad < 0 || Kp < k * k * k * C || Kp % 32) return fail(LDM_ERR_BAD_ARG, "bad argument");
+}  // extern "C" (templates need C++ linkage)
+template <class T>
+static int op_im2col(const void* x, void* col, int N, int D, int H, int W, int Cs, int C, int k, int stride, int pad, int Kp, int kmul, void* stream) {
+    if (!x || !col || N < 1 || C < 1 || C > Cs || k < 1 || stride < 1 || pad < 0 || Kp < k * k * k * C || Kp % kmul) return fail(LDM_ERR_BAD_ARG, "bad argument");
     const int Do = (D + 2 * pad - k) / stride + 1, Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
     if (Do < 1 || Ho < 1 || Wo < 1) return fail(LDM_ERR_BAD_ARG, "empty output");
-    hipLaunchKernelGGL(im2col_generic_kernel, dim3(grid_for((long)N * Do * Ho * Wo * Kp, 256, 16384)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)x, (bf16_t*)col, N, D, H, W, Cs, C, k, stride, pad, Do, Ho, Wo, Kp);
+    hipLaunchKernelGGL(im2col_generic_kernel<T>, dim3(grid_for((long)N * Do * Ho * Wo * Kp, 256, 16384)), dim3(256), 0, (hipStream_t)stream,
+                       (const T*)x, (T*)col, N, D, H, W, Cs, C, k, stride, pad, Do, Ho, Wo, Kp);
     HIP_TRY(hipGetLastError());
     return 0;
 }
-int ldm_op_col2im(const void* dcol, void* dx, int N, int D, int H, int W, int Cs, int C, int k, int stride, int pad, int Kp, void* stream) {
-    if (!dcol || !dx || N < 1 || C < 1 || C > Cs || k < 1 || stride < 1 || pad < 0 || Kp < k * k * k * C || Kp % 32) return fail(LDM_ERR_BAD_ARG, "bad argument");
+template <class T>
+static int op_col2im(const void* dcol, void* dx, int N, int D, int H, int W, int Cs, int C, int k, int stride, int pad, int Kp, int kmul, void* stream) {
+    if (!dcol || !dx || N < 1 || C < 1 || C > Cs || k < 1 || stride < 1 || pad < 0 || Kp < k * k * k * C || Kp % kmul) return fail(LDM_ERR_BAD_ARG, "bad argument");
     const int Do = (D + 2 * pad - k) / stride + 1, Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
     if (Do < 1 || Ho < 1 || Wo < 1) return fail(LDM_ERR_BAD_ARG, "empty output");
-    hipLaunchKernelGGL(col2im_generic_kernel, dim3(grid_for((long)N * D * H * W * Cs, 256, 16384)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)dcol, (bf16_t*)dx, N, D, H, W, Cs, C, k, stride, pad, Do, Ho, Wo, Kp);
+    hipLaunchKernelGGL(col2im_generic_kernel<T>, dim3(grid_for((long)N * D * H * W * Cs, 256, 16384)), dim3(256), 0, (hipStream_t)stream,
+                       (const T*)dcol, (T*)dx, N, D, H, W, Cs, C, k, stride, pad, Do, Ho, Wo, Kp);
     HIP_TRY(hipGetLastError());
     return 0;
+}
+extern "C" {
+int ldm_op_im2col(const void* x, void* col, int N, int D, int H, int W, int Cs, int C, int k, int stride, int pad, int Kp, void* stream) {
+    return op_im2col<bf16_t>(x, col, N, D, H, W, Cs, C, k, stride, pad, Kp, 32, stream);
+}
+int ldm_op_col2im(const void* dcol, void* dx, int N, int D, int H, int W, int Cs, int C, int k, int stride, int pad, int Kp, void* stream) {
+    return op_col2im<bf16_t>(dcol, dx, N, D, H, W, Cs, C, k, stride, pad, Kp, 32, stream);
 }
 int ldm_op_leaky_relu(const void* x, void* y, int64_t n, float slope, void* stream) {
     if (!x || !y || n < 0) return fail(LDM_ERR_BAD_ARG, "bad argument");
-    hipLaunchKernelGGL(leaky_relu_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, (long)n, slope);
+    hipLaunchKernelGGL(leaky_relu_kernel<bf16_t>, dim3(grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, (long)n, slope);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 int ldm_op_leaky_relu_bwd(const void* x, const void* dy, void* dx, int64_t n, float slope, void* stream) {
     if (!x || !dy || !dx || n < 0) return fail(LDM_ERR_BAD_ARG, "bad argument");
-    hipLaunchKernelGGL(leaky_relu_bwd_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, (long)n, slope);
+    hipLaunchKernelGGL(leaky_relu_bwd_kernel<bf16_t>, dim3(grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, (long)n, slope);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -3180,14 +3190,128 @@ int ldm_op_pack_ncdhw(const float* x, void* out, int N, int C, int Cs, int64_t D
 }
 int ldm_op_unpack_ndhwc(const void* act, float* out, int N, int C, int Cs, int64_t DHW, void* stream) {
     if (!act || !out || N < 1 || C < 1 || C > Cs || DHW < 1 || DHW >= (1L << 31)) return fail(LDM_ERR_BAD_ARG, "bad argument");
-    hipLaunchKernelGGL(unpack_ndhwc_kernel, dim3(grid_for((long)N * C * DHW)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)act, out, N, C, Cs, (int)DHW);
+    hipLaunchKernelGGL(unpack_ndhwc_kernel<bf16_t>, dim3(grid_for((long)N * C * DHW)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)act, out, N, C, Cs, (int)DHW);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
-/* ---- data path: ScaleIntensityRangePercentiles(lower, upper -> b_min, b_max) of the reference's loader
- * (3d_ldm/utils.py:94-107: lower 0, upper 99.5 -> [0, 1], no clipping) per volume, on the device: B volumes of n fp32 values each.
- * Exact order statistics (radix select), percentile = linear interpolation between the two neighbouring ranks (numpy "linear"). */
+/* ---- the same building blocks on fp32 NDHWC tensors (the reference trains the PatchDiscriminator in fp32 when AMP is off,
+ *      3d_ldm/train_autoencoder.py:150-158,454-494; `--precision fp32`): exact fp32 MFMA (csrc/f32_path.h, f32_train.h).
+ *      Channels / K are multiples of 16, Cout padded to 64 weight rows. ------------------------------------------------------ */
+int ldm_op_im2col_f32(const float* x, float* col, int N, int D, int H, int W, int Cs, int C, int k, int stride, int pad, int Kp, void* stream) {
+    return op_im2col<float>(x, col, N, D, H, W, Cs, C, k, stride, pad, Kp, 16, stream);
+}
+int ldm_op_col2im_f32(const float* dcol, float* dx, int N, int D, int H, int W, int Cs, int C, int k, int stride, int pad, int Kp, void* stream) {
+    return op_col2im<float>(dcol, dx, N, D, H, W, Cs, C, k, stride, pad, Kp, 16, stream);
+}
+int ldm_op_leaky_relu_f32(const float* x, float* y, int64_t n, float slope, void* stream) {
+    if (!x || !y || n < 0) return fail(LDM_ERR_BAD_ARG, "bad argument");
+    hipLaunchKernelGGL(leaky_relu_kernel<float>, dim3(grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, y, (long)n, slope);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int ldm_op_leaky_relu_bwd_f32(const float* x, const float* dy, float* dx, int64_t n, float slope, void* stream) {
+    if (!x || !dy || !dx || n < 0) return fail(LDM_ERR_BAD_ARG, "bad argument");
+    hipLaunchKernelGGL(leaky_relu_bwd_kernel<float>, dim3(grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, (long)n, slope);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int ldm_op_pack_ncdhw_f32(const float* x, float* out, int N, int C, int Cs, int64_t DHW, void* stream) {
+    if (!x || !out || N < 1 || C < 1 || C > Cs || DHW < 1 || DHW >= (1L << 31)) return fail(LDM_ERR_BAD_ARG, "bad argument");
+    hipLaunchKernelGGL(pack2_ncdhw_f32_kernel, dim3(grid_for((long)N * DHW * Cs)), dim3(256), 0, (hipStream_t)stream, x, C, (const float*)nullptr, 0, out, N, Cs, (int)DHW);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int ldm_op_unpack_ndhwc_f32(const float* act, float* out, int N, int C, int Cs, int64_t DHW, void* stream) {
+    if (!act || !out || N < 1 || C < 1 || C > Cs || DHW < 1 || DHW >= (1L << 31)) return fail(LDM_ERR_BAD_ARG, "bad argument");
+    hipLaunchKernelGGL(unpack_ndhwc_kernel<float>, dim3(grid_for((long)N * C * DHW)), dim3(256), 0, (hipStream_t)stream, act, out, N, C, Cs, (int)DHW);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+/* out[M][couts] = x[M][K] w[cout_pad][K]^T + bias (fp32, exact fp32 MFMA): K % 16 == 0, cout_pad % 64 == 0 weight rows (rows >= cout zero),
+ * couts = stored output channels (% 4 == 0, >= cout; columns >= cout receive the products of the zero rows). */
+int ldm_op_gemm_f32(const float* x, int K, const float* w, const float* bias, float* out, int64_t M, int cout, int cout_pad, int couts, void* stream) {
+    if (!x || !w || !out || M < 1 || M >= (1L << 31) || K < 16 || K % 16 || cout < 1 || cout_pad % 64 || cout_pad < cout || couts % 4 || couts < cout || couts > cout_pad)
+        return fail(LDM_ERR_BAD_ARG, "bad argument");
+    Conv32Params p{}; p.xa = x; p.ca = K; p.w = w; p.N = 1; p.Din = p.Dout = (int)M; p.Hin = p.Win = p.Hout = p.Wout = 1;
+    p.ksize = 1; p.stride = 1; p.pad = 0; p.M = (int)M; p.CoutS = couts; p.CoutPad = cout_pad; p.CoutReal = cout;
+    p.nchunk = K / 16; p.steps = p.nchunk; p.splitk = 1; p.steps_per_split = p.steps; p.mtiles = (int)((M + 127) / 128);
+    p.bias = bias; p.out = out;
+    if (cout_pad % 128 == 0) { p.ntiles = cout_pad / 128; hipLaunchKernelGGL(conv_f32_kernel<128>, dim3(p.mtiles * p.ntiles), dim3(256), 0, (hipStream_t)stream, p); }
+    else { p.ntiles = cout_pad / 64; hipLaunchKernelGGL(conv_f32_kernel<64>, dim3(p.mtiles * p.ntiles), dim3(256), 0, (hipStream_t)stream, p); }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+/* dw[ksplit][cout][K] = sum over the rows of dy[M][cdy]^T x[M][K] (partial matrices of `ksplit` row ranges; the caller sums them) */
+int ldm_op_gemm_wgrad_f32(const float* dy, int cdy, const float* x, int K, float* dw, int cout, int64_t M, int ksplit, void* stream) {
+    if (!dy || !x || !dw || M < 1 || M >= (1L << 31) || K < 4 || K % 4 || cdy % 4 || cout < 1 || cout > cdy || ksplit < 1 || ksplit > 64) return fail(LDM_ERR_BAD_ARG, "bad argument");
+    Wgrad32Params q{}; q.dy = dy; q.cdy = cdy; q.x = x; q.cx = K; q.dw = dw; q.Cout = cout; q.Cin = K; q.dw_ld = K; q.dw_ci_off = 0;
+    q.N = 1; q.Din = q.Dout = (int)M; q.Hin = q.Win = q.Hout = q.Wout = 1; q.ksize = 1; q.stride = 1; q.pad = 0; q.ups = 0; q.M = (int)M;
+    q.co_tiles = (cout + 127) / 128; q.ci_tiles = (K + 127) / 128; q.ksplit = ksplit; q.slab_stride = (long)cout * K;
+    hipLaunchKernelGGL(wgrad_f32_kernel, dim3(q.co_tiles * q.ci_tiles * q.ksplit), dim3(256), 0, (hipStream_t)stream, q);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+static void gn32_slabs(int N, int C, int DHW, int* nslab, int* rps) {
+    const int cvec = C / 4, rows_par = std::max(1, 256 / std::max(1, cvec));
+    int ns = std::min((DHW + rows_par - 1) / rows_par, std::max(1, 512 / N));
+    *rps = (DHW + ns - 1) / ns; *nslab = (DHW + *rps - 1) / *rps;
+}
+size_t ldm_op_group_norm_f32_scratch_bytes(int N, int C, int DHW, int groups) {
+    int nslab = 1, rps = 1; gn32_slabs(std::max(1, N), std::max(4, C), std::max(1, DHW), &nslab, &rps);
+    return ((size_t)N * nslab * C * 2 * 2 + (size_t)N * C * 2 + (size_t)N * groups * 4 + (size_t)N * C * 2) * 4 + 1024;
+}
+/* y = act(GroupNorm(x)) on fp32 NDHWC [N][DHW][C] (act 0 none, 1 SiLU, 2 LeakyReLU(0.2)); C % 4 == 0, C <= 1024 */
+int ldm_op_group_norm_f32(const float* x, int C, const float* gamma, const float* beta, int groups, float eps, int act, float* out,
+                          int N, int DHW, void* scratch, size_t scratch_bytes, void* stream) {
+    if (!x || !gamma || !beta || !out || !scratch || N < 1 || DHW < 1 || C < 4 || C % 4 || C > 1024 || groups < 1 || C % groups || act < 0 || act > 2)
+        return fail(LDM_ERR_BAD_ARG, "bad argument");
+    if (scratch_bytes < ldm_op_group_norm_f32_scratch_bytes(N, C, DHW, groups)) return fail(LDM_ERR_WORKSPACE, "scratch too small");
+    int nslab, rps; gn32_slabs(N, C, DHW, &nslab, &rps);
+    float* partial = (float*)scratch; float* ab = partial + (size_t)N * nslab * C * 2;
+    hipStream_t s = (hipStream_t)stream;
+    Gn32Params p{}; p.xa = x; p.ca = C; p.DHW = DHW; p.N = N; p.nslab = nslab; p.rows_per_slab = rps; p.silu = act; p.partial = partial; p.ab = ab; p.out = out;
+    hipLaunchKernelGGL(gn_stats_f32_kernel, dim3(nslab, N), dim3(256), 0, s, p);
+    GnFinalizeParams fp{}; fp.partial = partial; fp.nslab = nslab; fp.C = C; fp.Creal = C; fp.groups = groups; fp.DHW = DHW; fp.eps = eps;
+    fp.gamma = gamma; fp.beta = beta; fp.ab = ab;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, N), dim3(256), 0, s, fp);
+    hipLaunchKernelGGL(gn_apply_f32_kernel, dim3(grid_for((long)N * DHW * (C / 4), 256, 4096)), dim3(256), 0, s, p);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+/* backward of the above: dx (fp32), dgamma / dbeta (fp32 [C], summed over the batch); recomputes the forward statistics */
+int ldm_op_group_norm_bwd_f32(const float* dy, const float* x, int C, const float* gamma, const float* beta, int groups, float eps, int act,
+                              float* dx, float* dgamma, float* dbeta, int N, int DHW, void* scratch, size_t scratch_bytes, void* stream) {
+    if (!dy || !x || !gamma || !beta || !dx || !dgamma || !dbeta || !scratch || N < 1 || DHW < 1 || C < 4 || C % 4 || C > 1024 || groups < 1 || C % groups)
+        return fail(LDM_ERR_BAD_ARG, "bad argument");
+    if (scratch_bytes < ldm_op_group_norm_f32_scratch_bytes(N, C, DHW, groups)) return fail(LDM_ERR_WORKSPACE, "scratch too small");
+    int nslab, rps; gn32_slabs(N, C, DHW, &nslab, &rps);
+    float* partial = (float*)scratch;                       // [N][nslab][C][2] (forward stats), then reused by the backward sums
+    float* partial2 = partial + (size_t)N * nslab * C * 2;  // [N][nslab][C][2]
+    float* ab = partial2 + (size_t)N * nslab * C * 2;       // [N][C][2]
+    float* mr = ab + (size_t)N * C * 2;                     // [N][G][2]
+    float* gsum = mr + (size_t)N * groups * 2;              // [N][G][2]
+    float* dgn = gsum + (size_t)N * groups * 2;             // [N][C]
+    float* dbn = dgn + (size_t)N * C;                       // [N][C]
+    hipStream_t s = (hipStream_t)stream;
+    Gn32Params p{}; p.xa = x; p.ca = C; p.DHW = DHW; p.N = N; p.nslab = nslab; p.rows_per_slab = rps; p.partial = partial;
+    hipLaunchKernelGGL(gn_stats_f32_kernel, dim3(nslab, N), dim3(256), 0, s, p);
+    GnFinalizeParams fp{}; fp.partial = partial; fp.nslab = nslab; fp.C = C; fp.Creal = C; fp.groups = groups; fp.DHW = DHW; fp.eps = eps;
+    fp.gamma = gamma; fp.beta = beta; fp.ab = ab; fp.mr = mr;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, N), dim3(256), 0, s, fp);
+    Gnb32Params q{}; q.dy = dy; q.xa = x; q.ca = C; q.ab = ab; q.mr = mr; q.gamma = gamma; q.groups = groups; q.DHW = DHW; q.N = N; q.silu = act;
+    q.nslab = nslab; q.rows_per_slab = rps; q.partial = partial2; q.gsum = gsum; q.dxa = dx;
+    GnBwdParams f{}; f.ca = C; f.cb = 0; f.gamma = gamma; f.groups = groups; f.DHW = DHW; f.N = N; f.nslab = nslab;
+    f.partial = partial2; f.gsum = gsum; f.dgamma_n = dgn; f.dbeta_n = dbn;
+    hipLaunchKernelGGL(gnb32_stats_kernel, dim3(nslab, N), dim3(256), 0, s, q);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(groups, N), dim3(256), 0, s, f);
+    hipLaunchKernelGGL(gnb32_apply_kernel, dim3(grid_for((long)N * DHW * (C / 4), 256, 4096)), dim3(256), 0, s, q);
+    hipLaunchKernelGGL(rowsum_n_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)dgn, dgamma, N, C);
+    hipLaunchKernelGGL(rowsum_n_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)dbn, dbeta, N, C);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 size_t ldm_op_scale_intensity_percentiles_scratch_bytes(int B) { return (size_t)(B < 1 ? 1 : B) * (4 * 4096 * 4 + sizeof(PctState)) + 256; }
 int ldm_op_scale_intensity_percentiles(const float* x, float* out, int B, int64_t n, float lower, float upper, float b_min, float b_max,
                                        void* scratch, size_t scratch_bytes, void* stream) {

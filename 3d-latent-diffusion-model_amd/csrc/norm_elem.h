@@ -633,14 +633,22 @@ __global__ void sampler_reset_kernel(SamplerState* st, const float* coef, float*
 // PatchDiscriminator support (stage-1 GAN tail, 3d_ldm/train_autoencoder.py:150-158,407-424,454-494): its 4^3 convolutions run as
 // im2col + the 1x1 GEMM kernels.  col[m][tap * C + c] = x[voxel(m, tap)][c] (zero where the tap falls into the padding; columns
 // beyond taps * C up to Kp are zero), taps ordered (kd, kh, kw); x NDHWC bf16 with Cs stored channels of which C are used.
-__global__ __launch_bounds__(256) void im2col_generic_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ col, int N, int D, int H, int W,
+// T = bf16_t (raw bits) or float: the fp32 forms serve the discriminator under --precision fp32 (ldm_op_*_f32)
+template <class T> __device__ __forceinline__ float el_ld(const T* p);
+template <> __device__ __forceinline__ float el_ld<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+template <> __device__ __forceinline__ float el_ld<float>(const float* p) { return *p; }
+template <class T> __device__ __forceinline__ void el_st(T* p, float v);
+template <> __device__ __forceinline__ void el_st<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
+template <> __device__ __forceinline__ void el_st<float>(float* p, float v) { *p = v; }
+template <class T>
+__global__ __launch_bounds__(256) void im2col_generic_kernel(const T* __restrict__ x, T* __restrict__ col, int N, int D, int H, int W,
                                                              int Cs, int C, int k, int stride, int pad, int Do, int Ho, int Wo, int Kp) {
     const long total = (long)N * Do * Ho * Wo * Kp;
     const int taps = k * k * k;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int kk = (int)(i % Kp);
         const long m = i / Kp;
-        bf16_t v = 0;
+        T v = 0;
         if (kk < taps * C) {
             const int tap = kk / C, c = kk - tap * C;
             const int kd = tap / (k * k), kh = (tap / k) % k, kw = tap % k;
@@ -654,7 +662,8 @@ __global__ __launch_bounds__(256) void im2col_generic_kernel(const bf16_t* __res
 }
 // adjoint: dx[voxel][c] = sum over the (output position, tap) pairs that read that voxel of dcol[m][tap * C + c] (gather form: no
 // atomics, fixed summation order); channels C..Cs of dx are written as zeros.
-__global__ __launch_bounds__(256) void col2im_generic_kernel(const bf16_t* __restrict__ dcol, bf16_t* __restrict__ dx, int N, int D, int H, int W,
+template <class T>
+__global__ __launch_bounds__(256) void col2im_generic_kernel(const T* __restrict__ dcol, T* __restrict__ dx, int N, int D, int H, int W,
                                                              int Cs, int C, int k, int stride, int pad, int Do, int Ho, int Wo, int Kp) {
     const long total = (long)N * D * H * W * Cs;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -670,32 +679,35 @@ __global__ __launch_bounds__(256) void col2im_generic_kernel(const bf16_t* __res
                     for (int kw = 0; kw < k; ++kw) {
                         const int tw = iw + pad - kw; if (tw < 0 || tw % stride) continue; const int ow = tw / stride; if (ow >= Wo) continue;
                         const size_t m = (((size_t)n * Do + od) * Ho + oh) * Wo + ow;
-                        s += bf2f(dcol[m * Kp + ((kd * k + kh) * k + kw) * C + c]);
+                        s += el_ld<T>(dcol + m * Kp + ((kd * k + kh) * k + kw) * C + c);
                     }
                 }
             }
-        dx[i] = f2bf(s);
+        el_st<T>(dx + i, s);
     }
 }
-__global__ __launch_bounds__(256) void leaky_relu_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, long n, float slope) {
+template <class T>
+__global__ __launch_bounds__(256) void leaky_relu_kernel(const T* __restrict__ x, T* __restrict__ y, long n, float slope) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const float v = bf2f(x[i]);
-        y[i] = f2bf(v > 0.f ? v : slope * v);
+        const float v = el_ld<T>(x + i);
+        el_st<T>(y + i, v > 0.f ? v : slope * v);
     }
 }
-__global__ __launch_bounds__(256) void leaky_relu_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx,
+template <class T>
+__global__ __launch_bounds__(256) void leaky_relu_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
                                                              long n, float slope) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-        dx[i] = f2bf(bf2f(x[i]) > 0.f ? bf2f(dy[i]) : slope * bf2f(dy[i]));
+        el_st<T>(dx + i, el_ld<T>(x + i) > 0.f ? el_ld<T>(dy + i) : slope * el_ld<T>(dy + i));
 }
 // bf16 NDHWC (Cs stored channels) -> fp32 NCDHW (first C channels): the op-level counterpart of pack2_ncdhw_kernel
-__global__ __launch_bounds__(256) void unpack_ndhwc_kernel(const bf16_t* __restrict__ act, float* __restrict__ out, int N, int C, int Cs, int DHW) {
+template <class T>
+__global__ __launch_bounds__(256) void unpack_ndhwc_kernel(const T* __restrict__ act, float* __restrict__ out, int N, int C, int Cs, int DHW) {
     const long total = (long)N * C * DHW;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int sp = (int)(i % DHW);
         const long r = i / DHW;
         const int c = (int)(r % C), n = (int)(r / C);
-        out[i] = bf2f(act[((size_t)n * DHW + sp) * Cs + c]);
+        out[i] = el_ld<T>(act + ((size_t)n * DHW + sp) * Cs + c);
     }
 }
 

@@ -16,6 +16,11 @@ MI355X side: every 4^3 convolution is ``ldm_op_im2col`` + the bf16-MFMA 1x1 GEMM
 the same GEMM on the transposed weights followed by ``ldm_op_col2im`` (gather form, no atomics), its weight gradient
 ``ldm_op_conv3d_wgrad``; InstanceNorm + LeakyReLU is ``ldm_op_group_norm`` with groups = C and activation code 2.  Activations are
 bf16 NDHWC between the layers; the module boundary is fp32 NCDHW like the rest of the library.  No CPU fallback.
+
+``precision="fp32"`` (``set_precision``, or ``LDM_PRECISION=fp32`` / ``--precision fp32`` at construction): the reference trains the
+discriminator in fp32 when AMP is off (3d_ldm/train_autoencoder.py:150-158,454-494).  The same structure then runs on fp32 NDHWC
+tensors through the ``ldm_op_*_f32`` entries: im2col + exact-fp32-MFMA GEMM, col2im, fp32 weight gradient, InstanceNorm + LeakyReLU on
+the fp32 GroupNorm kernels.
 """
 from __future__ import annotations
 
@@ -183,6 +188,147 @@ class _UnpackFn(torch.autograd.Function):
         return out, None
 
 
+# ------------------------------------------------------------------------------------------------ fp32 forms (precision="fp32")
+class _ConvFn32(torch.autograd.Function):
+    """y[M][couts] (fp32 NDHWC) = conv_k(x NDHWC fp32) + bias as im2col + the exact-fp32 GEMM; saves the column matrix."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, geom):
+        L = _lib.lib()
+        N, D, H, W, Cs, C, k, stride, pad = geom
+        cout, cin = weight.shape[0], weight.shape[1]
+        Do, Ho, Wo = [(s + 2 * pad - k) // stride + 1 for s in (D, H, W)]
+        M, taps = N * Do * Ho * Wo, k ** 3
+        Kp, cout_pad, couts = _rup(taps * C, 16), _rup(cout, 64), _rup(cout, 16)
+        dev = x.device
+        col = torch.empty((M, Kp), dtype=torch.float32, device=dev)
+        _lib.check(L.ldm_op_im2col_f32(x.data_ptr(), col.data_ptr(), N, D, H, W, Cs, C, k, stride, pad, Kp, _st()))
+        wm = torch.zeros((cout_pad, Kp), dtype=torch.float32, device=dev)
+        wm[:cout, :taps * C] = weight.detach().float().permute(0, 2, 3, 4, 1).reshape(cout, taps * cin)
+        bp = torch.zeros((cout_pad,), dtype=torch.float32, device=dev)
+        if bias is not None:
+            bp[:cout] = bias.detach().float()
+        y = torch.empty((N, Do, Ho, Wo, couts), dtype=torch.float32, device=dev)
+        _lib.check(L.ldm_op_gemm_f32(col.data_ptr(), Kp, wm.data_ptr(), bp.data_ptr(), y.data_ptr(), M, cout, cout_pad, couts, _st()))
+        ctx.save_for_backward(col, wm)
+        ctx.geom, ctx.shape, ctx.has_bias = geom, (cout, cin, Kp, cout_pad, couts, M, Do, Ho, Wo), bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        col, wm = ctx.saved_tensors
+        N, D, H, W, Cs, C, k, stride, pad = ctx.geom
+        cout, cin, Kp, cout_pad, couts, M, Do, Ho, Wo = ctx.shape
+        taps = k ** 3
+        dev = dy.device
+        dy = dy.contiguous().float()
+        ks = max(1, min(16, M // 4096))                          # row ranges of the contraction: partial matrices summed below
+        dw = torch.empty((ks, cout, Kp), dtype=torch.float32, device=dev)
+        _lib.check(L.ldm_op_gemm_wgrad_f32(dy.data_ptr(), couts, col.data_ptr(), Kp, dw.data_ptr(), cout, M, ks, _st()))
+        dw = dw.sum(0) if ks > 1 else dw[0]
+        gw = dw[:, :taps * C].reshape(cout, k, k, k, cin).permute(0, 4, 1, 2, 3).contiguous()
+        gb = dy.reshape(M, couts)[:, :cout].sum(0) if ctx.has_bias else None
+        gx = None
+        if ctx.needs_input_grad[0]:
+            # data gradient: dcol[M][Kp] = dy[M][couts] W[couts][Kp]: the same GEMM with the transposed weight matrix as its "weights"
+            kp_pad = _rup(Kp, 64)
+            wt = torch.zeros((kp_pad, couts), dtype=torch.float32, device=dev)
+            wt[:Kp, :min(couts, cout_pad)] = wm[:couts].t()
+            dcol = torch.empty((M, Kp), dtype=torch.float32, device=dev)
+            _lib.check(L.ldm_op_gemm_f32(dy.data_ptr(), couts, wt.data_ptr(), None, dcol.data_ptr(), M, Kp, kp_pad, Kp, _st()))
+            gx = torch.empty((N, D, H, W, Cs), dtype=torch.float32, device=dev)
+            _lib.check(L.ldm_op_col2im_f32(dcol.data_ptr(), gx.data_ptr(), N, D, H, W, Cs, C, k, stride, pad, Kp, _st()))
+        return gx, gw, gb, None
+
+
+class _InstanceNormLeakyFn32(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, C):
+        L = _lib.lib()
+        N, DHW = x.shape[0], x.shape[1] * x.shape[2] * x.shape[3]
+        dev = x.device
+        ones = torch.ones((C,), dtype=torch.float32, device=dev)
+        zeros = torch.zeros((C,), dtype=torch.float32, device=dev)
+        y = torch.empty_like(x)
+        scratch = torch.empty((L.ldm_op_group_norm_f32_scratch_bytes(N, C, DHW, C),), dtype=torch.uint8, device=dev)
+        _lib.check(L.ldm_op_group_norm_f32(x.data_ptr(), C, ones.data_ptr(), zeros.data_ptr(), C, 1e-5, 2, y.data_ptr(), N, DHW,
+                                           scratch.data_ptr(), scratch.numel(), _st()))
+        ctx.save_for_backward(x, ones, zeros)
+        ctx.C = C
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        x, ones, zeros = ctx.saved_tensors
+        C = ctx.C
+        N, DHW = x.shape[0], x.shape[1] * x.shape[2] * x.shape[3]
+        dev = x.device
+        dx = torch.empty_like(x)
+        dg, db = torch.empty((C,), dtype=torch.float32, device=dev), torch.empty((C,), dtype=torch.float32, device=dev)
+        scratch = torch.empty((L.ldm_op_group_norm_f32_scratch_bytes(N, C, DHW, C),), dtype=torch.uint8, device=dev)
+        _lib.check(L.ldm_op_group_norm_bwd_f32(dy.contiguous().float().data_ptr(), x.data_ptr(), C, ones.data_ptr(), zeros.data_ptr(), C, 1e-5, 2,
+                                               dx.data_ptr(), dg.data_ptr(), db.data_ptr(), N, DHW, scratch.data_ptr(), scratch.numel(), _st()))
+        return dx, None
+
+
+class _LeakyFn32(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        y = torch.empty_like(x)
+        _lib.check(_lib.lib().ldm_op_leaky_relu_f32(x.data_ptr(), y.data_ptr(), x.numel(), 0.2, _st()))
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        _lib.check(_lib.lib().ldm_op_leaky_relu_bwd_f32(x.data_ptr(), dy.contiguous().float().data_ptr(), dx.data_ptr(), x.numel(), 0.2, _st()))
+        return dx
+
+
+class _PackFn32(torch.autograd.Function):
+    """fp32 NCDHW -> fp32 NDHWC (channels padded to 16) and its adjoint."""
+
+    @staticmethod
+    def forward(ctx, x, Cs):
+        N, C = x.shape[:2]
+        DHW = x[0, 0].numel()
+        out = torch.empty((N, *x.shape[2:], Cs), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().ldm_op_pack_ncdhw_f32(x.contiguous().data_ptr(), out.data_ptr(), N, C, Cs, DHW, _st()))
+        ctx.meta = (N, C, Cs, DHW, tuple(x.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        N, C, Cs, DHW, shape = ctx.meta
+        out = torch.empty(shape, dtype=torch.float32, device=g.device)
+        _lib.check(_lib.lib().ldm_op_unpack_ndhwc_f32(g.contiguous().float().data_ptr(), out.data_ptr(), N, C, Cs, DHW, _st()))
+        return out, None
+
+
+class _UnpackFn32(torch.autograd.Function):
+    """fp32 NDHWC -> fp32 NCDHW (first C channels) and its adjoint."""
+
+    @staticmethod
+    def forward(ctx, a, C):
+        N, Cs = a.shape[0], a.shape[-1]
+        DHW = a.shape[1] * a.shape[2] * a.shape[3]
+        out = torch.empty((N, C, *a.shape[1:4]), dtype=torch.float32, device=a.device)
+        _lib.check(_lib.lib().ldm_op_unpack_ndhwc_f32(a.data_ptr(), out.data_ptr(), N, C, Cs, DHW, _st()))
+        ctx.meta = (N, C, Cs, DHW, tuple(a.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        N, C, Cs, DHW, shape = ctx.meta
+        out = torch.empty(shape, dtype=torch.float32, device=g.device)
+        _lib.check(_lib.lib().ldm_op_pack_ncdhw_f32(g.contiguous().float().data_ptr(), out.data_ptr(), N, C, Cs, DHW, _st()))
+        return out, None
+
+
 class _Conv(nn.Module):
     """``Convolution`` wrapper of MONAI: parameters live under ``.conv``."""
 
@@ -206,12 +352,21 @@ class PatchDiscriminator(nn.Module):
         if channels % 32:
             raise NotImplementedError("PatchDiscriminator: channels must be a multiple of 32")
         self.in_channels, self.out_channels, self.num_layers_d = in_channels, out_channels, num_layers_d
+        import os
+        self.precision = "fp32" if os.environ.get("LDM_PRECISION", "bf16").lower() == "fp32" else "bf16"
         self.add_module("initial_conv", _Conv(in_channels, channels, True))
         cin, cout = channels, channels * 2
         for l_ in range(num_layers_d):
             self.add_module(str(l_), _Conv(cin, cout, bias))
             cin, cout = cout, cout * 2
         self.add_module("final_conv", _Conv(cin, out_channels, True))
+
+    def set_precision(self, precision: str) -> "PatchDiscriminator":
+        """"bf16" (default) or "fp32": the reference's arithmetic when AMP is off (3d_ldm/train_autoencoder.py:150-158,454-494)."""
+        if precision not in ("bf16", "fp32"):
+            raise ValueError("precision must be 'bf16' or 'fp32'")
+        self.precision = precision
+        return self
 
     def forward(self, x: torch.Tensor) -> List[torch.Tensor]:
         if not x.is_cuda:
@@ -220,27 +375,30 @@ class PatchDiscriminator(nn.Module):
         if C != self.in_channels:
             raise ValueError(f"expected {self.in_channels} input channels, got {C}")
         outs = []
+        f32 = self.precision == "fp32"
+        Pack, Unpack, Conv, Leaky, Norm = ((_PackFn32, _UnpackFn32, _ConvFn32, _LeakyFn32, _InstanceNormLeakyFn32) if f32 else
+                                           (_PackFn, _UnpackFn, _ConvFn, _LeakyFn, _InstanceNormLeakyFn))
         with torch.cuda.device(x.device):
-            Cs = _rup(C, 32)
-            h = _PackFn.apply(x.float(), Cs)
+            Cs = _rup(C, 16 if f32 else 32)
+            h = Pack.apply(x.float(), Cs)
             geom = (N, D, H, W, Cs, C, 4, 2, 1)
             layer = self.initial_conv
-            h = _LeakyFn.apply(_ConvFn.apply(h, layer.conv.weight, layer.conv.bias, geom))
+            h = Leaky.apply(Conv.apply(h, layer.conv.weight, layer.conv.bias, geom))
             c = layer.conv.weight.shape[0]
             outs.append((h, c))
             for l_ in range(self.num_layers_d):
                 layer = getattr(self, str(l_))
                 stride = 1 if l_ == self.num_layers_d - 1 else 2
                 geom = (N, h.shape[1], h.shape[2], h.shape[3], h.shape[4], c, 4, stride, 1)
-                h = _ConvFn.apply(h, layer.conv.weight, layer.conv.bias, geom)
+                h = Conv.apply(h, layer.conv.weight, layer.conv.bias, geom)
                 c = layer.conv.weight.shape[0]
-                h = _InstanceNormLeakyFn.apply(h, c)
+                h = Norm.apply(h, c)
                 outs.append((h, c))
             layer = self.final_conv
             geom = (N, h.shape[1], h.shape[2], h.shape[3], h.shape[4], c, 4, 1, 1)
-            h = _ConvFn.apply(h, layer.conv.weight, layer.conv.bias, geom)
+            h = Conv.apply(h, layer.conv.weight, layer.conv.bias, geom)
             outs.append((h, self.out_channels))
-            return [_UnpackFn.apply(t, cc) for t, cc in outs]
+            return [Unpack.apply(t, cc) for t, cc in outs]
 
 
 class PatchAdversarialLoss(nn.Module):

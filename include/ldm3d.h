@@ -256,6 +256,27 @@ int ldm_op_leaky_relu(const void* x, void* y, int64_t n, float slope, void* stre
 int ldm_op_leaky_relu_bwd(const void* x, const void* dy, void* dx, int64_t n, float slope, void* stream);
 int ldm_op_pack_ncdhw(const float* x, void* out_bf16_ndhwc, int N, int C, int Cs, int64_t DHW, void* stream);
 int ldm_op_unpack_ndhwc(const void* act_bf16_ndhwc, float* out, int N, int C, int Cs, int64_t DHW, void* stream);
+/* The same PatchDiscriminator building blocks on fp32 NDHWC tensors: the reference trains the discriminator in fp32 when AMP is off
+ * (3d_ldm/train_autoencoder.py:150-158 construction, :454-494 discriminator step); `--precision fp32` selects them
+ * (ldm3d/discriminator.py).  Exact fp32 MFMA (csrc/f32_path.h, f32_train.h).  K / stored channels are multiples of 16, weight
+ * matrices have cout_pad % 64 == 0 rows (rows >= cout zero), bias cout_pad entries.
+ *   gemm_f32:        out[M][couts] = x[M][K] w[cout_pad][K]^T + bias          (couts % 4 == 0, cout <= couts <= cout_pad)
+ *   gemm_wgrad_f32:  dw[ksplit][cout][K] = partial sums over row ranges of dy[M][cdy]^T x[M][K]
+ *   group_norm_f32 / _bwd_f32: y = act(GroupNorm(x)) with act 0 none, 1 SiLU, 2 LeakyReLU(0.2) (InstanceNorm: groups = C), and its
+ *                    backward (dx, dgamma, dbeta summed over the batch); scratch from ldm_op_group_norm_f32_scratch_bytes. */
+int ldm_op_pack_ncdhw_f32(const float* x, float* out_f32_ndhwc, int N, int C, int Cs, int64_t DHW, void* stream);
+int ldm_op_unpack_ndhwc_f32(const float* act_f32_ndhwc, float* out, int N, int C, int Cs, int64_t DHW, void* stream);
+int ldm_op_im2col_f32(const float* x, float* col, int N, int D, int H, int W, int Cs, int C, int k, int stride, int pad, int Kp, void* stream);
+int ldm_op_col2im_f32(const float* dcol, float* dx, int N, int D, int H, int W, int Cs, int C, int k, int stride, int pad, int Kp, void* stream);
+int ldm_op_leaky_relu_f32(const float* x, float* y, int64_t n, float slope, void* stream);
+int ldm_op_leaky_relu_bwd_f32(const float* x, const float* dy, float* dx, int64_t n, float slope, void* stream);
+int ldm_op_gemm_f32(const float* x, int K, const float* w, const float* bias, float* out, int64_t M, int cout, int cout_pad, int couts, void* stream);
+int ldm_op_gemm_wgrad_f32(const float* dy, int cdy, const float* x, int K, float* dw, int cout, int64_t M, int ksplit, void* stream);
+size_t ldm_op_group_norm_f32_scratch_bytes(int N, int C, int DHW, int groups);
+int ldm_op_group_norm_f32(const float* x, int C, const float* gamma, const float* beta, int groups, float eps, int act, float* out,
+                          int N, int DHW, void* scratch, size_t scratch_bytes, void* stream);
+int ldm_op_group_norm_bwd_f32(const float* dy, const float* x, int C, const float* gamma, const float* beta, int groups, float eps, int act,
+                              float* dx, float* dgamma, float* dbeta, int N, int DHW, void* scratch, size_t scratch_bytes, void* stream);
 /* producer -> GroupNorm pair as the inference plans launch it (conv epilogue / write-through split-K finalize leave the statistics
  * slabs, one-launch GroupNorm(+SiLU) with write-through stores folds them): the per-kernel gate of exactly those kernel variants */
 size_t ldm_op_conv3d_gn_scratch_bytes(int N, int D, int H, int W, int cout_pad, int splitk);

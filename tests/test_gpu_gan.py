@@ -180,3 +180,39 @@ def test_perceptual_term_from_user_weights_reaches_the_autoencoder(cuda, tmp_pat
     assert not tr1.perceptual_dropped and not s1 and bool(torch.isfinite(out1["perceptual"])) and float(out1["perceptual"]) > 0
     assert torch.isfinite(g1).all() and not torch.equal(g0, g1)
     assert abs(float(out1["loss_g"]) - (float(out1["recons"]) + 1e-6 * float(out1["kl"]) + 0.5 * float(out1["perceptual"]))) <= 1e-5
+
+
+@pytest.mark.parametrize("dims,b,cin", [((32, 32, 32), 2, 1), ((48, 32, 40), 1, 2)])
+def test_patch_discriminator_fp32_mode_meets_the_reference_arithmetic(cuda, dims, b, cin):
+    """``PatchDiscriminator.set_precision("fp32")`` (``--precision fp32``): the reference trains the discriminator in fp32 when AMP is off
+    (3d_ldm/train_autoencoder.py:150-158,454-494).  Same checks as the bf16 test, against the fp32 oracle, at the 1e-3 parity bar of
+    BASELINE.json with no floor allowance: all five layer outputs, the generator-side gradient w.r.t. the input, the discriminator loss
+    and every parameter gradient of the discriminator step."""
+    from oracle import discriminator as od
+    d, sd = _pair(cuda, cin)
+    d.set_precision("fp32")
+    g = torch.Generator().manual_seed(3)
+    fake, real = torch.rand((b, cin, *dims), generator=g), torch.rand((b, cin, *dims), generator=g)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xf = fake.clone().requires_grad_(True)
+    o_outs = od.forward(leaves, xf)
+    od.lsgan(o_outs[-1], True).backward()
+    gx_ref = xf.grad.clone()
+    for v in leaves.values():
+        v.grad = None
+    loss_d_ref = 0.5 * (od.lsgan(od.forward(leaves, fake)[-1], False) + od.lsgan(od.forward(leaves, real)[-1], True))
+    loss_d_ref.backward()
+    xd = fake.to(cuda).requires_grad_(True)
+    outs = d(xd)
+    errs = [rel_l2(a.detach().cpu(), r.detach()) for a, r in zip(outs, o_outs)]
+    F.mse_loss(outs[-1], torch.ones_like(outs[-1])).backward()
+    e_gx = rel_l2(xd.grad.cpu(), gx_ref)
+    d.zero_grad(set_to_none=True)
+    loss_d = 0.5 * (torch.mean(d(fake.to(cuda))[-1] ** 2) + torch.mean((d(real.to(cuda))[-1] - 1.0) ** 2))
+    loss_d.backward()
+    torch.cuda.synchronize()
+    gerrs = {k: rel_l2(p.grad.cpu(), leaves[k].grad) for k, p in d.named_parameters()}
+    print("fp32 PatchDiscriminator vs fp32 oracle: layer outputs", " ".join(f"{e:.1e}" for e in errs), "| input gradient", f"{e_gx:.1e}",
+          "| parameter gradients", " ".join(f"{e:.1e}" for e in gerrs.values()))
+    assert max(errs) <= 1e-3 and e_gx <= 1e-3 and max(gerrs.values()) <= 1e-3
+    assert abs(float(loss_d) - float(loss_d_ref)) <= 1e-5 * abs(float(loss_d_ref))
