@@ -97,6 +97,11 @@ class LpipsSqueeze(torch.nn.Module):
         """LPIPS distance per image: [B, 1, 1, 1]."""
         if a.shape[1] == 1:
             a, b = a.repeat(1, 3, 1, 1), b.repeat(1, 3, 1, 1)
+        elif a.shape[1] != 3:
+            # neither grey nor RGB (the 2-channel images of config_train_16g.json): the network has 3 input channels, so the channels
+            # are scored one by one as grey images and averaged (what MONAI's ``channel_wise=True`` does; the reference's default
+            # ``channel_wise=False`` would fail on such an input)
+            return sum(self.forward(a[:, c:c + 1], b[:, c:c + 1]) for c in range(a.shape[1])) / a.shape[1]
         fa, fb = self._features((a - self.shift) / self.scale), self._features((b - self.shift) / self.scale)
         total = 0.0
         for k, (x, y) in enumerate(zip(fa, fb)):

@@ -157,7 +157,7 @@ def test_perceptual_term_from_user_weights_reaches_the_autoencoder(cuda, tmp_pat
     sd = {k: (torch.rand(s, generator=g) if k.startswith("lin") else 0.1 * torch.randn(s, generator=g)) for k, s in expected_keys().items()}
     path = str(tmp_path / "lpips_squeeze.pt")
     torch.save(sd, path)
-    cfg = cfgs.VAE_TINY
+    cfg = cfgs.VAE_TINY                                      # 2 image channels: scored channel by channel (perceptual.py)
     x = torch.rand((1, 2, 32, 32, 32), generator=g).to(cuda)
     eps = torch.randn((1, 8, 8, 8, 8), generator=g).to(cuda)
 
