@@ -194,24 +194,39 @@ def test_patch_discriminator_fp32_mode_meets_the_reference_arithmetic(cuda, dims
     g = torch.Generator().manual_seed(3)
     fake, real = torch.rand((b, cin, *dims), generator=g), torch.rand((b, cin, *dims), generator=g)
     leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xd = fake.to(cuda).requires_grad_(True)
+    outs = d(xd)
+    # LeakyReLU's derivative jumps at 0: the oracle takes, element by element, the side of the kink the HIP path took (an element
+    # whose normalised value is within rounding distance of 0 may legitimately fall on either side; one such element in a 64-voxel
+    # instance moves the whole instance's gradient by ~1e-2, seen at seed 0).  Values are compared WITHOUT that help first.
+    free = od.forward(sd, fake)
+    errs = [rel_l2(a.detach().cpu(), r) for a, r in zip(outs, free)]
+    br_f = [o.detach().cpu() > 0 for o in outs[:4]]
+    def other_side(ref_outs, br):                       # (count, largest |oracle activation| among them)
+        vals = [r[(r > 0) != m].abs() for r, m in zip(ref_outs[:4], br)]
+        return sum(v.numel() for v in vals), max([float(v.max()) for v in vals if v.numel()] or [0.0])
+    flips, flip_mag = other_side(free, br_f)
     xf = fake.clone().requires_grad_(True)
-    o_outs = od.forward(leaves, xf)
+    o_outs = od.forward(leaves, xf, branches=br_f)
     od.lsgan(o_outs[-1], True).backward()
     gx_ref = xf.grad.clone()
     for v in leaves.values():
         v.grad = None
-    loss_d_ref = 0.5 * (od.lsgan(od.forward(leaves, fake)[-1], False) + od.lsgan(od.forward(leaves, real)[-1], True))
-    loss_d_ref.backward()
-    xd = fake.to(cuda).requires_grad_(True)
-    outs = d(xd)
-    errs = [rel_l2(a.detach().cpu(), r.detach()) for a, r in zip(outs, o_outs)]
     F.mse_loss(outs[-1], torch.ones_like(outs[-1])).backward()
     e_gx = rel_l2(xd.grad.cpu(), gx_ref)
     d.zero_grad(set_to_none=True)
-    loss_d = 0.5 * (torch.mean(d(fake.to(cuda))[-1] ** 2) + torch.mean((d(real.to(cuda))[-1] - 1.0) ** 2))
+    of, orl = d(fake.to(cuda)), d(real.to(cuda))
+    loss_d = 0.5 * (torch.mean(of[-1] ** 2) + torch.mean((orl[-1] - 1.0) ** 2))
     loss_d.backward()
     torch.cuda.synchronize()
+    br_r = [o.detach().cpu() > 0 for o in orl[:4]]
+    more, mag2 = other_side(od.forward(sd, real), br_r)
+    flips, flip_mag = flips + more, max(flip_mag, mag2)
+    loss_d_ref = 0.5 * (od.lsgan(od.forward(leaves, fake, branches=br_f)[-1], False) + od.lsgan(od.forward(leaves, real, branches=br_r)[-1], True))
+    loss_d_ref.backward()
     gerrs = {k: rel_l2(p.grad.cpu(), leaves[k].grad) for k, p in d.named_parameters()}
+    print(f"activations on the other side of the LeakyReLU kink than the free-running oracle: {flips} (largest |value| {flip_mag:.1e})")
+    assert flips <= 8 and flip_mag <= 1e-5, "only elements within rounding distance of 0 may change sides"
     print("fp32 PatchDiscriminator vs fp32 oracle: layer outputs", " ".join(f"{e:.1e}" for e in errs), "| input gradient", f"{e_gx:.1e}",
           "| parameter gradients", " ".join(f"{e:.1e}" for e in gerrs.values()))
     assert max(errs) <= 1e-3 and e_gx <= 1e-3 and max(gerrs.values()) <= 1e-3
