@@ -362,6 +362,7 @@ struct Builder {
     // LDM_HALO_TALL: 0 = never, 1 = wherever the cost model prefers it, 2 (default) = only for Cout % 128 != 0
     static int tall_mode() { const char* e = getenv("LDM_HALO_TALL"); return e ? atoi(e) : 2; }
     static bool light_enabled() { const char* e = getenv("LDM_GEMM_LIGHT"); return e ? atoi(e) != 0 : true; }
+    static bool two_wg_enabled() { const char* e = getenv("LDM_IGEMM_2WG"); return e ? atoi(e) != 0 : true; }
     static bool phase_enabled() { const char* e = getenv("LDM_CONV_PHASE"); return e ? atoi(e) != 0 : true; }
     // halo_n > 0: the conv is eligible for conv3_halo_kernel (3^3, stride 1, pad 1, single source, BK 64); halo_n = N
     // and halo_dhw = voxels per sample (its 126-row tiles never straddle samples).
@@ -523,14 +524,21 @@ struct Builder {
             return out;
         }
         const int taps = phase ? 8 : a.k * a.k * a.k;
-        const int nchunk0 = cin0 / bk, nchunk1 = cin1 / bk;
-        const int steps0 = taps * nchunk0, steps1 = nchunk1;
         const bool halo_ok = a.k == 3 && a.stride == 1 && a.pad == 1 && a.ups == 0 && !a.exact && !a.xb.valid && !a.w1 &&
                              a.xa.D == a.Do && a.xa.H == a.Ho && a.xa.W == a.Wo;
+        int nchunk0 = cin0 / bk, nchunk1 = cin1 / bk;
+        int steps0 = taps * nchunk0, steps1 = nchunk1;
         ConvCfg cc = choose_cfg(M, w.cout_pad, steps0 + steps1, bk, halo_ok ? N : 0, (long)a.Do * a.Ho * a.Wo);
         const int bm = 64 * cc.wgm, bn = 64 * cc.wgn;
         const int couts = a.f32_out ? 0 : rup(w.cout, 32);
         const int mtiles_pp = (int)(((long)a.xa.D * a.xa.H * a.xa.W + bm - 1) / bm);      // phase mode: tiles per (sample, parity)
+        // Two workgroups per CU on the general kernel: with 32-channel K steps a 128-row tile runs on four waves and 78 KiB of LDS, so
+        // a CU holds two and one's prologue / epilogue sits under the other's K loop.  Measured on the 96^3 phase-upsample conv of the
+        // AutoencoderKL decoder (16 K steps per tile: fixed cost = half of a tile): 474 -> 328 us; 4 x 1 tiles (108 KiB) do not fit twice.
+        if (!cc.halo && cc.bk == 64 && cc.wgm <= 2 && cc.splitk == 1 && two_wg_enabled() &&
+            (phase ? (long)N * 8 * mtiles_pp : (M + bm - 1) / bm) * (w.cout_pad / bn) >= 512) {
+            cc.bk = 32; nchunk0 = cin0 / 32; nchunk1 = cin1 / 32; steps0 = taps * nchunk0; steps1 = nchunk1;
+        }
         Act out;
         if (!a.f32_out) {
             out = new_act(N, a.Do, a.Ho, a.Wo, couts);
