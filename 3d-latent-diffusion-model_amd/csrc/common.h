@@ -45,13 +45,16 @@ __device__ __forceinline__ float wave_sum(float v) {
 // instrumented kernel draws a ticket (= launch order) and records 100 MHz s_memrealtime stamps: [0] = kernel id, [1] = entry,
 // [1 + k] = KSTAMP(k).  Read back with ldm_debug_kstamps (tools/kstamps.py).  Compiled out of the product library.
 #ifdef LDM_KSTAMPS
+#ifndef LDM_KSTAMP_BLOCK
+#define LDM_KSTAMP_BLOCK 0        // which blockIdx.x records (a late block of a many-round grid shows the steady state, not the cold start)
+#endif
 __device__ unsigned long long g_kstamp[8192 * 8];
 __device__ unsigned g_kstamp_seq;
 struct KStamp {
     unsigned slot;
     __device__ __forceinline__ KStamp(int id) {
         slot = 0xffffffffu;
-        if ((blockIdx.x | blockIdx.y | blockIdx.z) == 0 && threadIdx.x == 0) {
+        if (blockIdx.x == LDM_KSTAMP_BLOCK && (blockIdx.y | blockIdx.z) == 0 && threadIdx.x == 0) {
             const unsigned long long t = __builtin_amdgcn_s_memrealtime();
             slot = atomicAdd(&g_kstamp_seq, 1u) & 8191u;
             g_kstamp[slot * 8] = (unsigned long long)id; g_kstamp[slot * 8 + 1] = t;

@@ -64,7 +64,9 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
     const int q_begin = split * p.q_per_split;
     int q_end = q_begin + p.q_per_split; if (q_end > Q) q_end = Q;
     const int nsteps = 3 * (q_end - q_begin);                  // K steps of this workgroup, relative index 0 .. nsteps-1
-    const unsigned cin2 = (unsigned)p.c0a * 2u;
+    const unsigned cin2 = (unsigned)p.c0a * 2u;                  // bytes per voxel row
+    const int x3n = p.x3_n;
+    const unsigned wrow2 = x3n ? (unsigned)x3n * 3u * (BK * 2) : cin2;   // bytes per weight row
     const int dbgflag = p.dbg;
 
     int* const tab = reinterpret_cast<int*>(smem + TOFF);          // (pair, LDS row) -> source voxel, built in the prologue
@@ -87,9 +89,9 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
         const unsigned b_kb = (unsigned)((pchunk ^ ((R >> 1) & 7)) * 16);
         const int q = R >> 6, nt = (R >> 4) & 3, i = R & 15;
         const int co = n0 + 64 * q + 16 * (i >> 2) + 4 * nt + (i & 3);      // see conv_igemm.h: lane ends up with 16 consecutive couts
-        b_vo[j] = (ABL & 32) ? 0xFFFFFFFFu : (unsigned)co * cin2 + b_kb;      // ABL 32: every copy out of range (zero fill, no memory traffic)
+        b_vo[j] = ((ABL & 32) || (dbgflag & 2)) ? 0xFFFFFFFFu : (unsigned)co * wrow2 + b_kb;     // ABL 32: every copy out of range (zero fill, no memory traffic)
     }
-    const unsigned wtap = (unsigned)p.CoutPad * cin2;          // bytes between two taps of the weight tensor
+    const unsigned wtap = (unsigned)p.CoutPad * wrow2;          // bytes between two taps of the weight tensor
     __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.x0a, 0, (int)((unsigned)(p.N * DHW) * cin2), 0x00020000);
     __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.w0, 0, (int)(27u * wtap), 0x00020000);
 
@@ -110,9 +112,10 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
     } while (0)
 #define HL_ISSUE_A() do {                                                                           \
         if (!(ABL & 4)) {                                                                           \
+            const int ac_ = (x3n && i_chunk >= x3n) ? i_chunk - x3n : i_chunk;     /* x3: hi, hi again, lo */ \
             _Pragma("unroll") for (int j = 0; j < PA; ++j)                                          \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr_t)(smem + AOFF + i_aslot + (wave * PA + j) * 1024), 16, a_vo[j], \
-                                                         (unsigned)i_chunk * (BK * 2), 0, 0);      \
+                                                         (unsigned)ac_ * (BK * 2), 0, 0);          \
         }                                                                                           \
     } while (0)
 #define HL_ISSUE(KW, BSLOT) do {                                                                    \
@@ -216,23 +219,39 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
     // ---- prologue.  The first macro step's copies are requested BEFORE the tap table exists (a lane works out the source voxels of
     //      its own PA rows for that one (kd, kh) pair by itself), so that their round trip to memory (cold: the weights come from HBM,
     //      the voxels from another XCD's write-back) overlaps the table's integer divisions and its barrier.
-    auto src_voxel = [&](const int pr, const int j) -> int {   // LDS row j holds the voxel under tap (kd, kh, kw = 1) of output l0 - 1 + j
+    //      Integer divisions are the expensive part (~40 instructions each): a lane decomposes an output voxel ONCE and derives the
+    //      source voxel of any (kd, kh) pair from it with adds and compares.
+    auto decompose = [&](const int j, int& od, int& oh, int& ow) -> bool {   // LDS row j <-> output voxel l0 - 1 + j (kw = 1 tap)
         const int l = l0 - 1 + j;
+        if (l < 0 || l >= DHW) return false;
+        od = l / HW; const int r = l - od * HW; oh = r / p.Wout; ow = r - oh * p.Wout;
+        return true;
+    };
+    auto src_of = [&](const bool ok, const int od, const int oh, const int ow, const int pr) -> int {
+        const int id = od + pr / 3 - 1, ih = oh + pr % 3 - 1;
         int v = -1;
-        if (l >= 0 && l < DHW) {
-            const int od = l / HW, r = l - od * HW, oh = r / p.Wout, ow = r - oh * p.Wout;
-            const int id = od + pr / 3 - 1, ih = oh + pr % 3 - 1;
-            if ((unsigned)id < (unsigned)p.Din && (unsigned)ih < (unsigned)p.Hin) v = smp * DHW + (id * p.Hin + ih) * p.Win + ow;
+        if (ok && (unsigned)id < (unsigned)p.Din && (unsigned)ih < (unsigned)p.Hin) {
+            v = smp * DHW + (id * p.Hin + ih) * p.Win + ow;
+            if (dbgflag & 1) v &= 1023;                            // timing experiment: every voxel copy hits the same 1024 rows (L2 resident)
         }
         return v;
     };
+    HL_ISSUE_W(0, 0); HL_ISSUE_W(1, 1); HL_ISSUE_W(2, 2);      // the weight tiles need no voxel arithmetic: on their way first
 #pragma unroll
     for (int j = 0; j < PA; ++j) {
-        const int v_ = src_voxel(i_pair, a_row[j]);
+        int od = 0, oh = 0, ow = 0;
+        const bool ok = decompose(a_row[j], od, oh, ow);
+        const int v_ = src_of(ok, od, oh, ow, i_pair);
         a_vo[j] = (v_ >= 0 && !(ABL & 32)) ? (unsigned)v_ * cin2 + a_kb[j] : 0xFFFFFFFFu;
     }
-    HL_ISSUE(0, 0); HL_ISSUE(1, 1); HL_ISSUE(2, 2);            // issue order from here on as in the steady state: w0 a0 w1 w2 | w3 a3 w4 w5
-    for (int e = tid; e < 9 * BM; e += 512) tab[e] = src_voxel(e / BM, e % BM);
+    HL_ISSUE_A(); i_s += 3;                                    // issue order of the first macro step: w0 w1 w2 a0; from the next on w a w w
+    {
+        constexpr int NPART = 512 / BM;                        // lanes per LDS row: each takes every NPART-th (kd, kh) pair
+        const int row = tid % BM, part = tid / BM;
+        int od = 0, oh = 0, ow = 0;
+        const bool ok = decompose(row, od, oh, ow);
+        for (int pr = part; pr < 9; pr += NPART) tab[pr * BM + row] = src_of(ok, od, oh, ow, pr);
+    }
     // table complete.  A raw barrier behind an LDS-only wait: __syncthreads() would drain vmcnt(0) and with it the copies in flight
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -241,7 +260,7 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
     HL_STAMP(0);
     if (nsteps >= 6) {
         HL_ADVANCE(); HL_ISSUE(0, 3); HL_ISSUE(1, 4); HL_ISSUE(2, 5);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * PB + PA) : "memory");      // step 0 landed; steps 1..5 = 5 weight tiles + one voxel tile in flight
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PB + PA) : "memory");      // steps 0..2 landed (w0 w1 w2 a0 went first); steps 3..5 = 3 weight tiles + one voxel tile in flight
     } else {                                                   // a single macro step in this K range
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -305,7 +324,8 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
     // The epilogue's operands (bias, time-embedding row, residual rows) are requested HERE, in front of the exchange: they are one more
     // round trip to memory nobody has touched in this launch, which the K-group exchange and its two barriers then hide
     const int cbase = n0 + wn * 64 + 16 * fg;
-    const bool fused_ep = p.splitk == 1;
+    const bool to_slab = p.splitk > 1 || p.raw_partial;
+    const bool fused_ep = !to_slab;
     float4 ebias[4], etemb[4]; u32x4 eres[2][2];
 #pragma unroll
     for (int q = 0; q < 4; ++q) { ebias[q] = make_float4(0.f, 0.f, 0.f, 0.f); etemb[q] = ebias[q]; }
@@ -363,7 +383,7 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
     // ---- epilogue (conv_igemm.h's, with the 126-row tile mapping).  After the exchange this wave owns the 32-row block
     //      rows [64 wm + 32 grp, +32) of the tile = 16-row tiles mt_base + {0, 1}; GroupNorm partials of the whole tile go to slab
     //      row `mtile` (bitwise reproducible: no atomics).
-    const bool do_stats = (p.stats != nullptr) && (p.splitk == 1) && (p.out != nullptr);
+    const bool do_stats = (p.stats != nullptr) && !to_slab && (p.out != nullptr);
     float ssum[16], ssq[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) { ssum[q] = 0.f; ssq[q] = 0.f; }
@@ -377,7 +397,7 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[nt * 4 + r] = (grp == 0) ? acc[nt][ml][r] : acc[nt][2 + ml][r];
-        if (p.splitk > 1) {
+        if (to_slab) {
             float* dst = p.partial + ((size_t)split * p.M + m) * p.CoutPad + cbase;
 #pragma unroll
             for (int q = 0; q < 4; ++q)

@@ -50,6 +50,11 @@ struct ConvParams {
     // the same source voxel pre-summed (phase_weights_kernel).  Tiles are [sample][parity][mtiles_pp] over the source voxels;
     // M, partial slabs, stats and the output rows stay in output order.
     int phase_mode, mtiles_pp;
+    // conv3_halo_kernel as the fp32 precision mode's 3 x bf16 product (x3_n > 0 = 64-channel chunks of the REAL Cin): the voxel operand
+    // is [rows][hi | lo] bf16 (2 x3_n chunks per row), the weights [tap][cout][hi | lo | hi] (3 x3_n chunks); K chunk c reads voxel
+    // chunk c (c < x3_n: hi), c - x3_n (hi again) or c - x3_n (c >= 2 x3_n: lo) against weight chunk c:  hi*Whi + hi*Wlo + lo*Whi.
+    int x3_n;
+    int raw_partial;                  // write the fp32 accumulators to the partial slab even with splitk == 1 (the fp32 finalize follows)
     // epilogue (splitk == 1) ------------------------------------------------------------
     const float* bias;                // [CoutPad] or null
     const float* bias2;               // [CoutPad] or null (bias of the fused 1x1 skip)

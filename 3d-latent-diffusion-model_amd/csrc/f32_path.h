@@ -412,6 +412,7 @@ __global__ __launch_bounds__(256) void gn_apply_f32_kernel(const Gn32Params p) {
 struct Gn32FusedParams {
     const float* xa; const float* xb; int ca, cb, DHW, N, nslab, groups, silu, rows_per_block; float eps;
     const float* partial; const float* gamma; const float* beta; float* out;
+    bf16_t* out_hl;                    // instead of `out`: [rows][hi(C) | lo(C)] bf16, y = hi + lo to ~2^-17 (the voxel operand of the 3 x bf16 halo conv)
 };
 __global__ __launch_bounds__(256) void gn32_fold_apply_kernel(const Gn32FusedParams p) {
     __shared__ __attribute__((aligned(16))) float part[8][96][4];
@@ -457,7 +458,23 @@ __global__ __launch_bounds__(256) void gn32_fold_apply_kernel(const Gn32FusedPar
         else if (p.silu == 2) {                           // LeakyReLU(0.2) (InstanceNorm + LeakyReLU of the PatchDiscriminator)
             y.x = y.x > 0.f ? y.x : 0.2f * y.x; y.y = y.y > 0.f ? y.y : 0.2f * y.y; y.z = y.z > 0.f ? y.z : 0.2f * y.z; y.w = y.w > 0.f ? y.w : 0.2f * y.w;
         }
+        if (p.out_hl) {
+            uint2 hi, lo; split_bf16x4(y, hi, lo);
+            *reinterpret_cast<uint2*>(p.out_hl + row * (2 * C) + c) = hi;
+            *reinterpret_cast<uint2*>(p.out_hl + row * (2 * C) + C + c) = lo;
+        } else
         *reinterpret_cast<float4*>(p.out + row * C + c) = y;
+    }
+}
+
+// Weights of the 3 x bf16 halo conv (ConvParams::x3_n): fp32 [taps * cout_pad][cin] -> bf16 [taps * cout_pad][hi(cin) | lo(cin) | hi(cin)]
+__global__ __launch_bounds__(256) void x3_weights_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, long rows, int cin) {
+    const long total = rows * (cin / 4);
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long r = e / (cin / 4); const int c = (int)(e - r * (cin / 4)) * 4;
+        uint2 hi, lo; split_bf16x4(*reinterpret_cast<const float4*>(w + r * cin + c), hi, lo);
+        bf16_t* dst = out + r * (3 * cin) + c;
+        *reinterpret_cast<uint2*>(dst) = hi; *reinterpret_cast<uint2*>(dst + cin) = lo; *reinterpret_cast<uint2*>(dst + 2 * cin) = hi;
     }
 }
 

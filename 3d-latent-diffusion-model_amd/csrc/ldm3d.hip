@@ -69,6 +69,7 @@ struct Act {                                         // NDHWC bf16 activation li
     size_t stats_off = 0; bool has_stats = false;   // GroupNorm partials [blocks][C][2] written by the producer
     int stats_nrb = 0;                               // blocks per sample (0: one per 32 rows of the whole tensor)
     int esz = 2;                                     // bytes per element: 2 = bf16, 4 = fp32 (LDM_PREC_FP32 plans)
+    bool hl = false;                                 // fp32 plans: the tensor is stored as [rows][hi(C) | lo(C)] bf16 (same bytes), for the 3 x bf16 halo conv
     size_t cs_off = 0; int cs_rows = 0;              // gradient tensors: column-sum partials [N][cs_rows][C][2] left by the GroupNorm backward that wrote it
     size_t bytes() const { return (size_t)N * D * H * W * C * esz; }
     long rows() const { return (long)N * D * H * W; }
@@ -173,7 +174,8 @@ struct ParamDesc {
 };
 
 struct ConvW { size_t w_off = 0; size_t b_off = 0; int cout = 0, cout_pad = 0, cin_s = 0, k = 1; bool has = false;
-               size_t wp_off = 0; };                 // upsample convs: the derived phase weights [8][8][cout_pad][cin_s] (0 = none)
+               size_t wp_off = 0;                    // upsample convs: the derived phase weights [8][8][cout_pad][cin_s] (0 = none)
+               size_t x3_off = (size_t)-1; };        // fp32 precision: [27][cout_pad][hi | lo | hi] bf16 behind the fp32 arena ((size_t)-1 = none)
 struct GnW { size_t g_off = 0, b_off = 0; int C = 0; };
 struct LinW { size_t w_off = 0, b_off = 0; int in = 0, out = 0; };
 
@@ -219,6 +221,10 @@ struct ldm_model {
     // call after any parameter upload
     struct PhaseW { size_t w_off, wp_off; int cout_pad, cin_s; };
     std::vector<PhaseW> phase_ws; bool derived_dirty = true;
+    // fp32 precision: bf16 (hi | lo | hi) weights of the 3^3 convs for the 3 x bf16 halo conv, derived from the fp32 arena; they live
+    // behind it (arena32 = [2 * arena_bytes fp32 twins][x3_bytes])
+    struct X3W { size_t w_off, x3_off; long rows; int cin_s; };
+    std::vector<X3W> x3_ws; size_t x3_bytes = 0;
     struct Im2colW { size_t w_off, wi_off; int cout_pad, cin_s, cin, Kp; };     // first convs run as im2col + GEMM (inference plans)
     std::vector<Im2colW> im2col_ws;
     static int im2col_k(int cin) { const int k = 27 * cin; return k <= 96 ? rup(k, 32) : rup(k, 128); }
@@ -263,6 +269,10 @@ struct ldm_model {
         if (phase && k == 3) {
             c.wp_off = arena_alloc((size_t)64 * c.cout_pad * cin_s * 2);
             phase_ws.push_back(PhaseW{c.w_off, c.wp_off, c.cout_pad, cin_s});
+        }
+        if (k == 3 && cin_s % 64 == 0) {
+            c.x3_off = x3_bytes; x3_bytes += rup_sz((size_t)27 * c.cout_pad * 3 * cin_s * 2, 256);
+            x3_ws.push_back(X3W{c.w_off, c.x3_off, 27L * c.cout_pad, cin_s});
         }
         reg_conv_into(name, c, cin, cout, k, 0, false);
         convs[name] = c;
@@ -366,11 +376,11 @@ struct Builder {
     static bool phase_enabled() { const char* e = getenv("LDM_CONV_PHASE"); return e ? atoi(e) != 0 : true; }
     // halo_n > 0: the conv is eligible for conv3_halo_kernel (3^3, stride 1, pad 1, single source, BK 64); halo_n = N
     // and halo_dhw = voxels per sample (its 126-row tiles never straddle samples).
-    static ConvCfg choose_cfg(long M, int cout_pad, int steps, int bk, int halo_n = 0, long halo_dhw = 0) {
+    static ConvCfg choose_cfg(long M, int cout_pad, int steps, int bk, int halo_n = 0, long halo_dhw = 0, bool halo_only = false) {
         ConvCfg best{2, 2, bk, 1}; double best_t = 1e30;
         const int rb = bk * 2;
         static const int splits[] = {1, 2, 3, 4, 6, 8, 9, 12, 16, 18, 24, 27, 32, 48, 64};
-        for (int wgn = 1; wgn <= 4; wgn *= 2) {
+        for (int wgn = 1; wgn <= 4 && !halo_only; wgn *= 2) {
             const int bn = 64 * wgn, bm = 64 * (4 / wgn);
             if (cout_pad % bn) continue;
             const long tiles = ((M + bm - 1) / bm) * (cout_pad / bn);
@@ -434,6 +444,34 @@ struct Builder {
         const int N = a.xa.N;
         const long M = (long)N * a.Do * a.Ho * a.Wo;
         if (M >= (1L << 31)) { err = "conv " + tag + ": M too large"; return Act(); }
+        if (a.xa.hl) {                                   // 3 x bf16 product on conv3_halo_kernel (x3_halo_ok decided it when the GroupNorm was planned)
+            const int C = a.xa.C, n3 = C / 64;
+            if (a.k != 3 || a.stride != 1 || a.pad != 1 || a.ups || a.exact || a.xb.valid || a.f32_out || a.w_over.base != BASE_NULL ||
+                w.x3_off == (size_t)-1 || C != w.cin_s || a.xa.D != a.Do || a.xa.H != a.Ho || a.xa.W != a.Wo || (long)M * C * 4 >= (1L << 32)) {
+                err = "conv " + tag + ": hi/lo input reached a conv that cannot take it"; return Act();
+            }
+            ConvCfg cc = choose_cfg(M, w.cout_pad, 27 * 3 * n3, 64, N, (long)a.Do * a.Ho * a.Wo, true);
+            if (!cc.halo) { err = "conv " + tag + ": no halo configuration"; return Act(); }
+            const int couts = rup(w.cout, 32);
+            Act out = new_act(N, a.Do, a.Ho, a.Wo, couts);
+            Op op{}; op.kind = OP_CONV; op.cc = cc;
+            op.r[0] = ws_ref(a.xa.off); op.r[2] = Ref{BASE_W32, 2 * m->arena_bytes + w.x3_off};
+            int* i = op.i;
+            i[0] = 2 * C; i[4] = N; i[5] = a.xa.D; i[6] = a.xa.H; i[7] = a.xa.W; i[8] = a.Do; i[9] = a.Ho; i[10] = a.Wo;
+            i[11] = 3; i[12] = 1; i[13] = 1; i[14] = 8; i[15] = (int)M; i[16] = couts; i[17] = w.cout_pad; i[18] = w.cout;
+            i[19] = 3 * n3; i[23] = N * cc.mtps;
+            partial_bytes = std::max(partial_bytes, (size_t)cc.splitk * M * w.cout_pad * 4);
+            partial_fixups.push_back(plan->ops.size()); plan->ops.push_back(op);
+            Op f{}; f.kind = OP_FIN32; f.cc = ConvCfg{2, 2, 32, cc.splitk};
+            f.r[2] = w32_ref(w.w_off); f.r[6] = a.no_bias ? Ref() : w_ref(w.b_off);
+            f.r[8] = a.temb; f.r[9] = a.residual.valid ? ws_ref(a.residual.off) : Ref(); f.r[10] = ws_ref(out.off);
+            int* j = f.i;
+            j[0] = C; j[4] = N; j[5] = a.xa.D; j[6] = a.xa.H; j[7] = a.xa.W; j[8] = a.Do; j[9] = a.Ho; j[10] = a.Wo;
+            j[11] = 3; j[12] = 1; j[13] = 1; j[15] = (int)M; j[16] = couts; j[17] = w.cout_pad; j[18] = w.cout;
+            j[19] = C / 32; j[20] = w.cout_pad / 128 ? w.cout_pad / 128 : 1; j[21] = a.temb_stride; j[23] = (int)((M + 127) / 128);
+            partial_fixups.push_back(plan->ops.size()); plan->ops.push_back(f);
+            return out;
+        }
         // 3 x bf16 form of the product (conv_x3_kernel, K steps of 32 channels) in the INFERENCE plans wherever the channel counts allow:
         // ~5e-6 per block, 5e-5 end to end (gate 1e-3).  Training plans keep the exact fp32 MFMA: at unit weight gain the backward of
         // these networks amplifies a 1e-5 perturbation to 1e-3 of the gradient (measured), which is the whole parity budget.
@@ -591,7 +629,19 @@ struct Builder {
     }
 
     // ---- GroupNorm (+SiLU) over (xa | xb) -> contiguous bf16 --------------------------------------------
-    Act gn_apply(const GnW& g, const Act& xa, const Act& xb, int groups, float eps, bool silu) {
+    // fp32 inference plans: LDM_X3_HALO (default 1) runs the 3^3 stride-1 convs behind a GroupNorm with >= LDM_X3_HALO_ROWS (default 1) output rows
+    // as conv3_halo_kernel on the bf16 (hi | lo) split of the normalised tensor (ConvParams::x3_n): the GroupNorm writes the split
+    // instead of fp32 values (same bytes), the conv leaves fp32 slabs, finalize_f32_kernel applies the epilogue.  Measured at 24^3:
+    // 256 -> 256 channels 250 -> 160 us, 512 -> 256 493 -> 297 us (conv_x3_kernel splits every operand on its way into LDS, in every tile).
+    static bool x3_halo_ok(const ConvW& w, long rows, int C) {
+        static const int on = [] { const char* e = getenv("LDM_X3_HALO"); return e ? atoi(e) : 1; }();
+        static const long min_rows = [] { const char* e = getenv("LDM_X3_HALO_ROWS"); return e ? atol(e) : 1L; }();
+        static const int f32_x3 = [] { const char* e = getenv("LDM_F32_X3"); return e ? atoi(e) : 1; }();
+        return on && f32_x3 != 0 && halo_enabled() && w.k == 3 && w.x3_off != (size_t)-1 && C == w.cin_s && C % 64 == 0 && rows >= min_rows &&
+               rows * C * 4 < (1L << 32);                  // the halo kernel addresses its voxel operand with 32-bit byte offsets
+    }
+    // next3: the 3^3 stride-1 pad-1 convolution that is the ONLY reader of the result (resblock), or null
+    Act gn_apply(const GnW& g, const Act& xa, const Act& xb, int groups, float eps, bool silu, const ConvW* next3 = nullptr) {
         const int C = xa.C + (xb.valid ? xb.C : 0);
         if (C != g.C || C % 8 || (C / groups) * groups != C || xa.C % 8) { err = "groupnorm: channel mismatch"; return Act(); }
         const int DHW = xa.D * xa.H * xa.W, N = xa.N;
@@ -649,6 +699,7 @@ struct Builder {
             gnpart_fixups.push_back(plan->ops.size()); plan->ops.push_back(st);
             if (fold32) {
                 Act out = new_act(N, xa.D, xa.H, xa.W, C);
+                out.hl = next3 && x3_halo_ok(*next3, (long)N * DHW, C);
                 const int slices = (C + 63) / 64;
                 int chunks = std::max(1, std::min(256 / (slices * N), (DHW + 15) / 16));
                 const int rpb = rup((DHW + chunks - 1) / chunks, 16);
@@ -657,7 +708,7 @@ struct Builder {
                 ap.r[0] = ws_ref(xa.off); ap.r[1] = xb.valid ? ws_ref(xb.off) : Ref(); ap.r[3] = ws_ref(out.off);
                 ap.r[6] = w_ref(g.g_off); ap.r[7] = w_ref(g.b_off);
                 ap.i[0] = xa.C; ap.i[1] = xb.valid ? xb.C : 0; ap.i[2] = DHW; ap.i[3] = N; ap.i[4] = silu ? 1 : 0;
-                ap.i[5] = nslab; ap.i[6] = groups; ap.i[7] = rpb; ap.i[8] = chunks; ap.f[0] = eps;
+                ap.i[5] = nslab; ap.i[6] = groups; ap.i[7] = rpb; ap.i[8] = chunks; ap.i[9] = out.hl ? 1 : 0; ap.f[0] = eps;
                 gnpart_fixups.push_back(plan->ops.size()); plan->ops.push_back(ap);
                 return out;
             }
@@ -719,7 +770,7 @@ struct Builder {
             sk = conv(cs, p + skip_name);
             if (!sk.valid) return Act();
         }
-        Act h0 = gn_apply(m->gns.at(p + ".norm1"), xa, xb, groups, eps, true);
+        Act h0 = gn_apply(m->gns.at(p + ".norm1"), xa, xb, groups, eps, true, &m->convs.at(p + ".conv1"));
         if (!h0.valid) return Act();
         ConvArgs c1; c1.xa = h0; c1.w = &m->convs.at(p + ".conv1"); c1.Do = xa.D; c1.Ho = xa.H; c1.Wo = xa.W;
         if (with_temb) {
@@ -729,7 +780,7 @@ struct Builder {
         Act h1 = conv(c1, p + ".conv1");
         free_act(h0);
         if (!h1.valid) return Act();
-        Act h2 = gn_apply(m->gns.at(p + ".norm2"), h1, Act(), groups, eps, true);
+        Act h2 = gn_apply(m->gns.at(p + ".norm2"), h1, Act(), groups, eps, true, &m->convs.at(p + ".conv2"));
         free_act(h1);
         if (!h2.valid) return Act();
         ConvArgs c2; c2.xa = h2; c2.w = &m->convs.at(p + ".conv2"); c2.Do = xa.D; c2.Ho = xa.H; c2.Wo = xa.W;
@@ -1848,7 +1899,8 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                 } else if (i[5] > 0) {       // statistics fold + apply in one launch (inference plans)
                     Gn32FusedParams q{}; q.xa = p.xa; q.xb = p.xb; q.ca = p.ca; q.cb = p.cb; q.DHW = i[2]; q.N = i[3]; q.silu = i[4];
                     q.nslab = i[5]; q.groups = i[6]; q.rows_per_block = i[7]; q.eps = o.f[0]; q.partial = (const float*)rp(bs, o.r[4]);
-                    q.gamma = (const float*)rp(bs, o.r[6]); q.beta = (const float*)rp(bs, o.r[7]); q.out = (float*)rp(bs, o.r[3]);
+                    q.gamma = (const float*)rp(bs, o.r[6]); q.beta = (const float*)rp(bs, o.r[7]);
+                    if (i[9]) q.out_hl = (bf16_t*)rp(bs, o.r[3]); else q.out = (float*)rp(bs, o.r[3]);
                     hipLaunchKernelGGL(gn32_fold_apply_kernel, dim3(i[8], (p.ca + p.cb + 63) / 64, i[3]), dim3(256), 0, s, q);
                 } else {
                     p.DHW = i[2]; p.N = i[3]; p.silu = i[4]; p.ab = (const float*)rp(bs, o.r[5]); p.out = (float*)rp(bs, o.r[3]);
@@ -1889,6 +1941,7 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                 p.N = i[4]; p.Din = i[5]; p.Hin = i[6]; p.Win = i[7]; p.Dout = i[8]; p.Hout = i[9]; p.Wout = i[10];
                 p.ksize = i[11]; p.stride = i[12]; p.pad = i[13]; p.ups = i[14] & 1; p.exact = (i[14] >> 1) & 1; p.M = i[15];
                 p.phase_mode = (i[14] >> 2) & 1; p.mtiles_pp = p.phase_mode ? i[23] / (8 * i[4]) : 0;
+                if (i[14] & 8) { p.x3_n = i[19] / 3; p.raw_partial = 1; }      // fp32 precision: 3 x bf16 product on the halo kernel
                 p.CoutS = i[16]; p.CoutPad = i[17]; p.CoutReal = i[18]; p.nchunk0 = i[19]; p.nchunk1 = i[20];
                 p.steps0 = i[11] * i[11] * i[11] * i[19]; p.steps1 = i[20];
                 p.splitk = o.cc.splitk; p.steps_per_split = (p.steps0 + p.steps1 + p.splitk - 1) / p.splitk;
@@ -2229,8 +2282,8 @@ static int ensure_arena(ldm_model* m) {
 
 static int ensure_arena32(ldm_model* m) {
     if (m->arena32) return 0;
-    HIP_TRY(hipMalloc((void**)&m->arena32, 2 * m->arena_bytes));
-    HIP_TRY(hipMemset(m->arena32, 0, 2 * m->arena_bytes));
+    HIP_TRY(hipMalloc((void**)&m->arena32, 2 * m->arena_bytes + m->x3_bytes));
+    HIP_TRY(hipMemset(m->arena32, 0, 2 * m->arena_bytes + m->x3_bytes));
     HIP_TRY(hipDeviceSynchronize());
     return 0;
 }
@@ -2303,6 +2356,10 @@ static int ensure_derived(ldm_model* m, hipStream_t s) {
         hipLaunchKernelGGL(phase_weights_kernel, dim3((unsigned)((vecs + 255) / 256), 64), dim3(256), 0, s,
                            (const bf16_t*)(m->arena + pw.w_off), (bf16_t*)(m->arena + pw.wp_off), pw.cout_pad, pw.cin_s);
     }
+    if (m->precision == 1 && m->arena32)
+        for (const auto& xw : m->x3_ws)
+            hipLaunchKernelGGL(x3_weights_kernel, dim3(grid_for(xw.rows * (xw.cin_s / 4), 256, 2048)), dim3(256), 0, s,
+                               (const float*)(m->arena32 + 2 * xw.w_off), (bf16_t*)(m->arena32 + 2 * m->arena_bytes + xw.x3_off), xw.rows, xw.cin_s);
     HIP_TRY(hipGetLastError());
     m->derived_dirty = false;
     return 0;

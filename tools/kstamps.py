@@ -21,6 +21,11 @@ NAMES = {1: "sinusoid", 2: "gemv", 3: "gn_fused", 4: "finalize", 5: "gemm_light"
 
 
 def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--what", default="unet", choices=["unet", "enc", "dec"], help="the headline step, or the VAE encode / decode at 96^3 "
+                    "(build with EXTRA='-DLDM_KSTAMPS -DLDM_KSTAMP_BLOCK=2000' to see a steady-state tile of the 96^3 convolutions)")
+    args = ap.parse_args()
     import torch
     import bench
     import cfgs
@@ -28,21 +33,33 @@ def main():
     from ldm3d.schedulers import DDPMScheduler
     dev = torch.device("cuda:0")
     L = _lib.lib()
-    unet = bench.make_unet(dev, seed=0)
-    unet.enable_graph_replay(True)
-    sch = DDPMScheduler(**cfgs.SCHED)
-    x = torch.randn((1, 4, 24, 24, 24), device=dev)
-    tbuf = torch.empty((1,), dtype=torch.float32, device=dev)
-    sampler = sch.device_sampler(seed=1)
-    sampler.reset(tbuf)
+    if args.what == "unet":
+        unet = bench.make_unet(dev, seed=0)
+        unet.enable_graph_replay(True)
+        sch = DDPMScheduler(**cfgs.SCHED)
+        x = torch.randn((1, 4, 24, 24, 24), device=dev)
+        tbuf = torch.empty((1,), dtype=torch.float32, device=dev)
+        sampler = sch.device_sampler(seed=1)
+        sampler.reset(tbuf)
+        run = lambda: unet.denoise_step(x, tbuf, sampler)
+    else:
+        from ldm3d.networks import AutoencoderKL
+        vae = AutoencoderKL(**cfgs.VAE_FULL)
+        with torch.no_grad():
+            for p in vae.parameters():
+                if p.dim() > 1:
+                    p.normal_(0.0, 0.02)
+        vae = vae.to(dev).eval()
+        img, lat = torch.rand((1, 1, 96, 96, 96), device=dev), torch.randn((1, 4, 24, 24, 24), device=dev)
+        run = (lambda: vae.encode(img)) if args.what == "enc" else (lambda: vae.decode(lat))
     with torch.no_grad():
-        for _ in range(30):
-            unet.denoise_step(x, tbuf, sampler)
+        for _ in range(30 if args.what == "unet" else 5):
+            run()
         torch.cuda.synchronize()
         buf = (C.c_uint64 * (8192 * 8))()
         L.ldm_debug_kstamps(buf, 8192, 1)                    # clear
         for _ in range(3):
-            unet.denoise_step(x, tbuf, sampler)
+            run()
         torch.cuda.synchronize()
     n = L.ldm_debug_kstamps(buf, 8192, 1)
     if n <= 0:
