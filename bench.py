@@ -353,8 +353,9 @@ def main():
             d32 = time.perf_counter() - t32
             fp32_leg = {"steps_per_s": n32 / d32, "ms_per_step": d32 / n32 * 1e3, "steps": n32,
                         "unet_step_tflops": UNET_STEP_GFLOP / (d32 / n32 * 1e3),
-                        "what": "set_precision('fp32'): fp32 activations / weights; convolutions as 3 x bf16 MFMA (every fp32 operand split into "
-                                "hi + lo bf16 on its way into LDS, hi*hi + hi*lo + lo*hi accumulated in fp32: csrc/f32_path.h conv_x3_kernel), "
+                        "what": "set_precision('fp32'): fp32 activations / weights; convolutions as 3 x bf16 MFMA (fp32 operands split into "
+                                "hi + lo bf16, hi*hi + hi*lo + lo*hi accumulated in fp32: the 3^3 convs of the ResBlocks on conv3_halo_kernel over "
+                                "the split the GroupNorm in front wrote, the rest on csrc/f32_path.h conv_x3_kernel), "
                                 "attention / GroupNorm / linears in fp32; same step, same graph replay; rel-L2 vs the fp32 CPU oracle ~5e-5 "
                                 "(bf16 path: ~3e-2; LDM_F32_X3=0 = exact fp32 MFMA everywhere: ~1e-5 at 84 steps/s)"}
             unet.set_precision("bf16")
