@@ -573,7 +573,8 @@ struct Builder {
         // Two workgroups per CU on the general kernel: with 32-channel K steps a 128-row tile runs on four waves and 78 KiB of LDS, so
         // a CU holds two and one's prologue / epilogue sits under the other's K loop.  Measured on the 96^3 phase-upsample conv of the
         // AutoencoderKL decoder (16 K steps per tile: fixed cost = half of a tile): 474 -> 328 us; 4 x 1 tiles (108 KiB) do not fit twice.
-        if (!cc.halo && cc.bk == 64 && cc.wgm <= 2 && cc.splitk == 1 && two_wg_enabled() &&
+        // Short K loops only (<= 64 steps of 64 channels): the 116-step convs of the configs[3] training step lost 1 % with it.
+        if (!cc.halo && cc.bk == 64 && cc.wgm <= 2 && cc.splitk == 1 && two_wg_enabled() && steps0 + steps1 <= 64 &&
             (phase ? (long)N * 8 * mtiles_pp : (M + bm - 1) / bm) * (w.cout_pad / bn) >= 512) {
             cc.bk = 32; nchunk0 = cin0 / 32; nchunk1 = cin1 / 32; steps0 = taps * nchunk0; steps1 = nchunk1;
         }
