@@ -326,11 +326,16 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
     const int cbase = n0 + wn * 64 + 16 * fg;
     const bool to_slab = p.splitk > 1 || p.raw_partial;
     const bool fused_ep = !to_slab;
-    float4 ebias[4], etemb[4]; u32x4 eres[2][2];
+    float4 ebias[4], etemb[4]; u32x4 eres[2][2]; float4 eres32[2][4];
+    const bool f32nd = p.out32 != nullptr;                     // fp32 precision mode: fp32 NDHWC output, fp32 residual
 #pragma unroll
     for (int q = 0; q < 4; ++q) { ebias[q] = make_float4(0.f, 0.f, 0.f, 0.f); etemb[q] = ebias[q]; }
 #pragma unroll
-    for (int ml = 0; ml < 2; ++ml) { eres[ml][0] = (u32x4){0u, 0u, 0u, 0u}; eres[ml][1] = eres[ml][0]; }
+    for (int ml = 0; ml < 2; ++ml) {
+        eres[ml][0] = (u32x4){0u, 0u, 0u, 0u}; eres[ml][1] = eres[ml][0];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) eres32[ml][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     if (fused_ep) {
         if (p.bias) {
 #pragma unroll
@@ -341,7 +346,18 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
 #pragma unroll
             for (int q = 0; q < 4; ++q) etemb[q] = *reinterpret_cast<const float4*>(te + 4 * q);
         }
-        if (p.residual && !p.out_f32 && cbase < p.CoutS) {
+        if (f32nd && p.residual32 && cbase < p.CoutS) {
+#pragma unroll
+            for (int ml = 0; ml < 2; ++ml) {
+                const int r_t = wm * 64 + (mt_base + ml) * 16 + fr;
+                if (r_t < TM && l0 + r_t < DHW) {
+                    const float4* rp = reinterpret_cast<const float4*>(p.residual32 + (size_t)(m_base + r_t) * p.CoutS + cbase);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) eres32[ml][q] = rp[q];
+                }
+            }
+        }
+        if (p.residual && !p.out_f32 && !f32nd && cbase < p.CoutS) {
 #pragma unroll
             for (int ml = 0; ml < 2; ++ml) {
                 const int r_t = wm * 64 + (mt_base + ml) * 16 + fr;
@@ -383,7 +399,7 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
     // ---- epilogue (conv_igemm.h's, with the 126-row tile mapping).  After the exchange this wave owns the 32-row block
     //      rows [64 wm + 32 grp, +32) of the tile = 16-row tiles mt_base + {0, 1}; GroupNorm partials of the whole tile go to slab
     //      row `mtile` (bitwise reproducible: no atomics).
-    const bool do_stats = (p.stats != nullptr) && !to_slab && (p.out != nullptr);
+    const bool do_stats = (p.stats != nullptr) && !to_slab && (p.out != nullptr || f32nd);
     float ssum[16], ssq[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) { ssum[q] = 0.f; ssq[q] = 0.f; }
@@ -420,6 +436,18 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
             continue;
         }
         if (cbase >= p.CoutS) continue;
+        if (f32nd) {                                           // statistics of the exact fp32 values the GroupNorm will read
+            float4* op32 = reinterpret_cast<float4*>(p.out32 + (size_t)m * p.CoutS + cbase);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 rv = eres32[ml][q];
+                v[4 * q] += rv.x; v[4 * q + 1] += rv.y; v[4 * q + 2] += rv.z; v[4 * q + 3] += rv.w;
+                op32[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { ssum[q] += v[q]; ssq[q] += v[q] * v[q]; }
+            continue;
+        }
         if (p.residual) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {

@@ -55,6 +55,7 @@ struct ConvParams {
     // chunk c (c < x3_n: hi), c - x3_n (hi again) or c - x3_n (c >= 2 x3_n: lo) against weight chunk c:  hi*Whi + hi*Wlo + lo*Whi.
     int x3_n;
     int raw_partial;                  // write the fp32 accumulators to the partial slab even with splitk == 1 (the fp32 finalize follows)
+    float* out32; const float* residual32;   // conv3_halo_kernel, fp32 precision, splitk == 1: fp32 NDHWC output [M][CoutS] (+ fp32 residual) from the fused epilogue
     // epilogue (splitk == 1) ------------------------------------------------------------
     const float* bias;                // [CoutPad] or null
     const float* bias2;               // [CoutPad] or null (bias of the fused 1x1 skip)

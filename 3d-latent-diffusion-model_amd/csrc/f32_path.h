@@ -412,6 +412,7 @@ __global__ __launch_bounds__(256) void gn_apply_f32_kernel(const Gn32Params p) {
 struct Gn32FusedParams {
     const float* xa; const float* xb; int ca, cb, DHW, N, nslab, groups, silu, rows_per_block; float eps;
     const float* partial; const float* gamma; const float* beta; float* out;
+    const float* sa; const float* sb; int nrb_a, nrb_b;   // producer statistics (conv3_halo_kernel's fused fp32 epilogue) instead of `partial`: one slab per source tensor
     bf16_t* out_hl;                    // instead of `out`: [rows][hi(C) | lo(C)] bf16, y = hi + lo to ~2^-17 (the voxel operand of the 3 x bf16 halo conv)
 };
 __global__ __launch_bounds__(256) void gn32_fold_apply_kernel(const Gn32FusedParams p) {
@@ -424,7 +425,8 @@ __global__ __launch_bounds__(256) void gn32_fold_apply_kernel(const Gn32FusedPar
     int c1 = c0 + 64; if (c1 > C) c1 = C;
     const int g_lo = c0 / cpg, g_hi = (c1 + cpg - 1) / cpg;
     const int cov_lo = g_lo * cpg, ncov = g_hi * cpg - cov_lo;
-    gn_fold_cover(GnFoldSrc{p.partial, nullptr, C, 0, p.nslab, 0}, n, cpg, cov_lo, ncov, part, csum);
+    if (p.sa) gn_fold_cover(GnFoldSrc{p.sa, p.sb, p.ca, p.cb, p.nrb_a, p.nrb_b}, n, cpg, cov_lo, ncov, part, csum);
+    else gn_fold_cover(GnFoldSrc{p.partial, nullptr, C, 0, p.nslab, 0}, n, cpg, cov_lo, ncov, part, csum);
     __syncthreads();
     if (tid < g_hi - g_lo) {
         double s = 0.0, q = 0.0;

@@ -460,6 +460,18 @@ struct Builder {
             i[0] = 2 * C; i[4] = N; i[5] = a.xa.D; i[6] = a.xa.H; i[7] = a.xa.W; i[8] = a.Do; i[9] = a.Ho; i[10] = a.Wo;
             i[11] = 3; i[12] = 1; i[13] = 1; i[14] = 8; i[15] = (int)M; i[16] = couts; i[17] = w.cout_pad; i[18] = w.cout;
             i[19] = 3 * n3; i[23] = N * cc.mtps;
+            static const int x3_fused = [] { const char* e = getenv("LDM_X3_FUSED_EP"); return e ? atoi(e) : 1; }();
+            if (cc.splitk == 1 && x3_fused) {                // no split: bias / time embedding / residual, the fp32 store and the GroupNorm partials in the conv's epilogue
+                i[14] |= 16; i[21] = a.temb_stride;
+                op.r[6] = a.no_bias ? Ref() : w_ref(w.b_off); op.r[8] = a.temb;
+                op.r[9] = a.residual.valid ? ws_ref(a.residual.off) : Ref(); op.r[10] = ws_ref(out.off);
+                if (a.want_stats) {
+                    out.stats_off = pool.alloc((size_t)N * cc.mtps * couts * 2 * 4); out.has_stats = true; out.stats_nrb = cc.mtps;
+                    op.r[12] = ws_ref(out.stats_off);
+                }
+                plan->ops.push_back(op);
+                return out;
+            }
             partial_bytes = std::max(partial_bytes, (size_t)cc.splitk * M * w.cout_pad * 4);
             partial_fixups.push_back(plan->ops.size()); plan->ops.push_back(op);
             Op f{}; f.kind = OP_FIN32; f.cc = ConvCfg{2, 2, 32, cc.splitk};
@@ -655,8 +667,26 @@ struct Builder {
         };
         auto blocks_ok = [&](const Act& t) { return t.has_stats && (t.stats_nrb > 0 || N == 1 || DHW % 32 == 0); };
         auto blocks_of = [&](const Act& t) { return t.stats_nrb > 0 ? t.stats_nrb : (N == 1 ? (DHW + 31) / 32 : DHW / 32); };
-        const bool fused = blocks_ok(xa) && (!xb.valid || blocks_ok(xb));
+        bool fused = blocks_ok(xa) && (!xb.valid || blocks_ok(xb));
         const int nrb_tot = fused ? blocks_of(xa) + (xb.valid ? blocks_of(xb) : 0) : 0;
+        if (hp && (train || C / groups > 64 || nrb_tot > 1024)) fused = false;
+        if (hp && fused) {                             // fp32 inference: the producing convs' epilogues left the partials; fold + apply in one launch
+            Act out = new_act(N, xa.D, xa.H, xa.W, C);
+            out.hl = next3 && x3_halo_ok(*next3, (long)N * DHW, C);
+            const int slices = (C + 63) / 64;
+            int chunks = std::max(1, std::min(256 / (slices * N), (DHW + 15) / 16));
+            const int rpb = rup((DHW + chunks - 1) / chunks, 16);
+            chunks = (DHW + rpb - 1) / rpb;
+            Op ap{}; ap.kind = OP_GN_APPLY32;
+            ap.r[0] = ws_ref(xa.off); ap.r[1] = xb.valid ? ws_ref(xb.off) : Ref(); ap.r[3] = ws_ref(out.off);
+            ap.r[6] = w_ref(g.g_off); ap.r[7] = w_ref(g.b_off);
+            ap.r[8] = ws_ref(xa.stats_off); ap.r[9] = xb.valid ? ws_ref(xb.stats_off) : Ref();
+            ap.i[0] = xa.C; ap.i[1] = xb.valid ? xb.C : 0; ap.i[2] = DHW; ap.i[3] = N; ap.i[4] = silu ? 1 : 0;
+            ap.i[5] = 1; ap.i[6] = groups; ap.i[7] = rpb; ap.i[8] = chunks; ap.i[9] = out.hl ? 1 : 0;
+            ap.i[10] = blocks_of(xa); ap.i[11] = xb.valid ? blocks_of(xb) : 0; ap.f[0] = eps;
+            plan->ops.push_back(ap);
+            return out;
+        }
         if (fused && C / groups <= 64 && nrb_tot <= 512) {   // few slab rows: ONE launch folds them per block and applies
             Act out = new_act(N, xa.D, xa.H, xa.W, C);
             const int slices = (C + 63) / 64;
@@ -1901,6 +1931,7 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                     Gn32FusedParams q{}; q.xa = p.xa; q.xb = p.xb; q.ca = p.ca; q.cb = p.cb; q.DHW = i[2]; q.N = i[3]; q.silu = i[4];
                     q.nslab = i[5]; q.groups = i[6]; q.rows_per_block = i[7]; q.eps = o.f[0]; q.partial = (const float*)rp(bs, o.r[4]);
                     q.gamma = (const float*)rp(bs, o.r[6]); q.beta = (const float*)rp(bs, o.r[7]);
+                    if (i[10]) { q.sa = (const float*)rp(bs, o.r[8]); q.sb = (const float*)rp(bs, o.r[9]); q.nrb_a = i[10]; q.nrb_b = i[11]; q.partial = nullptr; }
                     if (i[9]) q.out_hl = (bf16_t*)rp(bs, o.r[3]); else q.out = (float*)rp(bs, o.r[3]);
                     hipLaunchKernelGGL(gn32_fold_apply_kernel, dim3(i[8], (p.ca + p.cb + 63) / 64, i[3]), dim3(256), 0, s, q);
                 } else {
@@ -1942,7 +1973,7 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                 p.N = i[4]; p.Din = i[5]; p.Hin = i[6]; p.Win = i[7]; p.Dout = i[8]; p.Hout = i[9]; p.Wout = i[10];
                 p.ksize = i[11]; p.stride = i[12]; p.pad = i[13]; p.ups = i[14] & 1; p.exact = (i[14] >> 1) & 1; p.M = i[15];
                 p.phase_mode = (i[14] >> 2) & 1; p.mtiles_pp = p.phase_mode ? i[23] / (8 * i[4]) : 0;
-                if (i[14] & 8) { p.x3_n = i[19] / 3; p.raw_partial = 1; }      // fp32 precision: 3 x bf16 product on the halo kernel
+                if (i[14] & 8) { p.x3_n = i[19] / 3; p.raw_partial = (i[14] & 16) ? 0 : 1; }   // fp32 precision: 3 x bf16 product on the halo kernel
                 p.CoutS = i[16]; p.CoutPad = i[17]; p.CoutReal = i[18]; p.nchunk0 = i[19]; p.nchunk1 = i[20];
                 p.steps0 = i[11] * i[11] * i[11] * i[19]; p.steps1 = i[20];
                 p.splitk = o.cc.splitk; p.steps_per_split = (p.steps0 + p.steps1 + p.splitk - 1) / p.splitk;
@@ -1956,6 +1987,9 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                 else { p.out = (bf16_t*)rp(bs, o.r[10]); p.out_f32 = nullptr; }
                 p.partial = (float*)rp(bs, o.r[11]);
                 p.stats = (float*)rp(bs, o.r[12]);
+                if (i[14] & 16) {                          // ... with the epilogue fused (splitk 1): fp32 NDHWC output, fp32 residual
+                    p.out32 = (float*)rp(bs, o.r[10]); p.residual32 = (const float*)rp(bs, o.r[9]); p.out = nullptr; p.residual = nullptr;
+                }
                 if (o.kind == OP_CONV) { LDM_TRY(launch_conv(p, o.cc, s)); }
                 else {
                     FinalizeParams f{}; f.partial = p.partial; f.splitk = p.splitk; f.M = p.M; f.CoutPad = p.CoutPad;
