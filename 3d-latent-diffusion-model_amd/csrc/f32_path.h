@@ -328,7 +328,15 @@ __global__ __launch_bounds__(256) void finalize_f32_kernel(const Conv32Params p)
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         const size_t slab = (size_t)p.M * p.CoutPad;
         const float* src = p.partial + (size_t)m * p.CoutPad + c;
-        for (int s = 0; s < p.splitk; ++s) { const float4 a = *reinterpret_cast<const float4*>(src + s * slab); v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+        int s = 0;
+        for (; s + 8 <= p.splitk; s += 8) {              // eight slab loads in flight; summed in slab order (bitwise reproducible)
+            float4 a[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] = *reinterpret_cast<const float4*>(src + (size_t)(s + k) * slab);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { v.x += a[k].x; v.y += a[k].y; v.z += a[k].z; v.w += a[k].w; }
+        }
+        for (; s < p.splitk; ++s) { const float4 a = *reinterpret_cast<const float4*>(src + (size_t)s * slab); v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
         const int n = m / DHWo, sp = m - n * DHWo;
         if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + c); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
         if (p.temb) { const float4 b = *reinterpret_cast<const float4*>(p.temb + (size_t)n * p.temb_stride + c); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
@@ -466,6 +474,21 @@ __global__ __launch_bounds__(256) void gn32_fold_apply_kernel(const Gn32FusedPar
             *reinterpret_cast<uint2*>(p.out_hl + row * (2 * C) + C + c) = lo;
         } else
         *reinterpret_cast<float4*>(p.out + row * C + c) = y;
+    }
+}
+
+// Nearest x2 upsample of an fp32 NDHWC tensor straight into the (hi | lo) bf16 split: [N][2D][2H][2W][hi(C) | lo(C)].  The voxel operand
+// of the 3 x bf16 halo conv behind an Upsample block (the general fp32 kernels fold the upsample into their loader instead).
+__global__ __launch_bounds__(256) void upsample_split_f32_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, int N, int C, int D, int H, int W) {
+    const int cvec = C / 4, Ho = 2 * H, Wo = 2 * W;
+    const long total = (long)N * 8 * D * H * W * cvec;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long row = e / cvec; const int c = (int)(e - row * cvec) * 4;
+        long r = row; const int ow = (int)(r % Wo); r /= Wo; const int oh = (int)(r % Ho); r /= Ho; const int od = (int)(r % (2 * D)); const long n = r / (2 * D);
+        const long src = ((n * D + (od >> 1)) * H + (oh >> 1)) * W + (ow >> 1);
+        uint2 hi, lo; split_bf16x4(*reinterpret_cast<const float4*>(x + src * C + c), hi, lo);
+        *reinterpret_cast<uint2*>(out + row * (2 * C) + c) = hi;
+        *reinterpret_cast<uint2*>(out + row * (2 * C) + C + c) = lo;
     }
 }
 

@@ -85,7 +85,8 @@ enum OpKind { OP_PACK, OP_CONV, OP_FINALIZE, OP_GN_STATS, OP_GN_FINALIZE, OP_GN_
               // fp32 precision mode (f32_path.h)
               OP_PACK32, OP_CONV32, OP_FIN32, OP_GN_STATS32, OP_GN_APPLY32, OP_ATTN32, OP_GEMV32,
               OP_TAP,                              // debug tap: export an activation as fp32 NCDHW and / or overwrite it (teacher forcing)
-              OP_BUCKET, OP_BUCKET_JOIN };         // training plans: a tail range of the flat gradient buffer is final (all-reduce it now) / wait for every bucket
+              OP_BUCKET, OP_BUCKET_JOIN,
+              OP_UPS_SPLIT32 };                    // fp32 precision: nearest x2 upsample into the (hi | lo) bf16 split (upsample_split_f32_kernel)         // training plans: a tail range of the flat gradient buffer is final (all-reduce it now) / wait for every bucket
 
 struct ConvCfg { int wgm, wgn, bk, splitk; int halo = 0, mtps = 0, qps = 0; };   // halo: conv3_halo_kernel (126-row tiles)
 
@@ -444,6 +445,19 @@ struct Builder {
         const int N = a.xa.N;
         const long M = (long)N * a.Do * a.Ho * a.Wo;
         if (M >= (1L << 31)) { err = "conv " + tag + ": M too large"; return Act(); }
+        // Upsample block (nearest x2, then 3^3 conv) in an inference plan: one pass writes the upsampled tensor as the (hi | lo) split, the
+        // conv then runs on the halo kernel like the ResBlock convs (12^3 -> 24^3, 256 channels: 258 -> ~175 us)
+        if (!train && a.ups == 1 && !a.exact && a.k == 3 && a.stride == 1 && a.pad == 1 && !a.xb.valid && !a.w1 && !a.f32_out &&
+            a.w_over.base == BASE_NULL && !a.xa.hl && a.Do == 2 * a.xa.D && a.Ho == 2 * a.xa.H && a.Wo == 2 * a.xa.W && x3_halo_ok(w, M, a.xa.C)) {
+            Act up = new_act(N, a.Do, a.Ho, a.Wo, a.xa.C); up.hl = true;
+            Op u{}; u.kind = OP_UPS_SPLIT32; u.r[0] = ws_ref(a.xa.off); u.r[1] = ws_ref(up.off);
+            u.i[0] = N; u.i[1] = a.xa.C; u.i[2] = a.xa.D; u.i[3] = a.xa.H; u.i[4] = a.xa.W;
+            plan->ops.push_back(u);
+            ConvArgs a2 = a; a2.xa = up; a2.ups = 0;
+            Act out = conv32(a2, tag);
+            free_act(up);
+            return out;
+        }
         if (a.xa.hl) {                                   // 3 x bf16 product on conv3_halo_kernel (x3_halo_ok decided it when the GroupNorm was planned)
             const int C = a.xa.C, n3 = C / 64;
             if (a.k != 3 || a.stride != 1 || a.pad != 1 || a.ups || a.exact || a.xb.valid || a.f32_out || a.w_over.base != BASE_NULL ||
@@ -1894,6 +1908,10 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                 const long total = (long)i[0] * i[3] * i[4] * i[5] * (i[2] / 8);
                 hipLaunchKernelGGL(pack_im2col_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0, s, (const float*)rp(bs, o.r[0]), cx,
                                    (const float*)rp(bs, o.r[1]), cc, (bf16_t*)rp(bs, o.r[2]), i[0], i[3], i[4], i[5], i[2]);
+                break; }
+            case OP_UPS_SPLIT32: {      // i: N, C, D, H, W of the source
+                hipLaunchKernelGGL(upsample_split_f32_kernel, dim3(grid_for((long)i[0] * 8 * i[2] * i[3] * i[4] * (i[1] / 4), 256, 4096)), dim3(256), 0, s,
+                                   (const float*)rp(bs, o.r[0]), (bf16_t*)rp(bs, o.r[1]), i[0], i[1], i[2], i[3], i[4]);
                 break; }
             case OP_PACK32: {
                 const long total = (long)i[0] * i[3] * i[2];
