@@ -287,452 +287,3 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradParams p)
     }
 #endif
 }
-
-// ------------------------------------------------------------------------------------------------
-// kw-TRIPLET weight gradient for 3x3x3 / stride 1 / pad 1 convolutions (the 3^3 convs carry 96 % of the FLOPs).
-//
-// conv_wgrad_kernel above loads a dY tile and an X tile per 64-voxel K step for ONE tap: 32 KiB per 2.1 MFLOP, bound by
-// the per-CU global->LDS ingest like the forward conv was.  The dY tile is the same for all 27 taps and the X tiles of
-// the three kw taps of one (kd, kh) pair are the same rows shifted by one voxel along W, so one workgroup here computes
-// the THREE kw taps of a (kd, kh) pair from one dY tile + one 66-row X tile: 33 KiB per 6.3 MFLOP (3x the arithmetic
-// intensity) -> the loop is MFMA bound.
-// W borders without masks: the contraction index does not run over voxels but over PADDED line positions
-// q = line * (W + 2) + w', w' in [0, W + 2): positions w' = 0 and W + 1 are copied as zeros (out-of-range buffer offset),
-// on both operands, so a +-1 shift never leaves the line and border taps multiply zeros ((W+2)/W more K steps: 8 % at
-// W = 24).  X tile row i of a K step holds position 64 s + i - 1; tap kw pairs dY row j with X row j + kw.
-// Workgroup = 4 waves (one per SIMD: 192 accumulator VGPRs per lane for 3 taps x 64 x 64), tile 128 couts x 128 cins.
-struct Wgrad3Params {
-    const bf16_t* dy; int cdy;
-    const bf16_t* x; int cx;
-    float* dw;                        // [ksplit][27][Cout][dw_ld] fp32 (columns dw_ci_off .. + Cin written)
-    int Cout, Cin, dw_ld, dw_ci_off;
-    int N, D, H, W;                   // input == output volume
-    int co_tiles, ci_tiles, ksplit;
-    long slab_stride;
-};
-
-// ABL (timing experiments, LDM_CONV_DBG via the operator-level API): 4 = no copies, 8 = no MFMAs, 16 = no LDS fragment reads, 32 = no stores.
-template <int ABL = 0>
-__global__ __launch_bounds__(256, 1) void conv_wgrad3_kernel(const Wgrad3Params p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int KV = 64, TR = 256;
-    constexpr int XROWS = 80;                                  // 66 rows used (+ 2 rows of the 17th piece + 12 rows of dummy pieces)
-    constexpr int NROWS = KV + XROWS;                          // row slots of one ring stage: 64 dY rows then 80 X rows
-    constexpr int STAGE = NROWS * TR;                          // 36 KiB
-    constexpr int NS = 4, PF = NS - 1, LPS = 9;                // per wave and step: 4 dY pieces + 5 X pieces
-    constexpr int TOFF = NS * STAGE;                           // per-step source-offset table, double buffered: [2][NROWS] u32
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    typedef __attribute__((ext_vector_type(4))) short s16x4;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wa = wave & 1, wb = wave >> 1;                   // wave tile: couts [64 wa, +64) x cins [64 wb, +64)
-    int bid = blockIdx.x;
-    const int ci_t = bid % p.ci_tiles; bid /= p.ci_tiles;
-    const int co_t = bid % p.co_tiles; bid /= p.co_tiles;
-    const int pair = bid % 9; const int split = bid / 9;
-    const int kd = pair / 3, kh = pair - kd * 3;
-    const int WP = p.W + 2;                                    // padded line length
-    const long KP = (long)p.N * p.D * p.H * WP;                // padded positions
-    const int steps_all = (int)((KP + KV - 1) / KV);
-    const int sps = (steps_all + p.ksplit - 1) / p.ksplit;
-    const int s_begin = split * sps;
-    const int nsteps = (s_begin + sps < steps_all ? s_begin + sps : steps_all) - s_begin;
-
-    // ---- source-offset table: thread r < NROWS owns row slot r of the ring stage, keeps the padded coordinates
-    //      (w', h, d, n) of the position that slot holds at the step being prepared, advances them by 64 positions per step
-    //      (mixed-radix add, exact also from the start digit w' = -1 of position -1) and publishes the row's byte offset
-    //      (or 0xFFFFFFFF for pads / out-of-range taps / dummy rows: the copy then writes zeros).  Every lane then needs only
-    //      a table read + add per copy instead of the coordinate arithmetic of its nine rows.
-    unsigned* const tab = reinterpret_cast<unsigned*>(smem + TOFF);
-    int cw = 0, ch_ = 0, cd = 0, cn = 0;
-    const bool owner = tid < NROWS;
-    const bool own_x = tid >= KV;
-    const int own_row = own_x ? tid - KV : tid;                // row inside the dY / X tile
-    if (owner) {
-        const long q = (long)s_begin * KV + own_row - (own_x ? 1 : 0);      // X row i holds position 64 s + i - 1
-        long qq = q < 0 ? 0 : q;
-        cn = (int)(qq / ((long)p.D * p.H * WP)); qq -= (long)cn * p.D * p.H * WP;
-        cd = (int)(qq / (p.H * WP)); qq -= (long)cd * p.H * WP;
-        ch_ = (int)(qq / WP); cw = (int)(qq - (long)ch_ * WP);
-        if (q < 0) cw = -1;
-    }
-    const int q_d = KV / (p.H * WP), q_h = (KV - q_d * p.H * WP) / WP, q_w = KV - q_d * p.H * WP - q_h * WP;
-    const unsigned own_cs2 = (unsigned)(own_x ? p.cx : p.cdy) * 2u;
-#define W3_PUBLISH(PAR) do {                                                                                  \
-        if (owner) {                                                                                          \
-            const int w_ = cw - 1;                                                                            \
-            const int d_ = cd + (own_x ? kd - 1 : 0), h_ = ch_ + (own_x ? kh - 1 : 0);                         \
-            const bool ok_ = ((unsigned)w_ < (unsigned)p.W) & ((unsigned)d_ < (unsigned)p.D) & ((unsigned)h_ < (unsigned)p.H) & \
-                             (cn < p.N) & (cw >= 0) & (!own_x | (own_row < 66));                              \
-            const int src_ = ((cn * p.D + d_) * p.H + h_) * p.W + w_;                                         \
-            tab[(PAR) * NROWS + tid] = ok_ ? (unsigned)src_ * own_cs2 : 0xFFFFFFFFu;                          \
-            cw += q_w; if (cw >= WP) { cw -= WP; ++ch_; }                                                     \
-            ch_ += q_h; if (ch_ >= p.H) { ch_ -= p.H; ++cd; }                                                 \
-            cd += q_d; while (cd >= p.D) { cd -= p.D; ++cn; }                                                 \
-        }                                                                                                     \
-    } while (0)
-
-    // ---- loader lanes: 9 pieces per wave (dY pieces wave*4 + j, X pieces wave + 4 j and 16 + wave)
-    const int prow = lane >> 4, pch = lane & 15;
-    unsigned l_add[9]; int l_slot[9], l_dst[9];
-#pragma unroll
-    for (int j = 0; j < 9; ++j) {
-        const bool isx = j >= 4;
-        const int piece = !isx ? wave * 4 + j : ((j < 8) ? wave + 4 * (j - 4) : 16 + wave);
-        const int row = piece * 4 + prow;
-        const int f = (row & 3) + 4 * ((row >> 3) & 1);
-        const unsigned kb = (unsigned)(((((pch >> 1) ^ f) << 1) | (pch & 1)) * 16);
-        const unsigned cb = (unsigned)(isx ? ci_t : co_t) * 256u;
-        const unsigned cs2 = (unsigned)(isx ? p.cx : p.cdy) * 2u;
-        l_add[j] = (cb + kb < cs2) ? cb + kb : 0xFFFFFFFFu;    // channels beyond the tensor: out of range
-        l_slot[j] = (isx ? KV : 0) + row;
-        l_dst[j] = (isx ? KV * TR : 0) + piece * 1024;
-    }
-    __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (int)((unsigned)(p.N * p.D * p.H * p.W) * (unsigned)p.cdy * 2u), 0x00020000);
-    __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)((unsigned)(p.N * p.D * p.H * p.W) * (unsigned)p.cx * 2u), 0x00020000);
-    int ld_s = 0;
-#define W3_ISSUE(PAR) do {                                                                                    \
-        char* st_ = smem + (ld_s % NS) * STAGE;                                                               \
-        unsigned tb_[9];                                           /* all table reads first: one LDS round trip */ \
-        _Pragma("unroll") for (int j = 0; j < 9; ++j) tb_[j] = tab[(PAR) * NROWS + l_slot[j]];                \
-        _Pragma("unroll") for (int j = 0; j < 9; ++j) {                                                       \
-            const unsigned b_ = tb_[j];                                                                       \
-            const unsigned vo_ = ((b_ == 0xFFFFFFFFu) | (l_add[j] == 0xFFFFFFFFu)) ? 0xFFFFFFFFu : b_ + l_add[j]; \
-            if (ABL & 4) continue;                                                                           \
-            if (j >= 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(st_ + l_dst[j]), 16, vo_, 0, 0, 0); \
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, (lds_ptr_t)(st_ + l_dst[j]), 16, vo_, 0, 0, 0); \
-        }                                                                                                     \
-        ++ld_s;                                                                                               \
-    } while (0)
-
-    // ---- fragments (transposed LDS reads): lane (i = lane & 15, g = lane >> 4) gets k = 8 g .. 8 g + 7 of column i
-    const int fi = lane & 15, fg = lane >> 4, tq = fi >> 2, tp = fi & 3;
-    f32x4 acc[3][4][4];                                                  // [kw][cout tile][cin tile]
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) acc[k][a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // fragment loads of one (k-substep, row shift): 4 tiles, two transposed reads each
-    // addresses are rebuilt from two per-lane values (row0, made opaque once per step) with ~2 VALU per read: keeping the
-    // 64 distinct fragment addresses live costs more registers than the 1-wave-per-SIMD budget has next to 192 accumulators
-#define W3_LOAD(F, SB, BASE, COLBLK, ROWOFF) do {                                                   \
-        if (ABL & 16) break;                                                                        \
-        const int r_lo = (ROWOFF) + row0, r_hi = r_lo + 4;                                          \
-        const int f_lo = (r_lo & 3) + 4 * ((r_lo >> 3) & 1), f_hi = (r_hi & 3) + 4 * ((r_hi >> 3) & 1); \
-        const int a_lo = (BASE) + r_lo * TR + tp8, a_hi = a_lo + 4 * TR;                            \
-        _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                             \
-            const int c_ = (COLBLK) * 4 + t;                                                        \
-            const s16x4 l_ = ds_read_tr16_b64_raw((SB) + a_lo + ((c_ ^ f_lo) << 5)); \
-            const s16x4 h_ = ds_read_tr16_b64_raw((SB) + a_hi + ((c_ ^ f_hi) << 5)); \
-            F[t] = (bf16x8){l_[0], l_[1], l_[2], l_[3], h_[0], h_[1], h_[2], h_[3]};                \
-        }                                                                                           \
-    } while (0)
-    // The 192 accumulator registers live in the ACCUMULATOR half of the unified register file for the whole loop: the MFMAs are inline
-    // asm with "+a" operands.  Through the builtin hipcc (ROCm 7.2) split them between VGPRs and AGPRs at this size and moved them back
-    // and forth around every MFMA (128 v_accvgpr_read + 128 v_accvgpr_write per K step: the MFMAs alone took 1.33 us per step instead of
-    // 0.8).  Each accumulator is touched once per 48 MFMAs, so no dependent-MFMA wait states are needed inside the loop; the read-out
-    // after the loop sits behind explicit s_nops (the hazard recognizer cannot see into asm).
-#define W3_MFMA(KW, AF, BF) do {                                                                    \
-        if (ABL & 8) break;                                                                         \
-        _Pragma("unroll") for (int a = 0; a < 4; ++a)                                               \
-            _Pragma("unroll") for (int b = 0; b < 4; ++b)                                           \
-                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[KW][a][b]) : "v"(AF[a]), "v"(BF[b])); \
-    } while (0)
-
-    // ---- table protocol: publish #k (offsets of step k) goes to table parity k & 1.  The issue of step k reads it after a
-    //      workgroup barrier that follows the publish; publish #k overwrites #k-2, which every wave read one barrier ago.
-    // prologue: copies of the first NS steps
-    W3_PUBLISH(0);
-    __syncthreads();
-    for (int i = 0; i < NS; ++i) {
-        if (i < nsteps) W3_ISSUE(i & 1);
-        __syncthreads();                                       // table #i read by every wave
-        if (i + 1 < NS) W3_PUBLISH((i + 1) & 1);
-        __syncthreads();
-    }
-    // invariant at the top of step s: copies of steps <= s + NS - 1 issued (step NS - 1 + s by THIS step for s >= 1),
-    // tables #(s + NS - 1) published.
-    for (int s = 0; s < nsteps; ++s) {
-        __builtin_amdgcn_s_waitcnt(0xC07F);                    // own table writes / fragment reads retired
-        if (s + PF < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF - 1) * LPS) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                          // step s landed for everyone; everyone finished step s - 1
-        asm volatile("" ::: "memory");
-        const char* sb = smem + (s % NS) * STAGE;
-        int row0 = 8 * fg + tq, tp8 = tp * 8;
-        asm volatile("" : "+v"(row0), "+v"(tp8));              // opaque: no hoisting of the derived addresses out of the loop
-        bf16x8 af0[4], af1[4], b0[4], b1[4];
-        // fragment reads are inline asm (see ds_read_tr16_b64_raw): every use is ordered by hand: W3_WAIT retires all reads
-        // issued so far and pins the following MFMAs behind it; each MFMA group runs while the next group's reads are in flight
-#define W3_WAIT() do { __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } while (0)
-        W3_LOAD(af0, sb, 0, wa, 0);
-        W3_LOAD(b0, sb, KV * TR, wb, 0);
-        // the slot of step s - 1 is free (all waves passed the barrier): refill it with step s + NS - 1
-        if (s >= 1 && ld_s < nsteps) W3_ISSUE((s + NS - 1) & 1);
-        W3_WAIT();
-        W3_LOAD(b1, sb, KV * TR, wb, 1);
-        W3_MFMA(0, af0, b0);
-        W3_WAIT();
-        W3_LOAD(b0, sb, KV * TR, wb, 2);
-        W3_MFMA(1, af0, b1);
-        W3_WAIT();
-        W3_LOAD(af1, sb, 0, wa, 32);
-        W3_LOAD(b1, sb, KV * TR, wb, 32);
-        W3_MFMA(2, af0, b0);
-        W3_PUBLISH((s + NS) & 1);                              // offsets of step s + NS, read at step s + 1
-        W3_WAIT();
-        W3_LOAD(b0, sb, KV * TR, wb, 33);
-        W3_MFMA(0, af1, b1);
-        W3_WAIT();
-        W3_LOAD(b1, sb, KV * TR, wb, 34);
-        W3_MFMA(1, af1, b0);
-        W3_WAIT();
-        W3_MFMA(2, af1, b1);
-#undef W3_WAIT
-    }
-#undef W3_MFMA
-#undef W3_LOAD
-#undef W3_ISSUE
-#undef W3_PUBLISH
-
-    // ---- store: accumulator col = lane & 15 -> cin, row = 4 fg + r -> cout
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // last MFMA results -> v_accvgpr_read (see W3_MFMA)
-#pragma unroll
-    for (int kw = 0; kw < 3; ++kw) {
-        const int tap = pair * 3 + kw;
-        const size_t tap_off = (size_t)split * p.slab_stride + (size_t)tap * p.Cout * p.dw_ld + p.dw_ci_off;
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int ci = ci_t * 128 + wb * 64 + b * 16 + fi;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int co = co_t * 128 + wa * 64 + a * 16 + 4 * fg + r;
-                    if (co < p.Cout && ci < p.Cin && !((ABL & 32) && acc[kw][a][b][r] != 12345.f)) p.dw[tap_off + (size_t)co * p.dw_ld + ci] = acc[kw][a][b][r];
-                }
-            }
-    }
-#endif
-}
-
-// ------------------------------------------------------------------------------------------------
-// The same kw-triplet weight gradient with EIGHT waves (two per SIMD): wave tile 64 couts x 32 cins x 3 taps = 96 accumulator registers
-// instead of 192, so a wave's waits for its transposed fragment reads and for the LDS-DMA data are covered by its SIMD partner's MFMAs
-// (the four-wave kernel above runs one wave per SIMD and serialises read -> wait -> MFMA group six times per K step: 2.0 us per step
-// against 0.8 us of MFMAs).  Same workgroup tile (128 couts x 128 cins x 3 taps), same ring stage and table protocol; 40 copy pieces
-// per step = 5 per wave (the four spare ones are out-of-range copies into a scratch KiB behind the table).
-template <int ABL = 0>
-__global__ __launch_bounds__(512, 2) void conv_wgrad3b_kernel(const Wgrad3Params p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int KV = 64, TR = 256;
-    constexpr int XROWS = 80;                                  // 66 rows used (+ 2 rows of the 17th piece + 12 rows of dummy pieces)
-    constexpr int NROWS = KV + XROWS;                          // row slots of one ring stage: 64 dY rows then 80 X rows
-    constexpr int STAGE = NROWS * TR;                          // 36 KiB
-    constexpr int NS = 4, PF = NS - 1, LPS = 5;                // per wave and step: 2 dY pieces + 3 X pieces (4 of the 40 are dummies)
-    constexpr int TOFF = NS * STAGE;                           // per-step source-offset table, double buffered: [2][NROWS] u32
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    typedef __attribute__((ext_vector_type(4))) short s16x4;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wa = wave & 1, wb = wave >> 1;                   // wave tile: couts [64 wa, +64) x cins [32 wb, +32), wb = 0 .. 3
-    constexpr int SCRATCH = NS * STAGE + 2 * NROWS * 4;        // 1 KiB that the dummy pieces zero-fill
-    int bid = blockIdx.x;
-    const int ci_t = bid % p.ci_tiles; bid /= p.ci_tiles;
-    const int co_t = bid % p.co_tiles; bid /= p.co_tiles;
-    const int pair = bid % 9; const int split = bid / 9;
-    const int kd = pair / 3, kh = pair - kd * 3;
-    const int WP = p.W + 2;                                    // padded line length
-    const long KP = (long)p.N * p.D * p.H * WP;                // padded positions
-    const int steps_all = (int)((KP + KV - 1) / KV);
-    const int sps = (steps_all + p.ksplit - 1) / p.ksplit;
-    const int s_begin = split * sps;
-    const int nsteps = (s_begin + sps < steps_all ? s_begin + sps : steps_all) - s_begin;
-
-    // ---- source-offset table: thread r < NROWS owns row slot r of the ring stage, keeps the padded coordinates
-    //      (w', h, d, n) of the position that slot holds at the step being prepared, advances them by 64 positions per step
-    //      (mixed-radix add, exact also from the start digit w' = -1 of position -1) and publishes the row's byte offset
-    //      (or 0xFFFFFFFF for pads / out-of-range taps / dummy rows: the copy then writes zeros).  Every lane then needs only
-    //      a table read + add per copy instead of the coordinate arithmetic of its nine rows.
-    unsigned* const tab = reinterpret_cast<unsigned*>(smem + TOFF);
-    int cw = 0, ch_ = 0, cd = 0, cn = 0;
-    const bool owner = tid < NROWS;
-    const bool own_x = tid >= KV;
-    const int own_row = own_x ? tid - KV : tid;                // row inside the dY / X tile
-    if (owner) {
-        const long q = (long)s_begin * KV + own_row - (own_x ? 1 : 0);      // X row i holds position 64 s + i - 1
-        long qq = q < 0 ? 0 : q;
-        cn = (int)(qq / ((long)p.D * p.H * WP)); qq -= (long)cn * p.D * p.H * WP;
-        cd = (int)(qq / (p.H * WP)); qq -= (long)cd * p.H * WP;
-        ch_ = (int)(qq / WP); cw = (int)(qq - (long)ch_ * WP);
-        if (q < 0) cw = -1;
-    }
-    const int q_d = KV / (p.H * WP), q_h = (KV - q_d * p.H * WP) / WP, q_w = KV - q_d * p.H * WP - q_h * WP;
-    const unsigned own_cs2 = (unsigned)(own_x ? p.cx : p.cdy) * 2u;
-#define W3_PUBLISH(PAR) do {                                                                                  \
-        if (owner) {                                                                                          \
-            const int w_ = cw - 1;                                                                            \
-            const int d_ = cd + (own_x ? kd - 1 : 0), h_ = ch_ + (own_x ? kh - 1 : 0);                         \
-            const bool ok_ = ((unsigned)w_ < (unsigned)p.W) & ((unsigned)d_ < (unsigned)p.D) & ((unsigned)h_ < (unsigned)p.H) & \
-                             (cn < p.N) & (cw >= 0) & (!own_x | (own_row < 66));                              \
-            const int src_ = ((cn * p.D + d_) * p.H + h_) * p.W + w_;                                         \
-            tab[(PAR) * NROWS + tid] = ok_ ? (unsigned)src_ * own_cs2 : 0xFFFFFFFFu;                          \
-            cw += q_w; if (cw >= WP) { cw -= WP; ++ch_; }                                                     \
-            ch_ += q_h; if (ch_ >= p.H) { ch_ -= p.H; ++cd; }                                                 \
-            cd += q_d; while (cd >= p.D) { cd -= p.D; ++cn; }                                                 \
-        }                                                                                                     \
-    } while (0)
-
-    // ---- loader lanes: 5 pieces per wave (dY pieces wave*2 + j, X pieces wave + 8 (j - 2), and 16 + wave for waves 0 .. 3)
-    const int prow = lane >> 4, pch = lane & 15;
-    unsigned l_add[5]; int l_slot[5], l_dst[5];
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        const bool isx = j >= 2;
-        const bool dummy = j == 4 && wave >= 4;
-        const int piece = !isx ? wave * 2 + j : ((j < 4) ? wave + 8 * (j - 2) : 16 + (wave & 3));
-        const int row = piece * 4 + prow;
-        const int f = (row & 3) + 4 * ((row >> 3) & 1);
-        const unsigned kb = (unsigned)(((((pch >> 1) ^ f) << 1) | (pch & 1)) * 16);
-        const unsigned cb = (unsigned)(isx ? ci_t : co_t) * 256u;
-        const unsigned cs2 = (unsigned)(isx ? p.cx : p.cdy) * 2u;
-        l_add[j] = (cb + kb < cs2 && !dummy) ? cb + kb : 0xFFFFFFFFu;    // channels beyond the tensor / dummy piece: out of range
-        l_slot[j] = (isx ? KV : 0) + row;
-        l_dst[j] = dummy ? -1 : (isx ? KV * TR : 0) + piece * 1024;
-    }
-    __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (int)((unsigned)(p.N * p.D * p.H * p.W) * (unsigned)p.cdy * 2u), 0x00020000);
-    __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)((unsigned)(p.N * p.D * p.H * p.W) * (unsigned)p.cx * 2u), 0x00020000);
-    int ld_s = 0;
-#define W3_ISSUE(PAR) do {                                                                                    \
-        char* st_ = smem + (ld_s % NS) * STAGE;                                                               \
-        unsigned tb_[5];                                           /* all table reads first: one LDS round trip */ \
-        _Pragma("unroll") for (int j = 0; j < 5; ++j) tb_[j] = tab[(PAR) * NROWS + l_slot[j]];                \
-        _Pragma("unroll") for (int j = 0; j < 5; ++j) {                                                       \
-            const unsigned b_ = tb_[j];                                                                       \
-            const unsigned vo_ = ((b_ == 0xFFFFFFFFu) | (l_add[j] == 0xFFFFFFFFu)) ? 0xFFFFFFFFu : b_ + l_add[j]; \
-            if (ABL & 4) continue;                                                                           \
-            char* d_ = (l_dst[j] < 0) ? smem + SCRATCH : st_ + l_dst[j];                                      \
-            if (j >= 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)d_, 16, vo_, 0, 0, 0);      \
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, (lds_ptr_t)d_, 16, vo_, 0, 0, 0);            \
-        }                                                                                                     \
-        ++ld_s;                                                                                               \
-    } while (0)
-
-    // ---- fragments (transposed LDS reads): lane (i = lane & 15, g = lane >> 4) gets k = 8 g .. 8 g + 7 of column i
-    const int fi = lane & 15, fg = lane >> 4, tq = fi >> 2, tp = fi & 3;
-    f32x4 acc[3][4][2];                                                  // [kw][cout tile][cin tile]
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) acc[k][a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // fragment loads of one (k-substep, row shift): 4 tiles, two transposed reads each
-    // addresses are rebuilt from two per-lane values (row0, made opaque once per step) with ~2 VALU per read: keeping the
-    // 64 distinct fragment addresses live costs more registers than the 1-wave-per-SIMD budget has next to 192 accumulators
-#define W3_LOAD(F, SB, BASE, COLBASE, NT_, ROWOFF) do {                                             \
-        if (ABL & 16) break;                                                                        \
-        const int r_lo = (ROWOFF) + row0, r_hi = r_lo + 4;                                          \
-        const int f_lo = (r_lo & 3) + 4 * ((r_lo >> 3) & 1), f_hi = (r_hi & 3) + 4 * ((r_hi >> 3) & 1); \
-        const int a_lo = (BASE) + r_lo * TR + tp8, a_hi = a_lo + 4 * TR;                            \
-        _Pragma("unroll") for (int t = 0; t < (NT_); ++t) {                                         \
-            const int c_ = (COLBASE) + t;                                                           \
-            const s16x4 l_ = ds_read_tr16_b64_raw((SB) + a_lo + ((c_ ^ f_lo) << 5)); \
-            const s16x4 h_ = ds_read_tr16_b64_raw((SB) + a_hi + ((c_ ^ f_hi) << 5)); \
-            F[t] = (bf16x8){l_[0], l_[1], l_[2], l_[3], h_[0], h_[1], h_[2], h_[3]};                \
-        }                                                                                           \
-    } while (0)
-    // The 192 accumulator registers live in the ACCUMULATOR half of the unified register file for the whole loop: the MFMAs are inline
-    // asm with "+a" operands.  Through the builtin hipcc (ROCm 7.2) split them between VGPRs and AGPRs at this size and moved them back
-    // and forth around every MFMA (128 v_accvgpr_read + 128 v_accvgpr_write per K step: the MFMAs alone took 1.33 us per step instead of
-    // 0.8).  Each accumulator is touched once per 48 MFMAs, so no dependent-MFMA wait states are needed inside the loop; the read-out
-    // after the loop sits behind explicit s_nops (the hazard recognizer cannot see into asm).
-#define W3_MFMA(KW, AF, BF) do {                                                                    \
-        if (ABL & 8) break;                                                                         \
-        _Pragma("unroll") for (int a = 0; a < 4; ++a)                                               \
-            _Pragma("unroll") for (int b = 0; b < 2; ++b)                                           \
-                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[KW][a][b]) : "v"(AF[a]), "v"(BF[b])); \
-    } while (0)
-
-    // ---- table protocol: publish #k (offsets of step k) goes to table parity k & 1.  The issue of step k reads it after a
-    //      workgroup barrier that follows the publish; publish #k overwrites #k-2, which every wave read one barrier ago.
-    // prologue: copies of the first NS steps
-    W3_PUBLISH(0);
-    __syncthreads();
-    for (int i = 0; i < NS; ++i) {
-        if (i < nsteps) W3_ISSUE(i & 1);
-        __syncthreads();                                       // table #i read by every wave
-        if (i + 1 < NS) W3_PUBLISH((i + 1) & 1);
-        __syncthreads();
-    }
-    // invariant at the top of step s: copies of steps <= s + NS - 1 issued (step NS - 1 + s by THIS step for s >= 1),
-    // tables #(s + NS - 1) published.
-    for (int s = 0; s < nsteps; ++s) {
-        __builtin_amdgcn_s_waitcnt(0xC07F);                    // own table writes / fragment reads retired
-        if (s + PF < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF - 1) * LPS) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                          // step s landed for everyone; everyone finished step s - 1
-        asm volatile("" ::: "memory");
-        const char* sb = smem + (s % NS) * STAGE;
-        int row0 = 8 * fg + tq, tp8 = tp * 8;
-        asm volatile("" : "+v"(row0), "+v"(tp8));              // opaque: no hoisting of the derived addresses out of the loop
-        bf16x8 af0[4], af1[4], b0[2], b1[2];
-        // fragment reads are inline asm (see ds_read_tr16_b64_raw): every use is ordered by hand: W3_WAIT retires all reads
-        // issued so far and pins the following MFMAs behind it; each MFMA group runs while the next group's reads are in flight
-#define W3_WAIT() do { __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } while (0)
-        W3_LOAD(af0, sb, 0, wa * 4, 4, 0);
-        W3_LOAD(b0, sb, KV * TR, wb * 2, 2, 0);
-        // the slot of step s - 1 is free (all waves passed the barrier): refill it with step s + NS - 1
-        if (s >= 1 && ld_s < nsteps) W3_ISSUE((s + NS - 1) & 1);
-        W3_WAIT();
-        W3_LOAD(b1, sb, KV * TR, wb * 2, 2, 1);
-        W3_MFMA(0, af0, b0);
-        W3_WAIT();
-        W3_LOAD(b0, sb, KV * TR, wb * 2, 2, 2);
-        W3_MFMA(1, af0, b1);
-        W3_WAIT();
-        W3_LOAD(af1, sb, 0, wa * 4, 4, 32);
-        W3_LOAD(b1, sb, KV * TR, wb * 2, 2, 32);
-        W3_MFMA(2, af0, b0);
-        W3_PUBLISH((s + NS) & 1);                              // offsets of step s + NS, read at step s + 1
-        W3_WAIT();
-        W3_LOAD(b0, sb, KV * TR, wb * 2, 2, 33);
-        W3_MFMA(0, af1, b1);
-        W3_WAIT();
-        W3_LOAD(b1, sb, KV * TR, wb * 2, 2, 34);
-        W3_MFMA(1, af1, b0);
-        W3_WAIT();
-        W3_MFMA(2, af1, b1);
-#undef W3_WAIT
-    }
-#undef W3_MFMA
-#undef W3_LOAD
-#undef W3_ISSUE
-#undef W3_PUBLISH
-
-    // ---- store: accumulator col = lane & 15 -> cin, row = 4 fg + r -> cout
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // last MFMA results -> v_accvgpr_read (see W3_MFMA)
-#pragma unroll
-    for (int kw = 0; kw < 3; ++kw) {
-        const int tap = pair * 3 + kw;
-        const size_t tap_off = (size_t)split * p.slab_stride + (size_t)tap * p.Cout * p.dw_ld + p.dw_ci_off;
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const int ci = ci_t * 128 + wb * 32 + b * 16 + fi;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int co = co_t * 128 + wa * 64 + a * 16 + 4 * fg + r;
-                    if (co < p.Cout && ci < p.Cin && !((ABL & 32) && acc[kw][a][b][r] != 12345.f)) p.dw[tap_off + (size_t)co * p.dw_ld + ci] = acc[kw][a][b][r];
-                }
-            }
-    }
-#endif
-}

@@ -308,9 +308,6 @@ struct ldm_model {
 
 // ================================================================================================ builder
 static int wgrad_ksplit(long M, int taps, int cout, int cin, bool hp = false);
-static bool wgrad3_enabled();
-static int wgrad3_mode();
-static int wgrad3_ksplit(long KP, int cout, int cin);
 
 struct Builder {
     ldm_model* m; Plan* plan; Pool pool;
@@ -1008,10 +1005,10 @@ struct Builder {
         int* i = o.i;
         i[0] = dy.C; i[1] = x.C; i[2] = cout; i[3] = cin; i[4] = ld; i[5] = ci_off; i[6] = x.N; i[7] = x.D; i[8] = x.H; i[9] = x.W;
         i[10] = dy.D; i[11] = dy.H; i[12] = dy.W; i[13] = k; i[14] = stride; i[15] = pad; i[16] = ups; i[17] = (int)dy.rows();
-        i[18] = cur_ksplit; i[19] = cur_rows_total; i[20] = cur_w3; i[21] = hp ? 1 : 0;
+        i[18] = cur_ksplit; i[19] = cur_rows_total; i[21] = hp ? 1 : 0;
         plan->ops.push_back(o);
     }
-    int cur_ksplit = 1, cur_rows_total = 0, cur_w3 = 0;   // voxel split / slab rows / kw-triplet kernel of the gradient being staged
+    int cur_ksplit = 1, cur_rows_total = 0;   // voxel split / slab rows of the gradient being staged
     // dX of one source tensor `src` (channels [ci_off, ci_off + src.C) of the conv input) given dY.
     bool emit_dgrad(const Act& dy, const Act& src, const ConvW& w, int ci_off, int k, int stride, int pad, int ups) {
         if (stride == 2 && !(k == 3 && (pad == 1 || pad == 0))) { err = "backward of a stride-2 conv needs k = 3, pad 0 | 1"; return false; }
@@ -1061,26 +1058,7 @@ struct Builder {
         if (a.w1) export_bias(*a.w1);
         if (a.temb_row >= 0) emit_colsum(dout, true, ws_ref(dtemb_off + (size_t)a.temb_row * 4), w.cout, tproj_stride);
         // weights
-        // which weight-gradient kernel (OP_WGRAD i[20]): 0 = one tap per workgroup, 1 / 2 = kw triplet on four / eight waves
-        cur_w3 = 0; cur_ksplit = 0;
-        if (!hp && a.k == 3 && a.stride == 1 && a.pad == 1 && a.ups == 0) {
-            const long KP = (long)dout.N * dout.D * dout.H * (dout.W + 2);
-            const int mode = wgrad3_mode();
-            if (mode == 1 || mode == 2) { cur_w3 = mode; cur_ksplit = wgrad3_ksplit(KP, w.cout, cin_real); }
-            else if (mode == 3) {
-                // auto (measured per shape, tools/bench_wgrad.py): the eight-wave triplet where a workgroup gets a long voxel range
-                // (24^3 and larger: 62 vs 81 us at 256 -> 256, 123 vs 156 us at 512 -> 256, voxel split chosen for ONE round of the
-                // CUs) and at 6^3 (one short K range per workgroup, three taps per pass over it: 16 vs 21 us); the one-tap kernel
-                // in between (12^3: 18 vs 20 us)
-                const long steps = (KP + 63) / 64;
-                const long wgs = 9L * ((w.cout + 127) / 128) * ((cin_real + 127) / 128);
-                if (steps >= 96) {
-                    long k = (256 + wgs / 2) / wgs; if (k > steps / 12) k = steps / 12; if (k < 1) k = 1; if (k > 32) k = 32;
-                    cur_w3 = 2; cur_ksplit = (int)k;
-                } else if (steps <= 8) { cur_w3 = 2; cur_ksplit = 1; }
-            }
-        }
-        if (!cur_w3) cur_ksplit = wgrad_ksplit(dout.rows(), a.k * a.k * a.k, w.cout, cin_real, hp);
+        cur_ksplit = wgrad_ksplit(dout.rows(), a.k * a.k * a.k, w.cout, cin_real, hp);
         cur_rows_total = w.cout;
         dw_off = pool.alloc((size_t)cur_ksplit * a.k * a.k * a.k * w.cout * cin_real * 4);
         if (a.xb.valid) {
@@ -1090,7 +1068,6 @@ struct Builder {
         export_conv_weights(w, cin_real);
         if (a.w1) {
             const int c1 = a.g1a.C + (a.g1b.valid ? a.g1b.C : 0);
-            cur_w3 = 0;
             cur_ksplit = wgrad_ksplit(dout.rows(), 1, a.w1->cout, c1, hp); cur_rows_total = a.w1->cout;
             dw_off = pool.alloc((size_t)cur_ksplit * a.w1->cout * c1 * 4);
             emit_wgrad(dout, a.g1a, a.w1->cout, a.g1a.C, c1, 0, 1, 1, 0, 0);
@@ -1805,41 +1782,6 @@ static int wgrad_ksplit(long M, int taps, int cout, int cin, bool hp) {
     if (k > 16) k = 16;
     return (int)(k < 1 ? 1 : k);
 }
-// conv_wgrad3_kernel (kw-triplet weight gradient) is correct but not yet faster than conv_wgrad_kernel: with 192 accumulator
-// registers per lane hipcc shuttles accumulators between VGPRs and AGPRs around every MFMA, so it is
-// opt-in (LDM_WGRAD3=1) until its inner loop is register-allocated by hand.
-// LDM_WGRAD3: 0 = one tap per workgroup (conv_wgrad_kernel), 1 = kw triplet on four waves, 2 = kw triplet on eight waves
-static int wgrad3_mode() { const char* e = getenv("LDM_WGRAD3"); return e ? atoi(e) : 0; }
-static bool wgrad3_enabled() { return wgrad3_mode() != 0; }
-// kw-triplet kernel: 9 (kd, kh) pairs x tiles x ksplit workgroups
-static int wgrad3_ksplit(long KP, int cout, int cin) {
-    const long wgs = 9L * ((cout + 127) / 128) * ((cin + 127) / 128);
-    const long steps = (KP + 63) / 64;
-    long k = (512 + wgs - 1) / wgs;
-    if (k > steps / 8) k = steps / 8;
-    if (k > 32) k = 32;
-    return (int)(k < 1 ? 1 : k);
-}
-static int launch_wgrad3(const Wgrad3Params& p, hipStream_t s, int variant = 0) {   // variant 0: by LDM_WGRAD3; 1 / 2: four / eight waves
-    constexpr int LDS = 4 * (64 + 80) * 256 + 2 * (64 + 80) * 4;   // ring + double-buffered source-offset table
-    static bool attr_set = false;
-    if (!attr_set) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad3_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr_set = true; }
-    { const char* e = getenv("LDM_CONV_DBG"); const int dbg = e ? atoi(e) : 0;      // timing ablations (results are wrong)
-#define W3_ABL(A) if (dbg == A) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad3_kernel<A>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); \
-          hipLaunchKernelGGL(conv_wgrad3_kernel<A>, dim3(9 * p.co_tiles * p.ci_tiles * p.ksplit), dim3(256), LDS, s, p); return 0; }
-      W3_ABL(4) W3_ABL(8) W3_ABL(16) W3_ABL(32) W3_ABL(12) W3_ABL(20) W3_ABL(24) W3_ABL(28)
-#undef W3_ABL
-    }
-    if (variant == 2 || (variant == 0 && wgrad3_mode() >= 2)) {   // eight waves, two per SIMD (conv_wgrad3b_kernel)
-        constexpr int LDSB = LDS + 1024;                    // + the KiB the dummy copy pieces zero-fill
-        static bool attr_b = false;
-        if (!attr_b) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad3b_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB)); attr_b = true; }
-        hipLaunchKernelGGL(conv_wgrad3b_kernel<0>, dim3(9 * p.co_tiles * p.ci_tiles * p.ksplit), dim3(512), LDSB, s, p);
-        return 0;
-    }
-    hipLaunchKernelGGL(conv_wgrad3_kernel<0>, dim3(9 * p.co_tiles * p.ci_tiles * p.ksplit), dim3(256), LDS, s, p);
-    return 0;
-}
 static int launch_wgrad(const WgradParams& p, hipStream_t s) {
     constexpr int LDS = 4 * 2 * 64 * 256 + 3 * 128 * 4;        // ring + triple-buffered source-offset table
     static bool attr_set = false;
@@ -2125,15 +2067,6 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                 p.ksize = i[13]; p.stride = i[14]; p.pad = i[15]; p.ups = i[16]; p.M = i[17];
                 p.co_tiles = (p.Cout + 127) / 128; p.ci_tiles = (p.Cin + 127) / 128;
                 p.ksplit = i[18]; p.slab_stride = (long)i[13] * i[13] * i[13] * i[19] * i[4];
-                if (i[20]) {
-                    Wgrad3Params q{}; q.dy = p.dy; q.cdy = p.cdy; q.x = p.x; q.cx = p.cx; q.dw = p.dw; q.Cout = p.Cout; q.Cin = p.Cin;
-                    q.dw_ld = p.dw_ld; q.dw_ci_off = p.dw_ci_off; q.N = p.N; q.D = p.Din; q.H = p.Hin; q.W = p.Win;
-                    q.co_tiles = p.co_tiles; q.ci_tiles = p.ci_tiles; q.ksplit = p.ksplit; q.slab_stride = p.slab_stride;
-                    if ((long)p.M * p.cdy * 2 >= (1L << 32) || (long)p.M * p.cx * 2 >= (1L << 32))
-                        return fail(LDM_ERR_UNSUPPORTED, "weight gradient: tensor exceeds 4 GiB");
-                    LDM_TRY(launch_wgrad3(q, s, i[20]));
-                    break;
-                }
                 if ((long)p.M * p.cdy * 2 >= (1L << 32) || (long)p.N * p.Din * p.Hin * p.Win * p.cx * 2 >= (1L << 32))
                     return fail(LDM_ERR_UNSUPPORTED, "weight gradient: tensor exceeds 4 GiB");
                 LDM_TRY(launch_wgrad(p, s));
@@ -3479,13 +3412,6 @@ int ldm_op_conv3d_wgrad(const void* dy, int cdy, const void* x, int cx, float* d
     p.M = (int)M; p.co_tiles = (cout + 127) / 128; p.ci_tiles = (cin + 127) / 128;
     if (ksplit < 1 || ksplit > 64) return fail(LDM_ERR_BAD_ARG, "ksplit must be in 1..64");
     p.ksplit = ksplit; p.slab_stride = (long)ksize * ksize * ksize * cout * cin;
-    if (ksize == 3 && stride == 1 && pad == 1 && ups == 0 && wgrad3_enabled()) {       // kw-triplet kernel
-        Wgrad3Params q{}; q.dy = p.dy; q.cdy = cdy; q.x = p.x; q.cx = cx; q.dw = dw; q.Cout = cout; q.Cin = cin; q.dw_ld = cin; q.dw_ci_off = 0;
-        q.N = N; q.D = Din; q.H = Hin; q.W = Win; q.co_tiles = p.co_tiles; q.ci_tiles = p.ci_tiles; q.ksplit = ksplit; q.slab_stride = p.slab_stride;
-        LDM_TRY(launch_wgrad3(q, (hipStream_t)stream));
-        HIP_TRY(hipGetLastError());
-        return 0;
-    }
     LDM_TRY(launch_wgrad(p, (hipStream_t)stream));
     HIP_TRY(hipGetLastError());
     return 0;

@@ -366,17 +366,6 @@ def test_attention_backward(cuda, built_lib, b, n, c):
         assert e <= 1.5e-2, (name, e)
 
 
-@pytest.mark.parametrize("cin,cout,dims,n,ksplit", [(64, 96, (6, 6, 6), 1, 1), (128, 256, (5, 7, 6), 2, 2), (256, 128, (12, 12, 12), 1, 4),
-                                                    (64, 64, (2, 3, 1), 1, 1), (96, 160, (4, 4, 30), 1, 3)])
-@pytest.mark.parametrize("mode", ["1", "2"])
-def test_conv_wgrad_kw_triplet_kernel(cuda, built_lib, monkeypatch, cin, cout, dims, n, ksplit, mode):
-    """conv_wgrad3_kernel (LDM_WGRAD3=1: four waves) and conv_wgrad3b_kernel (LDM_WGRAD3=2: eight waves): three kw taps per workgroup
-    over zero-padded line positions."""
-    monkeypatch.setenv("LDM_WGRAD3", mode)
-    err = _wgrad_case(cuda, built_lib, cin, cout, dims, 3, 1, 1, n, 0, ksplit=ksplit, seed=cin)
-    assert err <= 2e-5, err
-
-
 def test_conv3_halo_vs_general_kernel(cuda, built_lib, monkeypatch):
     """Both kernels for the same conv (LDM_CONV_HALO toggles the planner's choice): each within tolerance of torch and of
     each other (they differ only in fp32 summation order over K)."""

@@ -1,5 +1,5 @@
 """Micro-benchmark of the conv weight-gradient kernels through ldm_op_conv3d_wgrad.
-usage: python tools/bench_wgrad.py [cin,cout,D,H,W[,ksplit] ...]   (LDM_WGRAD3=0 selects the one-tap kernel)"""
+usage: python tools/bench_wgrad.py [cin,cout,D,H,W[,ksplit] ...]"""
 import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
