@@ -216,6 +216,36 @@ def test_headline_plan_launch_count(built_lib):
     assert 100 <= n <= 155, n
 
 
+def _bf16_conv_launches(model, kind, batch, dims):
+    """(wgm, wgn, bk, halo, splitk) of every launch of the bf16 conv kernels in a cached plan (`ldm_model_plan_conv_cfgs`)."""
+    import ctypes as C
+    from ldm3d import _lib
+    buf = (C.c_int * (4 * 512))()
+    n = _lib.lib().ldm_model_plan_conv_cfgs(model._h, kind, batch, *dims, buf, 512)
+    assert 0 <= n <= 512, n
+    return [(buf[4 * i], buf[4 * i + 1], buf[4 * i + 2] & 255, buf[4 * i + 2] >> 8, buf[4 * i + 3]) for i in range(n)]
+
+
+def test_planner_rules_added_in_round_3(built_lib, monkeypatch):
+    """Host-side planner decisions, checked without a GPU.
+    * fp32 precision mode, inference: every 3^3 ResBlock / Upsample convolution runs as the 3 x bf16 product on conv3_halo_kernel (the only
+      launches of the bf16 conv kernels in such a plan); the bf16 plan of the same network also uses the general kernel.
+    * AutoencoderKL decoder at 96^3: the phase-upsample and fused-skip convolutions with >= 512 tiles and <= 64 K steps take 32-channel K
+      steps (two four-wave workgroups per CU); LDM_IGEMM_2WG=0 plans them as before."""
+    from ldm3d.networks import AutoencoderKL, DiffusionModelUNet
+    unet = DiffusionModelUNet(**cfgs.UNET_FULL)
+    bf16 = _bf16_conv_launches(unet, b"unet", 1, (24, 24, 24))
+    assert any(c[3] for c in bf16) and any(not c[3] for c in bf16)
+    unet.set_precision("fp32")
+    fp32 = _bf16_conv_launches(unet, b"unet", 1, (24, 24, 24))
+    assert len(fp32) >= 30 and all(c[3] for c in fp32), fp32
+    assert all(c[4] == 1 for c in fp32[:4]), "the 24^3 level runs unsplit (and finishes in the conv's own epilogue)"
+    two = [c for c in _bf16_conv_launches(AutoencoderKL(**cfgs.VAE_FULL), b"dec", 1, (24, 24, 24)) if c[:4] == (2, 2, 32, 0)]
+    monkeypatch.setenv("LDM_IGEMM_2WG", "0")
+    one = [c for c in _bf16_conv_launches(AutoencoderKL(**cfgs.VAE_FULL), b"dec", 1, (24, 24, 24)) if c[:4] == (2, 2, 32, 0)]
+    assert len(one) == 1 and len(two) == 4, (one, two)      # conv_in (Cin = 32) always; + two phase-upsample convs and one fused-skip conv
+
+
 def test_shapes_the_networks_cannot_take_fail_loudly(built_lib):
     """The reference crops / pads every volume to a multiple of 2^(levels-1) (utils.py:87-95 `size_divisible`, DivisiblePadd) because
     MONAI's skip concatenation fails on odd sizes; here the planner refuses them with a message instead of a size mismatch deep inside."""
