@@ -128,6 +128,65 @@ def cpu_baseline(steps=3):
             "value_at_the_reference_4_threads": four}
 
 
+def other_paths_leg(dev):
+    """AutoencoderKL encode / decode of one 1x1x96^3 volume (BASELINE configs[1]; 3d_ldm/train_diffusion.py:104, inference.py:94-99) and the
+    UNet training step at 1x4x24^3 (forward + MSE + backward + clip + Adam + bf16 re-pack: train_diffusion.py:207-223), bf16, wall clock
+    around back-to-back calls with a device synchronisation on both sides."""
+    import torch
+    from ldm3d.networks import AutoencoderKL
+    from ldm3d.optim import FlatAdam, mse_loss
+    rec = {}
+    vae = AutoencoderKL(spatial_dims=3, in_channels=1, out_channels=1, latent_channels=4, channels=[64, 128, 256], num_res_blocks=2,
+                        norm_num_groups=32, norm_eps=1e-6, attention_levels=[False, False, False],
+                        with_encoder_nonlocal_attn=False, with_decoder_nonlocal_attn=False)
+    g = torch.Generator().manual_seed(0)
+    with torch.no_grad():
+        for prm in vae.parameters():
+            if prm.dim() > 1:
+                prm.copy_(torch.randn(prm.shape, generator=g) / prm[0].numel() ** 0.5)
+    vae = vae.to(dev).eval()
+    img = torch.rand((1, 1, 96, 96, 96), generator=g).to(dev)
+    lat = torch.randn((1, 4, 24, 24, 24), generator=g).to(dev)
+
+    def clock(fn, n=10, warm=2):
+        with torch.no_grad():
+            for _ in range(warm):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+    rec["vae_96cube"] = {"encode_ms": clock(lambda: vae.encode(img)), "decode_ms": clock(lambda: vae.decode(lat)),
+                         "what": "AutoencoderKL (64/128/256, 2 res blocks per level) on 1x1x96^3, bf16, random init"}
+    del vae
+    torch.cuda.empty_cache()
+    unet = make_unet(dev, seed=0).train()
+    opt = FlatAdam(unet, lr=5e-6, max_grad_norm=1.0)
+    x, noise = torch.randn((1, 4, 24, 24, 24), device=dev), torch.randn((1, 4, 24, 24, 24), device=dev)
+    t = torch.tensor([500.0], device=dev)
+
+    def step():
+        loss = mse_loss(unet(x=x, timesteps=t), noise)
+        loss.backward()
+        opt.step()
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 10
+    for _ in range(n):
+        step()
+    torch.cuda.synchronize()
+    rec["train_step_24cube"] = {"ms_per_step": (time.perf_counter() - t0) / n * 1e3, "skipped_steps": int(opt.skipped_steps()),
+                                "what": "benchmark UNet, batch 1, 1x4x24^3: training-plan forward + fused MSE + backward plan + gradient-norm "
+                                        "clip + fused Adam + bf16 re-pack, no host read inside the step"}
+    del unet, opt
+    torch.cuda.empty_cache()
+    return rec
+
+
 def ddp_train_leg(dev, rank, world, dist, rehearsal, steps=8, warmup=3, latent=(36, 44, 28)):
     """BASELINE configs[3] beside the headline: the data-parallel training step of 3d_ldm/train_diffusion.py:172-223 (two no-grad VAE
     encodes of the 144x176x112 patch pair, concat-conditioned benchmark UNet forward at the 36x44x28 latent, MSE, backward, clip,
@@ -224,6 +283,7 @@ def main():
     ap.add_argument("--eager", action="store_true", help="launch every kernel from the host instead of replaying the HIP graph")
     ap.add_argument("--host-step", action="store_true", help="scheduler step driven from the host (torch.randn + coefficient lookup) instead of the fused device sampler")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the fp32 precision mode figure reported beside the bf16 one")
+    ap.add_argument("--no-other-paths", action="store_true", help="skip the AutoencoderKL 96^3 and 24^3 training-step figures (BASELINE configs[1], a6) reported beside the headline")
     ap.add_argument("--no-ddp-train", action="store_true", help="skip the data-parallel training leg (configs[3]) reported beside the headline")
     args = ap.parse_args()
 
@@ -360,6 +420,10 @@ def main():
                                 "(bf16 path: ~3e-2; LDM_F32_X3=0 = exact fp32 MFMA everywhere: ~1e-5 at 84 steps/s)"}
             unet.set_precision("bf16")
     assert torch.isfinite(x).all()
+    # the other section-8 paths on rank 0 at N = 1, after the headline's timed region: reported beside the metric, never instead of it
+    other = None
+    if not args.no_other_paths and world == 1:
+        other = other_paths_leg(dev)
     # BASELINE configs[3] (DDP training over RCCL) on every rank, after the headline's timed region: its own record in the same line
     ddp = None
     if not args.no_ddp_train:
@@ -423,6 +487,8 @@ def main():
         }
     if fp32_leg is not None:
         out["fp32_mode"] = fp32_leg
+    if other is not None:
+        out["other_paths"] = other
     if ddp is not None:
         out["ddp_train"] = ddp
     if not args.no_cpu_baseline and world == 1:
