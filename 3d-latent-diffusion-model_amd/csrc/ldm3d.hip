@@ -265,16 +265,18 @@ struct ldm_model {
         c.b_off = arena_alloc((size_t)c.cout_pad * 4);
         return c;
     }
+    void reg_x3(ConvW& c) {                          // a 3^3 conv the fp32 inference plans may run on the halo kernel (x3_ws)
+        if (c.k != 3 || c.cin_s % 64) return;
+        c.x3_off = x3_bytes; x3_bytes += rup_sz((size_t)27 * c.cout_pad * 3 * c.cin_s * 2, 256);
+        x3_ws.push_back(X3W{c.w_off, c.x3_off, 27L * c.cout_pad, c.cin_s});
+    }
     void reg_conv(const std::string& name, int cin, int cin_s, int cout, int k, bool phase = false) {
         ConvW c = new_conv_slot(cin_s, cout, k);
         if (phase && k == 3) {
             c.wp_off = arena_alloc((size_t)64 * c.cout_pad * cin_s * 2);
             phase_ws.push_back(PhaseW{c.w_off, c.wp_off, c.cout_pad, cin_s});
         }
-        if (k == 3 && cin_s % 64 == 0) {
-            c.x3_off = x3_bytes; x3_bytes += rup_sz((size_t)27 * c.cout_pad * 3 * cin_s * 2, 256);
-            x3_ws.push_back(X3W{c.w_off, c.x3_off, 27L * c.cout_pad, cin_s});
-        }
+        reg_x3(c);
         reg_conv_into(name, c, cin, cout, k, 0, false);
         convs[name] = c;
     }
@@ -457,14 +459,15 @@ struct Builder {
         }
         if (a.xa.hl) {                                   // 3 x bf16 product on conv3_halo_kernel (x3_halo_ok decided it when the GroupNorm was planned)
             const int C = a.xa.C, n3 = C / 64;
-            if (a.k != 3 || a.stride != 1 || a.pad != 1 || a.ups || a.exact || a.xb.valid || a.f32_out || a.w_over.base != BASE_NULL ||
+            if (a.k != 3 || a.stride != 1 || a.pad != 1 || a.ups || a.exact || a.xb.valid || a.w_over.base != BASE_NULL ||
                 w.x3_off == (size_t)-1 || C != w.cin_s || a.xa.D != a.Do || a.xa.H != a.Ho || a.xa.W != a.Wo || (long)M * C * 4 >= (1L << 32)) {
                 err = "conv " + tag + ": hi/lo input reached a conv that cannot take it"; return Act();
             }
             ConvCfg cc = choose_cfg(M, w.cout_pad, 27 * 3 * n3, 64, N, (long)a.Do * a.Ho * a.Wo, true);
             if (!cc.halo) { err = "conv " + tag + ": no halo configuration"; return Act(); }
             const int couts = rup(w.cout, 32);
-            Act out = new_act(N, a.Do, a.Ho, a.Wo, couts);
+            Act out;                                         // f32_out (the network's last conv): fp32 NCDHW straight to the caller's buffer
+            if (!a.f32_out) out = new_act(N, a.Do, a.Ho, a.Wo, couts);
             Op op{}; op.kind = OP_CONV; op.cc = cc;
             op.r[0] = ws_ref(a.xa.off); op.r[2] = Ref{BASE_W32, 2 * m->arena_bytes + w.x3_off};
             int* i = op.i;
@@ -472,6 +475,12 @@ struct Builder {
             i[11] = 3; i[12] = 1; i[13] = 1; i[14] = 8; i[15] = (int)M; i[16] = couts; i[17] = w.cout_pad; i[18] = w.cout;
             i[19] = 3 * n3; i[23] = N * cc.mtps;
             static const int x3_fused = [] { const char* e = getenv("LDM_X3_FUSED_EP"); return e ? atoi(e) : 1; }();
+            if (cc.splitk == 1 && x3_fused && a.f32_out) {   // no split, last conv: the kernel's own fp32 NCDHW epilogue (bias only)
+                i[14] |= 32; i[22] = 1; i[18] = a.cout_real ? a.cout_real : w.cout;
+                op.r[6] = a.no_bias ? Ref() : w_ref(w.b_off); op.r[10] = a.out_ref;
+                plan->ops.push_back(op);
+                return out;
+            }
             if (cc.splitk == 1 && x3_fused) {                // no split: bias / time embedding / residual, the fp32 store and the GroupNorm partials in the conv's epilogue
                 i[14] |= 16; i[21] = a.temb_stride;
                 op.r[6] = a.no_bias ? Ref() : w_ref(w.b_off); op.r[8] = a.temb;
@@ -487,11 +496,12 @@ struct Builder {
             partial_fixups.push_back(plan->ops.size()); plan->ops.push_back(op);
             Op f{}; f.kind = OP_FIN32; f.cc = ConvCfg{2, 2, 32, cc.splitk};
             f.r[2] = w32_ref(w.w_off); f.r[6] = a.no_bias ? Ref() : w_ref(w.b_off);
-            f.r[8] = a.temb; f.r[9] = a.residual.valid ? ws_ref(a.residual.off) : Ref(); f.r[10] = ws_ref(out.off);
+            f.r[8] = a.temb; f.r[9] = a.residual.valid ? ws_ref(a.residual.off) : Ref(); f.r[10] = a.f32_out ? a.out_ref : ws_ref(out.off);
             int* j = f.i;
             j[0] = C; j[4] = N; j[5] = a.xa.D; j[6] = a.xa.H; j[7] = a.xa.W; j[8] = a.Do; j[9] = a.Ho; j[10] = a.Wo;
             j[11] = 3; j[12] = 1; j[13] = 1; j[15] = (int)M; j[16] = couts; j[17] = w.cout_pad; j[18] = w.cout;
             j[19] = C / 32; j[20] = w.cout_pad / 128 ? w.cout_pad / 128 : 1; j[21] = a.temb_stride; j[23] = (int)((M + 127) / 128);
+            if (a.f32_out) { j[22] = 1; j[18] = a.cout_real ? a.cout_real : w.cout; }
             partial_fixups.push_back(plan->ops.size()); plan->ops.push_back(f);
             return out;
         }
@@ -1412,7 +1422,7 @@ static int unet_build(ldm_model* m, int B, int D, int H, int W, Plan* plan, bool
             h = hu;
         }
     }
-    Act hn = b.gn_apply(m->gns.at("out.0"), h, Act(), G, eps, true);
+    Act hn = b.gn_apply(m->gns.at("out.0"), h, Act(), G, eps, true, &m->convs.at("out.2"));
     b.free_act(h);
     if (!hn.valid) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
     Builder::ConvArgs oa; oa.xa = hn; oa.w = &m->convs.at("out.2"); oa.Do = D; oa.Ho = H; oa.Wo = W;
@@ -1508,6 +1518,7 @@ static int vae_register(ldm_model* m) {
             switch (bl.kind) {
                 case 0: {   // plain Convolution: keys <p>.conv.*
                     ConvW cw = m->new_conv_slot(rup(bl.a, 32), bl.b, 3);
+                    m->reg_x3(cw);
                     m->reg_conv_into(p, cw, bl.a, bl.b, 3, 0, false); m->convs[p] = cw;
                     if (k == 0 && std::string(prefix) == "encoder") m->reg_im2col(p, bl.a);       // the encoder's first conv
                     break; }
@@ -1564,7 +1575,12 @@ static int vae_run_layout(Builder& b, const char* prefix, const std::vector<AeBl
         } else if (bl.kind == 4) {
             hn = b.conv3(std::string(p) + ".postconv", h, 1, 1, 1);
         } else if (bl.kind == 5) {
-            hn = b.gn_apply(b.m->gns.at(p), h, Act(), G, eps, false);
+            const ConvW* next3 = nullptr;                    // the network's last conv reads this norm (not in tapped plans: the tap would export the split)
+            if (k + 1 < lay.size() && lay[k + 1].kind == 0 && b.tap_mode == 0) {
+                char pn[96]; snprintf(pn, sizeof pn, "%s.blocks.%zu", prefix, k + 1);
+                next3 = &b.m->convs.at(pn);
+            }
+            hn = b.gn_apply(b.m->gns.at(p), h, Act(), G, eps, false, next3);
         } else return fail(LDM_ERR_UNSUPPORTED, "unsupported AutoencoderKL block");
         b.free_act(h);
         if (!hn.valid) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
@@ -1933,7 +1949,7 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                 p.N = i[4]; p.Din = i[5]; p.Hin = i[6]; p.Win = i[7]; p.Dout = i[8]; p.Hout = i[9]; p.Wout = i[10];
                 p.ksize = i[11]; p.stride = i[12]; p.pad = i[13]; p.ups = i[14] & 1; p.exact = (i[14] >> 1) & 1; p.M = i[15];
                 p.phase_mode = (i[14] >> 2) & 1; p.mtiles_pp = p.phase_mode ? i[23] / (8 * i[4]) : 0;
-                if (i[14] & 8) { p.x3_n = i[19] / 3; p.raw_partial = (i[14] & 16) ? 0 : 1; }   // fp32 precision: 3 x bf16 product on the halo kernel
+                if (i[14] & 8) { p.x3_n = i[19] / 3; p.raw_partial = (i[14] & (16 | 32)) ? 0 : 1; }   // fp32 precision: 3 x bf16 product on the halo kernel
                 p.CoutS = i[16]; p.CoutPad = i[17]; p.CoutReal = i[18]; p.nchunk0 = i[19]; p.nchunk1 = i[20];
                 p.steps0 = i[11] * i[11] * i[11] * i[19]; p.steps1 = i[20];
                 p.splitk = o.cc.splitk; p.steps_per_split = (p.steps0 + p.steps1 + p.splitk - 1) / p.splitk;
