@@ -53,6 +53,8 @@ struct ConvParams {
     // conv3_halo_kernel as the fp32 precision mode's 3 x bf16 product (x3_n > 0 = 64-channel chunks of the REAL Cin): the voxel operand
     // is [rows][hi | lo] bf16 (2 x3_n chunks per row), the weights [tap][cout][hi | lo | hi] (3 x3_n chunks); K chunk c reads voxel
     // chunk c (c < x3_n: hi), c - x3_n (hi again) or c - x3_n (c >= 2 x3_n: lo) against weight chunk c:  hi*Whi + hi*Wlo + lo*Whi.
+    // conv_igemm_kernel takes the same product through its two concatenated sources: x0a = the split tensor (hi | lo, c0a = 2 C), x0b = the
+    // same pointer again (c0b = C: hi), both with the split tensor's row stride, weights [.. ][hi | hi | lo]:  hi*Whi + lo*Whi + hi*Wlo.
     int x3_n;
     int raw_partial;                  // write the fp32 accumulators to the partial slab even with splitk == 1 (the fp32 finalize follows)
     float* out32; const float* residual32;   // conv3_halo_kernel, fp32 precision, splitk == 1: fp32 NDHWC output [M][CoutS] (+ fp32 residual) from the fused epilogue
@@ -213,6 +215,7 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_igemm_kernel(const ConvParam
     // that advances by BK*2 bytes per step, so a step costs one m0 write + one instruction per piece.  Three tiers
     // keep the rare work rare: per GROUP (descriptors, weight row offsets), per TAP (voxel index from the packed
     // candidates: ~10 VALU per row), per SOURCE (row byte offset = voxel * channels).
+    const unsigned x3s2 = p.x3_n ? (unsigned)p.x3_n * 256u : 0u;   // x3 form: both sources are views of one [rows][2 C] bf16 tensor (row stride 4 C bytes)
     int sg_grp, sg_tap, sg_src, sg_left;                           // scalar segment state
     int g_ca = 0, g_cb = 0;                                        // channels of the current group's two sources
     unsigned g_wtap = 0;                                           // bytes between two taps of the weight tensor
@@ -237,8 +240,8 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_igemm_kernel(const ConvParam
         g_ca = sg_grp ? p.c1a : p.c0a; g_cb = sg_grp ? p.c1b : p.c0b;                                         \
         const int cin_ = g_ca + g_cb;                                                                         \
         const unsigned rows_ = sg_grp ? (unsigned)p.M : (unsigned)rows_in0;                                   \
-        rs_a0 = __builtin_amdgcn_make_buffer_rsrc((void*)(sg_grp ? p.x1a : p.x0a), 0, (int)(rows_ * (unsigned)g_ca * 2u), 0x00020000); \
-        rs_a1 = __builtin_amdgcn_make_buffer_rsrc((void*)(sg_grp ? p.x1b : p.x0b), 0, (int)(rows_ * (unsigned)g_cb * 2u), 0x00020000); \
+        rs_a0 = __builtin_amdgcn_make_buffer_rsrc((void*)(sg_grp ? p.x1a : p.x0a), 0, (int)(rows_ * (x3s2 ? x3s2 : (unsigned)g_ca * 2u)), 0x00020000); \
+        rs_a1 = __builtin_amdgcn_make_buffer_rsrc((void*)(sg_grp ? p.x1b : p.x0b), 0, (int)(rows_ * (x3s2 ? x3s2 : (unsigned)g_cb * 2u)), 0x00020000); \
         g_wtap = (unsigned)p.CoutPad * (unsigned)cin_ * 2u;                                                   \
         rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)(sg_grp ? p.w1 : w0p), 0,                            \
                                                  (int)((unsigned)(sg_grp ? 1 : p.ksize * p.ksize * p.ksize) * g_wtap), 0x00020000); \
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_igemm_kernel(const ConvParam
             a_v[j] = (sg_grp == 0) ? tapv[sg_tap * BM + a_row[j]] : a_m[j];                                   \
     } while (0)
 #define LDM_SRC_SETUP() do {                                                                                  \
-        const unsigned cs2_ = (unsigned)(sg_src ? g_cb : g_ca) * 2u;                                          \
+        const unsigned cs2_ = x3s2 ? x3s2 : (unsigned)(sg_src ? g_cb : g_ca) * 2u;   /* bytes per source row */ \
         rs_a = sg_src ? rs_a1 : rs_a0;                                                                        \
         _Pragma("unroll") for (int j = 0; j < PA; ++j)                                                        \
             a_vo[j] = (a_v[j] >= 0) ? (unsigned)a_v[j] * cs2_ + (unsigned)a_kb[j] : 0xFFFFFFFFu;              \
@@ -535,7 +538,8 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_igemm_kernel(const ConvParam
     // Per lane: 16 consecutive couts of one voxel per 16-row tile.  Optionally also the GroupNorm partial sums of
     // the (bf16-rounded) output over each 32-row block, written to a slab (no atomics -> bitwise reproducible).
     const int cbase = n0 + wn * 64 + 16 * fg;          // this lane's 16 consecutive couts
-    const bool do_stats = (p.stats != nullptr) && (p.splitk == 1) && (p.out != nullptr);
+    const bool to_slab = p.splitk > 1 || p.raw_partial;
+    const bool do_stats = (p.stats != nullptr) && !to_slab && (p.out != nullptr);
     float ssum[16], ssq[16];                           // GroupNorm partials of this wave's rows (whole tile after the LDS fold)
 #pragma unroll
     for (int q = 0; q < 16; ++q) { ssum[q] = 0.f; ssq[q] = 0.f; }
@@ -560,7 +564,7 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_igemm_kernel(const ConvParam
                     if constexpr (NG == 2) v[nt * 4 + r] = (grp == 0) ? acc[nt][ml][r] : acc[nt][2 + ml][r];
                     else v[nt * 4 + r] = acc[nt][ml][r];
                 }
-            if (p.splitk > 1) {
+            if (to_slab) {
                 float* dst = p.partial + ((size_t)split * p.M + m) * p.CoutPad + cbase;
 #pragma unroll
                 for (int q = 0; q < 4; ++q)

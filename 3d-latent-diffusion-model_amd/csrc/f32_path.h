@@ -479,13 +479,14 @@ __global__ __launch_bounds__(256) void gn32_fold_apply_kernel(const Gn32FusedPar
 
 // Nearest x2 upsample of an fp32 NDHWC tensor straight into the (hi | lo) bf16 split: [N][2D][2H][2W][hi(C) | lo(C)].  The voxel operand
 // of the 3 x bf16 halo conv behind an Upsample block (the general fp32 kernels fold the upsample into their loader instead).
-__global__ __launch_bounds__(256) void upsample_split_f32_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, int N, int C, int D, int H, int W) {
-    const int cvec = C / 4, Ho = 2 * H, Wo = 2 * W;
-    const long total = (long)N * 8 * D * H * W * cvec;
+// up = 0: the split alone, same size (the voxel operand of the phase form of the Upsample conv, which walks the low-resolution grid).
+__global__ __launch_bounds__(256) void upsample_split_f32_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, int N, int C, int D, int H, int W, int up) {
+    const int cvec = C / 4, Do = D << up, Ho = H << up, Wo = W << up;
+    const long total = (long)N * Do * Ho * Wo * cvec;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
         const long row = e / cvec; const int c = (int)(e - row * cvec) * 4;
-        long r = row; const int ow = (int)(r % Wo); r /= Wo; const int oh = (int)(r % Ho); r /= Ho; const int od = (int)(r % (2 * D)); const long n = r / (2 * D);
-        const long src = ((n * D + (od >> 1)) * H + (oh >> 1)) * W + (ow >> 1);
+        long r = row; const int ow = (int)(r % Wo); r /= Wo; const int oh = (int)(r % Ho); r /= Ho; const int od = (int)(r % Do); const long n = r / Do;
+        const long src = ((n * D + (od >> up)) * H + (oh >> up)) * W + (ow >> up);
         uint2 hi, lo; split_bf16x4(*reinterpret_cast<const float4*>(x + src * C + c), hi, lo);
         *reinterpret_cast<uint2*>(out + row * (2 * C) + c) = hi;
         *reinterpret_cast<uint2*>(out + row * (2 * C) + C + c) = lo;
@@ -501,6 +502,35 @@ __global__ __launch_bounds__(256) void x3_weights_kernel(const float* __restrict
         bf16_t* dst = out + r * (3 * cin) + c;
         *reinterpret_cast<uint2*>(dst) = hi; *reinterpret_cast<uint2*>(dst + cin) = lo; *reinterpret_cast<uint2*>(dst + 2 * cin) = hi;
     }
+}
+
+// Phase weights (norm_elem.h phase_weights_kernel: the 3^3 taps that read the same low-resolution voxel, summed) of the 3 x bf16 form on
+// conv_igemm_kernel: fp32 [27][cout_pad][cin] -> bf16 [parity 8][tap 8][cout_pad][hi | hi | lo] (sums in fp32, then the split).
+// grid = (blocks over cout_pad * cin / 4, 64), 256 threads; thread = 4 consecutive cin of one cout row.
+__global__ __launch_bounds__(256) void x3_phase_weights_kernel(const float* __restrict__ w3, bf16_t* __restrict__ wp, int cout_pad, int cin) {
+    const long vecs = (long)cout_pad * cin / 4;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= vecs) return;
+    const int phase = blockIdx.y >> 3, tap = blockIdx.y & 7;
+    const int pb[3] = {phase >> 2, (phase >> 1) & 1, phase & 1}, tb[3] = {tap >> 2, (tap >> 1) & 1, tap & 1};
+    int lo[3], hi[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        if (pb[d] == 0) { lo[d] = tb[d] ? 1 : 0; hi[d] = tb[d] ? 2 : 0; }
+        else            { lo[d] = tb[d] ? 2 : 0; hi[d] = tb[d] ? 2 : 1; }
+    }
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const size_t mat = (size_t)cout_pad * cin;
+    for (int kd = lo[0]; kd <= hi[0]; ++kd)
+        for (int kh = lo[1]; kh <= hi[1]; ++kh)
+            for (int kw = lo[2]; kw <= hi[2]; ++kw) {
+                const float4 v = *reinterpret_cast<const float4*>(w3 + (size_t)((kd * 3 + kh) * 3 + kw) * mat + idx * 4);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+    const long row = idx / (cin / 4); const int c = (int)(idx - row * (cin / 4)) * 4;
+    uint2 h, l; split_bf16x4(acc, h, l);
+    bf16_t* dst = wp + ((size_t)blockIdx.y * cout_pad + row) * (3 * cin) + c;
+    *reinterpret_cast<uint2*>(dst) = h; *reinterpret_cast<uint2*>(dst + cin) = h; *reinterpret_cast<uint2*>(dst + 2 * cin) = l;
 }
 
 // ---- self-attention on fp32 q|k|v rows [B*N][3C] (q | k | v, heads of d channels each), flash style, fp32 MFMA.

@@ -176,7 +176,8 @@ struct ParamDesc {
 
 struct ConvW { size_t w_off = 0; size_t b_off = 0; int cout = 0, cout_pad = 0, cin_s = 0, k = 1; bool has = false;
                size_t wp_off = 0;                    // upsample convs: the derived phase weights [8][8][cout_pad][cin_s] (0 = none)
-               size_t x3_off = (size_t)-1; };        // fp32 precision: [27][cout_pad][hi | lo | hi] bf16 behind the fp32 arena ((size_t)-1 = none)
+               size_t x3_off = (size_t)-1;           // fp32 precision: [27][cout_pad][hi | lo | hi] bf16 behind the fp32 arena ((size_t)-1 = none)
+               size_t x3p_off = (size_t)-1; };       // ... and of the upsample convs: phase weights [8][8][cout_pad][hi | hi | lo]
 struct GnW { size_t g_off = 0, b_off = 0; int C = 0; };
 struct LinW { size_t w_off = 0, b_off = 0; int in = 0, out = 0; };
 
@@ -226,6 +227,8 @@ struct ldm_model {
     // behind it (arena32 = [2 * arena_bytes fp32 twins][x3_bytes])
     struct X3W { size_t w_off, x3_off; long rows; int cin_s; };
     std::vector<X3W> x3_ws; size_t x3_bytes = 0;
+    struct X3PW { size_t w_off, x3p_off; int cout_pad, cin_s; };
+    std::vector<X3PW> x3p_ws;
     struct Im2colW { size_t w_off, wi_off; int cout_pad, cin_s, cin, Kp; };     // first convs run as im2col + GEMM (inference plans)
     std::vector<Im2colW> im2col_ws;
     static int im2col_k(int cin) { const int k = 27 * cin; return k <= 96 ? rup(k, 32) : rup(k, 128); }
@@ -275,6 +278,10 @@ struct ldm_model {
         if (phase && k == 3) {
             c.wp_off = arena_alloc((size_t)64 * c.cout_pad * cin_s * 2);
             phase_ws.push_back(PhaseW{c.w_off, c.wp_off, c.cout_pad, cin_s});
+            if (cin_s % 64 == 0) {
+                c.x3p_off = x3_bytes; x3_bytes += rup_sz((size_t)64 * c.cout_pad * 3 * cin_s * 2, 256);
+                x3p_ws.push_back(X3PW{c.w_off, c.x3p_off, c.cout_pad, cin_s});
+            }
         }
         reg_x3(c);
         reg_conv_into(name, c, cin, cout, k, 0, false);
@@ -444,13 +451,56 @@ struct Builder {
         const int N = a.xa.N;
         const long M = (long)N * a.Do * a.Ho * a.Wo;
         if (M >= (1L << 31)) { err = "conv " + tag + ": M too large"; return Act(); }
+        // Upsample block in an inference plan, phase form (8 taps on the source grid instead of 27 on the upsampled one) as the
+        // 3 x bf16 product on conv_igemm_kernel: the source is split once (hi | lo, same size), the kernel reads it as two concatenated
+        // sources (hi | lo, then hi again) against phase weights [hi | hi | lo], fp32 slabs, fp32 finalize.
+        {
+            static const int x3_phase = [] { const char* e = getenv("LDM_X3_PHASE"); return e ? atoi(e) : 1; }();
+            const int C = a.xa.C;
+            if (x3_phase && !train && a.ups == 1 && !a.exact && a.k == 3 && a.stride == 1 && a.pad == 1 && !a.xb.valid && !a.w1 && !a.f32_out &&
+                a.w_over.base == BASE_NULL && !a.xa.hl && a.Do == 2 * a.xa.D && a.Ho == 2 * a.xa.H && a.Wo == 2 * a.xa.W && phase_enabled() &&
+                w.x3p_off != (size_t)-1 && x3_halo_ok(w, M, C) && a.temb.base == BASE_NULL && !a.residual.valid) {
+                const long rows_src = (long)N * a.xa.D * a.xa.H * a.xa.W;
+                Act sp = new_act(N, a.xa.D, a.xa.H, a.xa.W, C); sp.hl = true;
+                Op u{}; u.kind = OP_UPS_SPLIT32; u.r[0] = ws_ref(a.xa.off); u.r[1] = ws_ref(sp.off);
+                u.i[0] = N; u.i[1] = C; u.i[2] = a.xa.D; u.i[3] = a.xa.H; u.i[4] = a.xa.W; u.i[5] = 0;
+                plan->ops.push_back(u);
+                int bk = 64, nchunk0 = 3 * C / 64, steps0 = 8 * nchunk0;
+                ConvCfg cc = choose_cfg(M, w.cout_pad, steps0, 64);
+                if (cc.wgm > 2 || cc.splitk != 1) cc = ConvCfg{2, 2, 64, 1};
+                if (w.cout_pad % (64 * cc.wgn)) cc = ConvCfg{4, 1, 64, 1};
+                const int bm = 64 * cc.wgm, bn = 64 * cc.wgn;
+                const int mtiles_pp = (int)(((long)a.xa.D * a.xa.H * a.xa.W + bm - 1) / bm);
+                if (cc.wgm <= 2 && two_wg_enabled() && steps0 <= 64 && (long)N * 8 * mtiles_pp * (w.cout_pad / bn) >= 512) { cc.bk = bk = 32; nchunk0 = 3 * C / 32; steps0 = 8 * nchunk0; }
+                (void)rows_src;
+                const int couts = rup(w.cout, 32);
+                Act out = new_act(N, a.Do, a.Ho, a.Wo, couts);
+                Op op{}; op.kind = OP_CONV; op.cc = cc;
+                op.r[0] = ws_ref(sp.off); op.r[1] = ws_ref(sp.off); op.r[2] = Ref{BASE_W32, 2 * m->arena_bytes + w.x3p_off};
+                int* i = op.i;
+                i[0] = 2 * C; i[1] = C; i[4] = N; i[5] = a.xa.D; i[6] = a.xa.H; i[7] = a.xa.W; i[8] = a.Do; i[9] = a.Ho; i[10] = a.Wo;
+                i[11] = 2; i[12] = 1; i[13] = 1; i[14] = 4 | 8; i[15] = (int)M; i[16] = couts; i[17] = w.cout_pad; i[18] = w.cout;
+                i[19] = nchunk0; i[23] = N * 8 * mtiles_pp;
+                partial_bytes = std::max(partial_bytes, (size_t)M * w.cout_pad * 4);
+                partial_fixups.push_back(plan->ops.size()); plan->ops.push_back(op);
+                Op f{}; f.kind = OP_FIN32; f.cc = ConvCfg{2, 2, 32, 1};
+                f.r[2] = w32_ref(w.w_off); f.r[6] = a.no_bias ? Ref() : w_ref(w.b_off); f.r[10] = ws_ref(out.off);
+                int* j = f.i;
+                j[0] = C; j[4] = N; j[5] = a.xa.D; j[6] = a.xa.H; j[7] = a.xa.W; j[8] = a.Do; j[9] = a.Ho; j[10] = a.Wo;
+                j[11] = 3; j[12] = 1; j[13] = 1; j[15] = (int)M; j[16] = couts; j[17] = w.cout_pad; j[18] = w.cout;
+                j[19] = C / 32; j[20] = 1; j[23] = (int)((M + 127) / 128);
+                partial_fixups.push_back(plan->ops.size()); plan->ops.push_back(f);
+                free_act(sp);
+                return out;
+            }
+        }
         // Upsample block (nearest x2, then 3^3 conv) in an inference plan: one pass writes the upsampled tensor as the (hi | lo) split, the
         // conv then runs on the halo kernel like the ResBlock convs (12^3 -> 24^3, 256 channels: 258 -> ~175 us)
         if (!train && a.ups == 1 && !a.exact && a.k == 3 && a.stride == 1 && a.pad == 1 && !a.xb.valid && !a.w1 && !a.f32_out &&
             a.w_over.base == BASE_NULL && !a.xa.hl && a.Do == 2 * a.xa.D && a.Ho == 2 * a.xa.H && a.Wo == 2 * a.xa.W && x3_halo_ok(w, M, a.xa.C)) {
             Act up = new_act(N, a.Do, a.Ho, a.Wo, a.xa.C); up.hl = true;
             Op u{}; u.kind = OP_UPS_SPLIT32; u.r[0] = ws_ref(a.xa.off); u.r[1] = ws_ref(up.off);
-            u.i[0] = N; u.i[1] = a.xa.C; u.i[2] = a.xa.D; u.i[3] = a.xa.H; u.i[4] = a.xa.W;
+            u.i[0] = N; u.i[1] = a.xa.C; u.i[2] = a.xa.D; u.i[3] = a.xa.H; u.i[4] = a.xa.W; u.i[5] = 1;
             plan->ops.push_back(u);
             ConvArgs a2 = a; a2.xa = up; a2.ups = 0;
             Act out = conv32(a2, tag);
@@ -1867,9 +1917,9 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                 hipLaunchKernelGGL(pack_im2col_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0, s, (const float*)rp(bs, o.r[0]), cx,
                                    (const float*)rp(bs, o.r[1]), cc, (bf16_t*)rp(bs, o.r[2]), i[0], i[3], i[4], i[5], i[2]);
                 break; }
-            case OP_UPS_SPLIT32: {      // i: N, C, D, H, W of the source
-                hipLaunchKernelGGL(upsample_split_f32_kernel, dim3(grid_for((long)i[0] * 8 * i[2] * i[3] * i[4] * (i[1] / 4), 256, 4096)), dim3(256), 0, s,
-                                   (const float*)rp(bs, o.r[0]), (bf16_t*)rp(bs, o.r[1]), i[0], i[1], i[2], i[3], i[4]);
+            case OP_UPS_SPLIT32: {      // i: N, C, D, H, W of the source, upsample (1) or same size (0)
+                hipLaunchKernelGGL(upsample_split_f32_kernel, dim3(grid_for(((long)i[0] * i[2] * i[3] * i[4] << (3 * i[5])) * (i[1] / 4), 256, 4096)), dim3(256), 0, s,
+                                   (const float*)rp(bs, o.r[0]), (bf16_t*)rp(bs, o.r[1]), i[0], i[1], i[2], i[3], i[4], i[5]);
                 break; }
             case OP_PACK32: {
                 const long total = (long)i[0] * i[3] * i[2];
@@ -1949,7 +1999,7 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                 p.N = i[4]; p.Din = i[5]; p.Hin = i[6]; p.Win = i[7]; p.Dout = i[8]; p.Hout = i[9]; p.Wout = i[10];
                 p.ksize = i[11]; p.stride = i[12]; p.pad = i[13]; p.ups = i[14] & 1; p.exact = (i[14] >> 1) & 1; p.M = i[15];
                 p.phase_mode = (i[14] >> 2) & 1; p.mtiles_pp = p.phase_mode ? i[23] / (8 * i[4]) : 0;
-                if (i[14] & 8) { p.x3_n = i[19] / 3; p.raw_partial = (i[14] & (16 | 32)) ? 0 : 1; }   // fp32 precision: 3 x bf16 product on the halo kernel
+                if (i[14] & 8) { p.x3_n = (i[0] / 2) / 64; p.raw_partial = (i[14] & (16 | 32)) ? 0 : 1; }   // fp32 precision: 3 x bf16 product on the halo kernel
                 p.CoutS = i[16]; p.CoutPad = i[17]; p.CoutReal = i[18]; p.nchunk0 = i[19]; p.nchunk1 = i[20];
                 p.steps0 = i[11] * i[11] * i[11] * i[19]; p.steps1 = i[20];
                 p.splitk = o.cc.splitk; p.steps_per_split = (p.steps0 + p.steps1 + p.splitk - 1) / p.splitk;
@@ -2358,6 +2408,10 @@ static int ensure_derived(ldm_model* m, hipStream_t s) {
         hipLaunchKernelGGL(phase_weights_kernel, dim3((unsigned)((vecs + 255) / 256), 64), dim3(256), 0, s,
                            (const bf16_t*)(m->arena + pw.w_off), (bf16_t*)(m->arena + pw.wp_off), pw.cout_pad, pw.cin_s);
     }
+    if (m->precision == 1 && m->arena32)
+        for (const auto& xw : m->x3p_ws)
+            hipLaunchKernelGGL(x3_phase_weights_kernel, dim3((unsigned)(((long)xw.cout_pad * xw.cin_s / 4 + 255) / 256), 64), dim3(256), 0, s,
+                               (const float*)(m->arena32 + 2 * xw.w_off), (bf16_t*)(m->arena32 + 2 * m->arena_bytes + xw.x3p_off), xw.cout_pad, xw.cin_s);
     if (m->precision == 1 && m->arena32)
         for (const auto& xw : m->x3_ws)
             hipLaunchKernelGGL(x3_weights_kernel, dim3(grid_for(xw.rows * (xw.cin_s / 4), 256, 2048)), dim3(256), 0, s,
