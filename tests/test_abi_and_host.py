@@ -240,6 +240,11 @@ def test_planner_rules_added_in_round_3(built_lib, monkeypatch):
     fp32 = _bf16_conv_launches(unet, b"unet", 1, (24, 24, 24))
     assert len(fp32) >= 30 and all(c[3] for c in fp32), fp32
     assert all(c[4] == 1 for c in fp32[:4]), "the 24^3 level runs unsplit (and finishes in the conv's own epilogue)"
+    vae32 = AutoencoderKL(**cfgs.VAE_FULL).set_precision("fp32")
+    dec32 = _bf16_conv_launches(vae32, b"dec", 1, (24, 24, 24))
+    # the two Upsample convs in the 8-tap phase form on the general kernel (two views of the split tensor as its concatenated sources),
+    # every other 3^3 conv of the decoder, its last one included, on the halo kernel
+    assert sum(1 for c in dec32 if not c[3]) == 2 and sum(1 for c in dec32 if c[3]) >= 12, dec32
     two = [c for c in _bf16_conv_launches(AutoencoderKL(**cfgs.VAE_FULL), b"dec", 1, (24, 24, 24)) if c[:4] == (2, 2, 32, 0)]
     monkeypatch.setenv("LDM_IGEMM_2WG", "0")
     one = [c for c in _bf16_conv_launches(AutoencoderKL(**cfgs.VAE_FULL), b"dec", 1, (24, 24, 24)) if c[:4] == (2, 2, 32, 0)]
