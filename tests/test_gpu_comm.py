@@ -257,3 +257,35 @@ def test_fake_second_rank_on_the_benchmark_unet_and_the_autoencoder(cuda, monkey
     assert GradSync().attach(v, transport=vpeer, world=2)
     v.flat_grads.fill_(float("nan"))
     assert torch.equal(once(0), (vA + vB) * 0.5)
+
+
+def test_two_real_processes_share_the_gradient_exchange(cuda):
+    """World size 2 with two real PROCESSES on this GPU (tests/two_rank_gpu_worker.py; gloo carries the bytes, the library's bucketed
+    path does everything else: 3d_ldm/train_diffusion.py:121-123,147-149,214).  The fake-peer test above plays rank 1 inside one process;
+    here rendezvous, two independent backward plans, two comm streams and two optimizers meet: the averaged gradient must be
+    (g_0 + g_1) / 2 bit for bit in both ranks and the parameters must stay identical across the processes after two steps."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "tests", "two_rank_gpu_worker.py")], env=env, cwd=root,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    recs = []
+    for p in procs:
+        out, err = p.communicate(timeout=600)
+        assert p.returncode == 0, err[-2000:]
+        recs.append(json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1]))
+    print("two processes:", recs)
+    assert sorted(r["rank"] for r in recs) == [0, 1]
+    for r in recs:
+        assert r["mean_exact"] and r["tiled"] and r["buckets"] >= 4 and r["checksums_equal"] and r["moved"], r
+    assert recs[0]["checksum"] == recs[1]["checksum"]
+
