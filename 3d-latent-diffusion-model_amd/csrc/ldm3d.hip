@@ -25,6 +25,7 @@
 #include "attention.h"
 #include "conv_igemm.h"
 #include "conv_halo.h"
+#include "conv_thin.h"
 #include "gemm_light.h"
 #include "conv_wgrad.h"
 #include "norm_elem.h"
@@ -86,7 +87,8 @@ enum OpKind { OP_PACK, OP_CONV, OP_FINALIZE, OP_GN_STATS, OP_GN_FINALIZE, OP_GN_
               OP_PACK32, OP_CONV32, OP_FIN32, OP_GN_STATS32, OP_GN_APPLY32, OP_ATTN32, OP_GEMV32,
               OP_TAP,                              // debug tap: export an activation as fp32 NCDHW and / or overwrite it (teacher forcing)
               OP_BUCKET, OP_BUCKET_JOIN,
-              OP_UPS_SPLIT32 };                    // fp32 precision: nearest x2 upsample into the (hi | lo) bf16 split (upsample_split_f32_kernel)         // training plans: a tail range of the flat gradient buffer is final (all-reduce it now) / wait for every bucket
+              OP_UPS_SPLIT32,
+              OP_CONV_THIN };                      // 3^3 conv with Cout <= 4 and fp32 NCDHW output: the networks' last layer (conv_thin.h)                    // fp32 precision: nearest x2 upsample into the (hi | lo) bf16 split (upsample_split_f32_kernel)         // training plans: a tail range of the flat gradient buffer is final (all-reduce it now) / wait for every bucket
 
 struct ConvCfg { int wgm, wgn, bk, splitk; int halo = 0, mtps = 0, qps = 0; };   // halo: conv3_halo_kernel (126-row tiles)
 
@@ -618,6 +620,21 @@ struct Builder {
             const long big = std::max(std::max(rows0 * a.xa.C, a.xb.valid ? rows0 * a.xb.C : 0L),
                                       a.w1 ? std::max(M * a.g1a.C, a.g1b.valid ? M * a.g1b.C : 0L) : 0L) * 2;
             if (big >= (1L << 32)) { err = "conv " + tag + ": a source tensor exceeds 4 GiB (split the batch)"; return Act(); }
+        }
+        {   // the networks' last layer (Cout <= 4, fp32 NCDHW output) in inference plans: conv_thin.h
+            static const int thin = [] { const char* e = getenv("LDM_CONV_THIN"); return e ? atoi(e) : 1; }();
+            const int cr = a.cout_real ? a.cout_real : w.cout;
+            if (thin && !train && a.f32_out && a.k == 3 && a.stride == 1 && a.pad == 1 && !a.ups && !a.exact && !a.xb.valid && !a.w1 &&
+                a.temb.base == BASE_NULL && !a.residual.valid && a.w_over.base == BASE_NULL && cr <= 4 && cin0 % 32 == 0 && cin0 <= 128 &&
+                a.xa.D == a.Do && a.xa.H == a.Ho && a.xa.W == a.Wo &&
+                // enough blocks to fill the chip and few channel chunks: measured 64 -> 1 at 96^3 247 -> ~100 us; 256 -> 4 at 24^3 (72 blocks, 8 chunks) 22 -> 44 us
+                (long)N * ((a.Do + THIN_TD - 1) / THIN_TD) * ((a.Ho + THIN_TH - 1) / THIN_TH) * ((a.Wo + THIN_TW - 1) / THIN_TW) >= 512) {
+                Op op{}; op.kind = OP_CONV_THIN;
+                op.r[0] = ws_ref(a.xa.off); op.r[2] = w_ref(w.w_off); op.r[6] = a.no_bias ? Ref() : w_ref(w.b_off); op.r[10] = a.out_ref;
+                op.i[0] = N; op.i[1] = a.xa.D; op.i[2] = a.xa.H; op.i[3] = a.xa.W; op.i[4] = cin0; op.i[5] = w.cout_pad; op.i[6] = cr;
+                plan->ops.push_back(op);
+                return Act();
+            }
         }
         // inference plans run (nearest x2 upsample -> 3^3 conv) as eight 2^3 convs on the source grid (conv_igemm.h, phase mode)
         const bool phase = a.ups == 1 && !a.exact && a.k == 3 && a.stride == 1 && a.pad == 1 && !train && !a.xb.valid && !a.w1 &&
@@ -1916,6 +1933,14 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                 const long total = (long)i[0] * i[3] * i[4] * i[5] * (i[2] / 8);
                 hipLaunchKernelGGL(pack_im2col_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0, s, (const float*)rp(bs, o.r[0]), cx,
                                    (const float*)rp(bs, o.r[1]), cc, (bf16_t*)rp(bs, o.r[2]), i[0], i[3], i[4], i[5], i[2]);
+                break; }
+            case OP_CONV_THIN: {        // i: N, D, H, W, Cin, CoutPad, CoutReal
+                ThinParams q{}; q.x = (const bf16_t*)rp(bs, o.r[0]); q.w = (const bf16_t*)rp(bs, o.r[2]); q.bias = (const float*)rp(bs, o.r[6]);
+                q.out = (float*)rp(bs, o.r[10]); q.N = i[0]; q.D = i[1]; q.H = i[2]; q.W = i[3]; q.Cin = i[4]; q.CoutPad = i[5]; q.CoutReal = i[6];
+                q.td = (q.D + THIN_TD - 1) / THIN_TD; q.th = (q.H + THIN_TH - 1) / THIN_TH; q.tw = (q.W + THIN_TW - 1) / THIN_TW;
+                static bool attr_set = false;
+                if (!attr_set) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_thin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, THIN_LDS)); attr_set = true; }
+                hipLaunchKernelGGL(conv3_thin_kernel, dim3((unsigned)((long)q.N * q.td * q.th * q.tw)), dim3(256), THIN_LDS, s, q);
                 break; }
             case OP_UPS_SPLIT32: {      // i: N, C, D, H, W of the source, upsample (1) or same size (0)
                 hipLaunchKernelGGL(upsample_split_f32_kernel, dim3(grid_for(((long)i[0] * i[2] * i[3] * i[4] << (3 * i[5])) * (i[1] / 4), 256, 4096)), dim3(256), 0, s,
