@@ -16,6 +16,9 @@ struct ThinParams {
     const float* bias; float* out;         // bias [>= CoutReal] or null; out fp32 [N][CoutReal][D*H*W]
     int N, D, H, W, Cin, CoutPad, CoutReal;
     int td, th, tw;                        // blocks per dimension
+    // fp32 precision mode (3 x bf16 product): x = the (hi | lo) split [..][2 C] bf16, w = [27][CoutPad][hi | lo | hi] (Cin = 3 C here);
+    // channel chunk c of the weights meets chunk c (hi), c - n (hi again) or c - n (lo) of a voxel row, n = x3_c / 32 (conv_halo.h's mapping)
+    int x3_c;                              // 0, or the real channel count C
 };
 
 constexpr int THIN_TD = 4, THIN_TH = 4, THIN_TW = 16;
@@ -34,6 +37,7 @@ __global__ __launch_bounds__(256) void conv3_thin_kernel(const ThinParams p) {
     const int bw = b % p.tw; b /= p.tw; const int bh = b % p.th; b /= p.th; const int bd = b % p.td; const int n = b / p.td;
     const int d0 = bd * THIN_TD, h0 = bh * THIN_TH, w0 = bw * THIN_TW;
     const size_t xn = (size_t)n * p.D * p.H * p.W;
+    const int xstride = p.x3_c ? 2 * p.x3_c : p.Cin;    // channels per voxel row of x
     f32x4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -42,6 +46,7 @@ __global__ __launch_bounds__(256) void conv3_thin_kernel(const ThinParams p) {
         __syncthreads();                                  // the previous chunk's reads are done
         // halo block: voxel hv, 16-byte chunk c16 (XOR-swizzled by the voxel index).  All of a lane's loads are issued before the first LDS
         // store (a load -> store -> load chain costs one global round trip per item: 21 of them)
+        const int xc0 = (p.x3_c && c0 >= p.x3_c) ? c0 - p.x3_c : c0;       // channel offset of this chunk inside a voxel row
         constexpr int NIT = (THIN_HV * THIN_NC + 255) / 256;
         u32x4 hv_v[NIT];
 #pragma unroll
@@ -52,7 +57,7 @@ __global__ __launch_bounds__(256) void conv3_thin_kernel(const ThinParams p) {
             const int gd = d0 - 1 + dz, gh = h0 - 1 + hy, gw = w0 - 1 + wx;
             hv_v[k] = zero;
             if (e < THIN_HV * THIN_NC && (unsigned)gd < (unsigned)p.D && (unsigned)gh < (unsigned)p.H && (unsigned)gw < (unsigned)p.W)
-                hv_v[k] = *reinterpret_cast<const u32x4*>(p.x + (xn + ((size_t)gd * p.H + gh) * p.W + gw) * p.Cin + c0 + c16 * 8);
+                hv_v[k] = *reinterpret_cast<const u32x4*>(p.x + (xn + ((size_t)gd * p.H + gh) * p.W + gw) * xstride + xc0 + c16 * 8);
         }
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {

@@ -527,6 +527,18 @@ struct Builder {
             i[11] = 3; i[12] = 1; i[13] = 1; i[14] = 8; i[15] = (int)M; i[16] = couts; i[17] = w.cout_pad; i[18] = w.cout;
             i[19] = 3 * n3; i[23] = N * cc.mtps;
             static const int x3_fused = [] { const char* e = getenv("LDM_X3_FUSED_EP"); return e ? atoi(e) : 1; }();
+            {   // the last layer with <= 4 output channels: conv3_thin_kernel over the split (conv_thin.h, ThinParams::x3_c)
+                static const int thin = [] { const char* e = getenv("LDM_CONV_THIN"); return e ? atoi(e) : 1; }();
+                const int cr = a.cout_real ? a.cout_real : w.cout;
+                if (thin && a.f32_out && cr <= 4 && C <= 128 && a.temb.base == BASE_NULL && !a.residual.valid &&
+                    (long)N * ((a.Do + THIN_TD - 1) / THIN_TD) * ((a.Ho + THIN_TH - 1) / THIN_TH) * ((a.Wo + THIN_TW - 1) / THIN_TW) >= 512) {
+                    Op t{}; t.kind = OP_CONV_THIN;
+                    t.r[0] = ws_ref(a.xa.off); t.r[2] = Ref{BASE_W32, 2 * m->arena_bytes + w.x3_off}; t.r[6] = a.no_bias ? Ref() : w_ref(w.b_off); t.r[10] = a.out_ref;
+                    t.i[0] = N; t.i[1] = a.xa.D; t.i[2] = a.xa.H; t.i[3] = a.xa.W; t.i[4] = 3 * C; t.i[5] = w.cout_pad; t.i[6] = cr; t.i[7] = C;
+                    plan->ops.push_back(t);
+                    return Act();
+                }
+            }
             if (cc.splitk == 1 && x3_fused && a.f32_out) {   // no split, last conv: the kernel's own fp32 NCDHW epilogue (bias only)
                 i[14] |= 32; i[22] = 1; i[18] = a.cout_real ? a.cout_real : w.cout;
                 op.r[6] = a.no_bias ? Ref() : w_ref(w.b_off); op.r[10] = a.out_ref;
@@ -1937,6 +1949,8 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
             case OP_CONV_THIN: {        // i: N, D, H, W, Cin, CoutPad, CoutReal
                 ThinParams q{}; q.x = (const bf16_t*)rp(bs, o.r[0]); q.w = (const bf16_t*)rp(bs, o.r[2]); q.bias = (const float*)rp(bs, o.r[6]);
                 q.out = (float*)rp(bs, o.r[10]); q.N = i[0]; q.D = i[1]; q.H = i[2]; q.W = i[3]; q.Cin = i[4]; q.CoutPad = i[5]; q.CoutReal = i[6];
+                q.x3_c = i[7];
+                if (!q.w) return fail(LDM_ERR_NOT_LOADED, "the weight arena is empty");
                 q.td = (q.D + THIN_TD - 1) / THIN_TD; q.th = (q.H + THIN_TH - 1) / THIN_TH; q.tw = (q.W + THIN_TW - 1) / THIN_TW;
                 static bool attr_set = false;
                 if (!attr_set) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_thin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, THIN_LDS)); attr_set = true; }
