@@ -146,6 +146,11 @@ SIGNATURES = {
     "ldm_comm_rank": (C.c_int, [_P]),
     "ldm_comm_world": (C.c_int, [_P]),
     "ldm_model_set_grad_sync": (C.c_int, [_P, _P]),
+    "ldm_model_set_grad_wire": (C.c_int, [_P, C.c_int]),
+    "ldm_model_grad_sync_pending": (C.c_int, [_P]),
+    "ldm_comm_stats": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "ldm_comm_is_rccl": (C.c_int, [_P]),
+    "ldm_comm_rccl_version": (C.c_int, []),
     "ldm_model_plan_launches": (C.c_int, [_P, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "ldm_model_grad_sync_trace": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]),
     "ldm_model_grad_schedule": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64),

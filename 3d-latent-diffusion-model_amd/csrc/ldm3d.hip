@@ -46,6 +46,8 @@ static int fail(int code, const char* fmt, ...) {
     return fail(LDM_ERR_HIP, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
 #define LDM_TRY(x) do { int r_ = (x); if (r_ != 0) return r_; } while (0)
 
+// "has hipFuncSetAttribute been called for this kernel" is a per-DEVICE fact: launchers keep a flag per device ordinal
+static inline bool& attr_flag(bool (&tab)[32]) { int d = 0; if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 32) d = 0; return tab[d]; }
 static inline int rup(int v, int m) { return (v + m - 1) / m * m; }
 static inline size_t rup_sz(size_t v, size_t m) { return (v + m - 1) / m * m; }
 
@@ -191,6 +193,9 @@ struct GradSyncState {
     ldm_comm* comm = nullptr; hipStream_t stream = nullptr;
     std::vector<hipEvent_t> ev;                      // per bucket: issue (launch stream), done (comm stream); [0] = backward start
     size_t used = 0; std::vector<int64_t> elems;
+    int wire = 0;                                    // 0 = fp32 on the wire (the reference's DDP), 1 = bf16 (ldm_model_set_grad_wire)
+    void* stage = nullptr; size_t stage_bytes = 0;   // bf16 staging slice of the largest bucket seen (comm stream is in order: one suffices)
+    int pending = 0;                                 // buckets handed to the comm stream since the last join
 };
 static int grad_sync_begin(GradSyncState& g, hipStream_t s);
 static int grad_sync_bucket(GradSyncState& g, float* buf, int64_t count, hipStream_t s);
@@ -1786,7 +1791,7 @@ static int launch_conv_t(const ConvParams& p_in, hipStream_t s) {
     constexpr int NG = (BK == 64) ? 2 : 1;
     constexpr int NS = (STAGE * 4 <= 131072) ? 4 : 3;
     constexpr int LDS = NS * STAGE + 28 * 64 * WGM * 4;       // ring + (tap, row) -> voxel table (+1 sentinel tap)
-    static bool attr_set = false;
+    static bool attr_tab[32] = {}; bool& attr_set = attr_flag(attr_tab);   // per device
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<WGM, WGN, BK, NS, NG>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -1833,7 +1838,7 @@ static int launch_conv_halo(const ConvParams& p_in, hipStream_t s, bool tall = f
     ConvParams p = p_in; p.tile_order = conv_tile_order(p);
     constexpr int LDS = 6 * 16384 + 3 * 16384 + 9 * 128 * 4;
     constexpr int LDS_TALL = 6 * 8192 + 3 * 32768 + 9 * 256 * 4;
-    static bool attr_set = false;
+    static bool attr_tab[32] = {}; bool& attr_set = attr_flag(attr_tab);   // per device
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_halo_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_halo_kernel<6, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TALL));
@@ -1879,7 +1884,7 @@ static int wgrad_ksplit(long M, int taps, int cout, int cin, bool hp) {
 }
 static int launch_wgrad(const WgradParams& p, hipStream_t s) {
     constexpr int LDS = 4 * 2 * 64 * 256 + 3 * 128 * 4;        // ring + triple-buffered source-offset table
-    static bool attr_set = false;
+    static bool attr_tab[32] = {}; bool& attr_set = attr_flag(attr_tab);   // per device
     if (!attr_set) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr_set = true; }
     { const char* e = getenv("LDM_CONV_DBG"); const int dbg = e ? atoi(e) : 0;      // timing ablations (results are wrong)
 #define W1_ABL(A) if (dbg == A) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<A>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); \
@@ -1952,7 +1957,7 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                 q.x3_c = i[7];
                 if (!q.w) return fail(LDM_ERR_NOT_LOADED, "the weight arena is empty");
                 q.td = (q.D + THIN_TD - 1) / THIN_TD; q.th = (q.H + THIN_TH - 1) / THIN_TH; q.tw = (q.W + THIN_TW - 1) / THIN_TW;
-                static bool attr_set = false;
+                static bool attr_tab[32] = {}; bool& attr_set = attr_flag(attr_tab);   // per device
                 if (!attr_set) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_thin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, THIN_LDS)); attr_set = true; }
                 hipLaunchKernelGGL(conv3_thin_kernel, dim3((unsigned)((long)q.N * q.td * q.th * q.tw)), dim3(256), THIN_LDS, s, q);
                 break; }
@@ -2339,6 +2344,7 @@ void ldm_model_destroy(ldm_model* m) {
     for (auto& g : m->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
     if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
     if (m->gsync.stream) (void)hipStreamDestroy(m->gsync.stream);
+    if (m->gsync.stage) (void)hipFree(m->gsync.stage);
     for (auto e : m->gsync.ev) (void)hipEventDestroy(e);
     if (m->arena) (void)hipFree(m->arena);
     if (m->arena32) (void)hipFree(m->arena32);
@@ -2880,10 +2886,20 @@ int ldm_vae_train_backward(ldm_model* m, const float* d_recon, const float* d_mu
 
 /* loss_out[0] = mean((pred - target)^2) over n fp32 elements; grad_out (optional, n elements) = 2 (pred - target) / n: the loss of
  * 3d_ldm/train_diffusion.py:207 and the gradient autograd hands to the network's backward (:214), in two launches. */
-static float* g_mse_parts = nullptr;
+// reduction scratch of ldm_op_mse_loss / ldm_grad_sq_norm: one buffer per (device, entry point), allocated at the first call on
+// that device (one process drives one GPU, but a caller with several devices current in turn must not get a foreign pointer);
+// calls on the SAME device are expected on one stream at a time (include/ldm3d.h)
+static float* device_scratch(int slot, size_t bytes) {
+    static float* tab[32][2] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return nullptr;
+    if (!tab[dev][slot] && hipMalloc((void**)&tab[dev][slot], bytes) != hipSuccess) tab[dev][slot] = nullptr;
+    return tab[dev][slot];
+}
 int ldm_op_mse_loss(const float* pred, const float* target, int64_t n, float* loss_out, float* grad_out, void* stream) {
     if (!pred || !target || !loss_out || n < 1) return fail(LDM_ERR_BAD_ARG, "bad argument");
-    if (!g_mse_parts) HIP_TRY(hipMalloc((void**)&g_mse_parts, 1024 * 4));
+    float* g_mse_parts = device_scratch(0, 1024 * 4);
+    if (!g_mse_parts) return fail(LDM_ERR_HIP, "scratch allocation failed");
     const int nb = grid_for(n, 256 * 4, 1024);
     hipLaunchKernelGGL(mse_part_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, pred, target, (long)n, grad_out, g_mse_parts);
     hipLaunchKernelGGL(mse_fold_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)g_mse_parts, nb, (long)n, loss_out);
@@ -2891,11 +2907,11 @@ int ldm_op_mse_loss(const float* pred, const float* target, int64_t n, float* lo
     return 0;
 }
 
-static float* g_norm_parts = nullptr;
 int ldm_grad_sq_norm(const float* flat_grads, int64_t n, float* out, void* stream) {
     if (!flat_grads || !out || n < 0) return fail(LDM_ERR_BAD_ARG, "bad argument");
     if (((uintptr_t)flat_grads) & 15) return fail(LDM_ERR_BAD_ARG, "gradient buffer must be 16-byte aligned");
-    if (!g_norm_parts) HIP_TRY(hipMalloc((void**)&g_norm_parts, 2048 * 4));
+    float* g_norm_parts = device_scratch(1, 2048 * 4);
+    if (!g_norm_parts) return fail(LDM_ERR_HIP, "scratch allocation failed");
     const int nb = grid_for((n + 3) / 4, 256, 2048);
     hipLaunchKernelGGL(sq_norm_part_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, flat_grads, (long)n, g_norm_parts);
     hipLaunchKernelGGL(sq_norm_fold_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)g_norm_parts, nb, out);
@@ -3612,6 +3628,7 @@ struct RcclApi {
     int (*Broadcast)(const void*, void*, size_t, int, int, rccl_comm_t, hipStream_t) = nullptr;
     int (*CommDestroy)(rccl_comm_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
+    int (*GetVersion)(int*) = nullptr;
 };
 static RcclApi g_rccl;
 static int rccl_load() {
@@ -3630,6 +3647,7 @@ static int rccl_load() {
     g_rccl.Broadcast = (int (*)(const void*, void*, size_t, int, int, rccl_comm_t, hipStream_t))dlsym(h, "ncclBroadcast");
     g_rccl.CommDestroy = (int (*)(rccl_comm_t))dlsym(h, "ncclCommDestroy");
     g_rccl.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+    g_rccl.GetVersion = (int (*)(int*))dlsym(h, "ncclGetVersion");
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.Broadcast || !g_rccl.CommDestroy)
         return fail(LDM_ERR_RCCL, "librccl.so lacks a required symbol");
     g_rccl.lib = h;
@@ -3639,7 +3657,8 @@ static int rccl_load() {
     g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "?"); } while (0)
 
 struct ldm_comm { rccl_comm_t comm = nullptr; int rank = 0, world = 1; float* token = nullptr;
-                  ldm_allreduce_fn fn = nullptr; void* user = nullptr; };   // fn: caller-supplied transport (ldm_comm_init_custom)
+                  ldm_allreduce_fn fn = nullptr; void* user = nullptr;      // fn: caller-supplied transport (ldm_comm_init_custom)
+                  int64_t n_allreduce = 0, bytes_allreduce = 0, n_broadcast = 0, bytes_broadcast = 0; };   // as handed to the transport
 
 int ldm_comm_unique_id(char id[128]) {
     if (!id) return fail(LDM_ERR_BAD_ARG, "null id");
@@ -3673,6 +3692,7 @@ int ldm_comm_init_custom(int rank, int world, ldm_allreduce_fn fn, void* user, l
 // ncclDataType: float32 = 7, bfloat16 = 9; ncclRedOp: sum = 0, avg = 4
 int ldm_comm_allreduce(ldm_comm* c, void* buf, int64_t count, int dtype, int op, void* stream) {
     if (!c || !buf || count < 0 || dtype < 0 || dtype > 1 || op < 0 || op > 1) return fail(LDM_ERR_BAD_ARG, "bad argument");
+    c->n_allreduce += 1; c->bytes_allreduce += count * (dtype == 0 ? 4 : 2);
     if (c->fn) {
         const int r = c->fn(c->user, buf, count, dtype, op, stream);
         return r ? fail(LDM_ERR_RCCL, "custom all-reduce returned %d", r) : 0;
@@ -3680,9 +3700,27 @@ int ldm_comm_allreduce(ldm_comm* c, void* buf, int64_t count, int dtype, int op,
     RCCL_TRY(g_rccl.AllReduce(buf, buf, (size_t)count, dtype == 0 ? 7 : 9, op == 0 ? 0 : 4, c->comm, (hipStream_t)stream));
     return 0;
 }
+/* What this communicator has carried so far, counted where the bytes are handed to the transport (RCCL or the custom function):
+ * out = {all-reduce calls, all-reduce bytes in the wire dtype, broadcast calls, broadcast bytes}. */
+int ldm_comm_stats(const ldm_comm* c, int64_t out[4]) {
+    if (!c || !out) return fail(LDM_ERR_BAD_ARG, "bad argument");
+    out[0] = c->n_allreduce; out[1] = c->bytes_allreduce; out[2] = c->n_broadcast; out[3] = c->bytes_broadcast;
+    return 0;
+}
+/* 1 if the communicator's transport is RCCL (ncclAllReduce), 0 for a caller-supplied function */
+int ldm_comm_is_rccl(const ldm_comm* c) { return c ? (c->fn ? 0 : 1) : -1; }
+/* ncclGetVersion of the librccl this process uses (e.g. 22606), or a negative status when it cannot be loaded */
+int ldm_comm_rccl_version(void) {
+    LDM_TRY(rccl_load());
+    int v = 0;
+    if (!g_rccl.GetVersion) return fail(LDM_ERR_RCCL, "librccl.so lacks ncclGetVersion");
+    RCCL_TRY(g_rccl.GetVersion(&v));
+    return v;
+}
 int ldm_comm_broadcast(ldm_comm* c, void* buf, int64_t count, int dtype, int root, void* stream) {
     if (!c || !buf || count < 0 || dtype < 0 || dtype > 1 || root < 0 || root >= c->world) return fail(LDM_ERR_BAD_ARG, "bad argument");
     if (c->fn) return fail(LDM_ERR_UNSUPPORTED, "broadcast on a custom-transport communicator");
+    c->n_broadcast += 1; c->bytes_broadcast += count * (dtype == 0 ? 4 : 2);
     RCCL_TRY(g_rccl.Broadcast(buf, buf, (size_t)count, dtype == 0 ? 7 : 9, root, c->comm, (hipStream_t)stream));
     return 0;
 }
@@ -3714,6 +3752,18 @@ int ldm_model_set_grad_sync(ldm_model* m, ldm_comm* comm) {
     m->gsync.comm = comm;
     return 0;
 }
+/* Wire format of the bucketed exchange: 0 = fp32 (default: what DistributedDataParallel reduces, 3d_ldm/train_diffusion.py:147-149),
+ * 1 = bf16: on the communicator's stream every bucket is cast into a bf16 staging slice, all-reduced (avg) as bf16 and cast back into
+ * the fp32 gradient buffer -- half the bytes per step for a ring that is xGMI-link bound (765 -> 382 MB for the benchmark UNet).
+ * The staging slice (2 bytes per element of the largest bucket) is allocated at the first backward that needs it. */
+int ldm_model_set_grad_wire(ldm_model* m, int dtype) {
+    if (!m || dtype < 0 || dtype > 1) return fail(LDM_ERR_BAD_ARG, "wire dtype must be 0 (fp32) or 1 (bf16)");
+    m->gsync.wire = dtype;
+    return 0;
+}
+/* Buckets handed to the communicator's stream that no join has covered yet (0 = the exchange is quiescent: every collective of the
+ * library's communicator is ordered in front of whatever the launch stream does next).  Host-side bookkeeping, no synchronisation. */
+int ldm_model_grad_sync_pending(const ldm_model* m) { return m ? m->gsync.pending : -1; }
 /* Timeline of the buckets of the LAST backward call (synchronises): issue_ms[k] = when bucket k was handed to the comm stream,
  * done_ms[k] = when its all-reduce finished, both relative to the start of that backward call; elems[k] = its size; then, at index
  * n (if max > n), the end of the backward call itself in issue_ms[n] (done_ms[n] = the same, elems[n] = 0).  Returns n. */
@@ -3789,13 +3839,29 @@ static int grad_sync_bucket(GradSyncState& g, float* buf, int64_t count, hipStre
     hipEvent_t issue = g.ev[g.used], done = g.ev[g.used + 1];
     HIP_TRY(hipEventRecord(issue, s));
     HIP_TRY(hipStreamWaitEvent(g.stream, issue, 0));
-    LDM_TRY(ldm_comm_allreduce(g.comm, buf, count, 0, 1, g.stream));                 // fp32, mean over ranks
+    if (g.wire == 1) {                                                                // bf16 on the wire: cast -> all-reduce(avg) -> cast back
+        const size_t need = (size_t)count * 2;
+        if (g.stage_bytes < need) {                                                   // first backward (or a larger bucket): grow once
+            HIP_TRY(hipStreamSynchronize(g.stream));
+            if (g.stage) (void)hipFree(g.stage);
+            g.stage = nullptr; g.stage_bytes = 0;
+            HIP_TRY(hipMalloc(&g.stage, rup_sz(need, 256)));
+            g.stage_bytes = rup_sz(need, 256);
+        }
+        const int nb = grid_for((count + 7) / 8, 256, 2048);
+        hipLaunchKernelGGL(grad_wire_pack_kernel, dim3(nb), dim3(256), 0, g.stream, (const float*)buf, (bf16_t*)g.stage, (long)count);
+        LDM_TRY(ldm_comm_allreduce(g.comm, g.stage, count, 1, 1, g.stream));
+        hipLaunchKernelGGL(grad_wire_unpack_kernel, dim3(nb), dim3(256), 0, g.stream, (const bf16_t*)g.stage, buf, (long)count);
+        HIP_TRY(hipGetLastError());
+    } else
+        LDM_TRY(ldm_comm_allreduce(g.comm, buf, count, 0, 1, g.stream));             // fp32, mean over ranks
     HIP_TRY(hipEventRecord(done, g.stream));
-    g.used += 2; g.elems.push_back(count);
+    g.used += 2; g.elems.push_back(count); g.pending += 1;
     return 0;
 }
 static int grad_sync_join(GradSyncState& g, hipStream_t s) {
     if (g.used > 2) HIP_TRY(hipStreamWaitEvent(s, g.ev[g.used - 1], 0));             // the comm stream is in order: the last bucket covers all
     HIP_TRY(hipEventRecord(g.ev[1], s));
+    g.pending = 0;
     return 0;
 }

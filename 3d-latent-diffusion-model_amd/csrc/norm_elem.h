@@ -1361,6 +1361,28 @@ __global__ __launch_bounds__(256) void sq_norm_fold_kernel(const float* __restri
     for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
     if (threadIdx.x == 0) *out = (float)red[0];
 }
+// bf16 wire format of the bucketed gradient exchange (ldm_model_set_grad_wire): fp32 slice -> bf16 staging -> (all-reduce) -> fp32 slice.
+// The slice starts at an arbitrary element of the flat buffer, so the fp32 side is only 4-byte aligned: scalar accesses, 8 per thread.
+__global__ __launch_bounds__(256) void grad_wire_pack_kernel(const float* __restrict__ g, bf16_t* __restrict__ stage, long n) {
+    for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += (long)gridDim.x * blockDim.x * 8) {
+        if (i + 8 <= n) {
+            u32x4 v;
+            v[0] = pack2bf(g[i], g[i + 1]); v[1] = pack2bf(g[i + 2], g[i + 3]); v[2] = pack2bf(g[i + 4], g[i + 5]); v[3] = pack2bf(g[i + 6], g[i + 7]);
+            *reinterpret_cast<u32x4*>(stage + i) = v;
+        } else
+            for (long k = i; k < n; ++k) stage[k] = f2bf(g[k]);
+    }
+}
+__global__ __launch_bounds__(256) void grad_wire_unpack_kernel(const bf16_t* __restrict__ stage, float* __restrict__ g, long n) {
+    for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += (long)gridDim.x * blockDim.x * 8) {
+        if (i + 8 <= n) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(stage + i);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { g[i + 2 * k] = __uint_as_float(v[k] << 16); g[i + 2 * k + 1] = __uint_as_float(v[k] & 0xffff0000u); }
+        } else
+            for (long k = i; k < n; ++k) g[k] = bf2f(stage[k]);
+    }
+}
 // mean((pred - target)^2) and its gradient 2 (pred - target) / n in one pass (F.mse_loss + the first step of loss.backward(),
 // 3d_ldm/train_diffusion.py:207,214): partial sums per block, folded by mse_fold_kernel (deterministic two-stage reduction)
 __global__ __launch_bounds__(256) void mse_part_kernel(const float* __restrict__ pred, const float* __restrict__ target, long n,
@@ -1394,14 +1416,14 @@ struct AdamCoef { float lr, b1, b2, eps, bc1, bc2_sqrt, max_norm, decay; int ste
 // optimizer.step(): 3d_ldm/train_diffusion.py:210-212).  Returns false when this launch must do nothing.
 __device__ __forceinline__ bool adam_prologue(AdamCoef& k, const float* __restrict__ sq_norm, float& clip, const bool counter_block) {
     clip = 1.f;
-    if (!sq_norm || k.max_norm <= 0.f) return true;
+    if (!sq_norm) return true;                          // no norm supplied: plain Adam (raw ABI callers; the Python optimizers always pass one)
     const float nn = sq_norm[0];
     const float skipped = sq_norm[1];
     if (!(nn == nn) || nn > 3.0e38f) {                  // NaN or inf
         if (counter_block) const_cast<float*>(sq_norm)[1] = skipped + 1.f;
         return false;
     }
-    const float c = k.max_norm / (sqrtf(nn) + 1e-6f); clip = c < 1.f ? c : 1.f;
+    if (k.max_norm > 0.f) { const float c = k.max_norm / (sqrtf(nn) + 1e-6f); clip = c < 1.f ? c : 1.f; }   // max_norm <= 0: no clipping, the skip stays
     if (skipped > 0.f) {                                // rare: two powf per thread cost 0.37 ms of the 1.2 ms launch when always evaluated
         const float eff = fmaxf((float)k.step - skipped, 1.f);
         k.bc1 = 1.0f - powf(k.b1, eff); k.bc2_sqrt = sqrtf(1.0f - powf(k.b2, eff));

@@ -95,11 +95,12 @@ class FlatAdam(torch.optim.Optimizer):
         clip = self.max_grad_norm is not None and self.max_grad_norm > 0
         self.steps += 1
         with torch.cuda.device(p.device):
-            if clip:
-                _lib.check(L.ldm_grad_sq_norm(g.data_ptr(), g.numel(), self.sq_norm.data_ptr(), _lib.current_stream()))
+            # the squared norm is taken whether or not clipping is on: the device-side NaN-skip reads it (max_norm <= 0 only disables
+            # the clip factor inside the kernel; 3d_ldm/train_diffusion.py:210-212 skips a NaN batch regardless of clipping)
+            _lib.check(L.ldm_grad_sq_norm(g.data_ptr(), g.numel(), self.sq_norm.data_ptr(), _lib.current_stream()))
             args = (float(grp["lr"]), float(grp["betas"][0]), float(grp["betas"][1]), float(grp["eps"]),
-                    float(grp.get("weight_decay", 0.0)), self.steps, self.sq_norm.data_ptr() if clip else None,
-                    float(self.max_grad_norm or 0.0), _lib.current_stream())
+                    float(grp.get("weight_decay", 0.0)), self.steps, self.sq_norm.data_ptr(),
+                    float(self.max_grad_norm or 0.0) if clip else 0.0, _lib.current_stream())
             h = getattr(self.module, "_h", None)
             if self.fuse_repack and h is not None and not getattr(self.module, "_dirty", True):
                 # one pass: Adam on the flat master weights + the bf16 re-pack of the library's arena from the new values
@@ -156,9 +157,8 @@ class FlatModuleAdam:
         clip = self.max_grad_norm is not None and self.max_grad_norm > 0
         self.steps += 1
         with torch.cuda.device(p.device):
-            if clip:
-                _lib.check(L.ldm_grad_sq_norm(g.data_ptr(), g.numel(), self.sq_norm.data_ptr(), _lib.current_stream()))
+            _lib.check(L.ldm_grad_sq_norm(g.data_ptr(), g.numel(), self.sq_norm.data_ptr(), _lib.current_stream()))   # NaN-skip needs it, clip or not
             _lib.check(L.ldm_adam_step(p.data_ptr(), g.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), p.numel(),
                                        float(self.param_groups[0]["lr"]), float(self.betas[0]), float(self.betas[1]), float(self.eps),
-                                       float(self.weight_decay), self.steps, self.sq_norm.data_ptr() if clip else None,
-                                       float(self.max_grad_norm or 0.0), _lib.current_stream()))
+                                       float(self.weight_decay), self.steps, self.sq_norm.data_ptr(),
+                                       float(self.max_grad_norm or 0.0) if clip else 0.0, _lib.current_stream()))

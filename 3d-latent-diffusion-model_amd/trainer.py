@@ -38,15 +38,33 @@ class GradSync:
         self.world = dist.get_world_size() if self.on else 1
         self.chunk = int(chunk_elems)                    # 64 Mi elements = 256 MB per collective
         self._avg = self.on and dist.get_backend() == "nccl"
+        if grad_dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("grad_dtype must be torch.float32 or torch.bfloat16")
         self.grad_dtype = grad_dtype
+        self._modules = []                               # modules whose exchange runs inside backward on the library's communicator
+
+    def _quiescent(self) -> None:
+        """Two communicators live in a training process: torch.distributed's group (scalars, barriers, broadcasts, the fallback
+        mean) and the library's own RCCL communicator on its comm stream (the buckets).  RCCL requires that two communicators never
+        have collectives in flight in an order that differs between ranks; here that is excluded by construction -- every bucket is
+        joined into the launch stream at the end of backward, and torch's collectives are ordered behind the launch stream -- and
+        this check turns the construction into an assertion: a torch.distributed collective issued while a bucket is still un-joined
+        is a programming error, not a race to be debugged on eight GPUs."""
+        from . import _lib
+        L = _lib.lib()
+        for m in self._modules:
+            n = L.ldm_model_grad_sync_pending(m._h)
+            if n:
+                raise RuntimeError(f"torch.distributed collective while {n} gradient bucket(s) of the library's communicator are not joined")
 
     def attach(self, module, force_single: bool = False, transport=None, world: Optional[int] = None, rank: int = 0) -> bool:
         """Route the gradient exchange of ``module`` through the library's own RCCL communicator (``ldm_comm_*``) and overlap it
         with backward: ``loss.backward()`` then all-reduces (mean, fp32) the flat gradient buffer bucket by bucket on a comm
         stream while the backward plan is still running (``ldm_model_set_grad_sync``; DistributedDataParallel's bucketed hooks,
         3d_ldm/train_diffusion.py:147-149), and ``mean_`` becomes a no-op for that module.  The 128-byte RCCL unique id is made
-        on rank 0 and broadcast over the existing torch.distributed group.  Only with the "nccl" backend on GPUs and fp32
-        gradients; ``force_single`` builds a world-size-1 communicator without torch.distributed (tests, single-GPU traces).
+        on rank 0 and broadcast over the existing torch.distributed group.  Only with the "nccl" backend on GPUs;
+        ``grad_dtype=torch.bfloat16`` selects the library's bf16 wire format (``ldm_model_set_grad_wire``: cast, all-reduce, cast
+        back on the comm stream); ``force_single`` builds a world-size-1 communicator without torch.distributed (tests, traces).
 
         ``transport(buf_ptr, count, dtype, op, stream_ptr) -> int`` (with ``world`` / ``rank``) replaces RCCL by a caller-supplied
         all-reduce (``ldm_comm_init_custom``): the test seam that lets one GPU play a rank of a world > 1 job.
@@ -66,22 +84,31 @@ class GradSync:
             module._grad_transport = fn                      # the C function pointer must outlive the communicator
         else:
             single = force_single and not self.on
-            if not single and not (self.on and dist.get_backend() == "nccl" and self.grad_dtype == torch.float32):
+            if not single and not (self.on and dist.get_backend() == "nccl"):
                 return False
             rank = 0 if single else dist.get_rank()
             world = 1 if single else self.world
             uid = C.create_string_buffer(128)
-            ok = 1
-            if rank == 0 and L.ldm_comm_unique_id(uid) != 0:
+            # every rank probes librccl BEFORE any rank enters ncclCommInitRank (which blocks until all `world` ranks have joined):
+            # a rank that cannot load it must make all of them fall back, not leave the others waiting inside the rendezvous
+            ok = 1 if L.ldm_comm_rccl_version() > 0 else 0
+            if ok and rank == 0 and L.ldm_comm_unique_id(uid) != 0:
                 ok = 0
             if not single:
-                mb = int(os.environ.get("LDM_GRAD_BUCKET_MB", "48") or 48)
-                t = torch.tensor(list(uid.raw) + [ok, mb & 0xFF, (mb >> 8) & 0xFF], dtype=torch.uint8, device="cuda")
+                flag = torch.tensor([float(ok)], device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok = int(flag.item())
+            if ok and not single:
+                try:
+                    mb = int(os.environ.get("LDM_GRAD_BUCKET_MB", "48") or 48)
+                except ValueError:
+                    mb = 48
+                mb = min(max(mb, 1), 0xFFFF)
+                t = torch.tensor(list(uid.raw) + [mb & 0xFF, (mb >> 8) & 0xFF], dtype=torch.uint8, device="cuda")
                 dist.broadcast(t, src=0)
                 raw = bytes(t.cpu().tolist())
                 uid = C.create_string_buffer(raw[:128], 128)
-                ok = raw[128]
-                os.environ["LDM_GRAD_BUCKET_MB"] = str(raw[129] | (raw[130] << 8))
+                os.environ["LDM_GRAD_BUCKET_MB"] = str(raw[128] | (raw[129] << 8))
             if ok and L.ldm_comm_init(rank, world, uid, C.byref(comm)) != 0:
                 ok = 0
             if not single:                                   # all ranks or none
@@ -96,8 +123,10 @@ class GradSync:
                     L.ldm_comm_destroy(comm)
                 return False
         _lib.check(L.ldm_model_set_grad_sync(module._h, comm))
+        _lib.check(L.ldm_model_set_grad_wire(module._h, 1 if self.grad_dtype == torch.bfloat16 else 0))
         module._grad_comm = comm                         # keeps the handle alive as long as the module
         self._attached = getattr(self, "_attached", set()) | {id(module)}
+        self._modules.append(module)
         return True
 
     def attached(self, module) -> bool:
@@ -106,12 +135,14 @@ class GradSync:
     def broadcast(self, flat: torch.Tensor, src: int = 0) -> None:
         """Parameter broadcast at wrap time (what DistributedDataParallel.__init__ does)."""
         if self.on:
+            self._quiescent()
             dist.broadcast(flat, src=src)
 
     def mean_(self, flat: torch.Tensor) -> torch.Tensor:
         """In-place mean over ranks of a flat buffer; chunks are queued asynchronously and waited for together."""
         if not self.on:
             return flat
+        self._quiescent()
         works, staged = [], []
         for lo in range(0, flat.numel(), self.chunk):
             part = flat[lo:lo + self.chunk]
@@ -133,15 +164,22 @@ class GradSync:
     def any(self, flag: torch.Tensor) -> torch.Tensor:
         """Logical OR over ranks of a 0/1 device scalar (the agreed NaN-skip)."""
         if self.on:
+            self._quiescent()
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         return flag
 
     def mean_scalar(self, t: torch.Tensor) -> torch.Tensor:
         if not self.on:
             return t
+        self._quiescent()
         t = t.clone()
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return t / self.world
+
+    def barrier(self) -> None:
+        if self.on:
+            self._quiescent()
+            dist.barrier()
 
 
 @torch.no_grad()
@@ -223,6 +261,21 @@ class DiffusionTrainer:
 
 
 # ------------------------------------------------------------------------------------------------ stage 1: AutoencoderKL
+class _GateGrad(torch.autograd.Function):
+    """Identity whose backward passes the incoming gradient only where ``ok`` (a 0-dim device bool, filled in AFTER the branch behind
+    this node has run forward) is true and zeros otherwise.  Selection, not multiplication: a NaN gradient coming back from a
+    non-finite adversarial branch is replaced, not scaled (0 * NaN = NaN), so the branch is really dropped (train_autoencoder.py:417-422)."""
+
+    @staticmethod
+    def forward(ctx, x, ok):
+        ctx.ok = ok
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return torch.where(ctx.ok, g, torch.zeros_like(g)), None
+
+
 def kl_loss(z_mu: torch.Tensor, z_sigma: torch.Tensor) -> torch.Tensor:
     """The reference's KL term (3d_ldm/utils.py:249-262): 0.5 * sum(mu^2 + s^2 - log(s^2 + eps) - 1) over all but the batch
     dimension with s = clamp(sigma, min=1e-8), divided by the batch size, clamped to [0, 1000]."""
@@ -290,9 +343,12 @@ class AutoencoderTrainer:
         """-> (dict of detached scalar losses, skipped)."""
         self.autoencoder.train()
         images = torch.clamp(images.float(), 0.0, 1.0)
-        # No host read of a device value in this step: non-finite inputs or losses (:362-365,417-422,426-437,470-484 `continue`) make
-        # the gradient norm non-finite, the data-parallel mean carries that to every rank, and the fused clip + AdamW launches then
-        # leave parameters and moments untouched (optim.FlatAdam.skipped_steps); a non-finite adversarial term alone is dropped (:417-422).
+        # No host read of a device value in this step: non-finite inputs or losses (:362-365,426-437,470-484 `continue`) make the
+        # gradient norm non-finite, the data-parallel mean carries that to every rank, and the fused clip + AdamW launches then leave
+        # parameters and moments untouched (optim.FlatAdam.skipped_steps).  A non-finite adversarial term ALONE is dropped and the
+        # step continues on reconstruction + KL (:417-422): its value is selected away in the forward and its gradient is selected
+        # away where the branch leaves the reconstruction (_GateGrad), so no 0 * NaN reaches the autoencoder.  A skipped generator
+        # step also skips the discriminator step of that batch (the reference `continue`s before it).
         adversarial = epoch > self.warm_up_epochs
         reconstruction, z_mu, z_sigma = self.autoencoder(images, eps=eps)
         recons = self.intensity_loss(reconstruction, images)
@@ -304,9 +360,10 @@ class AutoencoderTrainer:
             loss_g = loss_g + self.perceptual_weight * p_loss
             out["perceptual"] = p_loss.detach()
         if adversarial:
-            logits_fake = self.discriminator(reconstruction.contiguous().float())[-1]
+            ok = torch.ones((), dtype=torch.bool, device=reconstruction.device)      # filled in below, read by _GateGrad.backward
+            logits_fake = self.discriminator(_GateGrad.apply(reconstruction.contiguous().float(), ok))[-1]
             generator_loss = self.adv_loss(logits_fake, target_is_real=True, for_discriminator=False)
-            ok = torch.isfinite(generator_loss.detach())
+            ok.copy_(torch.isfinite(generator_loss.detach()))
             loss_g = loss_g + self.adv_weight * torch.where(ok, generator_loss, torch.zeros_like(generator_loss))
             out["adv_g"] = generator_loss.detach()
         before = self.optimizer.skipped_steps().clone()
@@ -315,6 +372,7 @@ class AutoencoderTrainer:
             self.sync.mean_(self.autoencoder.flat_grads)
         self.optimizer.step()
         out["loss_g"] = loss_g.detach()
+        skipped_g = self.optimizer.skipped_steps() > before
         if adversarial:
             # discriminator step (:454-494): fake = the detached reconstruction, real = the images
             self.optimizer_d.zero_grad()
@@ -324,11 +382,14 @@ class AutoencoderTrainer:
             loss_d_real = self.adv_loss(logits_real, target_is_real=True, for_discriminator=True)
             discriminator_loss = (loss_d_fake + loss_d_real) * 0.5
             loss_d = self.adv_weight * discriminator_loss
+            # a batch whose generator step was skipped gets no discriminator step either: a NaN factor makes every discriminator
+            # gradient NaN and FlatModuleAdam skips itself on the device (still no host read)
+            loss_d = loss_d * torch.where(skipped_g, torch.full_like(loss_d, float("nan")), torch.ones_like(loss_d))
             loss_d.backward()
             self.sync.mean_(self.optimizer_d.flat_grads)
             self.optimizer_d.step()                          # skips itself on a non-finite gradient norm
             out["adv_d"] = discriminator_loss.detach()
-        return out, self.optimizer.skipped_steps() > before
+        return out, skipped_g
 
     @torch.no_grad()
     def validate(self, loader, device) -> float:

@@ -57,36 +57,50 @@ def make_unet(dev, seed=0, in_channels=None):
     return m.to(dev).eval()
 
 
+CPU_BASELINE_THREAD_CAP = 16                 # threads the CPU baseline uses at most (a 1-GPU box's CPU share on the pool this was tuned on)
+
+
 def host_cores():
-    """CPU share of this container (cgroup quota / affinity), not the host's core count."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    """(threads the CPU baseline will use, what was discovered): the affinity mask and the cgroup CPU quota of THIS process are read,
+    not assumed; the cap is reported separately in the bench line."""
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    found = {"os_cpu_count": os.cpu_count(), "sched_affinity": aff, "cgroup_quota_cores": None}
+    n = aff
     try:
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
         if quota != "max":
+            found["cgroup_quota_cores"] = int(quota) / int(period)
             n = min(n, max(1, int(int(quota) / int(period))))
     except (OSError, ValueError):
         try:
             q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
             per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
             if q > 0:
+                found["cgroup_quota_cores"] = q / per
                 n = min(n, max(1, q // per))
         except (OSError, ValueError):
             pass
-    return max(1, min(n, 16))               # a 1-GPU box's CPU share is 16 cores
+    found["available"] = max(1, n)
+    return max(1, min(n, CPU_BASELINE_THREAD_CAP)), found
 
 
 def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (None if absent)."""
+    """(HBM bytes per launch of the dominant kernel, where that number comes from): PMC counters need rocprofv3 around the process,
+    so the bench line carries the figure of the newest committed PMC summary under profiles/ and NAMES it (file, the commit the
+    profiled library was built from, the kernel it was taken on) -- a stale figure is then visible as such."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")))
     for f in reversed(files):
         try:
-            t = json.load(open(f)).get("conv_hbm_traffic_bytes_per_launch")
+            d = json.load(open(f))
+            t = d.get("conv_hbm_traffic_bytes_per_launch")
             if t:
-                return t["total"]
+                return t["total"], {"file": os.path.relpath(f, ROOT), "commit": d.get("commit"), "kernel": t.get("kernel"),
+                                    "launches_profiled": t.get("launches"), "note": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) "
+                                    "+ WRITE_SIZE passes of `bench.py --no-cpu-baseline`, NOT a measurement of this run"}
         except (OSError, ValueError):
             pass
-    return None
+    return None, None
 
 
 def cpu_baseline(steps=3):
@@ -95,7 +109,7 @@ def cpu_baseline(steps=3):
     import cfgs
     from oracle import unet as ou
     from oracle.schedulers import OracleDDPM
-    cores = host_cores()
+    cores, found = host_cores()
     torch.set_num_threads(cores)
     sd = ou.init_state_dict(ou.unet_param_shapes(cfgs.UNET_FULL), 0)
     sch = OracleDDPM(**cfgs.SCHED)
@@ -124,6 +138,7 @@ def cpu_baseline(steps=3):
             four = 1.0 / (time.perf_counter() - t4)
             torch.set_num_threads(cores)
     return {"value": steps / dt, "unit": "steps/s", "cores": cores, "kind": "port",
+            "cores_discovered": found, "cores_cap": CPU_BASELINE_THREAD_CAP,
             "sample": f"{steps} DDPM steps (UNet fwd + scheduler step) on 1x4x24^3 after 1 warm-up step, fp32 torch-CPU oracle",
             "value_at_the_reference_4_threads": four}
 
@@ -256,12 +271,23 @@ def ddp_train_leg(dev, rank, world, dist, rehearsal, steps=8, warmup=3, latent=(
            "exchange": ("in-library bucketed RCCL all-reduce overlapped with backward (ldm_model_set_grad_sync)" if tr.overlap else
                         "torch.distributed all-reduce after backward (GradSync.mean_)" + (" [rehearsal: gloo]" if rehearsal else "")),
            "param_checksum_after_3_steps": sums, "param_checksums_equal_on_all_ranks": equal}
+    rec["exchange_path"] = "in-library" if tr.overlap else "fallback"          # machine-readable form of "exchange"
+    rec["rccl_version"] = L.ldm_comm_rccl_version()                              # ncclGetVersion() of the librccl this process loaded
+    rec["phases_ms"] = ddp_phase_trace(tr, images, labels, dev)
     if tr.overlap:
         n_max = 64
         issue, done, elems = (C.c_double * n_max)(), (C.c_double * n_max)(), (C.c_int64 * n_max)()
         n = L.ldm_model_grad_sync_trace(unet._h, issue, done, elems, n_max)
         comm = getattr(unet, "_grad_comm", None)
         rec["ldm_comm_world"] = L.ldm_comm_world(comm) if comm else None
+        if comm:
+            st = (C.c_int64 * 4)()
+            L.ldm_comm_stats(comm, st)
+            calls = max(1, int(st[0]))
+            rec["ldm_comm"] = {"transport_is_rccl": bool(L.ldm_comm_is_rccl(comm) == 1), "allreduce_calls": int(st[0]),
+                               "allreduce_bytes": int(st[1]), "optimizer_steps_counted": steps + warmup + 3,
+                               "bytes_per_step": int(st[1]) // (steps + warmup + 3),
+                               "note": "counted inside the library where each bucket is handed to ncclAllReduce"}
         if 0 < n < n_max:
             end = issue[n]
             rec.update({"backward_ms": end, "buckets": n, "bucket_mb": [round(elems[k] * 4 / 2 ** 20, 1) for k in range(n)],
@@ -271,6 +297,44 @@ def ddp_train_leg(dev, rank, world, dist, rehearsal, steps=8, warmup=3, latent=(
                         "allreduce_busy_ms": sum(done[k] - max(issue[k], done[k - 1] if k else 0.0) for k in range(n)),
                         "trace_note": "times of the LAST step on rank 0, ms since its backward began; backward_ms includes the join"})
     return rec
+
+
+def ddp_phase_trace(tr, images, labels, dev, n=3):
+    """Where a configs[3] train step goes (outside every timed region): the calls of DiffusionTrainer.train_step in the same order
+    (3d_ldm/train_diffusion.py:194-219) with a HIP event between the phases, mean over n steps.  Steps through the real optimizer."""
+    import torch
+    from ldm3d.optim import mse_loss
+    names = ["vae_encode_condition", "vae_encode_labels", "add_noise_unet_forward", "mse_backward_incl_exchange", "clip_adam_repack"]
+    acc = [0.0] * len(names)
+    vae, unet, inf = tr.autoencoder, tr.unet, tr.inferer
+    for _ in range(n):
+        noise, timesteps = tr._draw(labels)
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(len(names) + 1)]
+        unet.train()
+        e[0].record()
+        with torch.no_grad():
+            z_img = vae.encode_stage_2_inputs(images)
+        e[1].record()
+        with torch.no_grad():
+            z = vae.encode_stage_2_inputs(labels)
+            if inf.scale_factor != 1.0:
+                z = z * inf.scale_factor
+        e[2].record()
+        noisy = inf.scheduler.add_noise(original_samples=z, noise=noise, timesteps=timesteps)
+        pred = unet(x=noisy, timesteps=timesteps, context=None, cond=z_img)
+        e[3].record()
+        mse_loss(pred, noise).backward()
+        if not tr.overlap:
+            tr.sync.mean_(unet.flat_grads)
+        e[4].record()
+        tr.optimizer.step()
+        e[5].record()
+        torch.cuda.synchronize()
+        for k in range(len(names)):
+            acc[k] += e[k].elapsed_time(e[k + 1]) / n
+    out = {k: round(v, 3) for k, v in zip(names, acc)}
+    out["sum"] = round(sum(acc), 3)
+    return out
 
 
 def main():
@@ -367,15 +431,31 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Host hygiene for a short timed region (the driver runs 20 steps = 42 ms): a step is ONE graph launch that costs the host
+    # ~0.06 ms against ~2.1 ms on the GPU, so the host runs ahead of the device -- except at the first steps after the fence, where a
+    # host stall (a garbage-collector pass over torch's heap, a page fault on a cold code path) is paid in full by the wall clock.
+    # The collector is therefore parked for the region and the stream has one event per step, which costs nothing measurable and
+    # shows in the JSON line whether a low figure was one stalled step, a ramp, or every step (ms_per_step_median / min / max).
+    import gc
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    host_at = [0.0] * args.steps
     with torch.no_grad():
         for i in range(args.warmup):
             x = step(i, x)
+        gc.collect()
+        gc.disable()
         fence()
         t0 = time.perf_counter()
+        ev[0].record()
         for i in range(args.steps):
+            host_at[i] = time.perf_counter()
             x = step(args.warmup + i, x)
+            ev[i + 1].record()
         fence()
         dt = time.perf_counter() - t0
+        gc.enable()
+        per_step = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]           # ms, on the launch stream
+        host_gap = [(host_at[i + 1] - host_at[i]) * 1e3 for i in range(args.steps - 1)]  # ms between two enqueues on the host
         # Roofline leg: the SAME K steps once more with HIP events recorded on the launch stream around every launch
         # of the dominant kernel (kept out of the timed region above: 2 events x ~60 launches per step cost ~25 %).
         profile = (not args.no_roofline) and rank == 0
@@ -446,6 +526,13 @@ def main():
         "value": world * args.steps / dt, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
+        # the same region per step (rank 0): HIP events between the graph launches; value / ms_per_step above stay the wall-clock mean
+        "ms_per_step_median": sorted(per_step)[len(per_step) // 2], "ms_per_step_min": min(per_step), "ms_per_step_max": max(per_step),
+        "timed_region": {"sum_of_step_events_ms": sum(per_step), "wall_ms": dt * 1e3,
+                         "slowest_step_index": per_step.index(max(per_step)),
+                         "host_enqueue_gap_ms_max": max(host_gap) if host_gap else 0.0,
+                         "note": "wall_ms - sum_of_step_events_ms = time before the first / after the last step; a host stall shows as a "
+                                 "large host_enqueue_gap with a long step behind it, a device-side one as a long step alone"},
         "config": {"workload": "DiffusionModelUNet (channels 256/256/512, attn at 12^3 and 6^3, 191.18 M params) fwd + DDPM "
                                "step on 1x4x24^3, 1000-step schedule scaled_linear_beta 0.0015-0.0195 (BASELINE configs[2])",
                    "per_gpu_batch": 1, "parallelism": f"replicas x{world} (independent chains, no collective)",
@@ -468,9 +555,10 @@ def main():
     }
     if profile and prof[0] > 0:
         achieved = prof[2] / (prof[1] * 1e-3) / 1e12
+        traffic, traffic_src = pmc_traffic()
         out["roofline"] = {
             "bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": pmc_traffic(),
+            "frac": achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
             "kernel": "conv3_halo_kernel<6> (implicit-GEMM 3x3x3 stride-1 conv3d, 126x128 tile, W-halo reuse, bf16 MFMA 16x16x32)",
             "launches": int(prof[0]), "avg_launch_us": prof[1] * 1e3 / prof[0],
             "algorithmic_gflop_per_launch": prof[2] / prof[0] / 1e9,

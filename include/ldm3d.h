@@ -129,7 +129,11 @@ int ldm_vae_train_backward(ldm_model* m, const float* d_recon, const float* d_mu
  *   sq_norm points at TWO device floats {sum g^2, skipped steps}: the NaN-skip of the reference's trainers (train_diffusion.py:210-212
  *   `continue`s in front of backward when the loss is NaN) without a host read: when sum g^2 is not finite (a NaN loss makes every
  *   gradient NaN; the data-parallel mean carries it to every rank) the step leaves params / exp_avg / exp_avg_sq untouched and adds 1
- *   to sq_norm[1]; the bias corrections use step - sq_norm[1].  The caller zeroes sq_norm[1] once; ldm_grad_sq_norm writes out[0] only. */
+ *   to sq_norm[1]; the bias corrections use step - sq_norm[1].  The caller zeroes sq_norm[1] once; ldm_grad_sq_norm writes out[0] only.
+ *   The skip depends on sq_norm alone: max_norm <= 0 switches the clip factor off, not the finite check (pass sq_norm = NULL for a
+ *   plain Adam step with neither).
+ *   ldm_grad_sq_norm and ldm_op_mse_loss reduce through ONE scratch buffer per process (allocated on the device that is current at
+ *   the first call): call them from one stream of one device at a time. */
 int ldm_grad_sq_norm(const float* flat_grads, int64_t n, float* out, void* stream);
 /* F.mse_loss(noise_pred, noise) of 3d_ldm/train_diffusion.py:207 together with the gradient loss.backward() (:214) hands to the network:
  * loss_out[0] = mean((pred - target)^2), grad_out (optional) = 2 (pred - target) / n; fp32 device buffers of n elements. */
@@ -343,6 +347,17 @@ int ldm_comm_world(const ldm_comm* c);
  * ldm_model_grad_sync_trace returns the bucket timeline of the last backward call (n buckets; entry n = end of the call). */
 int ldm_model_set_grad_sync(ldm_model* m, ldm_comm* comm);
 int ldm_model_grad_sync_trace(ldm_model* m, double* issue_ms, double* done_ms, int64_t* elems, int max);
+/* Wire dtype of the bucketed exchange: 0 = fp32 (default, what DDP reduces: 3d_ldm/train_diffusion.py:147-149), 1 = bf16 (each
+ * bucket cast into a staging slice on the communicator's stream, all-reduced (avg) as bf16, cast back: half the bytes on xGMI;
+ * SURVEY.md section 8a row a7 "382 MB if bf16 grads").  ldm_model_grad_sync_pending: buckets issued that no join has covered yet
+ * (0 = nothing of this communicator is in flight ahead of the launch stream; host bookkeeping, no synchronisation). */
+int ldm_model_set_grad_wire(ldm_model* m, int dtype);
+int ldm_model_grad_sync_pending(const ldm_model* m);
+/* Evidence for bench records / tests: {all-reduce calls, all-reduce bytes in the wire dtype, broadcast calls, broadcast bytes} as
+ * handed to the transport; whether that transport is RCCL; ncclGetVersion() of the loaded librccl (e.g. 22606; negative = status). */
+int ldm_comm_stats(const ldm_comm* c, int64_t out[4]);
+int ldm_comm_is_rccl(const ldm_comm* c);
+int ldm_comm_rccl_version(void);
 /* The exchange schedule of the training plan for this shape, built on the host (no GPU needed): events in launch order with
  * kind 0 = an op leaves final values in flat_grads[lo, lo + n), 1 = bucket [lo, lo + n) handed to the communicator, 2 = join,
  * 3 = unclassified write; op = index of the launch-plan op.  Returns the event count (only `max` are written). */

@@ -269,3 +269,21 @@ def test_shapes_the_networks_cannot_take_fail_loudly(built_lib):
     for dims in ((7, 8, 8), (2, 2, 2), (16, 16, 18)):
         assert L.ldm_model_plan_launches(vae._h, b"enc", 1, *dims) == -2, dims
     assert L.ldm_model_plan_launches(vae._h, b"enc", 1, 4, 4, 4) > 0
+
+
+def test_launcher_script_uses_torchrun_and_keeps_peer_to_peer_on():
+    """train_LDM.sh = the reference's 3d_ldm/train_LDM.sh:71-76 / train_stable.sh:54-66 for this build: one
+    torch.distributed.run line per stage over a 127.0.0.1 rendezvous, and -- unlike the reference (train_LDM.sh:41-42) -- it never sets
+    NCCL_P2P_DISABLE / NCCL_IB_DISABLE: xGMI peer-to-peer is the fabric."""
+    import subprocess
+    path = os.path.join(ROOT, "train_LDM.sh")
+    assert os.access(path, os.X_OK)
+    assert subprocess.run(["bash", "-n", path]).returncode == 0
+    text = open(path).read()
+    code = [ln for ln in text.splitlines() if not ln.lstrip().startswith("#")]
+    assert any("torch.distributed.run" in ln and "--nproc-per-node" in ln for ln in code)
+    assert any("--master-addr 127.0.0.1" in ln for ln in code)
+    assert not any("NCCL_P2P_DISABLE=" in ln or "NCCL_IB_DISABLE=" in ln for ln in code)
+    assert any("HSA_ENABLE_IPC_MODE_LEGACY" in ln for ln in code)
+    for stage in ("train_autoencoder.py", "train_diffusion.py"):
+        assert any(stage in ln for ln in code) and os.path.exists(os.path.join(ROOT, stage))

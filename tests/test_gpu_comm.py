@@ -259,6 +259,128 @@ def test_fake_second_rank_on_the_benchmark_unet_and_the_autoencoder(cuda, monkey
     assert torch.equal(once(0), (vA + vB) * 0.5)
 
 
+def _device_view_i16(ptr, count, device):
+    """An int16 torch view of `count` 2-byte elements at a raw device pointer (the library's bf16 staging slice)."""
+    class _Arr:
+        __cuda_array_interface__ = {"shape": (count,), "typestr": "<i2", "data": (int(ptr), False), "version": 2}
+    return torch.as_tensor(_Arr(), device=device)
+
+
+def test_bf16_wire_format_inside_the_bucketed_exchange(cuda, monkeypatch):
+    """GradSync(grad_dtype=torch.bfloat16).attach -> ldm_model_set_grad_wire(1): every bucket crosses the wire as bf16 (cast into the
+    library's staging slice on the comm stream, all-reduce(avg) on that slice, cast back into the fp32 gradient buffer): half the
+    bytes of the fp32 exchange (a link-bound ring exposes 2-3 ms at the 24^3 shape).
+    The fake second rank sees dtype = bf16, op = avg, counts that tile the buffer back to front, and pointers OUTSIDE the gradient
+    buffer; the result equals bf16(mean(bf16 gA, bf16 gB)) bit for bit, i.e. the fp32 mean to bf16 precision (the tolerances of the
+    torch-fallback wire test, tests/test_dist_cpu.py:73-78)."""
+    from ldm3d import _lib
+    from ldm3d.networks import DiffusionModelUNet
+    from ldm3d.trainer import GradSync
+    from oracle import unet as ou
+    monkeypatch.setenv("LDM_GRAD_BUCKET_MB", "1")
+    cfg = cfgs.UNET_TINY
+    m = DiffusionModelUNet(**cfg)
+    m.load_state_dict(ou.init_state_dict(ou.unet_param_shapes(cfg), 3, gain=0.5))
+    m = m.to(cuda).train()
+    m.flatten_parameters()
+    g = torch.Generator().manual_seed(7)
+    xs = torch.randn((2, 4, 8, 8, 8), generator=g).to(cuda)
+    tg = torch.randn((2, 4, 8, 8, 8), generator=g).to(cuda)
+    ts = torch.tensor([17.0, 803.0], device=cuda)
+    gA = _train_once(m, xs[:1], ts[:1], tg[:1])
+    gB = _train_once(m, xs[1:], ts[1:], tg[1:])
+    total = m.flat_grads.numel()
+    calls, pos = [], [total]
+
+    def peer(buf, count, dtype, op, stream):
+        inside = m.flat_grads.data_ptr() <= buf < m.flat_grads.data_ptr() + 4 * total
+        calls.append((count, dtype, op, inside))
+        pos[0] -= count
+        off = pos[0]
+        with torch.cuda.stream(torch.cuda.ExternalStream(stream)):
+            mine = _device_view_i16(buf, count, cuda).view(torch.bfloat16)
+            other = gB[off:off + count].to(torch.bfloat16)
+            mine.copy_(((mine.float() + other.float()) * (0.5 if op == 1 else 1.0)).to(torch.bfloat16))
+        return 0
+    sync = GradSync(grad_dtype=torch.bfloat16)
+    assert sync.attach(m, transport=peer, world=2, rank=0)
+    m.flat_grads.fill_(float("nan"))
+    got = _train_once(m, xs[:1], ts[:1], tg[:1])
+    assert pos[0] == 0 and len(calls) >= 4
+    assert all(d == 1 and op == 1 and not inside for _, d, op, inside in calls)          # bf16, avg, staging slice
+    want = ((gA.to(torch.bfloat16).float() + gB.to(torch.bfloat16).float()) * 0.5).to(torch.bfloat16).float()
+    assert torch.equal(got, want)
+    mean = (gA + gB) * 0.5
+    rel = float((got - mean).norm() / mean.norm())
+    print(f"bf16 wire vs fp32 mean: rel-L2 {rel:.2e}")
+    assert rel <= 1e-2 and torch.allclose(got, mean, rtol=2e-2, atol=1e-3 * float(mean.abs().max()))
+    st = (C.c_int64 * 4)()
+    assert _lib.lib().ldm_comm_stats(m._grad_comm, st) == 0
+    assert st[0] == len(calls) and st[1] == 2 * total and _lib.lib().ldm_comm_is_rccl(m._grad_comm) == 0   # half of 4 * total bytes
+
+
+def test_no_torch_collective_while_a_bucket_is_in_flight(cuda, monkeypatch):
+    """Two communicators live in a training process (torch.distributed's group for scalars / barriers, the library's own for the
+    buckets: trainer.py GradSync).  They must never have collectives in flight at the same time in rank-dependent order.  Driven
+    through DiffusionTrainer with the fake second rank: train -> validate -> train.  Every torch.distributed collective the trainer
+    issues (patched to record) finds ldm_model_grad_sync_pending == 0; inside backward (from the transport callback, while buckets
+    are un-joined) GradSync refuses to issue one."""
+    import torch.distributed as dist
+    from ldm3d import _lib
+    from ldm3d.inferer import LatentDiffusionInferer
+    from ldm3d.networks import AutoencoderKL, DiffusionModelUNet
+    from ldm3d.schedulers import DDPMScheduler
+    from ldm3d.trainer import DiffusionTrainer
+    from oracle import autoencoder as oa
+    from oracle import unet as ou
+    monkeypatch.setenv("LDM_GRAD_BUCKET_MB", "1")
+    L = _lib.lib()
+    vcfg = dict(cfgs.VAE_TINY, in_channels=1, out_channels=1, latent_channels=4)
+    vae = AutoencoderKL(**vcfg)
+    vae.load_state_dict(ou.init_state_dict(oa.ae_param_shapes(vcfg), 2))
+    ucfg = dict(cfgs.UNET_TINY, in_channels=8)
+    unet = DiffusionModelUNet(**ucfg)
+    unet.load_state_dict(ou.init_state_dict(ou.unet_param_shapes(ucfg), 3, gain=0.5))
+    vae, unet = vae.to(cuda).eval(), unet.to(cuda)
+    tr = DiffusionTrainer(unet, vae, LatentDiffusionInferer(DDPMScheduler(**cfgs.SCHED), scale_factor=1.0), lr=1e-4)
+    assert not tr.overlap                                       # no process group: nothing attached yet
+    seen = {"in_backward": [], "refused": 0, "torch": []}
+
+    def peer(buf, count, dtype, op, stream):                    # rank 1 contributes the same gradients: mean == own
+        seen["in_backward"].append(L.ldm_model_grad_sync_pending(unet._h))
+        try:
+            tr.sync._quiescent()
+        except RuntimeError:
+            seen["refused"] += 1
+        return 0
+    tr.overlap = tr.sync.attach(unet, transport=peer, world=2, rank=0)
+    assert tr.overlap
+    tr.sync.on, tr.sync.world = True, 2                         # the trainer now believes it is rank 0 of 2
+
+    def recorded(name):
+        def fn(t, *a, **k):
+            seen["torch"].append((name, L.ldm_model_grad_sync_pending(unet._h)))
+            return None
+        return fn
+    monkeypatch.setattr(dist, "all_reduce", recorded("all_reduce"))
+    monkeypatch.setattr(dist, "broadcast", recorded("broadcast"))
+    monkeypatch.setattr(dist, "barrier", lambda *a, **k: seen["torch"].append(("barrier", L.ldm_model_grad_sync_pending(unet._h))))
+    g = torch.Generator().manual_seed(3)
+    images = torch.rand((1, 1, 32, 32, 32), generator=g).to(cuda)      # latent 8^3: the 3-level UNet needs a multiple of 4
+    labels = torch.rand((1, 1, 32, 32, 32), generator=g).to(cuda)
+    loss, skipped = tr.train_step(images, labels)
+    assert not bool(skipped) and L.ldm_model_grad_sync_pending(unet._h) == 0
+    val = tr.validate([{"image": images, "label": labels}], cuda)      # mean_scalar -> torch all_reduce
+    tr.sync.barrier()
+    loss2, skipped = tr.train_step(images, labels)
+    torch.cuda.synchronize()
+    assert not bool(skipped) and val == val
+    assert len(seen["in_backward"]) >= 8 and max(seen["in_backward"]) >= 1       # buckets were in flight while backward ran
+    assert seen["refused"] == sum(1 for n in seen["in_backward"] if n > 0)         # ... and a torch collective was refused there
+    assert [n for n, _ in seen["torch"]] == ["all_reduce", "barrier"]
+    assert all(p == 0 for _, p in seen["torch"])                                   # the trainer's own collectives: quiescent
+
+
 def test_two_real_processes_share_the_gradient_exchange(cuda):
     """World size 2 with two real PROCESSES on this GPU (tests/two_rank_gpu_worker.py; gloo carries the bytes, the library's bucketed
     path does everything else: 3d_ldm/train_diffusion.py:121-123,147-149,214).  The fake-peer test above plays rank 1 inside one process;
@@ -279,10 +401,16 @@ def test_two_real_processes_share_the_gradient_exchange(cuda):
         procs.append(subprocess.Popen([sys.executable, os.path.join(root, "tests", "two_rank_gpu_worker.py")], env=env, cwd=root,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     recs = []
-    for p in procs:
-        out, err = p.communicate(timeout=600)
-        assert p.returncode == 0, err[-2000:]
-        recs.append(json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1]))
+    try:
+        for p in procs:
+            out, err = p.communicate(timeout=600)
+            assert p.returncode == 0, err[-2000:]
+            recs.append(json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1]))
+    finally:                                                 # never leave a rank behind on the GPU (it would sit in the rendezvous)
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+            p.wait()
     print("two processes:", recs)
     assert sorted(r["rank"] for r in recs) == [0, 1]
     for r in recs:

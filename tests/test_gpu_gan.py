@@ -107,6 +107,50 @@ def test_vae_gan_step_trains_both_networks(cuda):
     print("discriminator loss on a fixed batch:", " ".join(f"{v:.4f}" for v in hist))
     assert all(v == v for v in hist) and min(hist[-3:]) < 0.7 * hist[0]
 
+def test_non_finite_adversarial_term_is_dropped_and_a_skipped_generator_step_skips_the_discriminator(cuda):
+    """3d_ldm/train_autoencoder.py:417-422: a NaN / inf adversarial term is dropped and the generator step continues on
+    reconstruction + KL; :362-365,426-437 `continue` before BOTH optimizers when the batch itself is bad.  Both decisions are taken on
+    the device.  (i) A discriminator that returns NaN logits (one poisoned weight): the generator step is NOT skipped, the
+    autoencoder's gradients are finite and equal those of the warm-up step (recon + KL only) bit for bit -- the branch's NaN gradient
+    is selected away, not multiplied by zero.  (ii) A NaN image: the generator step is skipped and the discriminator's parameters
+    and moments do not move either."""
+    from ldm3d.networks import AutoencoderKL
+    from ldm3d.trainer import AutoencoderTrainer
+    from oracle import autoencoder as oa
+    from oracle.unet import init_state_dict
+    cfg = cfgs.VAE_TINY
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand((1, 2, 16, 16, 16), generator=g).to(cuda)
+    eps = torch.randn((1, cfg["latent_channels"], 4, 4, 4), generator=g).to(cuda)
+
+    def make():
+        ae = AutoencoderKL(**cfg)
+        ae.load_state_dict(init_state_dict(oa.ae_param_shapes(cfg), 3, gain=0.7))
+        torch.manual_seed(0)
+        return AutoencoderTrainer(ae.to(cuda), lr=1e-4, kl_weight=1e-6, warm_up_epochs=1, adv_weight=0.5), ae
+    tr0, ae0 = make()
+    tr0.train_step(x, epoch=0, eps=eps)                       # warm-up step: reconstruction + KL only
+    g_ref = ae0.flat_grads.clone()
+    tr, ae = make()
+    with torch.no_grad():
+        next(iter(tr.discriminator.parameters())).view(-1)[0] = float("nan")
+    out, skipped = tr.train_step(x, epoch=2, eps=eps)
+    assert not bool(skipped) and not bool(torch.isfinite(out["adv_g"]))
+    assert bool(torch.isfinite(ae.flat_grads).all()) and torch.equal(ae.flat_grads, g_ref)
+    assert bool(torch.isfinite(ae.flat_params).all()) and bool(torch.isfinite(out["loss_g"]))
+    # (ii) a bad batch: neither network moves
+    tr2, ae2 = make()
+    p_g, p_d = ae2.flat_params.clone(), tr2.optimizer_d.flat_params.clone()
+    bad = x.clone()
+    bad[0, 0, 3, 3, 3] = float("nan")
+    out, skipped = tr2.train_step(bad, epoch=2, eps=eps)
+    assert bool(skipped)
+    assert torch.equal(ae2.flat_params, p_g) and torch.equal(tr2.optimizer_d.flat_params, p_d)
+    assert float(tr2.optimizer_d.exp_avg.abs().max()) == 0.0 and float(tr2.optimizer_d.sq_norm[1]) == 1.0
+    out, skipped = tr2.train_step(x, epoch=2, eps=eps)        # and the next good batch trains both
+    assert not bool(skipped) and not torch.equal(tr2.optimizer_d.flat_params, p_d) and not torch.equal(ae2.flat_params, p_g)
+
+
 @pytest.mark.parametrize("cin,cout,dims,stride,n", [(1, 32, (16, 16, 16), 2, 2), (32, 64, (12, 10, 8), 2, 1), (64, 32, (7, 7, 7), 1, 2), (128, 1, (6, 6, 6), 1, 1)])
 def test_discriminator_layers_match_torch_on_identical_inputs(cuda, cin, cout, dims, stride, n):
     """The building blocks one by one against torch autograd on the SAME bf16-rounded inputs (no compounding, no kink flips):

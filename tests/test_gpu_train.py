@@ -516,13 +516,15 @@ def test_fused_adam_repack_equals_adam_then_repack(cuda):
     assert rel_l2(res[True][3], res[False][3]) <= 1e-2
 
 
-def test_nan_step_is_skipped_on_the_device_and_does_not_count(cuda):
+@pytest.mark.parametrize("max_grad_norm", [1.0, None, 0.0])
+def test_nan_step_is_skipped_on_the_device_and_does_not_count(cuda, max_grad_norm):
     """The reference `continue`s in front of backward when the loss is NaN (3d_ldm/train_diffusion.py:210-212), so neither the
     parameters nor Adam's moments nor its step count move.  Here that decision is taken on the device, without a host read inside the
     step: a NaN loss makes every gradient NaN, the fused clip + Adam launch sees a non-finite gradient norm and leaves everything
     untouched (include/ldm3d.h: sq_norm[1] counts such steps, the bias corrections use step - skipped).  A run with one poisoned batch
     in the middle must therefore end where the run without it ends (to the last ulp of the bias corrections: after a skip they are
-    evaluated with the device's powf instead of the host's)."""
+    evaluated with the device's powf instead of the host's).  With clipping OFF (max_grad_norm None / 0: FlatAdam's own default)
+    the skip must work all the same: the reference skips a NaN batch whatever the clip setting."""
     from ldm3d.networks import DiffusionModelUNet
     from ldm3d.optim import FlatAdam
     from oracle import unet as ou
@@ -537,7 +539,7 @@ def test_nan_step_is_skipped_on_the_device_and_does_not_count(cuda):
         m = DiffusionModelUNet(**cfg)
         m.load_state_dict(sd)
         m = m.to(cuda).train()
-        opt = FlatAdam(m, lr=1e-3, max_grad_norm=1.0)
+        opt = FlatAdam(m, lr=1e-3, max_grad_norm=max_grad_norm)
         flags = []
         for k in range(3):
             if poison and k == 1:                           # a batch that produces a NaN loss between two good ones

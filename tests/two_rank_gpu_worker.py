@@ -25,7 +25,8 @@ def main():
     from ldm3d.trainer import GradSync
     from oracle import unet as ou
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))   # a lost peer must not park this rank for 30 min
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
     os.environ["LDM_GRAD_BUCKET_MB"] = "1"

@@ -11,8 +11,9 @@ import sys
 from collections import defaultdict
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01a"
+commit = sys.argv[2] if len(sys.argv) > 2 else None          # the commit the profiled library was built from (bench.py reports it)
 src = os.path.join("gpurun_out", f"prof_{tag}")
-out = {}
+out = {"commit": commit}
 
 
 def short(n):
@@ -45,6 +46,7 @@ per = {c: pmc[dom][c] / max(1, ndisp[dom][c]) for c in pmc[dom]}
 out["conv_pmc_per_launch"] = per
 if "FETCH_SIZE" in per and "WRITE_SIZE" in per:
     out["conv_hbm_traffic_bytes_per_launch"] = {
+        "kernel": dom, "launches": int(ndisp[dom]["FETCH_SIZE"]),
         "read_corrected": per["FETCH_SIZE"] * 1024 * 2, "write": per["WRITE_SIZE"] * 1024,
         "total": per["FETCH_SIZE"] * 1024 * 2 + per["WRITE_SIZE"] * 1024,
         "note": "FETCH_SIZE x1024 x2 (gfx950 half-count correction) + WRITE_SIZE x1024, averaged over all launches of the kernel"}
