@@ -416,8 +416,11 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
         if (to_slab) {
             float* dst = p.partial + ((size_t)split * p.M + m) * p.CoutPad + cbase;
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                *reinterpret_cast<float4*>(dst + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+            for (int q = 0; q < 4; ++q) {
+                const float4 t4 = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+                if (p.wt_slab) store16<true>(dst + 4 * q, __builtin_bit_cast(u32x4, t4));
+                else *reinterpret_cast<float4*>(dst + 4 * q) = t4;
+            }
             continue;
         }
         if (p.bias) {

@@ -57,6 +57,8 @@ struct ConvParams {
     // same pointer again (c0b = C: hi), both with the split tensor's row stride, weights [.. ][hi | hi | lo]:  hi*Whi + lo*Whi + hi*Wlo.
     int x3_n;
     int raw_partial;                  // write the fp32 accumulators to the partial slab even with splitk == 1 (the fp32 finalize follows)
+    int wt_slab;                      // split-K slabs stored write-through (sc1): the 12-17 MB of fp32 partials leave the XCDs' L2s while the
+                                      // kernel runs instead of in the write-back at its end (the finalize that reads them runs on every XCD)
     float* out32; const float* residual32;   // conv3_halo_kernel, fp32 precision, splitk == 1: fp32 NDHWC output [M][CoutS] (+ fp32 residual) from the fused epilogue
     // epilogue (splitk == 1) ------------------------------------------------------------
     const float* bias;                // [CoutPad] or null
@@ -567,8 +569,11 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_igemm_kernel(const ConvParam
             if (to_slab) {
                 float* dst = p.partial + ((size_t)split * p.M + m) * p.CoutPad + cbase;
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    *reinterpret_cast<float4*>(dst + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+                for (int q = 0; q < 4; ++q) {
+                    const float4 t4 = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+                    if (p.wt_slab) store16<true>(dst + 4 * q, __builtin_bit_cast(u32x4, t4));
+                    else *reinterpret_cast<float4*>(dst + 4 * q) = t4;
+                }
                 continue;
             }
             const int n = p.phase_mode ? n_ph : m / DHWo;

@@ -1896,6 +1896,7 @@ static int launch_wgrad(const WgradParams& p, hipStream_t s) {
     return 0;
 }
 
+static bool wt_slabs() { static const int v = [] { const char* e = getenv("LDM_WT_SLABS"); return e ? atoi(e) : 0; }(); return v != 0; }   // split-K slabs written through (ConvParams::wt_slab)
 static bool wt_stores() { static const int v = [] { const char* e = getenv("LDM_WT_STORES"); return e ? atoi(e) : 1; }(); return v != 0; }   // GroupNorm / finalize outputs written through (sc1): -24 us per step
 
 // per-op timeline of every launch plan that runs while it is on (ldm_set_plan_trace; initial state from LDM_PLAN_TRACE)
@@ -2060,6 +2061,7 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                 if (i[14] & 16) {                          // ... with the epilogue fused (splitk 1): fp32 NDHWC output, fp32 residual
                     p.out32 = (float*)rp(bs, o.r[10]); p.residual32 = (const float*)rp(bs, o.r[9]); p.out = nullptr; p.residual = nullptr;
                 }
+                p.wt_slab = (p.splitk > 1 && wt_slabs()) ? 1 : 0;
                 if (o.kind == OP_CONV) { LDM_TRY(launch_conv(p, o.cc, s)); }
                 else {
                     FinalizeParams f{}; f.partial = p.partial; f.splitk = p.splitk; f.M = p.M; f.CoutPad = p.CoutPad;

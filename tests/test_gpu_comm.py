@@ -313,7 +313,9 @@ def test_bf16_wire_format_inside_the_bucketed_exchange(cuda, monkeypatch):
     mean = (gA + gB) * 0.5
     rel = float((got - mean).norm() / mean.norm())
     print(f"bf16 wire vs fp32 mean: rel-L2 {rel:.2e}")
-    assert rel <= 1e-2 and torch.allclose(got, mean, rtol=2e-2, atol=1e-3 * float(mean.abs().max()))
+    # three bf16 roundings (both operands, the mean): every element within 2^-8 of the operand magnitudes (a cancelling pair may lose
+    # all RELATIVE accuracy of a small mean, which is why the default wire format stays fp32)
+    assert rel <= 1e-2 and bool(((got - mean).abs() <= 2.0 ** -8 * (gA.abs() + gB.abs()) + 1e-30).all())
     st = (C.c_int64 * 4)()
     assert _lib.lib().ldm_comm_stats(m._grad_comm, st) == 0
     assert st[0] == len(calls) and st[1] == 2 * total and _lib.lib().ldm_comm_is_rccl(m._grad_comm) == 0   # half of 4 * total bytes
