@@ -29,6 +29,7 @@
 #include "gemm_light.h"
 #include "conv_wgrad.h"
 #include "norm_elem.h"
+#include "fin_gn.h"
 #include "f32_path.h"
 #include "f32_train.h"
 
@@ -90,7 +91,8 @@ enum OpKind { OP_PACK, OP_CONV, OP_FINALIZE, OP_GN_STATS, OP_GN_FINALIZE, OP_GN_
               OP_TAP,                              // debug tap: export an activation as fp32 NCDHW and / or overwrite it (teacher forcing)
               OP_BUCKET, OP_BUCKET_JOIN,
               OP_UPS_SPLIT32,
-              OP_CONV_THIN };                      // 3^3 conv with Cout <= 4 and fp32 NCDHW output: the networks' last layer (conv_thin.h)                    // fp32 precision: nearest x2 upsample into the (hi | lo) bf16 split (upsample_split_f32_kernel)         // training plans: a tail range of the flat gradient buffer is final (all-reduce it now) / wait for every bucket
+              OP_CONV_THIN,
+              OP_FIN_GN };                         // split-K finalize + the GroupNorm(+SiLU) that consumes it, one launch (fin_gn.h)                      // 3^3 conv with Cout <= 4 and fp32 NCDHW output: the networks' last layer (conv_thin.h)                    // fp32 precision: nearest x2 upsample into the (hi | lo) bf16 split (upsample_split_f32_kernel)         // training plans: a tail range of the flat gradient buffer is final (all-reduce it now) / wait for every bucket
 
 struct ConvCfg { int wgm, wgn, bk, splitk; int halo = 0, mtps = 0, qps = 0; };   // halo: conv3_halo_kernel (126-row tiles)
 
@@ -226,6 +228,13 @@ struct ldm_model {
     size_t tproj_w_off = 0, tproj_b_off = 0; int tproj_rows = 0; std::map<std::string, int> tproj_row;
 
     size_t arena_alloc(size_t bytes) { size_t o = arena_bytes; arena_bytes += rup_sz(bytes, 256); return o; }
+    // inter-workgroup exchange area of the fused finalize + GroupNorm launches (fin_gn.h), inside the (zero-initialised) arena:
+    // [0, 256) error word; [256, 256 + 64 * 256) arrival / departure counters, 256 B per fused op of a plan; then 32 KiB of partial
+    // statistics per fused op.  Counters are zero between launches (the kernel restores them).
+    static constexpr int SYNC_SLOTS = 60;
+    static constexpr size_t SYNC_CNT_OFF = 256, SYNC_PART_OFF = 256 + 64 * 256, SYNC_PART_BYTES = 32 * 1024;
+    static constexpr size_t SYNC_BYTES = SYNC_PART_OFF + SYNC_SLOTS * SYNC_PART_BYTES;
+    size_t sync_off = 0;
     // weights derived from the packed ones (phase weights of the upsample convs): rebuilt on the stream of the next inference
     // call after any parameter upload
     struct PhaseW { size_t w_off, wp_off; int cout_pad, cin_s; };
@@ -746,6 +755,42 @@ struct Builder {
         return out;
     }
 
+    // ---- split-K finalize + the GroupNorm that consumes it, in one launch (fin_gn.h) ------------------------------------------
+    // Called right after conv() returned `raw`: if the plan's last op is that conv's OP_FINALIZE and the shapes allow, it becomes an
+    // OP_FIN_GN that also writes GroupNorm(+SiLU)(raw) into *y.  keep_raw = false: nobody else reads the un-normalised tensor (a
+    // ResBlock's conv1 output): it is not written at all and its workspace block returns to the pool.
+    // Measured (round 4, same box, headline step): 23 fused launches, 458.7 vs 468.6 steps/s for the three-launch form -- 2.2 % SLOWER.
+    // In-kernel stamps (profiles/r04_kstamps_fin_gn.txt): slab sum 2.7 us + block statistics 1.2 + EXCHANGE 4.2 - 8.2 + apply 0.9 + drain 0.4
+    // = 11.1 us against finalize 4.7 + boundary 1.2 + one-launch GroupNorm 4.0 = 9.9 us: an arrival counter in memory costs three
+    // dependent round trips (atomic lands, poll sees it, payload read) plus the arrival skew of the slice's 54 blocks, which is more
+    // than the kernel boundary (1.2 us) plus the statistics fold it replaces.  Off by default (LDM_FIN_GN=1 switches it on).
+    static bool fin_gn_enabled() { static const int v = [] { const char* e = getenv("LDM_FIN_GN"); return e ? atoi(e) : 0; }(); return v != 0; }
+    int fin_gn_slots = 0;
+    std::map<size_t, Act> prenorm;                   // un-normalised activation (by offset) -> its GroupNorm output, produced by an OP_FIN_GN
+    bool fuse_fin_gn(Act& raw, bool keep_raw, const GnW& g, int groups, float eps, bool silu, Act* y) {
+        if (hp || train || !fin_gn_enabled() || plan->ops.empty() || !raw.valid) return false;
+        Op& f = plan->ops.back();
+        if (f.kind != OP_FINALIZE || f.i[22] || f.r[10].base != BASE_WS || f.r[10].off != raw.off) return false;
+        const int C = raw.C, N = raw.N, DHW = raw.D * raw.H * raw.W;
+        if (C != g.C || C % groups) return false;
+        const int cpg = C / groups;
+        if (cpg < 4 || cpg > 64 || 64 % cpg) return false;                      // whole groups inside a 64-channel slice, <= 16 of them
+        const int slices = (C + 63) / 64, chunks = (DHW + 31) / 32;
+        if (N * slices > 32 || (long)N * slices * chunks > 256) return false;   // every block resident (one per CU) and inside its sync slot
+        if (fin_gn_slots >= ldm_model::SYNC_SLOTS) return false;
+        const int slot = fin_gn_slots++;
+        Act out = new_act(N, raw.D, raw.H, raw.W, C);
+        f.kind = OP_FIN_GN;
+        f.r[3] = w_ref(g.g_off); f.r[4] = w_ref(g.b_off); f.r[5] = ws_ref(out.off);
+        f.r[13] = w_ref(m->sync_off);
+        f.r[12] = Ref();                                                        // no statistics slab: the statistics never leave the launch
+        f.i[0] = groups; f.i[1] = silu ? 1 : 0; f.i[2] = chunks; f.i[3] = slot; f.f[0] = eps;
+        if (raw.has_stats) { pool.release(raw.stats_off); raw.has_stats = false; }
+        if (!keep_raw) { f.r[10] = Ref(); pool.release(raw.off); raw.valid = false; }
+        *y = out;
+        return true;
+    }
+
     // ---- GroupNorm (+SiLU) over (xa | xb) -> contiguous bf16 --------------------------------------------
     // fp32 inference plans: LDM_X3_HALO (default 1) runs the 3^3 stride-1 convs behind a GroupNorm with >= LDM_X3_HALO_ROWS (default 1) output rows
     // as conv3_halo_kernel on the bf16 (hi | lo) split of the normalised tensor (ConvParams::x3_n): the GroupNorm writes the split
@@ -893,8 +938,10 @@ struct Builder {
     }
 
     // ResBlock (UNet: with temb; VAE: without).  xb = skip tensor concatenated after xa (up path) or invalid.
+    // next_gn: the GroupNorm (no SiLU) of the attention block that reads this ResBlock's output next, or null: where conv2 is split
+    // over K its finalize then also produces that GroupNorm's output (prenorm), which attention() picks up
     Act resblock(const std::string& p, const Act& xa, const Act& xb, int cout, int groups, float eps,
-                 const std::string& skip_name, bool with_temb) {
+                 const std::string& skip_name, bool with_temb, const GnW* next_gn = nullptr) {
         const int cin = xa.C + (xb.valid ? xb.C : 0);
         // fp32 precision: the 1x1 skip projection runs as its own conv and enters conv2 as its residual (the bf16 plans fuse it
         // into conv2 as extra K steps).  A second stream for it (and for the time-embedding chain) was measured and removed: one
@@ -916,8 +963,11 @@ struct Builder {
         Act h1 = conv(c1, p + ".conv1");
         free_act(h0);
         if (!h1.valid) return Act();
-        Act h2 = gn_apply(m->gns.at(p + ".norm2"), h1, Act(), groups, eps, true, &m->convs.at(p + ".conv2"));
-        free_act(h1);
+        Act h2;
+        if (!fuse_fin_gn(h1, false, m->gns.at(p + ".norm2"), groups, eps, true, &h2)) {
+            h2 = gn_apply(m->gns.at(p + ".norm2"), h1, Act(), groups, eps, true, &m->convs.at(p + ".conv2"));
+            free_act(h1);
+        }
         if (!h2.valid) return Act();
         ConvArgs c2; c2.xa = h2; c2.w = &m->convs.at(p + ".conv2"); c2.Do = xa.D; c2.Ho = xa.H; c2.Wo = xa.W;
         if (sk.valid) c2.residual = sk;
@@ -926,6 +976,10 @@ struct Builder {
         Act out = conv(c2, p + ".conv2");
         free_act(h2);
         if (sk.valid) free_act(sk);
+        if (next_gn && out.valid && tap_mode != 2) {
+            Act yn;
+            if (fuse_fin_gn(out, true, *next_gn, groups, eps, false, &yn)) prenorm[out.off] = yn;
+        }
         return out;
     }
 
@@ -965,7 +1019,9 @@ struct Builder {
         if (C % head_ch || (head_ch != 32 && head_ch != 64 && head_ch != 128 && head_ch != 256)) {
             err = "attention: head dimension must be 32, 64, 128 or 256 (" + p + ": " + std::to_string(head_ch) + ")"; return Act();
         }
-        Act hn = gn_apply(m->gns.at(p + ".norm"), x, Act(), groups, eps, false);
+        Act hn;
+        { auto it = prenorm.find(x.off); if (it != prenorm.end()) { hn = it->second; prenorm.erase(it); } }
+        if (!hn.valid) hn = gn_apply(m->gns.at(p + ".norm"), x, Act(), groups, eps, false);
         if (!hn.valid) return Act();
         ConvArgs q; q.xa = hn; q.w = &m->convs.at(p + ".attn.qkv"); q.k = 1; q.pad = 0; q.Do = x.D; q.Ho = x.H; q.Wo = x.W;
         q.want_stats = false;
@@ -1397,6 +1453,7 @@ static int unet_register(ldm_model* m) {
     }
     collect = false;
     walk();                                                  // pass 2: everything else, in execution order
+    m->sync_off = m->arena_alloc(ldm_model::SYNC_BYTES);
     return 0;
 }
 
@@ -1442,7 +1499,8 @@ static int unet_build(ldm_model* m, int B, int D, int H, int W, Plan* plan, bool
     for (int i = 0; i < L; ++i) {
         for (int j = 0; j < c.num_res_blocks[i]; ++j) {
             snprintf(p, sizeof p, "down_blocks.%d.resnets.%d", i, j);
-            Act hn = b.resblock(p, h, Act(), ch[i], G, eps, ".skip_connection", true);
+            char pa[96]; snprintf(pa, sizeof pa, "down_blocks.%d.attentions.%d.norm", i, j);
+            Act hn = b.resblock(p, h, Act(), ch[i], G, eps, ".skip_connection", true, c.attention_levels[i] ? &m->gns.at(pa) : nullptr);
             if (!hn.valid) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
             b.tap(p, hn, ch[i]);
             if (c.attention_levels[i]) {
@@ -1465,7 +1523,7 @@ static int unet_build(ldm_model* m, int B, int D, int H, int W, Plan* plan, bool
         }
     }
     {   // middle: Res, Attn, Res.  `h` is also the last skip and stays alive.
-        Act h1 = b.resblock("middle_block.resnet_1", h, Act(), ch[L - 1], G, eps, ".skip_connection", true);
+        Act h1 = b.resblock("middle_block.resnet_1", h, Act(), ch[L - 1], G, eps, ".skip_connection", true, &m->gns.at("middle_block.attention.norm"));
         if (!h1.valid) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
         b.tap("middle_block.resnet_1", h1, ch[L - 1]);
         Act h2 = b.attention("middle_block.attention", h1, c.num_head_channels[L - 1], G, eps);
@@ -1483,7 +1541,8 @@ static int unet_build(ldm_model* m, int B, int D, int H, int W, Plan* plan, bool
         for (int j = 0; j < c.num_res_blocks[lvl] + 1; ++j) {
             Act s = skips.back(); skips.pop_back();
             snprintf(p, sizeof p, "up_blocks.%d.resnets.%d", i, j);
-            Act hn = b.resblock(p, h, s, ch[lvl], G, eps, ".skip_connection", true);
+            char pa[96]; snprintf(pa, sizeof pa, "up_blocks.%d.attentions.%d.norm", i, j);
+            Act hn = b.resblock(p, h, s, ch[lvl], G, eps, ".skip_connection", true, c.attention_levels[lvl] ? &m->gns.at(pa) : nullptr);
             b.free_act(h); b.free_act(s);
             if (!hn.valid) return fail(LDM_ERR_UNSUPPORTED, "%s", b.err.c_str());
             b.tap(p, hn, ch[lvl]);
@@ -1630,6 +1689,7 @@ static int vae_register(ldm_model* m) {
     m->reg_conv_into("post_quant_conv", pq, Lc, Lc, 1, 0, false);
     m->convs["post_quant_conv"] = pq;
     LDM_TRY(reg("decoder", ae_decoder_layout(c)));
+    m->sync_off = m->arena_alloc(ldm_model::SYNC_BYTES);
     return 0;
 }
 
@@ -2033,6 +2093,23 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                     if (i[4] == 4) hipLaunchKernelGGL(pack2_ncdhw_f32_kernel, dim3(grid_for(tot2)), dim3(256), 0, s, src, i[1], (const float*)nullptr, 0, (float*)rp(bs, o.r[0]), i[0], i[2], i[3]);
                     else hipLaunchKernelGGL(pack2_ncdhw_kernel, dim3(grid_for(tot2)), dim3(256), 0, s, src, i[1], (const float*)nullptr, 0, (bf16_t*)rp(bs, o.r[0]), i[0], i[2], i[3]);
                 }
+                break; }
+            case OP_FIN_GN: {            // an OP_FINALIZE whose r[3..5] = gamma, beta, normalised output; r[13] = sync region; i[0..3] = groups, silu, chunks, slot
+                FinGnParams q{}; FinalizeParams& f = q.f;
+                f.partial = (const float*)rp(bs, o.r[11]); f.splitk = o.cc.splitk; f.M = i[15]; f.CoutPad = i[17]; f.CoutS = i[16]; f.CoutReal = i[18];
+                f.DHWo = i[8] * i[9] * i[10];
+                f.bias = (const float*)rp(bs, o.r[6]); f.bias2 = (const float*)rp(bs, o.r[7]); f.temb = (const float*)rp(bs, o.r[8]); f.temb_stride = i[21];
+                f.residual = (const bf16_t*)rp(bs, o.r[9]); f.out = (bf16_t*)rp(bs, o.r[10]);
+                q.gamma = (const float*)rp(bs, o.r[3]); q.beta = (const float*)rp(bs, o.r[4]); q.y = (bf16_t*)rp(bs, o.r[5]);
+                q.groups = i[0]; q.silu = i[1]; q.chunks = i[2]; q.dhw = f.DHWo; q.eps = o.f[0];
+                char* sync = rp(bs, o.r[13]);
+                if (!sync) return fail(LDM_ERR_NOT_LOADED, "the weight arena is empty");
+                q.err = (unsigned*)sync;
+                q.cnt = (unsigned*)(sync + ldm_model::SYNC_CNT_OFF + (size_t)i[3] * 256);
+                q.xpart = (float*)(sync + ldm_model::SYNC_PART_OFF + (size_t)i[3] * ldm_model::SYNC_PART_BYTES);
+                const dim3 grid(i[2], (i[16] + 63) / 64, i[4]);
+                if (wt_stores()) hipLaunchKernelGGL(fin_gn_kernel<true>, grid, dim3(256), 0, s, q);
+                else hipLaunchKernelGGL(fin_gn_kernel<false>, grid, dim3(256), 0, s, q);
                 break; }
             case OP_CONV: case OP_FINALIZE: {
                 ConvParams p{};
@@ -2669,6 +2746,16 @@ int ldm_set_plan_trace(const char* path) {
 /* on != 0: ldm_unet_forward replays a HIP graph of its launch plan whenever it sees the same (x, cond, timesteps, out,
  * workspace, stream) pointers again (callers keep those buffers fixed: the Python shell stages through persistent tensors).
  * Same kernels, same results; only the host cost per step changes (one graph launch instead of ~150 launches). */
+/* Error word of the fused finalize + GroupNorm launches (fin_gn.h): 0 = every inter-workgroup wait of every launch so far completed,
+ * 1 = a wait gave up (results of that launch are wrong).  Synchronises the device; tests and smoke() read it. */
+int ldm_model_sync_errors(ldm_model* m) {
+    if (!m) return fail(LDM_ERR_BAD_ARG, "null model");
+    if (!m->arena || !m->sync_off) return 0;
+    unsigned v = 0;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(&v, m->arena + m->sync_off, 4, hipMemcpyDeviceToHost));
+    return (int)v;
+}
 int ldm_model_set_graph_mode(ldm_model* m, int on) {
     if (!m) return fail(LDM_ERR_BAD_ARG, "null model");
     m->graph_mode = on ? 1 : 0;
@@ -3152,8 +3239,8 @@ static int op_conv3d_impl(const void* xa, int ca, const void* xb, int cb, const 
                           const float* temb, int temb_stride, const void* residual, void* out_bf16, float* out_f32,
                           int N, int Din, int Hin, int Win, int ksize, int stride, int pad, int ups,
                           int cout, int cout_pad, int wgn, int splitk, void* scratch, size_t scratch_bytes, void* stream,
-                          float* stats, int* stats_nrb) {
-    if (!xa || !w || (!out_bf16 && !out_f32)) return fail(LDM_ERR_BAD_ARG, "null tensor argument");
+                          float* stats, int* stats_nrb, FinGnParams* fg = nullptr) {
+    if (!xa || !w || (!out_bf16 && !out_f32 && !fg)) return fail(LDM_ERR_BAD_ARG, "null tensor argument");
     if (!xb) cb = 0;
     if (!x1a) { c1a = 0; c1b = 0; }
     if (!x1b) c1b = 0;
@@ -3235,8 +3322,14 @@ static int op_conv3d_impl(const void* xa, int ca, const void* xb, int cb, const 
         FinalizeParams f{}; f.partial = p.partial; f.splitk = p.splitk; f.M = p.M; f.CoutPad = p.CoutPad; f.CoutS = p.CoutS;
         f.CoutReal = p.CoutReal; f.DHWo = Do * Ho * Wo; f.bias = bias; f.bias2 = bias2; f.temb = temb; f.temb_stride = temb_stride;
         f.residual = p.residual; f.out = p.out; f.out_f32 = p.out_f32; f.stats = stats;
-        launch_finalize(f, stats && wt_stores(), (hipStream_t)stream);
-    }
+        if (fg) {                                    // finalize + GroupNorm in one launch (fin_gn.h), as the plans' OP_FIN_GN
+            fg->f = f; fg->f.stats = nullptr; fg->dhw = f.DHWo; fg->chunks = (f.DHWo + 31) / 32;
+            const dim3 grid(fg->chunks, (p.CoutS + 63) / 64, N);
+            if (wt_stores()) hipLaunchKernelGGL(fin_gn_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, *fg);
+            else hipLaunchKernelGGL(fin_gn_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, *fg);
+        } else
+            launch_finalize(f, stats && wt_stores(), (hipStream_t)stream);
+    } else if (fg) return fail(LDM_ERR_UNSUPPORTED, "the fused finalize + GroupNorm needs a conv that is split over K");
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -3283,6 +3376,42 @@ int ldm_op_conv3d_gn(const void* x, int cin, const void* w, const float* bias, c
     if (wt_stores()) hipLaunchKernelGGL(gn_fused_apply_kernel<true>, dim3(chunks, slices, N), dim3(256), 0, (hipStream_t)stream, g);
     else hipLaunchKernelGGL(gn_fused_apply_kernel<false>, dim3(chunks, slices, N), dim3(256), 0, (hipStream_t)stream, g);
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+/* The split-K conv -> GroupNorm pair as the inference plans launch it at the 12^3 / 6^3 levels (OP_CONV + OP_FIN_GN, csrc/fin_gn.h): a 3^3
+ * stride-1 conv split over K (splitk >= 2), then ONE launch that sums the slabs, applies bias / per-sample channel bias `temb` /
+ * `residual`, rounds to bf16, exchanges the GroupNorm statistics between its workgroups and writes GroupNorm(+SiLU) of the rounded
+ * tensor to gn_out; conv_out (optional) receives the un-normalised bf16 tensor.  scratch: split-K slabs + 64 KiB exchange area
+ * (ldm_op_conv3d_fin_gn_scratch_bytes).  *err_out (host, optional; the call then synchronises the stream) = 1 if an inter-workgroup wait gave up.
+ * LDM_ERR_UNSUPPORTED where the plans keep the two launches (channels per group not dividing 64, more than 256 blocks). */
+size_t ldm_op_conv3d_fin_gn_scratch_bytes(int N, int D, int H, int W, int cout_pad, int splitk) {
+    return rup_sz((size_t)splitk * N * D * H * W * cout_pad * 4, 256) + 65536;
+}
+int ldm_op_conv3d_fin_gn(const void* x, int cin, const void* w, const float* bias, const float* temb, int temb_stride, const void* residual,
+                         const float* gamma, const float* beta, int groups, float eps, int silu, void* conv_out, void* gn_out,
+                         int N, int D, int H, int W, int cout, int cout_pad, int wgn, int splitk, void* scratch, size_t scratch_bytes,
+                         int* err_out, void* stream) {
+    if (!x || !w || !gamma || !beta || !gn_out || !scratch) return fail(LDM_ERR_BAD_ARG, "null tensor argument");
+    const int C = rup(cout, 32);
+    if (groups < 1 || C % groups || cout != C || splitk < 2) return fail(LDM_ERR_BAD_ARG, "cout must be a multiple of 32 and of groups, splitk >= 2");
+    const int cpg = C / groups, slices = (C + 63) / 64, chunks = (D * H * W + 31) / 32;
+    if (cpg < 4 || cpg > 64 || 64 % cpg || N * slices > 32 || (long)N * slices * chunks > 256)
+        return fail(LDM_ERR_UNSUPPORTED, "the plans keep finalize and GroupNorm apart here (%d channels per group, %ld blocks)", cpg, (long)N * slices * chunks);
+    if (scratch_bytes < ldm_op_conv3d_fin_gn_scratch_bytes(N, D, H, W, cout_pad, splitk)) return fail(LDM_ERR_WORKSPACE, "scratch too small");
+    const size_t slab_bytes = rup_sz((size_t)splitk * N * D * H * W * cout_pad * 4, 256);
+    char* sync = (char*)scratch + slab_bytes;
+    HIP_TRY(hipMemsetAsync(sync, 0, 32768, (hipStream_t)stream));       // error word + counters (the plans keep theirs in the zeroed arena)
+    FinGnParams q{}; q.gamma = gamma; q.beta = beta; q.y = (bf16_t*)gn_out; q.groups = groups; q.silu = silu; q.eps = eps;
+    q.err = (unsigned*)sync; q.cnt = (unsigned*)(sync + 256); q.xpart = (float*)(sync + 32768);
+    LDM_TRY(op_conv3d_impl(x, cin, nullptr, 0, w, bias, nullptr, 0, nullptr, 0, nullptr, nullptr, temb, temb_stride, residual, conv_out, nullptr,
+                           N, D, H, W, 3, 1, 1, 0, cout, cout_pad, wgn, splitk, scratch, slab_bytes, stream, nullptr, nullptr, &q));
+    if (err_out) {
+        unsigned v = 0;
+        HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+        HIP_TRY(hipMemcpy(&v, sync, 4, hipMemcpyDeviceToHost));
+        *err_out = (int)v;
+    }
     return 0;
 }
 

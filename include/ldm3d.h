@@ -281,6 +281,15 @@ int ldm_op_group_norm_f32(const float* x, int C, const float* gamma, const float
                           int N, int DHW, void* scratch, size_t scratch_bytes, void* stream);
 int ldm_op_group_norm_bwd_f32(const float* dy, const float* x, int C, const float* gamma, const float* beta, int groups, float eps, int act,
                               float* dx, float* dgamma, float* dbeta, int N, int DHW, void* scratch, size_t scratch_bytes, void* stream);
+/* The split-K conv -> GroupNorm pair as the inference plans launch it at the low-resolution levels (conv + ONE finalize-and-GroupNorm
+ * launch, csrc/fin_gn.h; MONAI ResBlock conv1 -> norm2 -> SiLU behind 3d_ldm/train_diffusion.py:197-205): gn_out = GroupNorm(+SiLU) of
+ * bf16(conv + bias + temb[n] + residual), conv_out (optional) = that bf16 tensor itself.  splitk >= 2.  *err_out (optional, host;
+ * synchronises) = 1 if an inter-workgroup wait gave up.  LDM_ERR_UNSUPPORTED for shapes the plans keep on two launches. */
+size_t ldm_op_conv3d_fin_gn_scratch_bytes(int N, int D, int H, int W, int cout_pad, int splitk);
+int ldm_op_conv3d_fin_gn(const void* x, int cin, const void* w, const float* bias, const float* temb, int temb_stride, const void* residual,
+                         const float* gamma, const float* beta, int groups, float eps, int silu, void* conv_out, void* gn_out,
+                         int N, int D, int H, int W, int cout, int cout_pad, int wgn, int splitk, void* scratch, size_t scratch_bytes,
+                         int* err_out, void* stream);
 /* producer -> GroupNorm pair as the inference plans launch it (conv epilogue / write-through split-K finalize leave the statistics
  * slabs, one-launch GroupNorm(+SiLU) with write-through stores folds them): the per-kernel gate of exactly those kernel variants */
 size_t ldm_op_conv3d_gn_scratch_bytes(int N, int D, int H, int W, int cout_pad, int splitk);
@@ -320,6 +329,9 @@ int ldm_debug_kstamps(unsigned long long* out, int max_entries, int reset);
 int ldm_model_plan_conv_cfgs(ldm_model* m, const char* kind, int B, int D, int H, int W, int* cfgs, int max_convs);
 /* launches of a cached inference plan ("unet"|"enc"|"dec"; builds it if needed) */
 int ldm_model_plan_launches(ldm_model* m, const char* kind, int B, int D, int H, int W);
+/* 0 = every inter-workgroup wait inside the fused split-K finalize + GroupNorm launches (csrc/fin_gn.h) has completed so far; 1 = one
+ * gave up (a resident-grid assumption was violated; the results of that launch are wrong).  Synchronises the device. */
+int ldm_model_sync_errors(ldm_model* m);
 
 /* ---- data-parallel collectives (replaces init_process_group("nccl") + DDP all-reduce,
  *      3d_ldm/utils.py:55-63, 3d_ldm/train_diffusion.py:121-123,147-149,281-283): RCCL over xGMI.

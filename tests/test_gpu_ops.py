@@ -2,6 +2,7 @@
 ops evaluated on the same bf16-rounded inputs.  Tolerance: fp32 accumulation-order noise plus one output rounding
 to bf16 -> rel-L2 <= 3e-3 against the UN-rounded fp32 result (a bf16 rounding alone is ~1.7e-3 rms... see below),
 and <= 2e-4 against the result rounded to bf16 the same way (the gate that matters: same rounding points)."""
+import ctypes as C
 import itertools
 
 import pytest
@@ -492,3 +493,94 @@ def test_conv_then_group_norm_as_the_plans_launch_them(cuda, built_lib, cin, cou
     assert e_conv <= TOL_SAME_ROUNDING, e_conv
     assert e_gn <= TOL_SAME_ROUNDING, e_gn
     assert e_pair <= TOL_SAME_ROUNDING, e_pair
+
+
+# conv (split over K) -> ONE finalize-and-GroupNorm launch (csrc/fin_gn.h: the statistics are exchanged between the launch's workgroups
+# behind an arrival counter), as the inference plans launch it at the 12^3 / 6^3 levels.  Checked: against torch on identical
+# bf16-rounded inputs (same rounding points as the two-launch path), against the two-launch path itself (the un-normalised tensor bit
+# for bit; the normalised one to the last bf16 ulp: the fold order of the statistics differs), and under 200 back-to-back replays with
+# CHANGING inputs (the counters restore themselves, nothing stale is read from the exchange area, the error word stays 0).
+@pytest.mark.parametrize("cin,cout,dims,n,wgn,splitk,groups,silu,temb,res,keep", [
+    (256, 256, (12, 12, 12), 1, 2, 6, 32, True, True, False, False),    # ResBlock conv1 -> norm2 at 12^3 (halo tile): nobody reads the raw tensor
+    (256, 256, (12, 12, 12), 1, 2, 8, 32, False, False, True, True),    # conv2 (+ residual) -> attention norm: the raw tensor is the residual stream
+    (512, 512, (6, 6, 6), 1, 2, 12, 32, True, True, False, False),      # the 6^3 level: 216 rows (ragged last 32-row block), 16 channels per group
+    (512, 512, (6, 6, 6), 1, 2, 27, 32, False, False, True, True),
+    (96, 128, (8, 8, 8), 2, 2, 3, 16, True, True, False, True),         # general kernel (K step 32), batch 2, 8 channels per group
+    (64, 96, (4, 6, 8), 1, 2, 2, 24, True, False, False, True),         # 96 channels: the second 64-channel slice is half empty; 4 channels per group
+])
+def test_split_k_conv_then_fused_finalize_group_norm(cuda, built_lib, cin, cout, dims, n, wgn, splitk, groups, silu, temb, res, keep):
+    from ldm3d import _lib
+    g = torch.Generator().manual_seed(cin + cout + dims[0] + splitk)
+    cout_pad = rup(cout, 64)
+    w = bf16_round(torch.randn((cout, cin, 3, 3, 3), generator=g) / (27 * cin) ** 0.5)
+    b = 0.1 * torch.randn((cout,), generator=g)
+    gamma = 1.0 + 0.1 * torch.randn((cout,), generator=g)
+    beta = 0.1 * torch.randn((cout,), generator=g)
+    tvec = 0.3 * torch.randn((n, cout_pad), generator=g) if temb else None
+    wp = pack_conv_weight(w, cin, cout_pad).to(cuda)
+    bp = pad_vec(b, cout_pad).to(cuda)
+    gd, bd = gamma.to(cuda), beta.to(cuda)
+    td = tvec.to(cuda) if temb else None
+    st = torch.cuda.current_stream().cuda_stream
+    nb = max(built_lib.ldm_op_conv3d_fin_gn_scratch_bytes(n, *dims, cout_pad, splitk), built_lib.ldm_op_conv3d_gn_scratch_bytes(n, *dims, cout_pad, splitk))
+    scratch = torch.empty((nb,), dtype=torch.uint8, device=cuda)
+    err = C.c_int(-1)
+
+    def fused(xa, ra, raw_out, gn_out, err_ptr):
+        _lib.check(built_lib.ldm_op_conv3d_fin_gn(xa.data_ptr(), cin, wp.data_ptr(), bp.data_ptr(), _lib.ptr(td), cout_pad if temb else 0, _lib.ptr(ra),
+                                                  gd.data_ptr(), bd.data_ptr(), groups, 1e-6, int(silu), _lib.ptr(raw_out), gn_out.data_ptr(),
+                                                  n, *dims, cout, cout_pad, wgn, splitk, scratch.data_ptr(), scratch.numel(), err_ptr, st))
+    worst = 0.0
+    for rep in range(3):
+        x = bf16_round(torch.randn((n, cin, *dims), generator=g))
+        r = bf16_round(torch.randn((n, cout, *dims), generator=g)) if res else None
+        y = F.conv3d(x, w, b, padding=1)
+        if temb:
+            y = y + tvec[:, :cout].reshape(n, cout, 1, 1, 1)
+        if res:
+            y = y + r
+        y = bf16_round(y)
+        ref = F.group_norm(y, groups, gamma, beta, 1e-6)
+        if silu:
+            ref = F.silu(ref)
+        xa = to_ndhwc_bf16(x).to(cuda)
+        ra = to_ndhwc_bf16(r).to(cuda) if res else None
+        raw = torch.full((n, *dims, cout), float("nan"), dtype=torch.bfloat16, device=cuda) if keep else None
+        gn_out = torch.full((n, *dims, cout), float("nan"), dtype=torch.bfloat16, device=cuda)
+        fused(xa, ra, raw, gn_out, C.byref(err))
+        assert err.value == 0
+        e_pair = rel_l2(from_ndhwc(gn_out.cpu(), cout), bf16_round(ref))
+        worst = max(worst, e_pair)
+        assert e_pair <= TOL_SAME_ROUNDING, e_pair
+        if keep:
+            assert rel_l2(from_ndhwc(raw.cpu(), cout), y) <= TOL_SAME_ROUNDING
+            yk = from_ndhwc(raw.cpu(), cout)                           # GroupNorm of the kernel's own un-normalised tensor
+            ref_k = F.group_norm(yk, groups, gamma, beta, 1e-6)
+            if silu:
+                ref_k = F.silu(ref_k)
+            assert rel_l2(from_ndhwc(gn_out.cpu(), cout), bf16_round(ref_k)) <= TOL_SAME_ROUNDING
+        if not temb and not res:                                       # the two-launch path takes bias only: compare where the forms coincide
+            c2 = torch.empty((n, *dims, cout), dtype=torch.bfloat16, device=cuda)
+            g2 = torch.empty((n, *dims, cout), dtype=torch.bfloat16, device=cuda)
+            _lib.check(built_lib.ldm_op_conv3d_gn(xa.data_ptr(), cin, wp.data_ptr(), bp.data_ptr(), gd.data_ptr(), bd.data_ptr(), groups, 1e-6, int(silu),
+                                                  c2.data_ptr(), g2.data_ptr(), n, *dims, cout, cout_pad, wgn, splitk, scratch.data_ptr(), scratch.numel(), st))
+            torch.cuda.synchronize()
+            assert torch.equal(c2, raw)
+            d = (g2.float() - gn_out.float()).abs()
+            assert float(d.max()) <= 2.0 ** -7 * float(g2.float().abs().max()) and float((d > 0).float().mean()) < 1e-2
+    # replays with changing inputs: results must follow the inputs (a stale exchange area or a counter left non-zero would show)
+    xs = [to_ndhwc_bf16(bf16_round(torch.randn((n, cin, *dims), generator=g))).to(cuda) for _ in range(2)]
+    outs = [torch.empty((n, *dims, cout), dtype=torch.bfloat16, device=cuda) for _ in range(2)]
+    first = []
+    ra = to_ndhwc_bf16(bf16_round(torch.randn((n, cout, *dims), generator=g))).to(cuda) if res else None
+    for k in range(2):
+        fused(xs[k], ra, None, outs[k], None)
+        first.append(outs[k].clone())
+    for it in range(200):
+        k = it & 1
+        fused(xs[k], ra, None, outs[k], None)
+        if it % 50 == 49:
+            assert torch.equal(outs[k], first[k])
+    fused(xs[0], ra, None, outs[0], C.byref(err))
+    assert err.value == 0 and torch.equal(outs[0], first[0]) and not torch.equal(first[0], first[1])
+    print(f"fused finalize + GroupNorm {cin}->{cout} {dims} n={n} splitk={splitk} groups={groups}: pair {worst:.2e}")

@@ -17,7 +17,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-NAMES = {1: "sinusoid", 2: "gemv", 3: "gn_fused", 4: "finalize", 5: "gemm_light", 6: "conv_halo", 7: "conv_igemm", 8: "attention", 9: "sampler"}
+NAMES = {1: "sinusoid", 2: "gemv", 3: "gn_fused", 4: "finalize", 5: "gemm_light", 6: "conv_halo", 7: "conv_igemm", 8: "attention", 9: "sampler", 10: "fin_gn"}
 
 
 def main():
