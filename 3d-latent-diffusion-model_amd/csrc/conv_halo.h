@@ -306,6 +306,66 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
         HL_TAIL_STEP(5, wfB, afB, wfA, afA);
 #undef HL_TAIL_STEP
     }
+    // ---- fused 1x1 skip convolution of a ResBlock (MONAI's skip_connection when Cin != Cout): p.steps1 extra K steps over the
+    //      channel-concatenated sources (x1a | x1b) at the CENTRE tap, i.e. LDS row = tile row + 1 of the (kd, kh) = (1, 1) table,
+    //      no border masks.  A short second loop behind the 3^3 one (8 steps for 512 channels against 108): one voxel tile + one
+    //      weight tile per step, three ring slots, copies two steps ahead.  Unsplit convs only (the planner keeps split-K ones with a
+    //      skip on conv_igemm_kernel).
+    if (p.steps1 > 0) {
+        const int n1 = p.steps1, nca = p.c1a / BK;
+        const unsigned c1a2 = (unsigned)p.c1a * 2u, c1b2 = (unsigned)p.c1b * 2u, w1row2 = (unsigned)(p.c1a + p.c1b) * 2u;
+        __amdgpu_buffer_rsrc_t rs_1a = __builtin_amdgcn_make_buffer_rsrc((void*)p.x1a, 0, (int)((unsigned)(p.N * DHW) * c1a2), 0x00020000);
+        __amdgpu_buffer_rsrc_t rs_1b = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x1b ? p.x1b : p.x1a), 0, (int)((unsigned)(p.N * DHW) * (p.x1b ? c1b2 : c1a2)), 0x00020000);
+        __amdgpu_buffer_rsrc_t rs_1w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w1, 0, (int)((unsigned)p.CoutPad * w1row2), 0x00020000);
+        unsigned va1[PA], vb1[PA], wo1[PB];
+#pragma unroll
+        for (int j = 0; j < PA; ++j) {
+            const int v_ = tab[4 * BM + a_row[j]];           // centre (kd, kh) pair: LDS row r <-> output voxel l0 - 1 + r itself
+            va1[j] = v_ >= 0 ? (unsigned)v_ * c1a2 + a_kb[j] : 0xFFFFFFFFu;
+            vb1[j] = v_ >= 0 ? (unsigned)v_ * c1b2 + a_kb[j] : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int j = 0; j < PB; ++j) {
+            const int R = (wave * PB + j) * 8 + prow;
+            const unsigned b_kb = (unsigned)((pchunk ^ ((R >> 1) & 7)) * 16);
+            const int q = R >> 6, nt = (R >> 4) & 3, i = R & 15;
+            const int co = n0 + 64 * q + 16 * (i >> 2) + 4 * nt + (i & 3);
+            wo1[j] = (unsigned)co * w1row2 + b_kb;
+        }
+        auto issue1 = [&](const int c, const int slot) {
+#pragma unroll
+            for (int j = 0; j < PB; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_1w, (lds_ptr_t)(smem + slot * BT + (wave * PB + j) * 1024), 16, wo1[j], (unsigned)c * (BK * 2), 0, 0);
+            if (c < nca) {
+#pragma unroll
+                for (int j = 0; j < PA; ++j)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_1a, (lds_ptr_t)(smem + AOFF + slot * AT + (wave * PA + j) * 1024), 16, va1[j], (unsigned)c * (BK * 2), 0, 0);
+            } else {
+#pragma unroll
+                for (int j = 0; j < PA; ++j)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_1b, (lds_ptr_t)(smem + AOFF + slot * AT + (wave * PA + j) * 1024), 16, vb1[j], (unsigned)(c - nca) * (BK * 2), 0, 0);
+            }
+        };
+        // every copy of the 3^3 loop has landed (vmcnt(0) in its last steps); its last fragment reads must be over before slots are refilled
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        issue1(0, 0);
+        if (n1 > 1) issue1(1, 1);
+        int slot = 0;
+        for (int s1 = 0; s1 < n1; ++s1) {
+            if (s1 + 1 < n1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PA + PB) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (s1 + 2 < n1) issue1(s1 + 2, slot == 0 ? 2 : slot - 1);      // (s1 + 2) % 3: the slot step s1 - 1 has just released
+            c_aslot = (unsigned)slot * AT;
+            HL_READ(wfA, afA, slot, 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            HL_MFMA(wfA, afA);
+            slot = slot == 2 ? 0 : slot + 1;
+        }
+    }
 #undef HL_STEP
 #undef HL_MFMA
 #undef HL_MASK
@@ -326,7 +386,7 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
     const int cbase = n0 + wn * 64 + 16 * fg;
     const bool to_slab = p.splitk > 1 || p.raw_partial;
     const bool fused_ep = !to_slab;
-    float4 ebias[4], etemb[4]; u32x4 eres[2][2]; float4 eres32[2][4];
+    float4 ebias[4], etemb[4]; u32x4 eres[2][2]; float4 eres32[2][4];     // ebias = bias + bias2 (the fused skip's)
     const bool f32nd = p.out32 != nullptr;                     // fp32 precision mode: fp32 NDHWC output, fp32 residual
 #pragma unroll
     for (int q = 0; q < 4; ++q) { ebias[q] = make_float4(0.f, 0.f, 0.f, 0.f); etemb[q] = ebias[q]; }
@@ -340,6 +400,13 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
         if (p.bias) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) ebias[q] = *reinterpret_cast<const float4*>(p.bias + cbase + 4 * q);
+        }
+        if (p.bias2) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 b2 = *reinterpret_cast<const float4*>(p.bias2 + cbase + 4 * q);
+                ebias[q].x += b2.x; ebias[q].y += b2.y; ebias[q].z += b2.z; ebias[q].w += b2.w;
+            }
         }
         if (p.temb) {
             const float* te = p.temb + (size_t)smp * p.temb_stride + cbase;
@@ -423,7 +490,7 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
             }
             continue;
         }
-        if (p.bias) {
+        if (p.bias || p.bias2) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) { v[4 * q] += ebias[q].x; v[4 * q + 1] += ebias[q].y; v[4 * q + 2] += ebias[q].z; v[4 * q + 3] += ebias[q].w; }
         }

@@ -399,8 +399,12 @@ struct Builder {
     static bool phase_enabled() { const char* e = getenv("LDM_CONV_PHASE"); return e ? atoi(e) != 0 : true; }
     // halo_n > 0: the conv is eligible for conv3_halo_kernel (3^3, stride 1, pad 1, single source, BK 64); halo_n = N
     // and halo_dhw = voxels per sample (its 126-row tiles never straddle samples).
-    static ConvCfg choose_cfg(long M, int cout_pad, int steps, int bk, int halo_n = 0, long halo_dhw = 0, bool halo_only = false) {
+    // steps = K steps of the 3^3 (or k^3) part; steps1 = extra K steps of a fused 1x1 skip (the halo kernel runs them as a second loop
+    // behind the 3^3 one, unsplit convs only)
+    static bool halo_skip_enabled() { static const int v = [] { const char* e = getenv("LDM_HALO_SKIP"); return e ? atoi(e) : 1; }(); return v != 0; }
+    static ConvCfg choose_cfg(long M, int cout_pad, int steps0, int bk, int halo_n = 0, long halo_dhw = 0, bool halo_only = false, int steps1 = 0) {
         ConvCfg best{2, 2, bk, 1}; double best_t = 1e30;
+        const int steps = steps0 + steps1;
         const int rb = bk * 2;
         static const int splits[] = {1, 2, 3, 4, 6, 8, 9, 12, 16, 18, 24, 27, 32, 48, 64};
         for (int wgn = 1; wgn <= 4 && !halo_only; wgn *= 2) {
@@ -421,7 +425,7 @@ struct Builder {
             }
         }
         if (halo_n > 0 && bk == 64 && cout_pad % 128 == 0 && halo_enabled()) {
-            const int mtps = (int)((halo_dhw + 125) / 126), Q = steps / 3;       // steps = 27 * nchunk
+            const int mtps = (int)((halo_dhw + 125) / 126), Q = steps0 / 3;      // steps0 = 27 * nchunk
             const long tiles = (long)halo_n * mtps * (cout_pad / 128);
             const double c_mfma = 128.0 * 128.0 * 64.0 * 2.0 / 4096.0;
             const double c_load = (128.0 / 3.0 + 128.0) * 128.0 / 28.0;          // the voxel tile is copied once per 3 steps
@@ -431,14 +435,15 @@ struct Builder {
                 const int qps = (Q + sk - 1) / sk, skr = (Q + qps - 1) / qps;    // every split non-empty
                 const long nwg = tiles * skr;
                 const double rounds = ceil((double)nwg / 256.0);
-                double t = rounds * (3.0 * qps * c_step + 2500.0);
+                double t = rounds * (3.0 * qps * c_step + 2500.0 + steps1 * 1.6 * c_step);
                 if (skr > 1) t += 6000.0 + (double)M * cout_pad * 4.0 * skr * 2.0 / 2500.0;
+                if (steps1 && skr > 1) continue;                               // the fused skip loop exists in the unsplit form only
                 if (t < best_t) { best_t = t; best = ConvCfg{2, 2, 64, skr}; best.halo = 1; best.mtps = mtps; best.qps = qps; }
             }
         }
         // the tall halo tile (254 voxels x 64 couts, halo = 2): always for Cout % 128 != 0, else where the model says so
         if (halo_n > 0 && bk == 64 && cout_pad % 64 == 0 && halo_enabled() && tall_mode() != 0) {
-            const int mtps = (int)((halo_dhw + 253) / 254), Q = steps / 3;
+            const int mtps = (int)((halo_dhw + 253) / 254), Q = steps0 / 3;
             const long tiles = (long)halo_n * mtps * (cout_pad / 64);
             const double c_mfma = 256.0 * 64.0 * 64.0 * 2.0 / 4096.0;
             const double c_load = (256.0 / 3.0 + 64.0) * 128.0 / 28.0;
@@ -448,8 +453,9 @@ struct Builder {
                 const int qps = (Q + sk - 1) / sk, skr = (Q + qps - 1) / qps;
                 const long nwg = tiles * skr;
                 const double rounds = ceil((double)nwg / 256.0);
-                double t = rounds * (3.0 * qps * c_step + 2500.0);
+                double t = rounds * (3.0 * qps * c_step + 2500.0 + steps1 * 1.6 * c_step);
                 if (skr > 1) t += 6000.0 + (double)M * cout_pad * 4.0 * skr * 2.0 / 2500.0;
+                if (steps1 && skr > 1) continue;
                 if (tall_mode() == 2 && cout_pad % 128 == 0) t = 1e31;           // mode 2: only where the 128-cout tile cannot run
                 if (tall_mode() == 3 && skr == 1 && best.halo == 1 && best.splitk == 1) t = 0.0;   // mode 3 (experiments): wherever the 128-cout tile runs unsplit
                 if (t < best_t) { best_t = t; best = ConvCfg{4, 1, 64, skr}; best.halo = 2; best.mtps = mtps; best.qps = qps; }
@@ -688,11 +694,11 @@ struct Builder {
             return out;
         }
         const int taps = phase ? 8 : a.k * a.k * a.k;
-        const bool halo_ok = a.k == 3 && a.stride == 1 && a.pad == 1 && a.ups == 0 && !a.exact && !a.xb.valid && !a.w1 &&
+        const bool halo_ok = a.k == 3 && a.stride == 1 && a.pad == 1 && a.ups == 0 && !a.exact && !a.xb.valid && (!a.w1 || (halo_skip_enabled() && bk == 64)) &&
                              a.xa.D == a.Do && a.xa.H == a.Ho && a.xa.W == a.Wo;
         int nchunk0 = cin0 / bk, nchunk1 = cin1 / bk;
         int steps0 = taps * nchunk0, steps1 = nchunk1;
-        ConvCfg cc = choose_cfg(M, w.cout_pad, steps0 + steps1, bk, halo_ok ? N : 0, (long)a.Do * a.Ho * a.Wo);
+        ConvCfg cc = choose_cfg(M, w.cout_pad, steps0, bk, halo_ok ? N : 0, (long)a.Do * a.Ho * a.Wo, false, steps1);
         const int bm = 64 * cc.wgm, bn = 64 * cc.wgn;
         const int couts = a.f32_out ? 0 : rup(w.cout, 32);
         const int mtiles_pp = (int)(((long)a.xa.D * a.xa.H * a.xa.W + bm - 1) / bm);      // phase mode: tiles per (sample, parity)
@@ -3279,9 +3285,9 @@ static int op_conv3d_impl(const void* xa, int ca, const void* xb, int cb, const 
     p.ksize = ksize; p.stride = stride; p.pad = pad; p.ups = ups; p.exact = exact; p.M = (int)M;
     p.CoutS = rup(cout, 32); p.CoutPad = cout_pad; p.CoutReal = cout;
     p.nchunk0 = cin0 / bk; p.nchunk1 = cin1 / bk; p.steps0 = taps * p.nchunk0; p.steps1 = p.nchunk1;
-    const bool halo_ok = ksize == 3 && stride == 1 && pad == 1 && ups == 0 && !exact && cb == 0 && cin1 == 0 && bk == 64 &&
-                         Builder::halo_enabled();
-    ConvCfg cc = Builder::choose_cfg(M, cout_pad, p.steps0 + p.steps1, bk, halo_ok ? N : 0, (long)Do * Ho * Wo);
+    const bool halo_ok = ksize == 3 && stride == 1 && pad == 1 && ups == 0 && !exact && cb == 0 && bk == 64 &&
+                         (cin1 == 0 || (Builder::halo_skip_enabled() && splitk <= 1)) && Builder::halo_enabled();
+    ConvCfg cc = Builder::choose_cfg(M, cout_pad, p.steps0, bk, halo_ok ? N : 0, (long)Do * Ho * Wo, false, p.steps1);
     if (wgn) {                                       // forced tile shape: wgn = 2 keeps the halo kernel where it applies
         if ((wgn != 1 && wgn != 2 && wgn != 4) || cout_pad % (64 * wgn)) return fail(LDM_ERR_BAD_ARG, "bad wgn");
         cc.wgn = wgn; cc.wgm = 4 / wgn; cc.halo = (wgn == 2 && halo_ok && cout_pad % 128 == 0) ? 1 : (wgn == 1 && halo_ok && Builder::tall_mode() != 0) ? 2 : 0;

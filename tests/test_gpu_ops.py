@@ -136,6 +136,19 @@ def test_conv_fused_skip_1x1_dual_source(cuda, built_lib, splitk):
     assert err <= tol, err
 
 
+@pytest.mark.parametrize("cin,cout,dims,n,skip,temb", [
+    (256, 256, (24, 24, 24), 1, (256, 256), False),    # up-block conv2 at 24^3: 1x1 skip over cat(h, skip) = 8 extra K steps, two sources
+    (128, 128, (6, 6, 6), 1, (192, 0), True),          # one source, 3 extra steps, ragged last tile, per-sample channel bias
+    (64, 128, (5, 3, 7), 3, (64, 64), False),          # several samples, tiles that end inside a sample, one chunk per source
+    (64, 256, (4, 4, 4), 2, (64, 0), False),           # a single extra step (no prefetch ahead)
+])
+def test_conv3_halo_kernel_with_the_fused_1x1_skip(cuda, built_lib, cin, cout, dims, n, skip, temb):
+    """conv3_halo_kernel with the ResBlock's 1x1 skip_connection fused as a second K loop at the centre tap (wgn = 2 on an eligible
+    unsplit conv): MONAI's `skip_connection(x) + conv2(h)` in one launch, as the inference plans run the up-block conv2s at 24^3."""
+    err, tol = _conv_case(cuda, built_lib, cin=(cin, 0), cout=cout, dims=dims, n=n, wgn=2, splitk=1, skip=skip, temb=temb, seed=cin + dims[2] + skip[0])
+    assert err <= tol, err
+
+
 @pytest.mark.parametrize("splitk", [1, 3])
 def test_conv_f32_ncdhw_output(cuda, built_lib, splitk):
     err, tol = _conv_case(cuda, built_lib, cin=(64, 0), cout=4, dims=(6, 6, 6), n=2, f32_out=True, splitk=splitk)
