@@ -203,28 +203,40 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnApplyParams p) {
     const int C = p.ca + p.cb;
     const int cvec = C / 8;
     const long total = (long)p.N * p.DHW * cvec;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long row = i / cvec;
-        const int c = (int)(i - row * cvec) * 8;
-        const int n = (int)(row / p.DHW);
-        const bool second = c >= p.ca;
-        const bf16_t* src = second ? p.xb + row * p.cb + (c - p.ca) : p.xa + row * p.ca + c;
-        const u32x4 v = *reinterpret_cast<const u32x4*>(src);
-        const float4* abp = reinterpret_cast<const float4*>(p.ab + ((size_t)n * C + c) * 2);
-        float y[8];
+    const long stride = (long)gridDim.x * blockDim.x;
+    // four 16-byte vectors in flight per thread (clamped, unconditional loads): at 96^3 the pass moves 226 MB and one load per
+    // iteration left it at 3.6 TB/s
+    for (long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x; i0 < total; i0 += 4 * stride) {
+        u32x4 v[4]; long row[4]; int c[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float4 ab = abp[k];
-            float lo = __uint_as_float(v[k] << 16) * ab.x + ab.y;
-            float hi = __uint_as_float(v[k] & 0xffff0000u) * ab.z + ab.w;
-            if (p.silu == 1) { lo = silu_f(lo); hi = silu_f(hi); }
-            else if (p.silu == 2) { lo = lo > 0.f ? lo : 0.2f * lo; hi = hi > 0.f ? hi : 0.2f * hi; }
-            y[2 * k] = lo; y[2 * k + 1] = hi;
+        for (int u = 0; u < 4; ++u) {
+            long i = i0 + u * stride; if (i >= total) i = total - 1;
+            row[u] = i / cvec;
+            c[u] = (int)(i - row[u] * cvec) * 8;
+            const bool second = c[u] >= p.ca;
+            const bf16_t* src = second ? p.xb + row[u] * p.cb + (c[u] - p.ca) : p.xa + row[u] * p.ca + c[u];
+            v[u] = *reinterpret_cast<const u32x4*>(src);
         }
-        u32x4 o;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) o[k] = pack2bf(y[2 * k], y[2 * k + 1]);
-        *reinterpret_cast<u32x4*>(p.out + row * C + c) = o;
+        for (int u = 0; u < 4; ++u) {
+            if (i0 + u * stride >= total) break;
+            const int n = (int)(row[u] / p.DHW);
+            const float4* abp = reinterpret_cast<const float4*>(p.ab + ((size_t)n * C + c[u]) * 2);
+            float y[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float4 ab = abp[k];
+                float lo = __uint_as_float(v[u][k] << 16) * ab.x + ab.y;
+                float hi = __uint_as_float(v[u][k] & 0xffff0000u) * ab.z + ab.w;
+                if (p.silu == 1) { lo = silu_f(lo); hi = silu_f(hi); }
+                else if (p.silu == 2) { lo = lo > 0.f ? lo : 0.2f * lo; hi = hi > 0.f ? hi : 0.2f * hi; }
+                y[2 * k] = lo; y[2 * k + 1] = hi;
+            }
+            u32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = pack2bf(y[2 * k], y[2 * k + 1]);
+            *reinterpret_cast<u32x4*>(p.out + row[u] * C + c[u]) = o;
+        }
     }
 }
 
