@@ -120,8 +120,8 @@ def test_non_finite_adversarial_term_is_dropped_and_a_skipped_generator_step_ski
     from oracle.unet import init_state_dict
     cfg = cfgs.VAE_TINY
     g = torch.Generator().manual_seed(1)
-    x = torch.rand((1, 2, 16, 16, 16), generator=g).to(cuda)
-    eps = torch.randn((1, cfg["latent_channels"], 4, 4, 4), generator=g).to(cuda)
+    x = torch.rand((1, 2, 32, 32, 32), generator=g).to(cuda)               # 32^3: the PatchDiscriminator's five 4^3 convs need >= 32 voxels per axis
+    eps = torch.randn((1, cfg["latent_channels"], 8, 8, 8), generator=g).to(cuda)
 
     def make():
         ae = AutoencoderKL(**cfg)
