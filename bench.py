@@ -456,6 +456,11 @@ def main():
         gc.enable()
         per_step = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]           # ms, on the launch stream
         host_gap = [(host_at[i + 1] - host_at[i]) * 1e3 for i in range(args.steps - 1)]  # ms between two enqueues on the host
+        # the headline is final HERE (MAX over ranks), before any of the legs reported beside it runs: nothing below can change or lose it
+        if dist is not None:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
         # Roofline leg: the SAME K steps once more with HIP events recorded on the launch stream around every launch
         # of the dominant kernel (kept out of the timed region above: 2 events x ~60 launches per step cost ~25 %).
         profile = (not args.no_roofline) and rank == 0
@@ -504,18 +509,45 @@ def main():
     other = None
     if not args.no_other_paths and world == 1:
         other = other_paths_leg(dev)
-    # BASELINE configs[3] (DDP training over RCCL) on every rank, after the headline's timed region: its own record in the same line
-    ddp = None
-    if not args.no_ddp_train:
-        del unet
-        torch.cuda.empty_cache()
-        ddp = ddp_train_leg(dev, rank, world, dist, rehearsal)
+    # BASELINE configs[3] (DDP training over RCCL) on every rank, after the headline's timed region: its own record in the same line.
+    # It is the one leg that exchanges data between ranks, on a fabric this code has never run on with N > 1: a watchdog on every rank
+    # bounds it, and if it expires rank 0 still prints the line (headline and the other legs, ddp_train = {"error": ...}) before
+    # the ranks exit -- a stuck collective must not cost the run its headline.
+    import threading
+    emitted = threading.Lock()
+    state = {"out": None, "done": False}
 
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    def emit(extra):
+        with emitted:
+            if state["done"] or state["out"] is None:
+                return
+            state["done"] = True
+            state["out"].update(extra)
+            print(json.dumps(state["out"]), file=json_out, flush=True)
+
+    def run_ddp():
+        budget = float(os.environ.get("LDM_BENCH_DDP_TIMEOUT_S", "300"))
+
+        def give_up():
+            if rank == 0:
+                emit({"ddp_train": {"error": f"the data-parallel training leg did not finish within {budget:.0f} s (stuck collective?); "
+                                             "the headline above was final before it started"}})
+            os._exit(0)
+        timer = threading.Timer(budget, give_up)
+        timer.daemon = True
+        timer.start()
+        try:
+            rec = ddp_train_leg(dev, rank, world, dist, rehearsal)
+        except Exception as e:                               # a failing leg is reported, never fatal for the line
+            rec = {"error": f"{type(e).__name__}: {e}"}
+        timer.cancel()
+        return rec
+
     if rank != 0:
+        if not args.no_ddp_train:
+            del unet
+            torch.cuda.empty_cache()
+            run_ddp()
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -577,11 +609,15 @@ def main():
         out["fp32_mode"] = fp32_leg
     if other is not None:
         out["other_paths"] = other
-    if ddp is not None:
-        out["ddp_train"] = ddp
+    state["out"] = out
+    extra = {}
+    if not args.no_ddp_train:
+        del unet
+        torch.cuda.empty_cache()
+        extra["ddp_train"] = run_ddp()
     if not args.no_cpu_baseline and world == 1:
-        out["cpu_baseline"] = cpu_baseline()
-    print(json.dumps(out), file=json_out, flush=True)
+        extra["cpu_baseline"] = cpu_baseline()
+    emit(extra)
     if dist is not None:
         dist.destroy_process_group()
 
