@@ -249,7 +249,14 @@ def test_planner_rules_added_in_round_3(built_lib, monkeypatch):
     two = [c for c in _bf16_conv_launches(AutoencoderKL(**cfgs.VAE_FULL), b"dec", 1, (24, 24, 24)) if c[:4] == (2, 2, 32, 0)]
     monkeypatch.setenv("LDM_IGEMM_2WG", "0")
     one = [c for c in _bf16_conv_launches(AutoencoderKL(**cfgs.VAE_FULL), b"dec", 1, (24, 24, 24)) if c[:4] == (2, 2, 32, 0)]
-    assert len(one) == 1 and len(two) == 4, (one, two)      # conv_in (Cin = 32) always; + two phase-upsample convs and one fused-skip conv
+    assert len(one) == 1 and len(two) == 3, (one, two)      # conv_in (Cin = 32) always; + the two phase-upsample convs
+    # round 4: the fused-skip convs (ResBlock conv2 + 1x1 nin_shortcut) run on the halo kernel's second K loop, unsplit; LDM_HALO_SKIP=0
+    # sends them back to the general kernel (where the 48^3 one takes the two-workgroups-per-CU form again)
+    monkeypatch.delenv("LDM_IGEMM_2WG")
+    halo_now = sum(1 for c in _bf16_conv_launches(AutoencoderKL(**cfgs.VAE_FULL), b"dec", 1, (24, 24, 24)) if c[3])
+    bf16_unet = _bf16_conv_launches(DiffusionModelUNet(**cfgs.UNET_FULL), b"unet", 1, (24, 24, 24))
+    assert sum(1 for c in bf16_unet if c[3] and c[4] == 1) >= 10        # 7 plain + 3 fused-skip convs at 24^3 on the halo kernel, unsplit
+    assert halo_now >= 12
 
 
 def test_shapes_the_networks_cannot_take_fail_loudly(built_lib):
