@@ -143,7 +143,7 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int l = l0 + wm * 64 + t * 16 + fr;
-        const int ow = l % p.Wout;
+        const int ow = l - (int)fastdiv((unsigned)l, p.fd_w_m, p.fd_w_s) * p.Wout;
         wmask |= (ow == 0 ? 1u : 0u) << t;
         wmask |= (ow == p.Wout - 1 ? 1u : 0u) << (4 + t);
     }
@@ -224,7 +224,8 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
     auto decompose = [&](const int j, int& od, int& oh, int& ow) -> bool {   // LDS row j <-> output voxel l0 - 1 + j (kw = 1 tap)
         const int l = l0 - 1 + j;
         if (l < 0 || l >= DHW) return false;
-        od = l / HW; const int r = l - od * HW; oh = r / p.Wout; ow = r - oh * p.Wout;
+        od = (int)fastdiv((unsigned)l, p.fd_hw_m, p.fd_hw_s); const int r = l - od * HW;
+        oh = (int)fastdiv((unsigned)r, p.fd_w_m, p.fd_w_s); ow = r - oh * p.Wout;
         return true;
     };
     auto src_of = [&](const bool ok, const int od, const int oh, const int ow, const int pr) -> int {

@@ -57,6 +57,9 @@ struct ConvParams {
     // same pointer again (c0b = C: hi), both with the split tensor's row stride, weights [.. ][hi | hi | lo]:  hi*Whi + lo*Whi + hi*Wlo.
     int x3_n;
     int raw_partial;                  // write the fp32 accumulators to the partial slab even with splitk == 1 (the fp32 finalize follows)
+    // exact unsigned division by Hout * Wout and by Wout as multiply-high + shifts (FastDiv; filled by the launchers): the prologues decompose
+    // ~14 voxel indices per lane, and a 32-bit division by a run-time value is a ~40-instruction sequence on this ISA
+    unsigned fd_hw_m, fd_hw_s, fd_w_m, fd_w_s;
     int wt_slab;                      // split-K slabs stored write-through (sc1): the 12-17 MB of fp32 partials leave the XCDs' L2s while the
                                       // kernel runs instead of in the write-back at its end (the finalize that reads them runs on every XCD)
     float* out32; const float* residual32;   // conv3_halo_kernel, fp32 precision, splitk == 1: fp32 NDHWC output [M][CoutS] (+ fp32 residual) from the fused epilogue
@@ -72,6 +75,19 @@ struct ConvParams {
     unsigned long long* stamps;       // diagnostic (dbg & 512): per-workgroup s_memrealtime stamps [nwg][8]
     int dbg;                          // timing experiments only (LDM_CONV_DBG): 1 = all voxel rows from the zero page, 2 = all weight rows = row 0
 };
+
+// n / d for 32-bit unsigned n and a divisor fixed at launch time (round-up multiplier with an add-shift fix-up, exact for every n):
+//   host: s = ceil(log2 d) - 1, m = floor(2^32 (2^(s+1) - d) / d) + 1;  device: q = mulhi(n, m); (((n - q) >> 1) + q) >> s.   d = 1: s = 255.
+static inline void fastdiv_make(unsigned d, unsigned* m, unsigned* s) {
+    if (d <= 1) { *m = 0; *s = 255u; return; }
+    unsigned l = 0; while ((1ull << l) < d) ++l;                  // ceil(log2 d)
+    *m = (unsigned)((((1ull << l) - d) << 32) / d + 1); *s = l - 1;
+}
+__device__ __forceinline__ unsigned fastdiv(unsigned n, unsigned m, unsigned s) {
+    if (s == 255u) return n;
+    const unsigned q = __umulhi(n, m);
+    return (((n - q) >> 1) + q) >> s;
+}
 
 // Bijective XCD-aware remap: blocks b, b+8, b+16.. share an XCD (observed round-robin dispatch); give each
 // XCD a contiguous range of logical tiles so neighbouring tiles share weights/halo rows in one L2.

@@ -1902,6 +1902,7 @@ static int launch_conv(const ConvParams& p, const ConvCfg& cc, hipStream_t s) {
 
 static int launch_conv_halo(const ConvParams& p_in, hipStream_t s, bool tall = false) {
     ConvParams p = p_in; p.tile_order = conv_tile_order(p);
+    fastdiv_make((unsigned)(p.Hout * p.Wout), &p.fd_hw_m, &p.fd_hw_s); fastdiv_make((unsigned)p.Wout, &p.fd_w_m, &p.fd_w_s);
     constexpr int LDS = 6 * 16384 + 3 * 16384 + 9 * 128 * 4;
     constexpr int LDS_TALL = 6 * 8192 + 3 * 32768 + 9 * 256 * 4;
     static bool attr_tab[32] = {}; bool& attr_set = attr_flag(attr_tab);   // per device
