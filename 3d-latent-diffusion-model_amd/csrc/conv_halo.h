@@ -46,8 +46,14 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
     const int grp = wave >> 2, wq = wave & 3;
     const int wm = TALL ? wq : (wq & 1), wn = TALL ? 0 : (wq >> 1);
 
-    const int nwg = gridDim.x;
-    int lid = xcd_remap(blockIdx.x, nwg);
+    // Persistent form: the grid is min(tiles, CUs) workgroups (one fits a CU: 148.5 KiB of LDS) and a workgroup walks the tiles
+    // vbid = blockIdx.x, + gridDim.x, ... (gridDim.x is a multiple of 8 whenever it is smaller than the tile count, so a workgroup's
+    // tiles keep its XCD residue).  Saves the ~1.2 us between the exit of one workgroup and the first instruction of the next on the
+    // same CU (dispatch, kernel-argument loads) for every tile but the first: the 96^3 convolutions of the AutoencoderKL run 13.6
+    // tiles per CU.  Launches with <= CUs tiles (every conv of the B = 1 UNet step) are unchanged: one trip through the loop.
+    const int nwg = p.mtiles * p.ntiles * p.splitk;
+    for (int vbid = blockIdx.x; vbid < nwg; vbid += gridDim.x) {
+    int lid = xcd_remap(vbid, nwg);
     int mtile, ntile, split;
     if (p.tile_order == 1) {                                   // cout tiles fastest: every XCD gets a contiguous range of M tiles with ALL their cout tiles
         ntile = lid % p.ntiles; lid /= p.ntiles; mtile = lid % p.mtiles; split = lid / p.mtiles;
@@ -214,8 +220,8 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
 
     // diagnostic (dbg & 512, operator-level API): shader-clock and 100 MHz stamps around the K loop -> effective clock
 #define HL_STAMP(I) do { if ((dbgflag & 512) && tid == 0) {                                         \
-        p.stamps[(size_t)blockIdx.x * 8 + 2 * (I)] = __builtin_amdgcn_s_memrealtime();             \
-        p.stamps[(size_t)blockIdx.x * 8 + 2 * (I) + 1] = __builtin_amdgcn_s_memtime(); } } while (0)
+        p.stamps[(size_t)vbid * 8 + 2 * (I)] = __builtin_amdgcn_s_memrealtime();                   \
+        p.stamps[(size_t)vbid * 8 + 2 * (I) + 1] = __builtin_amdgcn_s_memtime(); } } while (0)
     // ---- prologue.  The first macro step's copies are requested BEFORE the tap table exists (a lane works out the source voxels of
     //      its own PA rows for that one (kd, kh) pair by itself), so that their round trip to memory (cold: the weights come from HBM,
     //      the voxels from another XCD's write-back) overlaps the table's integer divisions and its barrier.
@@ -569,6 +575,8 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
         }
     }
     KSTAMP(5);
+    if (vbid + (int)gridDim.x < nwg) __syncthreads();          // next tile: its tap table / first copies reuse the LDS this epilogue has read
+    }   // tiles of this workgroup
     KSTAMP_DRAIN(6);
 #endif  // __HIP_DEVICE_COMPILE__
 }

@@ -1911,8 +1911,16 @@ static int launch_conv_halo(const ConvParams& p_in, hipStream_t s, bool tall = f
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_halo_kernel<6, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TALL));
         attr_set = true;
     }
+    // persistent grid (conv_halo.h): at most one workgroup per CU, each walks its tiles; LDM_HALO_PERSIST=0: one workgroup per tile
+    static const int persist = [] { const char* e = getenv("LDM_HALO_PERSIST"); return e ? atoi(e) : 1; }();
+    static int cus_tab[32] = {};
+    int dev_ = 0; if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 32) dev_ = 0;
+    int& cus = cus_tab[dev_];
+    if (!cus) { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev_) == hipSuccess) cus = pr.multiProcessorCount; if (cus < 8) cus = 256; cus -= cus % 8; }
+    const int tiles = p.mtiles * p.ntiles * p.splitk;
+    const int grid = (persist && tiles > cus) ? cus : tiles;
     if (tall) {
-        hipLaunchKernelGGL((conv3_halo_kernel<6, 0, true>), dim3(p.mtiles * p.ntiles * p.splitk), dim3(512), LDS_TALL, s, p);
+        hipLaunchKernelGGL((conv3_halo_kernel<6, 0, true>), dim3(grid), dim3(512), LDS_TALL, s, p);
         return 0;
     }
     if (p.dbg & (4 | 8 | 16 | 32 | 64)) {                  // timing ablations (operator-level API + LDM_CONV_DBG only)
@@ -1922,7 +1930,7 @@ static int launch_conv_halo(const ConvParams& p_in, hipStream_t s, bool tall = f
         ABL_CASE(4) ABL_CASE(8) ABL_CASE(16) ABL_CASE(12) ABL_CASE(20) ABL_CASE(24) ABL_CASE(32) ABL_CASE(40) ABL_CASE(84) ABL_CASE(68) ABL_CASE(64)
 #undef ABL_CASE
     }
-    hipLaunchKernelGGL((conv3_halo_kernel<6>), dim3(p.mtiles * p.ntiles * p.splitk), dim3(512), LDS, s, p);
+    hipLaunchKernelGGL((conv3_halo_kernel<6>), dim3(grid), dim3(512), LDS, s, p);
     return 0;
 }
 
