@@ -79,7 +79,7 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
 
     // ---- loader lanes: every wave copies PA pieces (8 rows x 128 B) of a voxel tile and PB of a weight tile
     const int prow = lane >> 3, pchunk = lane & 7;
-    int a_row[PA]; unsigned a_kb[PA], a_vo[PA], b_vo[PB];
+    int a_row[PA], t_next[PA]; unsigned a_kb[PA], a_vo[PA], b_vo[PB];
 #pragma unroll
     for (int j = 0; j < PA; ++j) {
         const int row = (wave * PA + j) * 8 + prow;
@@ -104,11 +104,14 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
     // issue-stream state (scalar): next step to copy = macro (i_pair, i_chunk), kw i_kw; i_s = its relative index
     int i_pair = q_begin / nch, i_chunk = q_begin - i_pair * nch, i_s = 0;
     unsigned i_aslot = 0;                                      // byte offset of the voxel ring slot of the macro being issued
+    // the table entries of a (kd, kh) pair are read ONE PAIR AHEAD (t_next): with Cin = 64 (one chunk per pair: the AutoencoderKL's
+    // 96^3 level) a new pair starts every third K step and its LDS read + address arithmetic sat in front of that step's waits
 #define HL_LOAD_TAB() do {                                                                          \
         _Pragma("unroll") for (int j = 0; j < PA; ++j) {                                            \
-            const int v_ = tab[i_pair * BM + a_row[j]];                                             \
+            const int v_ = t_next[j];                                                               \
             a_vo[j] = (v_ >= 0 && !(ABL & 32)) ? (unsigned)v_ * cin2 + a_kb[j] : 0xFFFFFFFFu;       \
         }                                                                                           \
+        if (i_pair + 1 < 9) { _Pragma("unroll") for (int j = 0; j < PA; ++j) t_next[j] = tab[(i_pair + 1) * BM + a_row[j]]; } \
     } while (0)
     // copies of one step; KW is the step's kw (static).  Slot of the weight tile = relative step % NSB (static: BSLOT).
 #define HL_ISSUE_W(KW, BSLOT) do {                                                                  \
@@ -263,6 +266,8 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < PA; ++j) t_next[j] = (i_pair + 1 < 9) ? tab[(i_pair + 1) * BM + a_row[j]] : -1;   // the pair after the first one
     KSTAMP(1);
     HL_STAMP(0);
     if (nsteps >= 6) {
