@@ -25,7 +25,9 @@
 // TALL: the same kernel on a 254-voxel x 64-cout tile (waves 4 x 1 instead of 2 x 2, every wave still 64 x 64): the layers with
 // Cout = 64 (the AutoencoderKL's 96^3 level) get the halo reuse too, and the copied bytes per K step drop to 8 KiB of weights +
 // 32 / 3 KiB of voxels = 18.7 KiB.
-template <int NSB, int ABL = 0, bool TALL = false>
+// PERSIST: the tile loop below exists (launches with more tiles than CUs); false = one tile per workgroup, straight-line code (every conv
+// of the B = 1 UNet step: the loop form keeps per-lane constants live across the K loop and costs registers that launch does not have)
+template <int NSB, int ABL = 0, bool TALL = false, bool PERSIST = false>
 __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int BM = TALL ? 256 : 128, TM = BM - 2, BN = TALL ? 64 : 128, BK = 64, RB = 128;
@@ -51,25 +53,16 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
     // tiles keep its XCD residue).  Saves the ~1.2 us between the exit of one workgroup and the first instruction of the next on the
     // same CU (dispatch, kernel-argument loads) for every tile but the first: the 96^3 convolutions of the AutoencoderKL run 13.6
     // tiles per CU.  Launches with <= CUs tiles (every conv of the B = 1 UNet step) are unchanged: one trip through the loop.
+    // Inside that loop a tile's K-group exchange and epilogue overlap the NEXT tile's set-up: right after the K loop (behind the barrier
+    // that ends its fragment reads) the workgroup works out the next tile, requests its first macro step (weight slots 0 - 2, voxel
+    // slot 0) and builds its tap table; the exchange and the statistics fold of the current tile live in the ring slots that step does
+    // not touch (XCH0 / XCH1 / RED below), and the epilogue's stores run while those copies are in flight.
     const int nwg = p.mtiles * p.ntiles * p.splitk;
-    for (int vbid = blockIdx.x; vbid < nwg; vbid += gridDim.x) {
-    int lid = xcd_remap(vbid, nwg);
-    int mtile, ntile, split;
-    if (p.tile_order == 1) {                                   // cout tiles fastest: every XCD gets a contiguous range of M tiles with ALL their cout tiles
-        ntile = lid % p.ntiles; lid /= p.ntiles; mtile = lid % p.mtiles; split = lid / p.mtiles;
-    } else {                                                   // M tiles fastest: every XCD streams one weight panel (one cout tile)
-        mtile = lid % p.mtiles; lid /= p.mtiles; ntile = lid % p.ntiles; split = lid / p.ntiles;
-    }
-    const int n0 = ntile * BN;
     const int DHW = p.Dout * p.Hout * p.Wout, HW = p.Hout * p.Wout;
-    const int smp = mtile / p.halo_mtps, tin = mtile - smp * p.halo_mtps;
-    const int l0 = tin * TM;                                   // first output voxel of the tile inside its sample
-    const int m_base = smp * DHW + l0;
     const int nch = p.nchunk0;
     const int Q = 9 * nch;                                     // macro steps: (kd, kh) x Cin chunk
-    const int q_begin = split * p.q_per_split;
-    int q_end = q_begin + p.q_per_split; if (q_end > Q) q_end = Q;
-    const int nsteps = 3 * (q_end - q_begin);                  // K steps of this workgroup, relative index 0 .. nsteps-1
+    // tile state (HL_TILE_SETUP): output tile, K range, issue stream
+    int mtile = 0, ntile = 0, split = 0, n0 = 0, smp = 0, l0 = 0, m_base = 0, q_begin = 0, q_end = 0, nsteps = 0;
     const unsigned cin2 = (unsigned)p.c0a * 2u;                  // bytes per voxel row
     const int x3n = p.x3_n;
     const unsigned wrow2 = x3n ? (unsigned)x3n * 3u * (BK * 2) : cin2;   // bytes per weight row
@@ -89,21 +82,36 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
         // the (row >> 1) key of conv_igemm.h is conflict free only for unshifted tiles (2-way conflicts at kw = 1, 2).
         a_kb[j] = (unsigned)((pchunk ^ (row & 7)) * 16);
     }
-#pragma unroll
-    for (int j = 0; j < PB; ++j) {
-        const int R = (wave * PB + j) * 8 + prow;              // row of the weight tile
-        const unsigned b_kb = (unsigned)((pchunk ^ ((R >> 1) & 7)) * 16);
-        const int q = R >> 6, nt = (R >> 4) & 3, i = R & 15;
-        const int co = n0 + 64 * q + 16 * (i >> 2) + 4 * nt + (i & 3);      // see conv_igemm.h: lane ends up with 16 consecutive couts
-        b_vo[j] = ((ABL & 32) || (dbgflag & 2)) ? 0xFFFFFFFFu : (unsigned)co * wrow2 + b_kb;     // ABL 32: every copy out of range (zero fill, no memory traffic)
-    }
     const unsigned wtap = (unsigned)p.CoutPad * wrow2;          // bytes between two taps of the weight tensor
     __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.x0a, 0, (int)((unsigned)(p.N * DHW) * cin2), 0x00020000);
     __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.w0, 0, (int)(27u * wtap), 0x00020000);
 
     // issue-stream state (scalar): next step to copy = macro (i_pair, i_chunk), kw i_kw; i_s = its relative index
-    int i_pair = q_begin / nch, i_chunk = q_begin - i_pair * nch, i_s = 0;
+    int i_pair = 0, i_chunk = 0, i_s = 0;
     unsigned i_aslot = 0;                                      // byte offset of the voxel ring slot of the macro being issued
+#define HL_TILE_SETUP(VB) do {                                                                      \
+        int lid_ = xcd_remap((VB), nwg);                                                            \
+        if (p.tile_order == 1) {       /* cout tiles fastest: every XCD gets a contiguous range of M tiles with ALL their cout tiles */ \
+            ntile = lid_ % p.ntiles; lid_ /= p.ntiles; mtile = lid_ % p.mtiles; split = lid_ / p.mtiles;                   \
+        } else {                       /* M tiles fastest: every XCD streams one weight panel (one cout tile) */          \
+            mtile = lid_ % p.mtiles; lid_ /= p.mtiles; ntile = lid_ % p.ntiles; split = lid_ / p.ntiles;                   \
+        }                                                                                           \
+        n0 = ntile * BN;                                                                            \
+        smp = mtile / p.halo_mtps;                                                                  \
+        l0 = (mtile - smp * p.halo_mtps) * TM;       /* first output voxel of the tile inside its sample */               \
+        m_base = smp * DHW + l0;                                                                    \
+        q_begin = split * p.q_per_split;                                                            \
+        q_end = q_begin + p.q_per_split; if (q_end > Q) q_end = Q;                                  \
+        nsteps = 3 * (q_end - q_begin);              /* K steps of this tile, relative index 0 .. nsteps-1 */              \
+        _Pragma("unroll") for (int j = 0; j < PB; ++j) {                                            \
+            const int R = (wave * PB + j) * 8 + prow;                      /* row of the weight tile */                   \
+            const unsigned b_kb = (unsigned)((pchunk ^ ((R >> 1) & 7)) * 16);                       \
+            const int q = R >> 6, nt = (R >> 4) & 3, i = R & 15;                                    \
+            const int co = n0 + 64 * q + 16 * (i >> 2) + 4 * nt + (i & 3);  /* see conv_igemm.h: lane ends up with 16 consecutive couts */ \
+            b_vo[j] = ((ABL & 32) || (dbgflag & 2)) ? 0xFFFFFFFFu : (unsigned)co * wrow2 + b_kb;   /* ABL 32: every copy out of range */ \
+        }                                                                                           \
+        i_pair = q_begin / nch; i_chunk = q_begin - i_pair * nch; i_s = 0; i_aslot = 0;             \
+    } while (0)
     // the table entries of a (kd, kh) pair are read ONE PAIR AHEAD (t_next): with Cin = 64 (one chunk per pair: the AutoencoderKL's
     // 96^3 level) a new pair starts every third K step and its LDS read + address arithmetic sat in front of that step's waits
 #define HL_LOAD_TAB() do {                                                                          \
@@ -147,23 +155,14 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
     int a_rdk[3];                                              // voxel rows shifted by kw: LDS row = tile row + kw
 #pragma unroll
     for (int k = 0; k < 3; ++k) a_rdk[k] = AOFF + (ra0 + k) * RB + ((cfrag ^ ((ra0 + k) & 7)) << 4);
-    // W-border masks of this lane's 4 voxel rows (one per 16-row tile t): bit t = w == 0, bit 4 + t = w == W - 1
-    unsigned wmask = 0;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int l = l0 + wm * 64 + t * 16 + fr;
-        const int ow = l - (int)fastdiv((unsigned)l, p.fd_w_m, p.fd_w_s) * p.Wout;
-        wmask |= (ow == 0 ? 1u : 0u) << t;
-        wmask |= (ow == p.Wout - 1 ? 1u : 0u) << (4 + t);
-    }
-
+    unsigned wmask = 0;                                        // W-border masks of this lane's 4 voxel rows (per tile, below)
     f32x4 acc[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
     bf16x8 wfA[4], afA[4], wfB[4], afB[4];
     unsigned c_aslot = 0;                                      // voxel ring slot (byte offset) of the macro step being read NEXT
+    // LDS the K-group exchange (two 32 KiB halves, one per receiving group) and the statistics fold use: ring slots the next tile's first
+    // macro step (weight slots 0 - 2, voxel slot 0) does not touch
+    constexpr int XCH0 = TALL ? AOFF + AT : 3 * BT, XCH1 = TALL ? AOFF + AT + 32768 : AOFF + AT, RED = TALL ? 3 * BT : 3 * BT + 32768;
+    static_assert(XCH0 + 32768 <= (TALL ? XCH1 : AOFF) && XCH1 + 32768 <= TOFF && RED + 4096 <= (TALL ? AOFF : AOFF), "exchange areas must avoid the first macro step's slots");
 
 #define HL_READ(WF, AF, BSLOT, KW) do {                                                             \
         if (!(ABL & 16)) {                                                                          \
@@ -246,23 +245,43 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
         }
         return v;
     };
-    HL_ISSUE_W(0, 0); HL_ISSUE_W(1, 1); HL_ISSUE_W(2, 2);      // the weight tiles need no voxel arithmetic: on their way first
+    // first macro step of the tile HL_TILE_SETUP has just selected + its tap table (no barrier: the caller's next barrier completes it)
+#define HL_TILE_EARLY() do {                                                                        \
+        HL_ISSUE_W(0, 0); HL_ISSUE_W(1, 1); HL_ISSUE_W(2, 2);  /* the weight tiles need no voxel arithmetic: on their way first */ \
+        _Pragma("unroll") for (int j = 0; j < PA; ++j) {                                            \
+            int od = 0, oh = 0, ow = 0;                                                             \
+            const bool ok = decompose(a_row[j], od, oh, ow);                                        \
+            const int v_ = src_of(ok, od, oh, ow, i_pair);                                          \
+            a_vo[j] = (v_ >= 0 && !(ABL & 32)) ? (unsigned)v_ * cin2 + a_kb[j] : 0xFFFFFFFFu;       \
+        }                                                                                           \
+        HL_ISSUE_A(); i_s += 3;        /* issue order of the first macro step: w0 w1 w2 a0; from the next on w a w w */   \
+        {                                                                                           \
+            constexpr int NPART = 512 / BM;          /* lanes per LDS row: each takes every NPART-th (kd, kh) pair */      \
+            const int row = tid % BM, part = tid / BM;                                              \
+            int od = 0, oh = 0, ow = 0;                                                             \
+            const bool ok = decompose(row, od, oh, ow);                                             \
+            for (int pr = part; pr < 9; pr += NPART) tab[pr * BM + row] = src_of(ok, od, oh, ow, pr); \
+        }                                                                                           \
+    } while (0)
+    HL_TILE_SETUP((int)blockIdx.x);
+    HL_TILE_EARLY();
+    int vbid = blockIdx.x;
+    do {
+    wmask = 0;                                                 // bit t = w == 0, bit 4 + t = w == W - 1 for the lane's voxel row of 16-row tile t
 #pragma unroll
-    for (int j = 0; j < PA; ++j) {
-        int od = 0, oh = 0, ow = 0;
-        const bool ok = decompose(a_row[j], od, oh, ow);
-        const int v_ = src_of(ok, od, oh, ow, i_pair);
-        a_vo[j] = (v_ >= 0 && !(ABL & 32)) ? (unsigned)v_ * cin2 + a_kb[j] : 0xFFFFFFFFu;
+    for (int t = 0; t < 4; ++t) {
+        const int l = l0 + wm * 64 + t * 16 + fr;
+        const int ow = l - (int)fastdiv((unsigned)l, p.fd_w_m, p.fd_w_s) * p.Wout;
+        wmask |= (ow == 0 ? 1u : 0u) << t;
+        wmask |= (ow == p.Wout - 1 ? 1u : 0u) << (4 + t);
     }
-    HL_ISSUE_A(); i_s += 3;                                    // issue order of the first macro step: w0 w1 w2 a0; from the next on w a w w
-    {
-        constexpr int NPART = 512 / BM;                        // lanes per LDS row: each takes every NPART-th (kd, kh) pair
-        const int row = tid % BM, part = tid / BM;
-        int od = 0, oh = 0, ow = 0;
-        const bool ok = decompose(row, od, oh, ow);
-        for (int pr = part; pr < 9; pr += NPART) tab[pr * BM + row] = src_of(ok, od, oh, ow, pr);
-    }
-    // table complete.  A raw barrier behind an LDS-only wait: __syncthreads() would drain vmcnt(0) and with it the copies in flight
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    c_aslot = 0;
+    // table complete (and, from the second tile on, the previous tile's exchange / statistics reads of the LDS that the next copies
+    // overwrite are over).  A raw barrier behind an LDS-only wait: __syncthreads() would drain vmcnt(0) and with it the copies in flight
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -378,24 +397,19 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
             slot = slot == 2 ? 0 : slot + 1;
         }
     }
-#undef HL_STEP
-#undef HL_MFMA
-#undef HL_MASK
-#undef HL_READ
-#undef HL_ISSUE
-#undef HL_ISSUE_W
-#undef HL_ISSUE_A
-#undef HL_ADVANCE
-#undef HL_LOAD_TAB
-
     HL_STAMP(1);
     KSTAMP(3);
-#undef HL_STAMP
+    // the epilogue below belongs to THIS tile; the tile state is about to move on to the next one
+    const int e_mtile = mtile, e_split = split, e_smp = smp, e_l0 = l0, e_mbase = m_base, e_n0 = n0;
+    // (loop form: the lane constants the epilogue derives its addresses from are made opaque here, so that the compiler recomputes the
+    //  epilogue's per-lane values per tile instead of hoisting them out of the tile loop and keeping them live across the K loop)
+    int fr_e = fr, fg_e = fg, lane_e = lane, tid_e = tid;
+    if (PERSIST) asm volatile("" : "+v"(fr_e), "+v"(fg_e), "+v"(lane_e), "+v"(tid_e));
     // ---- intra-workgroup K reduction (the two wave groups took the two 32-deep halves of every K step)
     const int mt_base = 2 * grp;
     // The epilogue's operands (bias, time-embedding row, residual rows) are requested HERE, in front of the exchange: they are one more
     // round trip to memory nobody has touched in this launch, which the K-group exchange and its two barriers then hide
-    const int cbase = n0 + wn * 64 + 16 * fg;
+    const int cbase = e_n0 + wn * 64 + 16 * fg_e;
     const bool to_slab = p.splitk > 1 || p.raw_partial;
     const bool fused_ep = !to_slab;
     float4 ebias[4], etemb[4]; u32x4 eres[2][2]; float4 eres32[2][4];     // ebias = bias + bias2 (the fused skip's)
@@ -408,58 +422,64 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
 #pragma unroll
         for (int q = 0; q < 4; ++q) eres32[ml][q] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    if (fused_ep) {
-        if (p.bias) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) ebias[q] = *reinterpret_cast<const float4*>(p.bias + cbase + 4 * q);
-        }
-        if (p.bias2) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 b2 = *reinterpret_cast<const float4*>(p.bias2 + cbase + 4 * q);
-                ebias[q].x += b2.x; ebias[q].y += b2.y; ebias[q].z += b2.z; ebias[q].w += b2.w;
-            }
-        }
-        if (p.temb) {
-            const float* te = p.temb + (size_t)smp * p.temb_stride + cbase;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) etemb[q] = *reinterpret_cast<const float4*>(te + 4 * q);
-        }
-        if (f32nd && p.residual32 && cbase < p.CoutS) {
-#pragma unroll
-            for (int ml = 0; ml < 2; ++ml) {
-                const int r_t = wm * 64 + (mt_base + ml) * 16 + fr;
-                if (r_t < TM && l0 + r_t < DHW) {
-                    const float4* rp = reinterpret_cast<const float4*>(p.residual32 + (size_t)(m_base + r_t) * p.CoutS + cbase);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) eres32[ml][q] = rp[q];
-                }
-            }
-        }
-        if (p.residual && !p.out_f32 && !f32nd && cbase < p.CoutS) {
-#pragma unroll
-            for (int ml = 0; ml < 2; ++ml) {
-                const int r_t = wm * 64 + (mt_base + ml) * 16 + fr;
-                if (r_t < TM && l0 + r_t < DHW) {
-                    const u32x4* rp = reinterpret_cast<const u32x4*>(p.residual + (size_t)(m_base + r_t) * p.CoutS + cbase);
-                    eres[ml][0] = rp[0]; eres[ml][1] = rp[1];
-                }
-            }
-        }
-    }
     {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // every LDS-DMA copy was waited for by the last K steps (vmcnt(0) there)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        float* xch = reinterpret_cast<float*>(smem);
+        // every wave is past its last fragment read: the ring and the tap table are free.  Next tile of this workgroup: first macro
+        // step + tap table now, so that the copies travel under the exchange and the epilogue of the current one
+        if (PERSIST && vbid + (int)gridDim.x < nwg) { HL_TILE_SETUP(vbid + (int)gridDim.x); HL_TILE_EARLY(); }
+        // the epilogue's operands (bias, time-embedding row, residual rows): one more round trip to memory nobody has touched in this
+        // launch, requested here so that the K-group exchange and its barrier hide it (after the next tile's set-up: fewer live registers there)
+        if (fused_ep) {
+            if (p.bias) {
+    #pragma unroll
+                for (int q = 0; q < 4; ++q) ebias[q] = *reinterpret_cast<const float4*>(p.bias + cbase + 4 * q);
+            }
+            if (p.bias2) {
+    #pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 b2 = *reinterpret_cast<const float4*>(p.bias2 + cbase + 4 * q);
+                    ebias[q].x += b2.x; ebias[q].y += b2.y; ebias[q].z += b2.z; ebias[q].w += b2.w;
+                }
+            }
+            if (p.temb) {
+                const float* te = p.temb + (size_t)e_smp * p.temb_stride + cbase;
+    #pragma unroll
+                for (int q = 0; q < 4; ++q) etemb[q] = *reinterpret_cast<const float4*>(te + 4 * q);
+            }
+            if (f32nd && p.residual32 && cbase < p.CoutS) {
+    #pragma unroll
+                for (int ml = 0; ml < 2; ++ml) {
+                    const int r_t = wm * 64 + (mt_base + ml) * 16 + fr_e;
+                    if (r_t < TM && e_l0 + r_t < DHW) {
+                        const float4* rp = reinterpret_cast<const float4*>(p.residual32 + (size_t)(e_mbase + r_t) * p.CoutS + cbase);
+    #pragma unroll
+                        for (int q = 0; q < 4; ++q) eres32[ml][q] = rp[q];
+                    }
+                }
+            }
+            if (p.residual && !p.out_f32 && !f32nd && cbase < p.CoutS) {
+    #pragma unroll
+                for (int ml = 0; ml < 2; ++ml) {
+                    const int r_t = wm * 64 + (mt_base + ml) * 16 + fr_e;
+                    if (r_t < TM && e_l0 + r_t < DHW) {
+                        const u32x4* rp = reinterpret_cast<const u32x4*>(p.residual + (size_t)(e_mbase + r_t) * p.CoutS + cbase);
+                        eres[ml][0] = rp[0]; eres[ml][1] = rp[1];
+                    }
+                }
+            }
+        }
         const int dst = 1 - grp;
+        float* const xw = reinterpret_cast<float*>(smem + (dst ? XCH1 : XCH0));       // the half the OTHER group reads
+        const float* const xr = reinterpret_cast<const float*>(smem + (grp ? XCH1 : XCH0));
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for (int ml = 0; ml < 2; ++ml)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    xch[(((dst * 4 + wq) * 32) + (nt * 2 + ml) * 4 + r) * 64 + lane] = (grp == 0) ? acc[nt][2 + ml][r] : acc[nt][ml][r];
+                    xw[((wq * 32) + (nt * 2 + ml) * 4 + r) * 64 + lane_e] = (grp == 0) ? acc[nt][2 + ml][r] : acc[nt][ml][r];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // LDS-only wait + raw barrier: the epilogue operands stay in flight
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -469,7 +489,7 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
             for (int ml = 0; ml < 2; ++ml)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float v = xch[(((grp * 4 + wq) * 32) + (nt * 2 + ml) * 4 + r) * 64 + lane];
+                    const float v = xr[((wq * 32) + (nt * 2 + ml) * 4 + r) * 64 + lane_e];
                     if (grp == 0) acc[nt][ml][r] += v; else acc[nt][2 + ml][r] += v;
                 }
     }
@@ -477,23 +497,23 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
     KSTAMP(4);
     // ---- epilogue (conv_igemm.h's, with the 126-row tile mapping).  After the exchange this wave owns the 32-row block
     //      rows [64 wm + 32 grp, +32) of the tile = 16-row tiles mt_base + {0, 1}; GroupNorm partials of the whole tile go to slab
-    //      row `mtile` (bitwise reproducible: no atomics).
+    //      row `e_mtile` (bitwise reproducible: no atomics).
     const bool do_stats = (p.stats != nullptr) && !to_slab && (p.out != nullptr || f32nd);
     float ssum[16], ssq[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) { ssum[q] = 0.f; ssq[q] = 0.f; }
 #pragma unroll
     for (int ml = 0; ml < 2; ++ml) {
-        const int r_t = wm * 64 + (mt_base + ml) * 16 + fr;                // row inside the tile
-        if (r_t >= TM || l0 + r_t >= DHW) continue;
-        const int m = m_base + r_t;
+        const int r_t = wm * 64 + (mt_base + ml) * 16 + fr_e;                // row inside the tile
+        if (r_t >= TM || e_l0 + r_t >= DHW) continue;
+        const int m = e_mbase + r_t;
         float v[16];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[nt * 4 + r] = (grp == 0) ? acc[nt][ml][r] : acc[nt][2 + ml][r];
         if (to_slab) {
-            float* dst = p.partial + ((size_t)split * p.M + m) * p.CoutPad + cbase;
+            float* dst = p.partial + ((size_t)e_split * p.M + m) * p.CoutPad + cbase;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4 t4 = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
@@ -511,10 +531,10 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
             for (int q = 0; q < 4; ++q) { v[4 * q] += etemb[q].x; v[4 * q + 1] += etemb[q].y; v[4 * q + 2] += etemb[q].z; v[4 * q + 3] += etemb[q].w; }
         }
         if (p.out_f32) {
-            const int sp = l0 + r_t;
+            const int sp = e_l0 + r_t;
 #pragma unroll
             for (int q = 0; q < 16; ++q)
-                if (cbase + q < p.CoutReal) p.out_f32[((size_t)smp * p.CoutReal + cbase + q) * DHW + sp] = v[q];
+                if (cbase + q < p.CoutReal) p.out_f32[((size_t)e_smp * p.CoutReal + cbase + q) * DHW + sp] = v[q];
             continue;
         }
         if (cbase >= p.CoutS) continue;
@@ -563,25 +583,41 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
             HL_ROW_ADD(ssq[q], 0x128); HL_ROW_ADD(ssq[q], 0x124); HL_ROW_ADD(ssq[q], 0x122); HL_ROW_ADD(ssq[q], 0x121);
         }
 #undef HL_ROW_ADD
-        // fold the tile's 32-row blocks through LDS (behind the 64 KiB exchange area) -> ONE slab row per tile
-        float* red = reinterpret_cast<float*>(smem + 65536);               // [2 WGM][BN couts][2]
-        __syncthreads();
-        if (fr == 0) {
-            float* d = red + (((wm * 2 + grp) * BN) + wn * 64 + 16 * fg) * 2;
+        // fold the tile's 32-row blocks through LDS (RED: a ring slot the next tile's first copies do not touch) -> ONE slab row per tile.
+        // Raw barriers behind LDS-only waits: __syncthreads() would also wait for the next tile's copies and this tile's stores
+        float* red = reinterpret_cast<float*>(smem + RED);                 // [2 WGM][BN couts][2]
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (fr_e == 0) {
+            float* d = red + (((wm * 2 + grp) * BN) + wn * 64 + 16 * fg_e) * 2;
 #pragma unroll
             for (int q = 0; q < 16; ++q) { d[2 * q] = ssum[q]; d[2 * q + 1] = ssq[q]; }
         }
-        __syncthreads();
-        if (tid < BN && n0 + tid < p.CoutS) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (tid_e < BN && e_n0 + tid_e < p.CoutS) {
             float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-            for (int b = 0; b < 2 * WGM; ++b) { s0 += red[(b * BN + tid) * 2]; s1 += red[(b * BN + tid) * 2 + 1]; }
-            *reinterpret_cast<float2*>(p.stats + ((size_t)mtile * p.CoutS + n0 + tid) * 2) = make_float2(s0, s1);
+            for (int b = 0; b < 2 * WGM; ++b) { s0 += red[(b * BN + tid_e) * 2]; s1 += red[(b * BN + tid_e) * 2 + 1]; }
+            *reinterpret_cast<float2*>(p.stats + ((size_t)e_mtile * p.CoutS + e_n0 + tid_e) * 2) = make_float2(s0, s1);
         }
     }
     KSTAMP(5);
-    if (vbid + (int)gridDim.x < nwg) __syncthreads();          // next tile: its tap table / first copies reuse the LDS this epilogue has read
-    }   // tiles of this workgroup
+    } while (PERSIST && (vbid += (int)gridDim.x) < nwg);   // the next trip's table barrier also orders this epilogue's LDS reads before the copies that overwrite them
+#undef HL_STEP
+#undef HL_MFMA
+#undef HL_MASK
+#undef HL_READ
+#undef HL_ISSUE
+#undef HL_ISSUE_W
+#undef HL_ISSUE_A
+#undef HL_ADVANCE
+#undef HL_LOAD_TAB
+#undef HL_TILE_SETUP
+#undef HL_TILE_EARLY
+#undef HL_STAMP
     KSTAMP_DRAIN(6);
 #endif  // __HIP_DEVICE_COMPILE__
 }

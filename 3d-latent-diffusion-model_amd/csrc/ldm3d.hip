@@ -1909,6 +1909,8 @@ static int launch_conv_halo(const ConvParams& p_in, hipStream_t s, bool tall = f
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_halo_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_halo_kernel<6, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TALL));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_halo_kernel<6, 0, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_halo_kernel<6, 0, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TALL));
         attr_set = true;
     }
     // persistent grid (conv_halo.h): at most one workgroup per CU, each walks its tiles; LDM_HALO_PERSIST=0: one workgroup per tile
@@ -1919,8 +1921,10 @@ static int launch_conv_halo(const ConvParams& p_in, hipStream_t s, bool tall = f
     if (!cus) { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev_) == hipSuccess) cus = pr.multiProcessorCount; if (cus < 8) cus = 256; cus -= cus % 8; }
     const int tiles = p.mtiles * p.ntiles * p.splitk;
     const int grid = (persist && tiles > cus) ? cus : tiles;
+    const bool loop = grid < tiles;                  // more tiles than workgroups: the persistent instantiation walks them
     if (tall) {
-        hipLaunchKernelGGL((conv3_halo_kernel<6, 0, true>), dim3(grid), dim3(512), LDS_TALL, s, p);
+        if (loop) hipLaunchKernelGGL((conv3_halo_kernel<6, 0, true, true>), dim3(grid), dim3(512), LDS_TALL, s, p);
+        else hipLaunchKernelGGL((conv3_halo_kernel<6, 0, true>), dim3(grid), dim3(512), LDS_TALL, s, p);
         return 0;
     }
     if (p.dbg & (4 | 8 | 16 | 32 | 64)) {                  // timing ablations (operator-level API + LDM_CONV_DBG only)
@@ -1930,7 +1934,8 @@ static int launch_conv_halo(const ConvParams& p_in, hipStream_t s, bool tall = f
         ABL_CASE(4) ABL_CASE(8) ABL_CASE(16) ABL_CASE(12) ABL_CASE(20) ABL_CASE(24) ABL_CASE(32) ABL_CASE(40) ABL_CASE(84) ABL_CASE(68) ABL_CASE(64)
 #undef ABL_CASE
     }
-    hipLaunchKernelGGL((conv3_halo_kernel<6>), dim3(grid), dim3(512), LDS, s, p);
+    if (loop) hipLaunchKernelGGL((conv3_halo_kernel<6, 0, false, true>), dim3(grid), dim3(512), LDS, s, p);
+    else hipLaunchKernelGGL((conv3_halo_kernel<6>), dim3(grid), dim3(512), LDS, s, p);
     return 0;
 }
 

@@ -43,5 +43,32 @@ def test_hot_kernels_do_not_spill(isa):
             continue
         seen += 1
         m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b)
+        if re.search(r"conv3_halo_kernelILi6ELi0ELb[01]ELb1E", name):
+            continue                                       # the persistent (tile-loop) instantiations: checked loop by loop below
         assert m and int(m.group(1)) == 0, (name, m and m.group(1))
     assert seen >= 8
+
+
+def test_persistent_halo_kernels_keep_scratch_out_of_their_k_loops(isa):
+    """conv3_halo_kernel<6, 0, *, true> walks several tiles per workgroup (launches with more tiles than CUs: the AutoencoderKL's 96^3 /
+    48^3 levels); the tile loop keeps more values live and the compiler parks some of them in scratch BETWEEN K loops (prologue, K-group
+    exchange, epilogue).  That is accepted; a scratch access inside a K loop is not: every loop of the kernel that consists of K steps
+    (16 MFMAs per step; 96 in the six-step steady block, 48 / 96 in the tails, 16 in the fused-skip loop) must be free of them.  The
+    one-tile-per-workgroup instantiations (every conv of the B = 1 UNet step) must not touch scratch at all (test above)."""
+    lines, res = isa
+    for tall in "01":
+        start = next(i for i, l in enumerate(lines) if l.startswith(f"_Z17conv3_halo_kernelILi6ELi0ELb{tall}ELb1EEv10ConvParams:"))
+        end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+        body = lines[start:end]
+        labels = {m.group(1): i for i, l in enumerate(body) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
+        k_loops = 0
+        for i, l in enumerate(body):
+            m = re.search(r"s_c?branch\w*\s+(\.LBB\d+_\d+)", l)
+            if not m or m.group(1) not in labels or labels[m.group(1)] >= i:
+                continue
+            seg = body[labels[m.group(1)]:i]
+            mfma = sum("v_mfma" in x for x in seg)
+            if 0 < mfma <= 96:
+                k_loops += 1
+                assert not any("scratch_" in x for x in seg), (tall, labels[m.group(1)], i)
+        assert k_loops >= 3, (tall, k_loops)
