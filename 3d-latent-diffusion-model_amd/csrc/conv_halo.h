@@ -35,6 +35,7 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
     constexpr int PA = BM / 64, PB = BN / 64;                  // 1 KiB copy pieces per wave: voxel tile, weight tile
     constexpr int WGM = TALL ? 4 : 2;                          // wave rows (x 2 K groups = row blocks of the GroupNorm fold)
     constexpr int NSA = 3;
+    constexpr bool SPLIT_A = !TALL;                            // voxel tile issued in two halves (kw = 0, kw = 1 steps)
     constexpr int AOFF = NSB * BT;                             // voxel ring behind the weight ring
     constexpr int TOFF = AOFF + NSA * AT;                      // (pair, row) -> voxel table
     static_assert(NSB == 6, "the static step schedule assumes a 6-deep weight ring (a multiple of the 3 kw steps)");
@@ -135,9 +136,21 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
                                                          (unsigned)ac_ * (BK * 2), 0, 0);          \
         }                                                                                           \
     } while (0)
+    // 126 x 128 tile (SPLIT_A): the voxel tile of a macro step travels in two halves, with the kw = 0 and the kw = 1 step of the macro
+    // step issued six steps earlier (3 / 3 / 2 copies per step instead of 4 / 2 / 2): +0.5 % on the UNet step, same box.  The tall tile
+    // keeps all PA = 4 pieces in the kw = 0 step: split 3 / 3 / 1 it measured 0.7 % SLOWER on the 96^3 convolutions (profiles/r04_ab_split_issue.txt)
+#define HL_ISSUE_A_HALF(H) do {                                                                     \
+        if (!(ABL & 4)) {                                                                           \
+            const int ac_ = (x3n && i_chunk >= x3n) ? i_chunk - x3n : i_chunk;     /* x3: hi, hi again, lo */ \
+            _Pragma("unroll") for (int j = (H) * (PA / 2); j < ((H) + 1) * (PA / 2); ++j)           \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr_t)(smem + AOFF + i_aslot + (wave * PA + j) * 1024), 16, a_vo[j], \
+                                                         (unsigned)ac_ * (BK * 2), 0, 0);          \
+        }                                                                                           \
+    } while (0)
 #define HL_ISSUE(KW, BSLOT) do {                                                                    \
         HL_ISSUE_W(KW, BSLOT);                                                                      \
-        if ((KW) == 0) HL_ISSUE_A();                                                                \
+        if (SPLIT_A) { if ((KW) == 0) HL_ISSUE_A_HALF(0); if ((KW) == 1) HL_ISSUE_A_HALF(1); }      \
+        else if ((KW) == 0) HL_ISSUE_A();                                                           \
         ++i_s;                                                                                      \
     } while (0)
     // issue stream moves on to the next macro step: next Cin chunk, or next (kd, kh) pair (table read + multiply-add per
@@ -190,8 +203,13 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
     // ISSUE: 1 = steady state (step S+6 exists), 0 = tail (nothing left to issue: drain).
 #define HL_STEP(J, WC, AC, WN, AN) do {                                                             \
         constexpr int kw_ = (J) % 3, kn_ = ((J) + 1) % 3;                                           \
-        constexpr int vm_ = 4 * PB + PA * ((((J) + 2) % 3 == 0) + (((J) + 3) % 3 == 0) + (((J) + 4) % 3 == 0) + (((J) + 5) % 3 == 0)); \
-        constexpr int nc_ = (kw_ == 0) ? PB + PA : PB;         /* copies issued by this step */     \
+        /* copies that may stay in flight while the operands of step S+1 must have landed (in-order retirement).  kn_ == 0: S+1 opens a  \
+           macro step: both halves of its voxel tile (issue slots S-5, S-4) are needed, slots S-3 .. S-1 (kw 2, 0, 1) may fly; kn_ == 1 / 2:  \
+           only the weight tile of S+1 (slot S-5) is new, slots S-4 .. S-1 may fly */                                                        \
+        constexpr int vm_ = SPLIT_A ? ((kn_ == 0) ? 3 * PB + PA : (kn_ == 1) ? 4 * PB + PA : 4 * PB + 3 * (PA / 2))                          \
+            /* whole tile with the kw = 0 step: steps S+2 .. S+5 -> their weight tiles + one voxel tile per kw == 0 step among them */       \
+            : 4 * PB + PA * ((((J) + 2) % 3 == 0) + (((J) + 3) % 3 == 0) + (((J) + 4) % 3 == 0) + (((J) + 5) % 3 == 0));                     \
+        constexpr int nc_ = SPLIT_A ? ((kw_ < 2) ? PB + PA / 2 : PB) : ((kw_ == 0) ? PB + PA : PB);   /* copies issued by this step */ \
         if (kw_ == 0) HL_ADVANCE();                                                                 \
         if (kn_ == 0) c_aslot = (c_aslot == 2 * AT) ? 0u : c_aslot + AT;                            \
         /* hard boundary: s_barrier alone does not stop register-only MFMAs from drifting into the neighbouring step  \
@@ -313,7 +331,12 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
     for (; s < nsteps; s += 6) {
 #define HL_TAIL_STEP(J, WC, AC, WN, AN) do {                                                        \
         constexpr int kw_ = (J) % 3, kn_ = ((J) + 1) % 3;                                           \
-        constexpr int vm_ = 4 * PB + PA * ((((J) + 2) % 3 == 0) + (((J) + 3) % 3 == 0) + (((J) + 4) % 3 == 0) + (((J) + 5) % 3 == 0)); \
+        /* copies that may stay in flight while the operands of step S+1 must have landed (in-order retirement).  kn_ == 0: S+1 opens a  \
+           macro step: both halves of its voxel tile (issue slots S-5, S-4) are needed, slots S-3 .. S-1 (kw 2, 0, 1) may fly; kn_ == 1 / 2:  \
+           only the weight tile of S+1 (slot S-5) is new, slots S-4 .. S-1 may fly */                                                        \
+        constexpr int vm_ = SPLIT_A ? ((kn_ == 0) ? 3 * PB + PA : (kn_ == 1) ? 4 * PB + PA : 4 * PB + 3 * (PA / 2))                          \
+            /* whole tile with the kw = 0 step: steps S+2 .. S+5 -> their weight tiles + one voxel tile per kw == 0 step among them */       \
+            : 4 * PB + PA * ((((J) + 2) % 3 == 0) + (((J) + 3) % 3 == 0) + (((J) + 4) % 3 == 0) + (((J) + 5) % 3 == 0));                     \
         if (kw_ == 0 && i_s < nsteps) HL_ADVANCE();                                                 \
         __builtin_amdgcn_s_waitcnt(0xC07F);                                                         \
         HL_MASK(AC, kw_);                                                                           \
@@ -613,6 +636,7 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
 #undef HL_ISSUE
 #undef HL_ISSUE_W
 #undef HL_ISSUE_A
+#undef HL_ISSUE_A_HALF
 #undef HL_ADVANCE
 #undef HL_LOAD_TAB
 #undef HL_TILE_SETUP
