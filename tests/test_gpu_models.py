@@ -156,8 +156,11 @@ def _vae_pair(cfg, seed, cuda):
     return m.to(cuda).eval(), sd
 
 
+# VAE_TINY at 40 x 48 x 44 / VAE_FULL at 64^3: enough 64-row tiles for the first layer's fused im2col GEMM (gemm_light_kernel<.., IM2>, K = 64
+# with two input channels, K = 32 with one; ragged last tile at 84 480 rows)
 @pytest.mark.parametrize("name,dims,b", [("VAE_TINY", (16, 16, 16), 1), ("VAE_TINY", (8, 16, 12), 2), ("VAE_FULL", (32, 32, 32), 1),
-                                         ("VAE_TINY_ATTN", (16, 16, 16), 2), ("VAE_FULL_ATTN", (32, 32, 32), 1)])
+                                         ("VAE_TINY_ATTN", (16, 16, 16), 2), ("VAE_FULL_ATTN", (32, 32, 32), 1),
+                                         ("VAE_TINY", (40, 48, 44), 1), ("VAE_TINY", (32, 32, 32), 2), ("VAE_FULL", (64, 64, 64), 1)])
 def test_vae_encode_decode_match_oracle(cuda, name, dims, b):
     from oracle import autoencoder as oa
     cfg = getattr(cfgs, name)
