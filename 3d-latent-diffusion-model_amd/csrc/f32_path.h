@@ -28,6 +28,7 @@ struct Conv32Params {
     float* out;                                       // [M][CoutS] fp32 NDHWC        (mode 0)
     float* out_ncdhw;                                 // [N][CoutReal][DHWo] fp32     (mode 1)
     float* partial;                                   // [splitk][M][CoutPad]         (splitk > 1)
+    float* stats; int stats_nrb, stats_rows;          // finalize_stats_f32_kernel: [N * stats_nrb][CoutS][2] (sum, sum of squares) over stats_rows rows per block
 };
 
 // Workgroup = 128 voxels x BN couts (128, or 64 for the layers with Cout % 128 != 0: no wasted MFMA rows), 4 waves (2 x 2), wave tile
@@ -349,6 +350,60 @@ __global__ __launch_bounds__(256) void finalize_f32_kernel(const Conv32Params p)
         if (c >= p.CoutS) continue;
         if (p.residual) { const float4 b = *reinterpret_cast<const float4*>(p.residual + (size_t)m * p.CoutS + c); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
         *reinterpret_cast<float4*>(p.out + (size_t)m * p.CoutS + c) = v;
+    }
+}
+
+// The same finalize for an output a GroupNorm reads next (fp32 inference plans): block = stats_rows consecutive rows of one sample x
+// all CoutS <= 1024 channels, thread = 4 channels x every rows_par-th row; beside the store it leaves the block's per-channel
+// (sum, sum of squares) in the layout gn_stats_f32_kernel writes, so gn32_fold_apply_kernel runs without a statistics pass of its own.
+__global__ __launch_bounds__(256) void finalize_stats_f32_kernel(const Conv32Params p) {
+    __shared__ float red[256 * 8];
+    const int DHWo = p.Dout * p.Hout * p.Wout;
+    const int cvec = p.CoutS / 4, tid = threadIdx.x;
+    const int n = blockIdx.y, blk = blockIdx.x;
+    const int rows_par = 256 / cvec > 0 ? 256 / cvec : 1;
+    const int cv = tid % cvec, rl = tid / cvec;
+    const int r0 = blk * p.stats_rows;
+    int r1 = r0 + p.stats_rows; if (r1 > DHWo) r1 = DHWo;
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+    if (rl < rows_par) {
+        const int c = cv * 4;
+        float4 bi = make_float4(0.f, 0.f, 0.f, 0.f), te = bi;
+        if (p.bias) bi = *reinterpret_cast<const float4*>(p.bias + c);
+        if (p.temb) te = *reinterpret_cast<const float4*>(p.temb + (size_t)n * p.temb_stride + c);
+        const size_t slab = (size_t)p.M * p.CoutPad;
+        for (int r = r0 + rl; r < r1; r += rows_par) {
+            const size_t m = (size_t)n * DHWo + r;
+            const float* src = p.partial + m * p.CoutPad + c;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            int k0 = 0;
+            for (; k0 + 8 <= p.splitk; k0 += 8) {        // slabs summed in order, as finalize_f32_kernel does
+                float4 a[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) a[k] = *reinterpret_cast<const float4*>(src + (size_t)(k0 + k) * slab);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { v.x += a[k].x; v.y += a[k].y; v.z += a[k].z; v.w += a[k].w; }
+            }
+            for (; k0 < p.splitk; ++k0) { const float4 a = *reinterpret_cast<const float4*>(src + (size_t)k0 * slab); v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+            if (p.bias) { v.x += bi.x; v.y += bi.y; v.z += bi.z; v.w += bi.w; }    // bias, then the time embedding, then the residual: finalize_f32_kernel's order, bit for bit
+            if (p.temb) { v.x += te.x; v.y += te.y; v.z += te.z; v.w += te.w; }
+            if (p.residual) { const float4 b = *reinterpret_cast<const float4*>(p.residual + m * p.CoutS + c); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+            *reinterpret_cast<float4*>(p.out + m * p.CoutS + c) = v;
+            s[0] += v.x; q[0] += v.x * v.x; s[1] += v.y; q[1] += v.y * v.y; s[2] += v.z; q[2] += v.z * v.z; s[3] += v.w; q[3] += v.w * v.w;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { red[tid * 8 + k] = s[k]; red[tid * 8 + 4 + k] = q[k]; }
+    __syncthreads();
+    if (tid < cvec) {
+        for (int rl2 = 1; rl2 < rows_par; ++rl2) {
+            const int t2 = rl2 * cvec + tid;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { s[k] += red[t2 * 8 + k]; q[k] += red[t2 * 8 + 4 + k]; }
+        }
+        float* dst = p.stats + (((size_t)n * p.stats_nrb + blk) * p.CoutS + tid * 4) * 2;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { dst[2 * k] = s[k]; dst[2 * k + 1] = q[k]; }
     }
 }
 

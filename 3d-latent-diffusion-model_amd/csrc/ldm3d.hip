@@ -27,6 +27,7 @@
 #include "conv_halo.h"
 #include "conv_thin.h"
 #include "gemm_light.h"
+#include "gemm_light_x3.h"
 #include "conv_wgrad.h"
 #include "norm_elem.h"
 #include "fin_gn.h"
@@ -89,10 +90,11 @@ enum OpKind { OP_PACK, OP_CONV, OP_FINALIZE, OP_GN_STATS, OP_GN_FINALIZE, OP_GN_
               // fp32 precision mode (f32_path.h)
               OP_PACK32, OP_CONV32, OP_FIN32, OP_GN_STATS32, OP_GN_APPLY32, OP_ATTN32, OP_GEMV32,
               OP_TAP,                              // debug tap: export an activation as fp32 NCDHW and / or overwrite it (teacher forcing)
-              OP_BUCKET, OP_BUCKET_JOIN,
-              OP_UPS_SPLIT32,
-              OP_CONV_THIN,
-              OP_FIN_GN };                         // split-K finalize + the GroupNorm(+SiLU) that consumes it, one launch (fin_gn.h)                      // 3^3 conv with Cout <= 4 and fp32 NCDHW output: the networks' last layer (conv_thin.h)                    // fp32 precision: nearest x2 upsample into the (hi | lo) bf16 split (upsample_split_f32_kernel)         // training plans: a tail range of the flat gradient buffer is final (all-reduce it now) / wait for every bucket
+              OP_BUCKET, OP_BUCKET_JOIN,           // training plans: a tail range of the flat gradient buffer is final (all-reduce it now) / wait for every bucket
+              OP_UPS_SPLIT32,                      // fp32 precision: nearest x2 upsample into the (hi | lo) bf16 split (upsample_split_f32_kernel)
+              OP_CONV_THIN,                        // 3^3 conv with Cout <= 4 and fp32 NCDHW output: the networks' last layer (conv_thin.h)
+              OP_FIN_GN,                           // split-K finalize + the GroupNorm(+SiLU) that consumes it, one launch (fin_gn.h)
+              OP_GEMM_LIGHT32 };                   // fp32 precision: 1x1 convolution as the light GEMM on fp32 operands split in registers (gemm_light_x3.h)
 
 struct ConvCfg { int wgm, wgn, bk, splitk; int halo = 0, mtps = 0, qps = 0; };   // halo: conv3_halo_kernel (126-row tiles)
 
@@ -465,6 +467,18 @@ struct Builder {
     }
 
     // fp32 precision: every conv form the inference plans use on conv_f32_kernel (the 1x1 skip runs as its own conv -> residual)
+    // fp32 inference plans: the split-K finalize also leaves the output's GroupNorm partials (finalize_stats_f32_kernel), so the
+    // GroupNorm that reads it folds them in its own launch (gn_apply's hp && fused branch) instead of a statistics pass.  LDM_FIN32_STATS=0: off.
+    void fin32_stats(Op& f, Act& out, const ConvArgs& a, int N, int dhwo, int couts) {
+        static const int on = [] { const char* e = getenv("LDM_FIN32_STATS"); return e ? atoi(e) : 1; }();
+        if (!on || train || !a.want_stats || a.f32_out || couts % 4 || couts > 1024) return;
+        const int cvec = couts / 4, rows_par = std::max(1, 256 / cvec);
+        int nrb = std::min((dhwo + rows_par - 1) / rows_par, std::max(1, 256 / N));
+        const int rows = (dhwo + nrb - 1) / nrb;
+        nrb = (dhwo + rows - 1) / rows;
+        out.stats_off = pool.alloc((size_t)N * nrb * couts * 2 * 4); out.has_stats = true; out.stats_nrb = nrb;
+        f.r[12] = ws_ref(out.stats_off); f.i[2] = nrb; f.i[3] = rows;
+    }
     Act conv32(const ConvArgs& a, const std::string& tag) {
         const ConvW& w = *a.w;
         if (a.w1) { err = "fp32 precision: unsupported conv form (" + tag + ")"; return Act(); }
@@ -511,6 +525,7 @@ struct Builder {
                 j[0] = C; j[4] = N; j[5] = a.xa.D; j[6] = a.xa.H; j[7] = a.xa.W; j[8] = a.Do; j[9] = a.Ho; j[10] = a.Wo;
                 j[11] = 3; j[12] = 1; j[13] = 1; j[15] = (int)M; j[16] = couts; j[17] = w.cout_pad; j[18] = w.cout;
                 j[19] = C / 32; j[20] = 1; j[23] = (int)((M + 127) / 128);
+                fin32_stats(f, out, a, N, a.Do * a.Ho * a.Wo, couts);
                 partial_fixups.push_back(plan->ops.size()); plan->ops.push_back(f);
                 free_act(sp);
                 return out;
@@ -586,6 +601,7 @@ struct Builder {
             j[11] = 3; j[12] = 1; j[13] = 1; j[15] = (int)M; j[16] = couts; j[17] = w.cout_pad; j[18] = w.cout;
             j[19] = C / 32; j[20] = w.cout_pad / 128 ? w.cout_pad / 128 : 1; j[21] = a.temb_stride; j[23] = (int)((M + 127) / 128);
             if (a.f32_out) { j[22] = 1; j[18] = a.cout_real ? a.cout_real : w.cout; }
+            fin32_stats(f, out, a, N, a.Do * a.Ho * a.Wo, couts);
             partial_fixups.push_back(plan->ops.size()); plan->ops.push_back(f);
             return out;
         }
@@ -595,6 +611,31 @@ struct Builder {
         // LDM_F32_X3=0: fp32 MFMA everywhere; 2: 3 x bf16 in training plans too.
         static const int f32_x3 = [] { const char* e = getenv("LDM_F32_X3"); return e ? atoi(e) : 1; }();
         const bool x3 = (f32_x3 == 2 || (f32_x3 == 1 && !train)) && cin0 % 32 == 0 && a.xa.C % 32 == 0;
+        {   // 1x1x1 convolutions of the 3 x bf16 plans: light GEMM on the fp32 operands, no slabs and no finalize (gemm_light_x3.h).  LDM_LIGHT_X3=0: off.
+            static const int light_x3 = [] { const char* e = getenv("LDM_LIGHT_X3"); return e ? atoi(e) : 1; }();
+            static const long light_x3_max_m = [] { const char* e = getenv("LDM_LIGHT_X3_MAX_M"); return e ? atol(e) : 4096L; }();   // above: conv_x3_kernel's LDS tiles (one split per tile) win: 24^3 x 512 -> 256: 61 vs 68 us
+            if (light_x3 && x3 && M <= light_x3_max_m && a.k == 1 && a.stride == 1 && a.pad == 0 && !a.ups && !a.exact && !a.f32_out && !a.xa.hl && a.temb.base == BASE_NULL &&
+                (!a.xb.valid || a.xb.C % 32 == 0) && w.cout_pad % 32 == 0 && a.xa.D == a.Do && a.xa.H == a.Ho && a.xa.W == a.Wo &&
+                M * (long)std::max(cin0, w.cout_pad) * 4 < (1L << 31)) {
+                const int big = gemm_light_x3_big(M, w.cout_pad), rows = big ? 64 : 32;
+                const int couts_l = rup(w.cout, 32);
+                Act out = new_act(N, a.Do, a.Ho, a.Wo, couts_l);
+                const long dhwo = (long)a.Do * a.Ho * a.Wo;
+                if (a.want_stats && !train && (N == 1 || dhwo % rows == 0)) {
+                    out.stats_off = pool.alloc((size_t)((M + rows - 1) / rows) * couts_l * 2 * 4); out.has_stats = true;
+                    out.stats_nrb = (int)(N == 1 ? (M + rows - 1) / rows : dhwo / rows);
+                }
+                Op op{}; op.kind = OP_GEMM_LIGHT32;
+                op.r[0] = ws_ref(a.xa.off); op.r[1] = a.xb.valid ? ws_ref(a.xb.off) : Ref();
+                op.r[2] = a.w_over.base != BASE_NULL ? a.w_over : w32_ref(w.w_off);
+                op.r[6] = a.no_bias ? Ref() : w_ref(w.b_off); op.r[9] = a.residual.valid ? ws_ref(a.residual.off) : Ref();
+                op.r[10] = ws_ref(out.off); op.r[12] = out.has_stats ? ws_ref(out.stats_off) : Ref();
+                op.i[0] = (int)M; op.i[1] = cin0; op.i[2] = couts_l; op.i[3] = w.cout_pad; op.i[4] = big; op.i[5] = a.xa.C;
+                plan->ops.push_back(op);
+                if (recording) { Tape t; t.kind = 0; t.c = a; t.out = out; tape.push_back(t); }
+                return out;
+            }
+        }
         const int kb = x3 ? 32 : 16;
         const int taps = a.k * a.k * a.k, nchunk = cin0 / kb, steps = taps * nchunk;
         static const int f32_bn = [] { const char* e = getenv("LDM_F32_BN"); return e ? atoi(e) : 0; }();        // tuning knobs
@@ -626,7 +667,7 @@ struct Builder {
         i[19] = nchunk; i[21] = a.temb_stride; i[22] = a.f32_out ? 1 : 0; i[23] = mtiles; i[20] = ntiles;
         if (sk > 1) { partial_bytes = std::max(partial_bytes, (size_t)sk * M * w.cout_pad * 4); partial_fixups.push_back(plan->ops.size()); }
         plan->ops.push_back(op);
-        if (sk > 1) { Op f = op; f.kind = OP_FIN32; partial_fixups.push_back(plan->ops.size()); plan->ops.push_back(f); }
+        if (sk > 1) { Op f = op; f.kind = OP_FIN32; fin32_stats(f, out, a, N, a.Do * a.Ho * a.Wo, couts); partial_fixups.push_back(plan->ops.size()); plan->ops.push_back(f); }
         if (recording) { Tape t; t.kind = 0; t.c = a; t.out = out; tape.push_back(t); }
         return out;
     }
@@ -2071,7 +2112,20 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                 else if (o.kind == OP_CONV32 && o.cc.bk == 32) hipLaunchKernelGGL(conv_x3_kernel<64>, dim3(p.mtiles * p.ntiles * p.splitk), dim3(256), 0, s, p);
                 else if (o.kind == OP_CONV32 && o.cc.wgn == 2) hipLaunchKernelGGL(conv_f32_kernel<128>, dim3(p.mtiles * p.ntiles * p.splitk), dim3(256), 0, s, p);
                 else if (o.kind == OP_CONV32) hipLaunchKernelGGL(conv_f32_kernel<64>, dim3(p.mtiles * p.ntiles * p.splitk), dim3(256), 0, s, p);
-                else hipLaunchKernelGGL(finalize_f32_kernel, dim3(grid_for((long)p.M * (p.CoutPad / 4), 256, 4096)), dim3(256), 0, s, p);
+                else if (o.kind == OP_FIN32 && i[2] > 0) {
+                    p.stats = (float*)rp(bs, o.r[12]); p.stats_nrb = i[2]; p.stats_rows = i[3];
+                    hipLaunchKernelGGL(finalize_stats_f32_kernel, dim3(i[2], p.N), dim3(256), 0, s, p);
+                } else hipLaunchKernelGGL(finalize_f32_kernel, dim3(grid_for((long)p.M * (p.CoutPad / 4), 256, 4096)), dim3(256), 0, s, p);
+                break; }
+            case OP_GEMM_LIGHT32: {
+                LightX3Params p{};
+                p.x = (const float*)rp(bs, o.r[0]); p.xb = (const float*)rp(bs, o.r[1]); p.ca = i[5];
+                p.w = (const float*)rp(bs, o.r[2]);
+                if (!p.w) return fail(LDM_ERR_NOT_LOADED, "fp32 precision: the fp32 weight arena is empty (re-upload the parameters after ldm_model_set_precision)");
+                p.bias = (const float*)rp(bs, o.r[6]); p.residual = (const float*)rp(bs, o.r[9]);
+                p.out = (float*)rp(bs, o.r[10]); p.stats = (float*)rp(bs, o.r[12]);
+                p.M = i[0]; p.K = i[1]; p.CoutS = i[2];
+                HIP_TRY(launch_gemm_light_x3(p, i[3], i[4], s));
                 break; }
             case OP_GN_STATS32: case OP_GN_APPLY32: {
                 Gn32Params p{}; p.xa = (const float*)rp(bs, o.r[0]); p.xb = (const float*)rp(bs, o.r[1]); p.ca = i[0]; p.cb = i[1];
@@ -3567,6 +3621,20 @@ int ldm_op_gemm_f32(const float* x, int K, const float* w, const float* bias, fl
     if (cout_pad % 128 == 0) { p.ntiles = cout_pad / 128; hipLaunchKernelGGL(conv_f32_kernel<128>, dim3(p.mtiles * p.ntiles), dim3(256), 0, (hipStream_t)stream, p); }
     else { p.ntiles = cout_pad / 64; hipLaunchKernelGGL(conv_f32_kernel<64>, dim3(p.mtiles * p.ntiles), dim3(256), 0, (hipStream_t)stream, p); }
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+/* out[M][couts] = (xa | xb)[M][ca + cb] w[cout_pad][ca + cb]^T + bias (+ residual[M][couts]) on fp32 operands as three bf16 MFMAs per product
+ * (gemm_light_x3.h: the 1x1x1 convolutions of the fp32 inference plans).  ca, cb % 32 == 0 (cb = 0: one source), cout_pad % 32 == 0,
+ * couts % 32 == 0.  stats (optional): [ceil(M / rows)][couts][2] per-tile (sum, sum of squares) of the stored values, rows = 64 when
+ * big else 32.  big: 64 x 64 tiles (cout_pad % 64 == 0) instead of 32 x 32; -1 = the planner's choice. */
+int ldm_op_linear_f32x3(const float* xa, int ca, const float* xb, int cb, const float* w, const float* bias, const float* residual, float* out,
+                        float* stats, int64_t M, int cout_pad, int couts, int big, void* stream) {
+    if (!xa || !w || !out || M < 1 || ca < 32 || ca % 32 || cb < 0 || cb % 32 || (cb > 0 && !xb) || cout_pad < 32 || cout_pad % 32 || couts < 32 || couts % 32 ||
+        couts > cout_pad || M * (int64_t)std::max(ca + cb, cout_pad) * 4 >= (1L << 31) || (big == 1 && cout_pad % 64))
+        return fail(LDM_ERR_BAD_ARG, "bad argument");
+    LightX3Params p{}; p.x = xa; p.xb = cb > 0 ? xb : nullptr; p.ca = ca; p.w = w; p.bias = bias; p.residual = residual; p.out = out; p.stats = stats;
+    p.M = (int)M; p.K = ca + cb; p.CoutS = couts;
+    HIP_TRY(launch_gemm_light_x3(p, cout_pad, big < 0 ? gemm_light_x3_big(M, cout_pad) : big, (hipStream_t)stream));
     return 0;
 }
 /* dw[ksplit][cout][K] = sum over the rows of dy[M][cdy]^T x[M][K] (partial matrices of `ksplit` row ranges; the caller sums them) */

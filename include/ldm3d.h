@@ -276,6 +276,13 @@ int ldm_op_leaky_relu_f32(const float* x, float* y, int64_t n, float slope, void
 int ldm_op_leaky_relu_bwd_f32(const float* x, const float* dy, float* dx, int64_t n, float slope, void* stream);
 int ldm_op_gemm_f32(const float* x, int K, const float* w, const float* bias, float* out, int64_t M, int cout, int cout_pad, int couts, void* stream);
 int ldm_op_gemm_wgrad_f32(const float* dy, int cdy, const float* x, int K, float* dw, int cout, int64_t M, int ksplit, void* stream);
+/* The 1x1x1 convolutions of the fp32 inference plans (SABlock's q|k|v and output projections, the ResBlock's nin_shortcut; SURVEY.md
+ * section 8a row a2.3) as one launch on fp32 operands: out[M][couts] = (xa | xb)[M][ca + cb] w[cout_pad][ca + cb]^T + bias (+ residual),
+ * every product as three bf16 MFMAs on hi / lo splits made in registers (csrc/gemm_light_x3.h; ~1e-5 relative).  ca, cb % 32 == 0
+ * (cb = 0: one source), cout_pad, couts % 32 == 0.  stats (optional): [ceil(M / rows)][couts][2] per-tile (sum, sum of squares), rows = 64
+ * when big else 32; big = -1: the planner's choice. */
+int ldm_op_linear_f32x3(const float* xa, int ca, const float* xb, int cb, const float* w, const float* bias, const float* residual, float* out,
+                        float* stats, int64_t M, int cout_pad, int couts, int big, void* stream);
 size_t ldm_op_group_norm_f32_scratch_bytes(int N, int C, int DHW, int groups);
 int ldm_op_group_norm_f32(const float* x, int C, const float* gamma, const float* beta, int groups, float eps, int act, float* out,
                           int N, int DHW, void* scratch, size_t scratch_bytes, void* stream);

@@ -195,3 +195,53 @@ print(json.dumps({"rel": float((y - ref).norm() / ref.norm())}))
         errs[knob] = json.loads(r.stdout.strip().splitlines()[-1])["rel"]
     print(f"UNET_TINY fp32 mode vs fp32 oracle: exact fp32 MFMA {errs['0']:.2e}, 3 x bf16 convolutions {errs['1']:.2e}")
     assert errs["0"] <= 3e-5 and errs["1"] <= TOL
+
+
+@pytest.mark.parametrize("M,ca,cb,cout,big,res", [
+    (216, 512, 0, 1536, 0, False),       # q|k|v at 6^3
+    (216, 512, 512, 512, 0, False),      # ResBlock skip over a concatenation
+    (1728, 256, 0, 256, 0, True),        # output projection + residual at 12^3
+    (1728, 256, 0, 768, 1, False),       # 64 x 64 tiles
+    (1000, 64, 32, 96, 0, True),         # ragged: rows past M, 3 K steps over 4 waves, padded couts
+    (77, 32, 0, 64, 1, False),           # one K step: three of the four waves contribute nothing
+])
+def test_linear_f32x3_matches_fp64(cuda, M, ca, cb, cout, big, res):
+    """gemm_light_x3_kernel (the 1x1x1 convolutions of the fp32 inference plans) against the product in fp64: three bf16 MFMAs per
+    product on hi / lo splits made in registers, K range split over the workgroup's four waves.  Bar 2e-5 relative to the row
+    norm (measured ~3e-6); the per-tile GroupNorm partials are the sums of the stored values."""
+    import ctypes as C
+    from ldm3d import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(M + ca + cout)
+    K = ca + cb
+    cout_pad = (cout + 63) // 64 * 64
+    couts = (cout + 31) // 32 * 32
+    xa = torch.randn((M, ca), generator=g).to(cuda)
+    xb = torch.randn((M, cb), generator=g).to(cuda) if cb else None
+    w = torch.zeros((cout_pad, K))
+    w[:cout] = torch.randn((cout, K), generator=g) / K ** 0.5
+    w = w.to(cuda)
+    bias = torch.zeros(cout_pad)
+    bias[:cout] = torch.randn(cout, generator=g)
+    bias = bias.to(cuda)
+    r = torch.randn((M, couts), generator=g).to(cuda) if res else None
+    rows = 64 if big else 32
+    mt = (M + rows - 1) // rows
+    out = torch.full((M, couts), float("nan"), device=cuda)
+    stats = torch.full((mt, couts, 2), float("nan"), device=cuda)
+    ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    _lib.check(L.ldm_op_linear_f32x3(ptr(xa), ca, ptr(xb), cb, ptr(w), ptr(bias), ptr(r), ptr(out), ptr(stats), M, cout_pad, couts, big,
+                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    x = torch.cat([xa, xb], 1) if cb else xa
+    ref = x.double() @ w[:couts].double().t() + bias[:couts].double()
+    if res:
+        ref = ref + r.double()
+    err = float(((out.double() - ref).norm(dim=1) / ref.norm(dim=1)).max())
+    print(f"linear_f32x3 M={M} K={K} cout={cout}: worst row error {err:.2e}")
+    assert torch.isfinite(out).all() and err <= 2e-5
+    o = out.double()
+    pad = mt * rows - M
+    o = torch.cat([o, torch.zeros((pad, couts), dtype=torch.float64, device=cuda)]).view(mt, rows, couts)
+    assert torch.allclose(stats[..., 0].double(), o.sum(1), rtol=1e-5, atol=1e-4)
+    assert torch.allclose(stats[..., 1].double(), (o * o).sum(1), rtol=1e-5, atol=1e-4)

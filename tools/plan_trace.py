@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 KINDS = ("PACK CONV FINALIZE GN_STATS GN_FINALIZE GN_PREP GN_APPLY ATTN SINUSOID GEMV VAE_HEADS GN_FUSED WT WT_BATCH WGRAD EXPORT "
          "EXPORT_BATCH COLSUM GNB ATTN_BWD ADD SUMPOOL LIN_DX LIN_DW VAE_HEADS_BWD GEMM_LIGHT COLSUM_BATCH IM2COL "
-         "PACK32 CONV32 FIN32 GN_STATS32 GN_APPLY32 ATTN32 GEMV32 TAP BUCKET BUCKET_JOIN UPS_SPLIT32 CONV_THIN").split()
+         "PACK32 CONV32 FIN32 GN_STATS32 GN_APPLY32 ATTN32 GEMV32 TAP BUCKET BUCKET_JOIN UPS_SPLIT32 CONV_THIN FIN_GN GEMM_LIGHT32").split()
 
 
 def main():
@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--what", default="unet", choices=["unet", "enc", "dec"], help="plan: UNet forward at 24^3, or the VAE encode / decode at 96^3")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     args = ap.parse_args()
     path = os.environ.get("LDM_PLAN_TRACE")
     if not path:
@@ -33,6 +34,8 @@ def main():
     dev = torch.device("cuda:0")
     if args.what == "unet":
         unet = bench.make_unet(dev, seed=0)
+        if args.precision == "fp32":
+            unet.set_precision("fp32")
         x = torch.randn((1, 4, 24, 24, 24), device=dev)
         t = torch.tensor([500.0], device=dev)
         run = lambda: unet(x=x, timesteps=t)
