@@ -1,0 +1,215 @@
+// 3x3x3 stride-1 "same" convolution with 64 output channels over a LARGE grid: the full-resolution level of the AutoencoderKL (64 -> 64 at
+// 96^3 in the benchmark configuration, 144 x 176 x 112 in the configs[3] training step: 45 % of an encode, 39 % of a decode; the
+// reference's Encoder / Decoder ResBlocks).
+//
+// conv3_halo_kernel's 254 x 64 tile runs these at 0.27 - 0.29 of the MFMA peak: with 64 couts every voxel fragment read from LDS feeds
+// only two MFMAs per wave (0.5 fragment read per MFMA: the K loop is LDS-read bound), and the tile's rows are copied again for every
+// (kd, kh): ~2 KB of LDS-DMA per output voxel.  Here a workgroup owns a TD x TH x 16 BLOCK of output voxels and copies its
+// (TD + 2)(TH + 2) 18 input halo ONCE per 32 input channels (LDS-DMA, 64-byte voxel rows, XOR-swizzled so that the 16 voxel lanes of a
+// fragment read hit 16 distinct 16-byte slots); every wave owns one d-slice = TH voxel tiles of 16 consecutive w and ALL 64 couts, so a
+// voxel fragment feeds four MFMAs (0.25 read per MFMA) and the 27 taps re-read the block from LDS, not from L2: 2.1 x (TH = 8) the
+// input bytes per output voxel instead of 9 x.  The weights (27 x 64 x Cin, L2-resident, shared by every workgroup) go straight from
+// global memory into the A-side registers, one tap ahead.  Two (TH = 8: 68 KB of LDS) or three (TH = 4: 41 KB) workgroups per CU: one's
+// copy phase sits under the others' multiplies.
+//
+// MFMA 16x16x32, A = weights with the cout rows permuted so that a lane ends with 16 CONSECUTIVE couts of one voxel (row i of cout tile
+// ct <-> cout 16 (i >> 2) + 4 ct + (i & 3)), B = voxels.  Epilogue: bias, per-sample channel bias, residual, bf16 NDHWC store, and the
+// GroupNorm partials of the stored (rounded) values, one row per block: [N * blocks][64][2].  Cin % 32 == 0, any D / H / W (ragged
+// blocks: out-of-volume halo voxels come back as zeros from the buffer load, out-of-volume outputs are masked).
+#pragma once
+#include "common.h"
+#include "conv_igemm.h"
+
+struct BlockParams {
+    const bf16_t* x; const bf16_t* w;      // x [N][D][H][W][Cin] bf16; w packed [27][64][Cin]
+    const float* bias; const float* temb; int temb_stride;
+    const bf16_t* residual;                // [N*D*H*W][64] or null
+    bf16_t* out;                           // [N*D*H*W][64]
+    float* stats;                          // [N * td * th * tw][64][2] or null
+    int N, D, H, W, Cin;
+    int td, th, tw;                        // blocks per dimension
+};
+
+constexpr int BLK_TD = 4, BLK_TW = 16;
+template <int TH> struct BlkGeom {
+    static constexpr int HD = BLK_TD + 2, HH = TH + 2, HW = BLK_TW + 2;
+    static constexpr int HV = HD * HH * HW;                    // halo voxels (1080 | 648)
+    static constexpr int PIECES = (HV + 15) / 16;              // 1 KiB LDS-DMA pieces of 16 voxel rows x 64 B
+    static constexpr int PPW = (PIECES + 3) / 4;               // pieces per wave
+    static constexpr int LDS = PPW * 4 * 1024;                 // 69632 | 45056 bytes
+};
+
+template <int TH, int DBG = 0>      // DBG: timing experiments only (LDM_BLOCK_DBG): 1 = weights of tap 0 for every tap, 2 = no fragment re-reads, 4 = no halo copies, 8 = no MFMAs
+__global__ __launch_bounds__(256, TH == 8 ? 2 : 3) void conv3_block_kernel(const BlockParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using G = BlkGeom<TH>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    const int tid = threadIdx.x, lane = tid & 63, fr = lane & 15, fg = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int b = xcd_remap(blockIdx.x, gridDim.x);
+    const int blk = b;
+    const int bw = b % p.tw; b /= p.tw; const int bh = b % p.th; b /= p.th; const int bd = b % p.td; const int n = b / p.td;
+    const int d0 = bd * BLK_TD, h0 = bh * TH, w0 = bw * BLK_TW;
+    const unsigned row_bytes = (unsigned)p.Cin * 2u;
+    const unsigned x_bytes = (unsigned)p.N * p.D * p.H * p.W * row_bytes;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)x_bytes, 0x00020000);
+
+    // this lane's voxel of each of the wave's DMA pieces: piece q covers halo voxels 16 q .. 16 q + 15, lane = (voxel L >> 2, slot L & 3);
+    // slot s of voxel hv holds the 16-byte channel chunk s ^ ((hv >> 2) & 3)
+    unsigned a_vo[G::PPW];
+#pragma unroll
+    for (int j = 0; j < G::PPW; ++j) {
+        const int hv = (wave * G::PPW + j) * 16 + (lane >> 2);
+        const int wx = hv % G::HW, r = hv / G::HW, hy = r % G::HH, dz = r / G::HH;
+        const int gd = d0 - 1 + dz, gh = h0 - 1 + hy, gw = w0 - 1 + wx;
+        const bool ok = hv < G::HV && (unsigned)gd < (unsigned)p.D && (unsigned)gh < (unsigned)p.H && (unsigned)gw < (unsigned)p.W;
+        const unsigned vox = (unsigned)(((n * p.D + gd) * p.H + gh) * p.W + gw);
+        a_vo[j] = ok ? vox * row_bytes + (unsigned)(((lane & 3) ^ ((hv >> 2) & 3)) << 4) : 0xFFFFFFFFu;   // out of range: the load returns zeros
+    }
+    // A side: row fr of cout tile ct <-> cout 16 (fr >> 2) + 4 ct + (fr & 3); k chunk fg.  Buffer loads: the lane's byte offset stays fixed,
+    // (tap, cout tile, channel chunk) ride in the scalar offset: no vector address arithmetic in the loop
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)(27u * 64u * row_bytes), 0x00020000);
+    const int w_vo = (int)((unsigned)(16 * (fr >> 2) + (fr & 3)) * row_bytes) + 16 * fg;
+    const int wtap = 64 * (int)row_bytes;                       // bytes between two taps
+    const int wct = 4 * (int)row_bytes;                         // bytes between two cout tiles
+    // B side: halo voxel of (tile vt, tap): hv = hv_base + ((kd HH + kh + vt) HW + kw).  MFMA column fr <-> voxel w0 + wm of the tile:
+    // ds_read_b128 is serviced in lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+32), i.e. eight lanes of chunk fg and eight of
+    // chunk fg ^ 1; with the even voxels on columns 0-3 / 12-15 and the odd ones on 4-11, the four voxels of a group that share a bank
+    // quarter (hv & 3) ask for the same logical chunk, which the (hv >> 2) & 3 swizzle spreads over four slots: conflict-free (4 LDS
+    // cycles per read) at every alignment; columns in voxel order cost 8 (MI355X_MICROARCH.md, LDS)
+    const int wm = fr < 4 ? 2 * fr : fr < 12 ? 2 * (fr - 4) + 1 : 2 * (fr - 8);
+    const int hv_base = wave * G::HH * G::HW + wm;
+
+    f32x4 acc[TH][4];
+#pragma unroll
+    for (int vt = 0; vt < TH; ++vt)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[vt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int c0 = 0; c0 < p.Cin; c0 += 32) {
+        __syncthreads();                                  // the previous chunk's fragment reads are done
+        if (!(DBG & 4))
+#pragma unroll
+        for (int j = 0; j < G::PPW; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(smem + (wave * G::PPW + j) * 1024), 16, a_vo[j], c0 * 2, 0, 0);
+        // weights: three register sets, tap t in set t % 3, loaded two taps ahead (one tap of 32 MFMAs is ~0.25 us, an L2 hit ~0.5 us)
+        bf16x8 wf[3][4];
+#define BK_WLOAD(SET, TAP) do {                                                                      \
+        const int t_ = (DBG & 1) ? 0 : (TAP) < 27 ? (TAP) : 26;   /* clamped: no branch in the hot block */ \
+        const int so_ = t_ * wtap + c0 * 2;                                                          \
+        _Pragma("unroll") for (int ct = 0; ct < 4; ++ct)                                             \
+            wf[SET][ct] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_vo, so_ + ct * wct, 0)); \
+    } while (0)
+        BK_WLOAD(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        BK_WLOAD(1, 1);
+        // voxel fragments: a rolling pipeline over (tap, tile): right after the four MFMAs of tile vt are issued, xf[vt] is re-read for the
+        // NEXT tap, so every LDS read has the 28 MFMAs of the other seven tiles to land in
+#define BK_READ(HV) (*reinterpret_cast<const bf16x8*>(smem + (HV) * 64 + ((fg ^ (((HV) >> 2) & 3)) << 4)))
+        bf16x8 xf[TH];
+#pragma unroll
+        for (int vt = 0; vt < TH; ++vt) { const int hv = hv_base + vt * G::HW; xf[vt] = BK_READ(hv); }
+#pragma unroll 1
+        for (int it = 0; it < 9; ++it) {                      // it = 3 kd + kh (wave-uniform)
+            const int kd = it / 3, kh = it - 3 * kd;
+            const int itn = it < 8 ? it + 1 : 8, kdn = itn / 3, khn = itn - 3 * kdn;
+            const int hv_it = hv_base + (kd * G::HH + kh) * G::HW, hv_nx = hv_base + (kdn * G::HH + khn) * G::HW;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                BK_WLOAD((kw + 2) % 3, 3 * it + kw + 2);
+                const int hv_n = kw < 2 ? hv_it + kw + 1 : hv_nx;     // first tile of the next tap (the last tap re-reads its own rows)
+#pragma unroll
+                for (int vt = 0; vt < TH; ++vt) {
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) if (!(DBG & 8) || ct == 0) acc[vt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kw][ct], xf[vt], acc[vt][ct], 0, 0, 0);
+                    const int hv = hv_n + vt * G::HW;
+                    if (!(DBG & 2)) xf[vt] = BK_READ(hv);
+                }
+                // one scheduling region per tap: the four weight loads up front, then (4 MFMA, 1 LDS read) per tile
+                __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
+#pragma unroll
+                for (int vt = 0; vt < TH; ++vt) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            }
+        }
+#undef BK_READ
+#undef BK_WLOAD
+    }
+
+    // ---- epilogue: lane = voxel (d0 + wave, h0 + vt, w0 + wm), couts 16 fg .. 16 fg + 15 ---------------------------------------
+    const int cb = 16 * fg;
+    float add[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) add[q] = (p.bias ? p.bias[cb + q] : 0.f) + (p.temb ? p.temb[(size_t)n * p.temb_stride + cb + q] : 0.f);
+    float ssum[16], ssq[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { ssum[q] = 0.f; ssq[q] = 0.f; }
+    const int gd = d0 + wave, gw = w0 + wm;
+    const bool col_ok = gd < p.D && gw < p.W;
+#pragma unroll
+    for (int vt = 0; vt < TH; ++vt) {
+        const int gh = h0 + vt;
+        if (!col_ok || gh >= p.H) continue;
+        const size_t m = (size_t)((n * p.D + gd) * p.H + gh) * p.W + gw;
+        float v[16];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[4 * ct + r] = acc[vt][ct][r] + add[4 * ct + r];
+        if (p.residual) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const u32x4 rv = *reinterpret_cast<const u32x4*>(p.residual + m * 64 + cb + 8 * h);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v[h * 8 + 2 * q] += __uint_as_float(rv[q] << 16);
+                    v[h * 8 + 2 * q + 1] += __uint_as_float(rv[q] & 0xffff0000u);
+                }
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            u32x4 o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                o[q] = pack2bf(v[h * 8 + 2 * q], v[h * 8 + 2 * q + 1]);
+                const float lo = __uint_as_float(o[q] << 16), hi = __uint_as_float(o[q] & 0xffff0000u);
+                ssum[h * 8 + 2 * q] += lo; ssq[h * 8 + 2 * q] += lo * lo;
+                ssum[h * 8 + 2 * q + 1] += hi; ssq[h * 8 + 2 * q + 1] += hi * hi;
+            }
+            *reinterpret_cast<u32x4*>(p.out + m * 64 + cb + 8 * h) = o;
+        }
+    }
+    if (p.stats) {
+        // sum over the 16 voxel lanes of each DPP row (lanes sharing fg), then over the four waves through LDS (fixed order: reproducible)
+#define BK_ROW_ADD(X, CTRL) X += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(X), CTRL, 0xf, 0xf, true))
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            BK_ROW_ADD(ssum[q], 0x128); BK_ROW_ADD(ssum[q], 0x124); BK_ROW_ADD(ssum[q], 0x122); BK_ROW_ADD(ssum[q], 0x121);
+            BK_ROW_ADD(ssq[q], 0x128); BK_ROW_ADD(ssq[q], 0x124); BK_ROW_ADD(ssq[q], 0x122); BK_ROW_ADD(ssq[q], 0x121);
+        }
+#undef BK_ROW_ADD
+        __syncthreads();                                  // every wave is past its last fragment read: the block area is free
+        float* red = reinterpret_cast<float*>(smem);      // [wave][64][2]
+        if (fr == 0) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { red[(wave * 64 + cb + q) * 2] = ssum[q]; red[(wave * 64 + cb + q) * 2 + 1] = ssq[q]; }
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const float t = (red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid]);
+            p.stats[(size_t)blk * 128 + tid] = t;
+        }
+    }
+#endif
+}
+
+static inline bool conv_block_enabled() { static const int on = [] { const char* e = getenv("LDM_CONV_BLOCK"); return e ? atoi(e) : 1; }(); return on != 0; }
+static inline int conv_block_th() { static const int th = [] { const char* e = getenv("LDM_CONV_BLOCK_TH"); return e ? atoi(e) : 8; }(); return th == 4 ? 4 : 8; }
+// 128 -> 64 channels at 96^3: 466 us here against 456 on the 254 x 64 halo tile (four channel chunks = four exposed copy phases): the plans
+// send only Cin <= 64 here (64 -> 64: 259 vs 288 us).  LDM_CONV_BLOCK_MAX_CIN overrides.
+static inline int conv_block_max_cin() { static const int c = [] { const char* e = getenv("LDM_CONV_BLOCK_MAX_CIN"); return e ? atoi(e) : 64; }(); return c; }

@@ -38,6 +38,9 @@ __global__ __launch_bounds__(256) void conv3_thin_kernel(const ThinParams p) {
     const int d0 = bd * THIN_TD, h0 = bh * THIN_TH, w0 = bw * THIN_TW;
     const size_t xn = (size_t)n * p.D * p.H * p.W;
     const int xstride = p.x3_c ? 2 * p.x3_c : p.Cin;    // channels per voxel row of x
+    // MFMA column fr <-> voxel w0 + wm: even voxels on columns 0-3 / 12-15, odd ones on 4-11, so that the lane groups of ds_read_b128
+    // ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, +32) read conflict-free under the (hv >> 2) & 3 slot swizzle (conv_block.h)
+    const int wm = fr < 4 ? 2 * fr : fr < 12 ? 2 * (fr - 4) + 1 : 2 * (fr - 8);
     f32x4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -63,7 +66,7 @@ __global__ __launch_bounds__(256) void conv3_thin_kernel(const ThinParams p) {
         for (int k = 0; k < NIT; ++k) {
             const int e = tid + k * 256;
             const int hv = e / THIN_NC, c16 = e % THIN_NC;
-            if (e < THIN_HV * THIN_NC) *reinterpret_cast<u32x4*>(sx + hv * THIN_RB + ((c16 ^ (hv & (THIN_NC - 1))) << 4)) = hv_v[k];
+            if (e < THIN_HV * THIN_NC) *reinterpret_cast<u32x4*>(sx + hv * THIN_RB + ((c16 ^ ((hv >> 2) & (THIN_NC - 1))) << 4)) = hv_v[k];
         }
         for (int e = tid; e < 27 * 4 * THIN_NC; e += 256) {   // weights of the chunk: [tap][row 0..3][THIN_CK channels], rows >= CoutReal zero
             const int c16 = e % THIN_NC, row = (e / THIN_NC) & 3, tap = e / (4 * THIN_NC);
@@ -80,15 +83,15 @@ __global__ __launch_bounds__(256) void conv3_thin_kernel(const ThinParams p) {
             const bf16x8 wf = *reinterpret_cast<const bf16x8*>(&wv);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const int hv = ((wave + kd) * THIN_HH + (t + kh)) * THIN_HW + fr + kw;
-                const bf16x8 xf = *reinterpret_cast<const bf16x8*>(sx + hv * THIN_RB + ((fg ^ (hv & (THIN_NC - 1))) << 4));
+                const int hv = ((wave + kd) * THIN_HH + (t + kh)) * THIN_HW + wm + kw;
+                const bf16x8 xf = *reinterpret_cast<const bf16x8*>(sx + hv * THIN_RB + ((fg ^ ((hv >> 2) & (THIN_NC - 1))) << 4));
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc[t], 0, 0, 0);
             }
         }
     }
     // accumulator row 4 fg + r = cout, column fr = voxel: the real couts live in the fg == 0 lanes
     if (fg != 0) return;
-    const int gd = d0 + wave, gw = w0 + fr;
+    const int gd = d0 + wave, gw = w0 + wm;
     if (gd >= p.D || gw >= p.W) return;
     const size_t dhw = (size_t)p.D * p.H * p.W;
 #pragma unroll

@@ -28,6 +28,7 @@
 #include "conv_thin.h"
 #include "gemm_light.h"
 #include "gemm_light_x3.h"
+#include "conv_block.h"
 #include "conv_wgrad.h"
 #include "norm_elem.h"
 #include "fin_gn.h"
@@ -50,6 +51,31 @@ static int fail(int code, const char* fmt, ...) {
 
 // "has hipFuncSetAttribute been called for this kernel" is a per-DEVICE fact: launchers keep a flag per device ordinal
 static inline bool& attr_flag(bool (&tab)[32]) { int d = 0; if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 32) d = 0; return tab[d]; }
+
+static hipError_t launch_conv_block(const BlockParams& q0, int TH, hipStream_t s) {
+    BlockParams q = q0;
+    q.td = (q.D + BLK_TD - 1) / BLK_TD; q.th = (q.H + TH - 1) / TH; q.tw = (q.W + BLK_TW - 1) / BLK_TW;
+    static const int dbg = [] { const char* e = getenv("LDM_BLOCK_DBG"); return e ? atoi(e) : 0; }();
+    const unsigned grid = (unsigned)((long)q.N * q.td * q.th * q.tw);
+    static bool attr_tab[32] = {}; bool& attr_set = attr_flag(attr_tab);
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_block_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, BlkGeom<8>::LDS);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_block_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, BlkGeom<4>::LDS);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+#ifdef LDM_BLOCK_EXPERIMENTS
+#define BLK_DBG(D) if (TH == 8 && dbg == D) { static bool set_ = false; if (!set_) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_block_kernel<8, D>), hipFuncAttributeMaxDynamicSharedMemorySize, BlkGeom<8>::LDS); set_ = true; } \
+        hipLaunchKernelGGL((conv3_block_kernel<8, D>), dim3(grid), dim3(256), BlkGeom<8>::LDS, s, q); return hipGetLastError(); }
+    BLK_DBG(1) BLK_DBG(2) BLK_DBG(4) BLK_DBG(3) BLK_DBG(7) BLK_DBG(8) BLK_DBG(15)
+#undef BLK_DBG
+#endif
+    (void)dbg;
+    if (TH == 8) hipLaunchKernelGGL(conv3_block_kernel<8>, dim3(grid), dim3(256), BlkGeom<8>::LDS, s, q);
+    else hipLaunchKernelGGL(conv3_block_kernel<4>, dim3(grid), dim3(256), BlkGeom<4>::LDS, s, q);
+    return hipGetLastError();
+}
 static inline int rup(int v, int m) { return (v + m - 1) / m * m; }
 static inline size_t rup_sz(size_t v, size_t m) { return (v + m - 1) / m * m; }
 
@@ -94,7 +120,9 @@ enum OpKind { OP_PACK, OP_CONV, OP_FINALIZE, OP_GN_STATS, OP_GN_FINALIZE, OP_GN_
               OP_UPS_SPLIT32,                      // fp32 precision: nearest x2 upsample into the (hi | lo) bf16 split (upsample_split_f32_kernel)
               OP_CONV_THIN,                        // 3^3 conv with Cout <= 4 and fp32 NCDHW output: the networks' last layer (conv_thin.h)
               OP_FIN_GN,                           // split-K finalize + the GroupNorm(+SiLU) that consumes it, one launch (fin_gn.h)
-              OP_GEMM_LIGHT32 };                   // fp32 precision: 1x1 convolution as the light GEMM on fp32 operands split in registers (gemm_light_x3.h)
+              OP_GEMM_LIGHT32,
+              OP_CONV_BLOCK };                     // 3^3 conv with 64 output channels over a large grid, one halo block in LDS per workgroup (conv_block.h)
+             //                   // fp32 precision: 1x1 convolution as the light GEMM on fp32 operands split in registers (gemm_light_x3.h)
 
 struct ConvCfg { int wgm, wgn, bk, splitk; int halo = 0, mtps = 0, qps = 0; };   // halo: conv3_halo_kernel (126-row tiles)
 
@@ -733,6 +761,25 @@ struct Builder {
             plan->ops.push_back(op);
             if (recording) { Tape t; t.kind = 0; t.c = a; t.out = out; tape.push_back(t); }
             return out;
+        }
+        // 64 output channels over a large grid (the AutoencoderKL's full-resolution level): one halo block in LDS per workgroup (conv_block.h)
+        if (conv_block_enabled() && a.k == 3 && a.stride == 1 && a.pad == 1 && a.ups == 0 && !a.exact && !a.xb.valid && !a.w1 && !a.f32_out &&
+            w.cout_pad == 64 && rup(w.cout, 32) == 64 && cin0 <= conv_block_max_cin() && a.w_over.base == BASE_NULL &&
+            a.xa.D == a.Do && a.xa.H == a.Ho && a.xa.W == a.Wo) {
+            const int TH = conv_block_th();
+            const int td = (a.Do + BLK_TD - 1) / BLK_TD, th = (a.Ho + TH - 1) / TH, tw = (a.Wo + BLK_TW - 1) / BLK_TW;
+            static const long min_blocks = [] { const char* e = getenv("LDM_CONV_BLOCK_MIN"); return e ? atol(e) : 512L; }();
+            if ((long)N * td * th * tw >= min_blocks) {
+                Act out = new_act(N, a.Do, a.Ho, a.Wo, 64);
+                if (a.want_stats) { out.stats_off = pool.alloc((size_t)N * td * th * tw * 64 * 2 * 4); out.has_stats = true; out.stats_nrb = td * th * tw; }
+                Op op{}; op.kind = OP_CONV_BLOCK;
+                op.r[0] = ws_ref(a.xa.off); op.r[2] = w_ref(w.w_off); op.r[6] = a.no_bias ? Ref() : w_ref(w.b_off); op.r[8] = a.temb;
+                op.r[9] = a.residual.valid ? ws_ref(a.residual.off) : Ref(); op.r[10] = ws_ref(out.off); op.r[12] = out.has_stats ? ws_ref(out.stats_off) : Ref();
+                op.i[0] = N; op.i[1] = a.Do; op.i[2] = a.Ho; op.i[3] = a.Wo; op.i[4] = cin0; op.i[5] = TH; op.i[6] = a.temb_stride;
+                plan->ops.push_back(op);
+                if (recording) { Tape t; t.kind = 0; t.c = a; t.out = out; tape.push_back(t); }
+                return out;
+            }
         }
         const int taps = phase ? 8 : a.k * a.k * a.k;
         const bool halo_ok = a.k == 3 && a.stride == 1 && a.pad == 1 && a.ups == 0 && !a.exact && !a.xb.valid && (!a.w1 || (halo_skip_enabled() && bk == 64)) &&
@@ -2083,6 +2130,13 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                 if (!attr_set) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_thin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, THIN_LDS)); attr_set = true; }
                 hipLaunchKernelGGL(conv3_thin_kernel, dim3((unsigned)((long)q.N * q.td * q.th * q.tw)), dim3(256), THIN_LDS, s, q);
                 break; }
+            case OP_CONV_BLOCK: {       // i: N, D, H, W, Cin, TH, temb stride
+                BlockParams q{}; q.x = (const bf16_t*)rp(bs, o.r[0]); q.w = (const bf16_t*)rp(bs, o.r[2]); q.bias = (const float*)rp(bs, o.r[6]);
+                q.temb = (const float*)rp(bs, o.r[8]); q.temb_stride = i[6]; q.residual = (const bf16_t*)rp(bs, o.r[9]); q.out = (bf16_t*)rp(bs, o.r[10]);
+                q.stats = (float*)rp(bs, o.r[12]); q.N = i[0]; q.D = i[1]; q.H = i[2]; q.W = i[3]; q.Cin = i[4];
+                if (!q.w) return fail(LDM_ERR_NOT_LOADED, "the weight arena is empty");
+                HIP_TRY(launch_conv_block(q, i[5], s));
+                break; }
             case OP_UPS_SPLIT32: {      // i: N, C, D, H, W of the source, upsample (1) or same size (0)
                 hipLaunchKernelGGL(upsample_split_f32_kernel, dim3(grid_for(((long)i[0] * i[2] * i[3] * i[4] << (3 * i[5])) * (i[1] / 4), 256, 4096)), dim3(256), 0, s,
                                    (const float*)rp(bs, o.r[0]), (bf16_t*)rp(bs, o.r[1]), i[0], i[1], i[2], i[3], i[4], i[5]);
@@ -3274,13 +3328,16 @@ int ldm_profile_stop(double out[5]) {
     g_prof.ev.clear(); g_prof.used = 0; g_prof.flops.clear();
     return 0;
 }
-/* Tile configuration the planner chose for each conv of a cached plan: fills cfgs[4*i..] = {wgm, wgn, bk, splitk} */
+/* Tile configuration the planner chose for each conv of a cached plan: fills cfgs[4*i..] = {wgm, wgn, bk | halo << 8, splitk} */
 int ldm_model_plan_conv_cfgs(ldm_model* m, const char* kind, int B, int D, int H, int W, int* cfgs, int max_convs) {
     if (!m || !kind) return fail(LDM_ERR_BAD_ARG, "null argument");
     std::shared_ptr<Plan> p; LDM_TRY(get_plan(m, kind, B, D, H, W, &p));
     int n = 0;
     for (const Op& o : p->ops) if (o.kind == OP_CONV) {
         if (cfgs && n < max_convs) { cfgs[4 * n] = o.cc.wgm; cfgs[4 * n + 1] = o.cc.wgn; cfgs[4 * n + 2] = o.cc.bk | (o.cc.halo << 8); cfgs[4 * n + 3] = o.cc.splitk; }
+        ++n;
+    } else if (o.kind == OP_CONV_BLOCK) {            // conv3_block_kernel: reported as a 4 x 1 tile, 32-channel chunks, halo = 3
+        if (cfgs && n < max_convs) { cfgs[4 * n] = 4; cfgs[4 * n + 1] = 1; cfgs[4 * n + 2] = 32 | (3 << 8); cfgs[4 * n + 3] = 1; }
         ++n;
     }
     return n;
@@ -3308,6 +3365,24 @@ static int ensure_zero_page() {
 
 // stats (optional): GroupNorm partial slabs of the bf16 output, exactly as the plans request them from the producing kernel;
 // *stats_nrb receives the slab rows per sample.  With stats the split-K finalize is the write-through variant the plans launch.
+/* 3x3x3 stride-1 pad-1 convolution with 64 output channels as conv3_block_kernel (conv_block.h; the plans pick it for the AutoencoderKL's
+ * full-resolution level): x [N][D][H][W][cin] bf16, w packed [27][64][cin] bf16, out [N*D*H*W][64] bf16; bias [64], temb [N][temb_stride],
+ * residual [N*D*H*W][64] optional.  stats (optional): [N * rows][64][2] per-block (sum, sum of squares) of the stored values,
+ * rows = ldm_op_conv3d_block_stats_rows(D, H, W, th); th = 8 (4 x 8 x 16 blocks) or 4 (4 x 4 x 16). */
+int ldm_op_conv3d_block_stats_rows(int D, int H, int W, int th) {
+    if (th != 4 && th != 8) return 0;
+    return ((D + BLK_TD - 1) / BLK_TD) * ((H + th - 1) / th) * ((W + BLK_TW - 1) / BLK_TW);
+}
+int ldm_op_conv3d_block(const void* x, int cin, const void* w, const float* bias, const float* temb, int temb_stride, const void* residual,
+                        void* out, float* stats, int N, int D, int H, int W, int th, void* stream) {
+    if (!x || !w || !out || N < 1 || D < 1 || H < 1 || W < 1 || cin < 32 || cin % 32 || (th != 4 && th != 8)) return fail(LDM_ERR_BAD_ARG, "bad argument");
+    if ((long)N * D * H * W * cin * 2 >= (1L << 32)) return fail(LDM_ERR_BAD_ARG, "the input tensor exceeds 4 GiB (split the batch)");
+    BlockParams q{}; q.x = (const bf16_t*)x; q.w = (const bf16_t*)w; q.bias = bias; q.temb = temb; q.temb_stride = temb_stride;
+    q.residual = (const bf16_t*)residual; q.out = (bf16_t*)out; q.stats = stats; q.N = N; q.D = D; q.H = H; q.W = W; q.Cin = cin;
+    HIP_TRY(launch_conv_block(q, th, (hipStream_t)stream));
+    return 0;
+}
+
 static int op_conv3d_impl(const void* xa, int ca, const void* xb, int cb, const void* w, const float* bias,
                           const void* x1a, int c1a, const void* x1b, int c1b, const void* w1, const float* bias2,
                           const float* temb, int temb_stride, const void* residual, void* out_bf16, float* out_f32,

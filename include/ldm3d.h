@@ -235,6 +235,13 @@ int ldm_op_conv3d(const void* xa, int ca, const void* xb, int cb, const void* w,
 /* ---- training building blocks (backward of train_diffusion.py:207-219) ----------------
  *      data gradient of a conv = ldm_op_conv3d on dY with flipped + transposed weights (ldm_op_weight_flip_transpose),
  *      pad' = k-1-pad; for a stride-2 forward conv pass ups = 2 (zero-insertion upsample: odd tap positions read 0). */
+/*      the same 3^3 stride-1 pad-1 convolution for 64 OUTPUT channels over a large grid (the AutoencoderKL's full-resolution ResBlocks:
+ *      3d_ldm/train_autoencoder.py:139-148 construction; Encoder / Decoder blocks at num_channels[0] = 64), conv3_block_kernel: one
+ *      (4, th, 16) block of output voxels per workgroup, its input halo copied into LDS once per 32 input channels.  x [N][D][H][W][cin],
+ *      w packed [27][64][cin], out [N*D*H*W][64]; stats (optional) [N * rows][64][2], rows = ldm_op_conv3d_block_stats_rows; th = 8 | 4. */
+int ldm_op_conv3d_block_stats_rows(int D, int H, int W, int th);
+int ldm_op_conv3d_block(const void* x, int cin, const void* w, const float* bias, const float* temb, int temb_stride, const void* residual,
+                        void* out, float* stats, int N, int D, int H, int W, int th, void* stream);
 int ldm_op_weight_flip_transpose(const void* w, void* wt, int ksize, int cout, int cout_pad, int cin, void* stream);
 /*      weight gradient: dw[tap][co][ci] (fp32) = sum_m dy[m][co] * x[src(m, tap)][ci]; deterministic (no atomics).
  *      ksplit > 1 splits the voxel range over workgroups: dw = ksplit partial matrices [ksplit][k^3][cout][cin] to sum. */
@@ -323,7 +330,8 @@ int ldm_op_attention_bwd(const void* qkv, const void* o, const void* d_o, const 
 /* ---- measurement support (bench.py): HIP events around every launch of ONE conv tile configuration
  *      (wgm x wgn waves, K depth bk), recorded on the launch stream.  stop() fills
  *      out = {instrumented launches, their total ms, their algorithmic FLOPs, all conv launches, all conv FLOPs}.
- *      plan_conv_cfgs lists the {wgm, wgn, bk, splitk} the planner chose per conv of a plan ("unet"|"enc"|"dec"). -- */
+ *      plan_conv_cfgs lists the {wgm, wgn, bk | halo << 8, splitk} the planner chose per conv of a plan ("unet"|"enc"|"dec");
+ *      halo: 0 = conv_igemm_kernel, 1 / 2 = conv3_halo_kernel (126 x 128 / 254 x 64 tiles), 3 = conv3_block_kernel. -- */
 int ldm_profile_start(int wgm, int wgn, int bk, int max_launches);
 int ldm_profile_detail(double* flops, double* ms, int max);   /* per instrumented launch; call before ldm_profile_stop; returns their number */
 int ldm_profile_stop(double out[5]);

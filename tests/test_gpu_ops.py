@@ -597,3 +597,51 @@ def test_split_k_conv_then_fused_finalize_group_norm(cuda, built_lib, cin, cout,
     fused(xs[0], ra, None, outs[0], C.byref(err))
     assert err.value == 0 and torch.equal(outs[0], first[0]) and not torch.equal(first[0], first[1])
     print(f"fused finalize + GroupNorm {cin}->{cout} {dims} n={n} splitk={splitk} groups={groups}: pair {worst:.2e}")
+
+
+@pytest.mark.parametrize("cin,cout,dims,n,th,temb,residual", [
+    (64, 64, (8, 16, 32), 1, 8, False, False),      # whole blocks
+    (64, 64, (8, 16, 32), 1, 4, False, True),
+    (128, 64, (5, 11, 20), 2, 8, True, True),       # ragged in every dimension, two samples, four channel chunks
+    (32, 40, (3, 3, 3), 1, 4, True, False),         # smaller than one block; real couts < 64 (padding written as zeros)
+    (64, 64, (4, 9, 17), 1, 8, False, False),       # one voxel past a block edge in h and w
+])
+def test_conv3_block_kernel(cuda, built_lib, cin, cout, dims, n, th, temb, residual):
+    """conv3_block_kernel (64 output channels, one halo block in LDS per workgroup: the AutoencoderKL's full-resolution ResBlock convs)
+    against F.conv3d on the same bf16-rounded operands; its per-block GroupNorm partials are the sums of the stored values."""
+    from ldm3d import _lib
+    g = torch.Generator().manual_seed(cin + dims[2] + th)
+    x = torch.randn((n, cin, *dims), generator=g)
+    w = torch.randn((cout, cin, 3, 3, 3), generator=g) / (cin * 27) ** 0.5
+    b = 0.1 * torch.randn((cout,), generator=g)
+    ref = F.conv3d(bf16_round(x), bf16_round(w), b, padding=1)
+    te = None
+    if temb:
+        tv = torch.randn((n, 64), generator=g)
+        tv[:, cout:] = 0.0                       # like the bias and the weight rows: padding channels carry zeros
+        ref = ref + tv[:, :cout, None, None, None]
+        te = tv.to(cuda)
+    res = None
+    if residual:
+        rv = bf16_round(torch.randn(ref.shape, generator=g))
+        ref = ref + rv
+        res = to_ndhwc_bf16(rv, 64).to(cuda)
+    xa = to_ndhwc_bf16(x).to(cuda)
+    wp = pack_conv_weight(w, cin, 64).to(cuda)
+    bp = pad_vec(b, 64).to(cuda)
+    rows = built_lib.ldm_op_conv3d_block_stats_rows(*dims, th)
+    out = torch.full((n, *dims, 64), float("nan"), dtype=torch.bfloat16, device=cuda)
+    stats = torch.full((n * rows, 64, 2), float("nan"), device=cuda)
+    _lib.check(built_lib.ldm_op_conv3d_block(xa.data_ptr(), cin, wp.data_ptr(), bp.data_ptr(), None if te is None else te.data_ptr(), 64,
+                                             None if res is None else res.data_ptr(), out.data_ptr(), stats.data_ptr(), n, *dims, th,
+                                             torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()
+    err = rel_l2(from_ndhwc(out.cpu(), cout), bf16_round(ref))
+    assert err <= TOL_SAME_ROUNDING, err
+    if cout < 64:
+        assert float(out[..., cout:].float().abs().max()) == 0.0, "channel padding must be written as zeros"
+    o = out.double().view(n, -1, 64)
+    tot = stats.double().view(n, rows, 64, 2).sum(1)
+    assert torch.allclose(tot[..., 0], o.sum(1), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(tot[..., 1], (o * o).sum(1), rtol=1e-4, atol=1e-2)
