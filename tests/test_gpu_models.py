@@ -492,3 +492,84 @@ print(json.dumps({"sum": float(a.double().sum()), "abs": float(a.double().abs().
     assert recs["0"]["replays_equal"] and recs["1"]["replays_equal"]
     assert recs["1"]["launches"] <= recs["0"]["launches"] - 15
     assert rel <= 5e-2                       # two correct bf16 evaluations of this network (statistics folded in another order): its noise floor
+
+
+def test_block_conv_plans_match_the_halo_plans_forward_and_gradients(cuda):
+    """conv3_block_kernel inside the launch plans (inference AND training: forward convs, data-gradient convs, GroupNorm partials per block):
+    an AutoencoderKL with 64 channels at full resolution on a ragged 12 x 20 x 24 volume, batch 2, with the kernel forced on
+    (LDM_CONV_BLOCK_MIN=1; the plans use it from 512 blocks up) against the same run with LDM_CONV_BLOCK=0.  Both are bf16 evaluations with
+    the same rounding points: they agree to the network's bf16 floor, and both sit equally close to the fp32 CPU oracle.  Child processes: the knobs are read
+    once per process."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import json, sys, torch
+import torch.nn.functional as F
+sys.path.insert(0, "tests")
+from ldm3d import _lib
+from ldm3d.networks import AutoencoderKL
+from oracle import autoencoder as oa
+from oracle.unet import init_state_dict
+cfg = dict(spatial_dims=3, in_channels=1, out_channels=1, latent_channels=4, channels=[64, 64, 128], num_res_blocks=[2, 1, 1],
+           norm_num_groups=16, norm_eps=1e-6, attention_levels=[False, False, False], with_encoder_nonlocal_attn=False,
+           with_decoder_nonlocal_attn=False)
+sd = init_state_dict(oa.ae_param_shapes(cfg), 3, gain=0.7)
+g = torch.Generator().manual_seed(4)
+dims = (12, 20, 24)
+x = torch.rand((2, 1, *dims), generator=g)
+eps = torch.randn((2, 4, 3, 5, 6), generator=g)
+dev = torch.device("cuda:0")
+m = AutoencoderKL(**cfg); m.load_state_dict(sd); m = m.to(dev)
+m.eval()
+with torch.no_grad():
+    mu, sig = m.encode(x.to(dev))
+    rec = m.decode(mu)
+L = _lib.lib()
+buf = (__import__("ctypes").c_int * 2048)()
+n = L.ldm_model_plan_conv_cfgs(m._h, b"enc", 2, *dims, buf, 512)
+blocks = sum(1 for i in range(n) if (buf[4 * i + 2] >> 8) == 3)
+m.train()
+recon, mu2, sigma2 = m(x.to(dev), eps=eps.to(dev))
+loss = F.l1_loss(recon, x.to(dev)) + 1e-3 * oa.kl_loss(mu2, sigma2).mean()
+loss.backward()
+torch.cuda.synchronize()
+names = sorted(k for k, _ in m.named_parameters())
+got = dict(m.named_parameters())
+grads = torch.cat([got[k].grad.reshape(-1) for k in names]).double().cpu()
+# the fp32 CPU oracle of the same forward / loss / gradients
+leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+o_rec, o_mu, o_sigma = oa.forward(leaves, cfg, x, eps, emulate_bf16=False)
+o_loss = F.l1_loss(o_rec, x) + 1e-3 * oa.kl_loss(o_mu, o_sigma).mean()
+o_loss.backward()
+o_grads = torch.cat([leaves[k].grad.reshape(-1) for k in names]).double()
+with torch.no_grad():
+    o_dec = oa.decode(sd, cfg, oa.encode(sd, cfg, x)[0])
+rel = lambda a, b: float((a.double().cpu() - b.double()).norm() / b.double().norm())
+print(json.dumps({"blocks": blocks, "rec": rec.flatten()[::7].double().cpu().tolist(), "mu": mu.flatten().double().cpu().tolist(),
+                  "loss": float(loss), "grads": grads[::11].tolist(), "gnorm": float(grads.norm()),
+                  "e_rec": rel(rec, o_dec), "e_mu": rel(mu, o_mu.detach()), "e_grads": rel(grads, o_grads), "o_loss": float(o_loss)}))
+'''
+    recs = {}
+    for tag, env in (("halo", {"LDM_CONV_BLOCK": "0"}), ("block", {"LDM_CONV_BLOCK_MIN": "1"})):
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        recs[tag] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert recs["halo"]["blocks"] == 0 and recs["block"]["blocks"] >= 3, (recs["halo"]["blocks"], recs["block"]["blocks"])
+    errs = {}
+    for k in ("rec", "mu", "grads"):
+        a, b = torch.tensor(recs["halo"][k], dtype=torch.float64), torch.tensor(recs["block"][k], dtype=torch.float64)
+        errs[k] = float((a - b).norm() / a.norm())
+    print(f"block-conv plans vs halo plans: decode {errs['rec']:.2e}, latent mean {errs['mu']:.2e}, parameter gradients {errs['grads']:.2e}; "
+          f"{recs['block']['blocks']} block launches in the encoder plan")
+    h, b = recs["halo"], recs["block"]
+    print(f"  vs the fp32 CPU oracle, halo / block plans: decode(encode) {h['e_rec']:.2e} / {b['e_rec']:.2e}, latent mean {h['e_mu']:.2e} / "
+          f"{b['e_mu']:.2e}, parameter gradients {h['e_grads']:.2e} / {b['e_grads']:.2e}; loss {h['loss']:.5f} / {b['loss']:.5f} / oracle {h['o_loss']:.5f}")
+    # two bf16 evaluations of one network differ by its rounding floor (same rounding points, other summation order inside a conv); what
+    # must hold is that the block plans sit as close to the fp32 oracle as the halo plans do
+    for k in ("e_rec", "e_mu", "e_grads"):
+        assert b[k] <= 1.3 * h[k] + 2e-3, (k, h[k], b[k])
+    assert errs["rec"] <= 2.0 * h["e_rec"] + 2e-3 and errs["mu"] <= 2.0 * h["e_mu"] + 2e-3 and errs["grads"] <= 2.0 * h["e_grads"] + 2e-3, errs
+    assert abs(h["loss"] - b["loss"]) <= 5e-3 * abs(h["loss"])
