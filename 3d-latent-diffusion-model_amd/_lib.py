@@ -134,6 +134,7 @@ SIGNATURES = {
     "ldm_op_leaky_relu_f32": (C.c_int, [_P, _P, C.c_int64, C.c_float, _P]),
     "ldm_op_leaky_relu_bwd_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_float, _P]),
     "ldm_op_gemm_f32": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, _P]),
+    "ldm_debug_conv_block_slots": (C.c_int, [C.c_int]),
     "ldm_op_conv3d_block_stats_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "ldm_op_conv3d_block": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "ldm_op_linear_f32x3": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, _P]),

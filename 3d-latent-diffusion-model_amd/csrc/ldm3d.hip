@@ -52,28 +52,40 @@ static int fail(int code, const char* fmt, ...) {
 // "has hipFuncSetAttribute been called for this kernel" is a per-DEVICE fact: launchers keep a flag per device ordinal
 static inline bool& attr_flag(bool (&tab)[32]) { int d = 0; if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 32) d = 0; return tab[d]; }
 
+static int g_block_slots = 0;                                  // ldm_debug_conv_block_slots: tests walk the tile loop on small volumes
 static hipError_t launch_conv_block(const BlockParams& q0, int TH, hipStream_t s) {
     BlockParams q = q0;
     q.td = (q.D + BLK_TD - 1) / BLK_TD; q.th = (q.H + TH - 1) / TH; q.tw = (q.W + BLK_TW - 1) / BLK_TW;
+    const long tiles = (long)q.N * q.td * q.th * q.tw;
     static const int dbg = [] { const char* e = getenv("LDM_BLOCK_DBG"); return e ? atoi(e) : 0; }();
-    const unsigned grid = (unsigned)((long)q.N * q.td * q.th * q.tw);
+    // the tile-loop form (two workgroups per CU walk the tiles, the next tile's first halo copy issued before the epilogue) is built and tested but
+    // OFF: 280 vs 255 us at 96^3 (AutoencoderKL encode 2.49 vs 2.35 ms).  A static share of 3 or 4 tiles per workgroup loses what the hardware
+    // dispatcher gives the one-tile form for free: the next tile goes to whichever CU frees a slot first.
+    static const int persist = [] { const char* e = getenv("LDM_CONV_BLOCK_PERSIST"); return e ? atoi(e) : 0; }();
+    static int cus_tab[32] = {};
+    int dev_ = 0; if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 32) dev_ = 0;
+    if (!cus_tab[dev_]) { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev_) != hipSuccess) return hipErrorUnknown; cus_tab[dev_] = pr.multiProcessorCount / 8 * 8; if (cus_tab[dev_] < 8) cus_tab[dev_] = 8; }
     static bool attr_tab[32] = {}; bool& attr_set = attr_flag(attr_tab);
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_block_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, BlkGeom<8>::LDS);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_block_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, BlkGeom<4>::LDS);
-        if (e != hipSuccess) return e;
+#define BLK_ATTR(...) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_block_kernel<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, BlkGeom<8>::LDS_ALL); if (e != hipSuccess) return e; }
+        BLK_ATTR(8, 0, false) BLK_ATTR(8, 0, true) BLK_ATTR(4, 0, false)
+#ifdef LDM_BLOCK_EXPERIMENTS
+        BLK_ATTR(8, 1, false) BLK_ATTR(8, 2, false) BLK_ATTR(8, 4, false) BLK_ATTR(8, 3, false) BLK_ATTR(8, 7, false) BLK_ATTR(8, 8, false) BLK_ATTR(8, 15, false)
+#endif
+#undef BLK_ATTR
         attr_set = true;
     }
+    const unsigned grid = (unsigned)tiles;
 #ifdef LDM_BLOCK_EXPERIMENTS
-#define BLK_DBG(D) if (TH == 8 && dbg == D) { static bool set_ = false; if (!set_) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_block_kernel<8, D>), hipFuncAttributeMaxDynamicSharedMemorySize, BlkGeom<8>::LDS); set_ = true; } \
-        hipLaunchKernelGGL((conv3_block_kernel<8, D>), dim3(grid), dim3(256), BlkGeom<8>::LDS, s, q); return hipGetLastError(); }
+#define BLK_DBG(D) if (TH == 8 && dbg == D) { hipLaunchKernelGGL((conv3_block_kernel<8, D, false>), dim3(grid), dim3(256), BlkGeom<8>::LDS_ALL, s, q); return hipGetLastError(); }
     BLK_DBG(1) BLK_DBG(2) BLK_DBG(4) BLK_DBG(3) BLK_DBG(7) BLK_DBG(8) BLK_DBG(15)
 #undef BLK_DBG
 #endif
     (void)dbg;
-    if (TH == 8) hipLaunchKernelGGL(conv3_block_kernel<8>, dim3(grid), dim3(256), BlkGeom<8>::LDS, s, q);
-    else hipLaunchKernelGGL(conv3_block_kernel<4>, dim3(grid), dim3(256), BlkGeom<4>::LDS, s, q);
+    const long slots = g_block_slots > 0 ? g_block_slots : 2L * cus_tab[dev_];     // two workgroups per CU
+    if (TH == 8 && persist && tiles > slots) hipLaunchKernelGGL((conv3_block_kernel<8, 0, true>), dim3((unsigned)slots), dim3(256), BlkGeom<8>::LDS_ALL, s, q);
+    else if (TH == 8) hipLaunchKernelGGL((conv3_block_kernel<8, 0, false>), dim3(grid), dim3(256), BlkGeom<8>::LDS_ALL, s, q);
+    else hipLaunchKernelGGL((conv3_block_kernel<4, 0, false>), dim3(grid), dim3(256), BlkGeom<4>::LDS_ALL, s, q);
     return hipGetLastError();
 }
 static inline int rup(int v, int m) { return (v + m - 1) / m * m; }
@@ -3369,6 +3381,8 @@ static int ensure_zero_page() {
  * full-resolution level): x [N][D][H][W][cin] bf16, w packed [27][64][cin] bf16, out [N*D*H*W][64] bf16; bias [64], temb [N][temb_stride],
  * residual [N*D*H*W][64] optional.  stats (optional): [N * rows][64][2] per-block (sum, sum of squares) of the stored values,
  * rows = ldm_op_conv3d_block_stats_rows(D, H, W, th); th = 8 (4 x 8 x 16 blocks) or 4 (4 x 4 x 16). */
+/* tests only: the grid of conv3_block_kernel's tile loop (0 = two workgroups per CU); returns the previous value */
+int ldm_debug_conv_block_slots(int slots) { const int old = g_block_slots; g_block_slots = slots < 0 ? 0 : slots; return old; }
 int ldm_op_conv3d_block_stats_rows(int D, int H, int W, int th) {
     if (th != 4 && th != 8) return 0;
     return ((D + BLK_TD - 1) / BLK_TD) * ((H + th - 1) / th) * ((W + BLK_TW - 1) / BLK_TW);

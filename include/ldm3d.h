@@ -240,6 +240,8 @@ int ldm_op_conv3d(const void* xa, int ca, const void* xb, int cb, const void* w,
  *      (4, th, 16) block of output voxels per workgroup, its input halo copied into LDS once per 32 input channels.  x [N][D][H][W][cin],
  *      w packed [27][64][cin], out [N*D*H*W][64]; stats (optional) [N * rows][64][2], rows = ldm_op_conv3d_block_stats_rows; th = 8 | 4. */
 int ldm_op_conv3d_block_stats_rows(int D, int H, int W, int th);
+/* tests only: number of workgroups of conv3_block_kernel's tile loop (0 = default: two per CU; a multiple of 8); returns the previous value */
+int ldm_debug_conv_block_slots(int slots);
 int ldm_op_conv3d_block(const void* x, int cin, const void* w, const float* bias, const float* temb, int temb_stride, const void* residual,
                         void* out, float* stats, int N, int D, int H, int W, int th, void* stream);
 int ldm_op_weight_flip_transpose(const void* w, void* wt, int ksize, int cout, int cout_pad, int cin, void* stream);

@@ -599,14 +599,18 @@ def test_split_k_conv_then_fused_finalize_group_norm(cuda, built_lib, cin, cout,
     print(f"fused finalize + GroupNorm {cin}->{cout} {dims} n={n} splitk={splitk} groups={groups}: pair {worst:.2e}")
 
 
-@pytest.mark.parametrize("cin,cout,dims,n,th,temb,residual", [
-    (64, 64, (8, 16, 32), 1, 8, False, False),      # whole blocks
-    (64, 64, (8, 16, 32), 1, 4, False, True),
-    (128, 64, (5, 11, 20), 2, 8, True, True),       # ragged in every dimension, two samples, four channel chunks
-    (32, 40, (3, 3, 3), 1, 4, True, False),         # smaller than one block; real couts < 64 (padding written as zeros)
-    (64, 64, (4, 9, 17), 1, 8, False, False),       # one voxel past a block edge in h and w
+@pytest.mark.parametrize("cin,cout,dims,n,th,temb,residual,slots", [
+    (64, 64, (8, 16, 32), 1, 8, False, False, 0),      # whole blocks
+    (64, 64, (8, 16, 32), 1, 4, False, True, 0),
+    (128, 64, (5, 11, 20), 2, 8, True, True, 0),       # ragged in every dimension, two samples, four channel chunks
+    (32, 40, (3, 3, 3), 1, 4, True, False, 0),         # smaller than one block; real couts < 64 (padding written as zeros)
+    (64, 64, (4, 9, 17), 1, 8, False, False, 0),       # one voxel past a block edge in h and w
+    (64, 64, (9, 20, 40), 2, 8, True, True, 8),        # the tile loop: 54 tiles on 8 workgroups (7 / 6 tiles each), ragged, two samples
+    (32, 64, (8, 16, 32), 1, 8, False, False, 16),     # the tile loop with a tile count that is no multiple of the grid... 8 tiles on 16: falls back to one tile per workgroup
+    (96, 64, (12, 8, 16), 1, 8, False, True, 8),       # three channel chunks per tile, 3 tiles on 8 workgroups -> one-tile form
+    (96, 64, (12, 24, 48), 1, 8, False, True, 8),      # three chunks, 27 tiles on 8 workgroups
 ])
-def test_conv3_block_kernel(cuda, built_lib, cin, cout, dims, n, th, temb, residual):
+def test_conv3_block_kernel(cuda, built_lib, cin, cout, dims, n, th, temb, residual, slots):
     """conv3_block_kernel (64 output channels, one halo block in LDS per workgroup: the AutoencoderKL's full-resolution ResBlock convs)
     against F.conv3d on the same bf16-rounded operands; its per-block GroupNorm partials are the sums of the stored values."""
     from ldm3d import _lib
@@ -632,10 +636,14 @@ def test_conv3_block_kernel(cuda, built_lib, cin, cout, dims, n, th, temb, resid
     rows = built_lib.ldm_op_conv3d_block_stats_rows(*dims, th)
     out = torch.full((n, *dims, 64), float("nan"), dtype=torch.bfloat16, device=cuda)
     stats = torch.full((n * rows, 64, 2), float("nan"), device=cuda)
-    _lib.check(built_lib.ldm_op_conv3d_block(xa.data_ptr(), cin, wp.data_ptr(), bp.data_ptr(), None if te is None else te.data_ptr(), 64,
-                                             None if res is None else res.data_ptr(), out.data_ptr(), stats.data_ptr(), n, *dims, th,
-                                             torch.cuda.current_stream().cuda_stream))
-    torch.cuda.synchronize()
+    prev = built_lib.ldm_debug_conv_block_slots(slots)
+    try:
+        _lib.check(built_lib.ldm_op_conv3d_block(xa.data_ptr(), cin, wp.data_ptr(), bp.data_ptr(), None if te is None else te.data_ptr(), 64,
+                                                 None if res is None else res.data_ptr(), out.data_ptr(), stats.data_ptr(), n, *dims, th,
+                                                 torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+    finally:
+        built_lib.ldm_debug_conv_block_slots(prev)
     assert torch.isfinite(out.float()).all()
     err = rel_l2(from_ndhwc(out.cpu(), cout), bf16_round(ref))
     assert err <= TOL_SAME_ROUNDING, err
