@@ -137,6 +137,7 @@ SIGNATURES = {
     "ldm_debug_conv_block_slots": (C.c_int, [C.c_int]),
     "ldm_op_conv3d_block_stats_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "ldm_op_conv3d_block": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "ldm_op_conv3d_block128": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "ldm_op_linear_f32x3": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, _P]),
     "ldm_op_gemm_wgrad_f32": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, C.c_int, C.c_int64, C.c_int, _P]),
     "ldm_op_group_norm_f32_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -248,6 +248,194 @@ __global__ __launch_bounds__(256, TH == 8 ? 2 : 3) void conv3_block_kernel(const
 #endif
 }
 
+// ---- the same block scheme for 128 OUTPUT channels (the AutoencoderKL's half-resolution level: 128 -> 128 at 48^3, 19 % of an encode + decode on
+// conv3_halo_kernel's 126 x 128 tile at 0.28 - 0.31 of the MFMA peak).  One workgroup of EIGHT waves per CU: wave = (d-slice w & 3, cout half
+// w >> 2), so two waves read every voxel fragment (still 0.25 LDS reads per MFMA per wave) and each loads the weights of its 64 couts.  With one
+// workgroup per CU nobody else covers a copy phase, so the halo chunk is DOUBLE-BUFFERED (2 x 72 KiB): the copy of chunk c + 1 is issued at the
+// top of the K loop of chunk c (nine 1 KiB pieces per wave; spreading them one per (kd, kh) over the loop measured the same: 130.5 us either
+// way, the copies are not what this kernel waits for).  Only a tile's first chunk is exposed.
+// Measured at 48^3 (tools/bench_conv_block.py, random data): 64 -> 128: 70 vs 80 us on the halo tile; 128 -> 128: 131 vs 125; 256 -> 128: 243 vs
+// 212 -- per MFMA it runs at the 64-cout kernel's rate (0.30 of peak), the halo tile gains with K.  Inside the AutoencoderKL (same-box A/B,
+// Cin <= 128 here): encode 2.37 -> 2.34 ms, decode 3.30 -> 3.27 ms (fewer GroupNorm partial rows behind it).
+#ifndef BLK128_BURST_AT
+#define BLK128_BURST_AT 0
+#endif
+struct Blk128 {
+    static constexpr int TH = 8;
+    using G = BlkGeom<8>;
+    static constexpr int PPW = 9;                              // pieces per wave per chunk: 8 x 9 = 72 >= 68
+    static constexpr int BUF = 8 * PPW * 1024;                 // 73728 bytes per buffer (pieces 68 .. 71 hold zeros)
+    static constexpr int LDS_ALL = 2 * BUF + 8 * 64 * 2 * 4;   // + the GroupNorm fold [wave][64][2]: 151552 bytes
+};
+
+__global__ __launch_bounds__(512, 1) void conv3_block128_kernel(const BlockParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using G = Blk128::G;
+    constexpr int TH = 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    const int tid = threadIdx.x, lane = tid & 63, fr = lane & 15, fg = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ds = wave & 3, ch = wave >> 2;
+    const int ntiles = p.N * p.td * p.th * p.tw;
+    const unsigned row_bytes = (unsigned)p.Cin * 2u;
+    const unsigned x_bytes = (unsigned)p.N * p.D * p.H * p.W * row_bytes;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)(27u * 128u * row_bytes), 0x00020000);
+    const int w_vo = (int)((unsigned)(64 * ch + 16 * (fr >> 2) + (fr & 3)) * row_bytes) + 16 * fg;
+    const int wtap = 128 * (int)row_bytes;
+    const int wct = 4 * (int)row_bytes;
+    const int wm = fr < 4 ? 2 * fr : fr < 12 ? 2 * (fr - 4) + 1 : 2 * (fr - 8);       // column map of conv3_block_kernel
+    const int hv_base = ds * G::HH * G::HW + wm;
+
+    int b_ = xcd_remap(blockIdx.x, ntiles);
+    const int blk = b_;
+    const int bw_ = b_ % p.tw; b_ /= p.tw; const int bh_ = b_ % p.th; b_ /= p.th; const int bd_ = b_ % p.td; const int n = b_ / p.td;
+    const int d0 = bd_ * BLK_TD, h0 = bh_ * TH, w0 = bw_ * BLK_TW;
+    // piece J of this wave (halo voxels 16 q .. 16 q + 15, q = wave + 8 J) of channel chunk C0 into buffer at byte offset BO
+#define B8_PIECE(BO, C0, J) do {                                                                      \
+        int lane_c = lane; asm volatile("" : "+v"(lane_c));                                           \
+        const int q_ = wave + 8 * (J);                                                                \
+        const int hv = q_ * 16 + (lane_c >> 2);                                                       \
+        const int wx = hv % G::HW, r = hv / G::HW, hy = r % G::HH, dz = r / G::HH;                    \
+        const int gd = d0 - 1 + dz, gh = h0 - 1 + hy, gw = w0 - 1 + wx;                               \
+        const bool ok = hv < G::HV && (unsigned)gd < (unsigned)p.D && (unsigned)gh < (unsigned)p.H && (unsigned)gw < (unsigned)p.W; \
+        const unsigned vox = (unsigned)(((n * p.D + gd) * p.H + gh) * p.W + gw);                      \
+        const unsigned vo = ok ? vox * row_bytes + (unsigned)(((lane_c & 3) ^ ((hv >> 2) & 3)) << 4) : 0xFFFFFFFFu; \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(smem + (BO) + q_ * 1024), 16, vo, (C0) * 2, 0, 0); \
+    } while (0)
+
+    f32x4 acc[TH][4];
+#pragma unroll
+    for (int vt = 0; vt < TH; ++vt)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[vt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int j = 0; j < Blk128::PPW; ++j) B8_PIECE(0, 0, j);
+    int cur = 0;                                              // byte offset of the buffer being read
+    for (int c0 = 0; c0 < p.Cin; c0 += 32) {
+        const bool more = c0 + 32 < p.Cin;                    // wave-uniform
+        const int nxt = Blk128::BUF - cur;
+        bf16x8 wf[3][4];
+#define B8_WLOAD(SET, TAP) do {                                                                       \
+        const int t_ = (TAP) < 27 ? (TAP) : 26;                                                       \
+        const int so_ = t_ * wtap + c0 * 2;                                                           \
+        _Pragma("unroll") for (int ct = 0; ct < 4; ++ct)                                              \
+            wf[SET][ct] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_vo, so_ + ct * wct, 0)); \
+    } while (0)
+        B8_WLOAD(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this chunk's pieces (all issued during the previous chunk) and the first weights
+        __syncthreads();                                      // ... of every wave; and every wave is done with the other buffer
+        B8_WLOAD(1, 1);
+#define B8_READ(HV) (*reinterpret_cast<const bf16x8*>(smem + cur + (HV) * 64 + ((fg ^ (((HV) >> 2) & 3)) << 4)))
+        bf16x8 xf[TH];
+#pragma unroll
+        for (int vt = 0; vt < TH; ++vt) { const int hv = hv_base + vt * G::HW; xf[vt] = B8_READ(hv); }
+#pragma unroll 1
+        for (int it = 0; it < 9; ++it) {
+            const int kd = it / 3, kh = it - 3 * kd;
+            const int itn = it < 8 ? it + 1 : 8, kdn = itn / 3, khn = itn - 3 * kdn;
+            const int hv_it = hv_base + (kd * G::HH + kh) * G::HW, hv_nx = hv_base + (kdn * G::HH + khn) * G::HW;
+            if (more && it == BLK128_BURST_AT) {               // the next chunk's copy, all nine pieces of this wave at once (see above)
+#pragma unroll
+                for (int j = 0; j < Blk128::PPW; ++j) B8_PIECE(nxt, c0 + 32, j);
+            }
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                B8_WLOAD((kw + 2) % 3, 3 * it + kw + 2);
+                const int hv_n = kw < 2 ? hv_it + kw + 1 : hv_nx;
+#pragma unroll
+                for (int vt = 0; vt < TH; ++vt) {
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) acc[vt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kw][ct], xf[vt], acc[vt][ct], 0, 0, 0);
+                    const int hv = hv_n + vt * G::HW;
+                    xf[vt] = B8_READ(hv);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
+#pragma unroll
+                for (int vt = 0; vt < TH; ++vt) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            }
+        }
+#undef B8_READ
+#undef B8_WLOAD
+        cur = nxt;
+    }
+#undef B8_PIECE
+
+    // ---- epilogue: lane = voxel (d0 + ds, h0 + vt, w0 + wm), couts 64 ch + 16 fg .. + 15 of 128 ---------------------------------
+    const int cb = 64 * ch + 16 * fg;
+    float add[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) add[q] = (p.bias ? p.bias[cb + q] : 0.f) + (p.temb ? p.temb[(size_t)n * p.temb_stride + cb + q] : 0.f);
+    float ssum[16], ssq[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { ssum[q] = 0.f; ssq[q] = 0.f; }
+    const int gd = d0 + ds, gw = w0 + wm;
+    const bool col_ok = gd < p.D && gw < p.W;
+#pragma unroll
+    for (int vt = 0; vt < TH; ++vt) {
+        const int gh = h0 + vt;
+        if (!col_ok || gh >= p.H) continue;
+        const size_t m = (size_t)((n * p.D + gd) * p.H + gh) * p.W + gw;
+        float v[16];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[4 * ct + r] = acc[vt][ct][r] + add[4 * ct + r];
+        if (p.residual) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const u32x4 rv = *reinterpret_cast<const u32x4*>(p.residual + m * 128 + cb + 8 * h);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v[h * 8 + 2 * q] += __uint_as_float(rv[q] << 16);
+                    v[h * 8 + 2 * q + 1] += __uint_as_float(rv[q] & 0xffff0000u);
+                }
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            u32x4 o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                o[q] = pack2bf(v[h * 8 + 2 * q], v[h * 8 + 2 * q + 1]);
+                const float lo = __uint_as_float(o[q] << 16), hi = __uint_as_float(o[q] & 0xffff0000u);
+                ssum[h * 8 + 2 * q] += lo; ssq[h * 8 + 2 * q] += lo * lo;
+                ssum[h * 8 + 2 * q + 1] += hi; ssq[h * 8 + 2 * q + 1] += hi * hi;
+            }
+            *reinterpret_cast<u32x4*>(p.out + m * 128 + cb + 8 * h) = o;
+        }
+    }
+    if (p.stats) {
+#define BK_ROW_ADD(X, CTRL) X += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(X), CTRL, 0xf, 0xf, true))
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            BK_ROW_ADD(ssum[q], 0x128); BK_ROW_ADD(ssum[q], 0x124); BK_ROW_ADD(ssum[q], 0x122); BK_ROW_ADD(ssum[q], 0x121);
+            BK_ROW_ADD(ssq[q], 0x128); BK_ROW_ADD(ssq[q], 0x124); BK_ROW_ADD(ssq[q], 0x122); BK_ROW_ADD(ssq[q], 0x121);
+        }
+#undef BK_ROW_ADD
+        float* red = reinterpret_cast<float*>(smem + 2 * Blk128::BUF);      // [wave][64][2]
+        if (fr == 0) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { red[(wave * 64 + 16 * fg + q) * 2] = ssum[q]; red[(wave * 64 + 16 * fg + q) * 2 + 1] = ssq[q]; }
+        }
+        __syncthreads();
+        if (tid < 256) {                                      // tid = (cout 0 .. 127, sum | sum of squares): fold the four d-slice waves of the cout half
+            const int c = tid >> 1, k = tid & 1, h2 = c >> 6, cc = c & 63;
+            const float* r0 = red + ((h2 * 4) * 64 + cc) * 2 + k;
+            const float t = (r0[0] + r0[128]) + (r0[256] + r0[384]);
+            p.stats[(size_t)blk * 256 + tid] = t;
+        }
+    }
+#endif
+}
+
+static inline int conv_block128_max_cin() { static const int c = [] { const char* e = getenv("LDM_CONV_BLOCK128_MAX_CIN"); return e ? atoi(e) : 128; }(); return c; }
+static inline bool conv_block128_enabled() { static const int on = [] { const char* e = getenv("LDM_CONV_BLOCK128"); return e ? atoi(e) : 1; }(); return on != 0; }
 static inline bool conv_block_enabled() { static const int on = [] { const char* e = getenv("LDM_CONV_BLOCK"); return e ? atoi(e) : 1; }(); return on != 0; }
 static inline int conv_block_th() { static const int th = [] { const char* e = getenv("LDM_CONV_BLOCK_TH"); return e ? atoi(e) : 8; }(); return th == 4 ? 4 : 8; }
 // 128 -> 64 channels at 96^3 alone: 464 us here against 451 on the 254 x 64 halo tile (four channel chunks = four exposed copy phases), but inside

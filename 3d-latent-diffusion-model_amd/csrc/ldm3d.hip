@@ -88,6 +88,18 @@ static hipError_t launch_conv_block(const BlockParams& q0, int TH, hipStream_t s
     else hipLaunchKernelGGL((conv3_block_kernel<4, 0, false>), dim3(grid), dim3(256), BlkGeom<4>::LDS_ALL, s, q);
     return hipGetLastError();
 }
+static hipError_t launch_conv_block128(const BlockParams& q0, hipStream_t s) {
+    BlockParams q = q0;
+    q.td = (q.D + BLK_TD - 1) / BLK_TD; q.th = (q.H + 7) / 8; q.tw = (q.W + BLK_TW - 1) / BLK_TW;
+    static bool attr_tab[32] = {}; bool& attr_set = attr_flag(attr_tab);
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_block128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, Blk128::LDS_ALL);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv3_block128_kernel, dim3((unsigned)((long)q.N * q.td * q.th * q.tw)), dim3(512), Blk128::LDS_ALL, s, q);
+    return hipGetLastError();
+}
 static inline int rup(int v, int m) { return (v + m - 1) / m * m; }
 static inline size_t rup_sz(size_t v, size_t m) { return (v + m - 1) / m * m; }
 
@@ -788,6 +800,23 @@ struct Builder {
                 op.r[0] = ws_ref(a.xa.off); op.r[2] = w_ref(w.w_off); op.r[6] = a.no_bias ? Ref() : w_ref(w.b_off); op.r[8] = a.temb;
                 op.r[9] = a.residual.valid ? ws_ref(a.residual.off) : Ref(); op.r[10] = ws_ref(out.off); op.r[12] = out.has_stats ? ws_ref(out.stats_off) : Ref();
                 op.i[0] = N; op.i[1] = a.Do; op.i[2] = a.Ho; op.i[3] = a.Wo; op.i[4] = cin0; op.i[5] = TH; op.i[6] = a.temb_stride;
+                plan->ops.push_back(op);
+                if (recording) { Tape t; t.kind = 0; t.c = a; t.out = out; tape.push_back(t); }
+                return out;
+            }
+        }
+        // 128 output channels (the AutoencoderKL's half-resolution level): eight-wave block kernel with double-buffered halo chunks (conv_block.h)
+        if (conv_block128_enabled() && a.k == 3 && a.stride == 1 && a.pad == 1 && a.ups == 0 && !a.exact && !a.xb.valid && !a.w1 && !a.f32_out &&
+            w.cout_pad == 128 && rup(w.cout, 32) == 128 && cin0 <= conv_block128_max_cin() && a.w_over.base == BASE_NULL && a.xa.D == a.Do && a.xa.H == a.Ho && a.xa.W == a.Wo) {
+            const int td = (a.Do + BLK_TD - 1) / BLK_TD, th = (a.Ho + 7) / 8, tw = (a.Wo + BLK_TW - 1) / BLK_TW;
+            static const long min_blocks = [] { const char* e = getenv("LDM_CONV_BLOCK128_MIN"); return e ? atol(e) : 128L; }();
+            if ((long)N * td * th * tw >= min_blocks) {
+                Act out = new_act(N, a.Do, a.Ho, a.Wo, 128);
+                if (a.want_stats) { out.stats_off = pool.alloc((size_t)N * td * th * tw * 128 * 2 * 4); out.has_stats = true; out.stats_nrb = td * th * tw; }
+                Op op{}; op.kind = OP_CONV_BLOCK;
+                op.r[0] = ws_ref(a.xa.off); op.r[2] = w_ref(w.w_off); op.r[6] = a.no_bias ? Ref() : w_ref(w.b_off); op.r[8] = a.temb;
+                op.r[9] = a.residual.valid ? ws_ref(a.residual.off) : Ref(); op.r[10] = ws_ref(out.off); op.r[12] = out.has_stats ? ws_ref(out.stats_off) : Ref();
+                op.i[0] = N; op.i[1] = a.Do; op.i[2] = a.Ho; op.i[3] = a.Wo; op.i[4] = cin0; op.i[5] = 8; op.i[6] = a.temb_stride; op.i[7] = 128;
                 plan->ops.push_back(op);
                 if (recording) { Tape t; t.kind = 0; t.c = a; t.out = out; tape.push_back(t); }
                 return out;
@@ -2142,12 +2171,12 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                 if (!attr_set) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_thin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, THIN_LDS)); attr_set = true; }
                 hipLaunchKernelGGL(conv3_thin_kernel, dim3((unsigned)((long)q.N * q.td * q.th * q.tw)), dim3(256), THIN_LDS, s, q);
                 break; }
-            case OP_CONV_BLOCK: {       // i: N, D, H, W, Cin, TH, temb stride
+            case OP_CONV_BLOCK: {       // i: N, D, H, W, Cin, TH, temb stride, couts (0 = 64 | 128: conv3_block128_kernel)
                 BlockParams q{}; q.x = (const bf16_t*)rp(bs, o.r[0]); q.w = (const bf16_t*)rp(bs, o.r[2]); q.bias = (const float*)rp(bs, o.r[6]);
                 q.temb = (const float*)rp(bs, o.r[8]); q.temb_stride = i[6]; q.residual = (const bf16_t*)rp(bs, o.r[9]); q.out = (bf16_t*)rp(bs, o.r[10]);
                 q.stats = (float*)rp(bs, o.r[12]); q.N = i[0]; q.D = i[1]; q.H = i[2]; q.W = i[3]; q.Cin = i[4];
                 if (!q.w) return fail(LDM_ERR_NOT_LOADED, "the weight arena is empty");
-                HIP_TRY(launch_conv_block(q, i[5], s));
+                if (i[7] == 128) HIP_TRY(launch_conv_block128(q, s)); else HIP_TRY(launch_conv_block(q, i[5], s));
                 break; }
             case OP_UPS_SPLIT32: {      // i: N, C, D, H, W of the source, upsample (1) or same size (0)
                 hipLaunchKernelGGL(upsample_split_f32_kernel, dim3(grid_for(((long)i[0] * i[2] * i[3] * i[4] << (3 * i[5])) * (i[1] / 4), 256, 4096)), dim3(256), 0, s,
@@ -3349,7 +3378,7 @@ int ldm_model_plan_conv_cfgs(ldm_model* m, const char* kind, int B, int D, int H
         if (cfgs && n < max_convs) { cfgs[4 * n] = o.cc.wgm; cfgs[4 * n + 1] = o.cc.wgn; cfgs[4 * n + 2] = o.cc.bk | (o.cc.halo << 8); cfgs[4 * n + 3] = o.cc.splitk; }
         ++n;
     } else if (o.kind == OP_CONV_BLOCK) {            // conv3_block_kernel: reported as a 4 x 1 tile, 32-channel chunks, halo = 3
-        if (cfgs && n < max_convs) { cfgs[4 * n] = 4; cfgs[4 * n + 1] = 1; cfgs[4 * n + 2] = 32 | (3 << 8); cfgs[4 * n + 3] = 1; }
+        if (cfgs && n < max_convs) { cfgs[4 * n] = 4; cfgs[4 * n + 1] = o.i[7] == 128 ? 2 : 1; cfgs[4 * n + 2] = 32 | ((o.i[7] == 128 ? 4 : 3) << 8); cfgs[4 * n + 3] = 1; }
         ++n;
     }
     return n;
@@ -3381,6 +3410,17 @@ static int ensure_zero_page() {
  * full-resolution level): x [N][D][H][W][cin] bf16, w packed [27][64][cin] bf16, out [N*D*H*W][64] bf16; bias [64], temb [N][temb_stride],
  * residual [N*D*H*W][64] optional.  stats (optional): [N * rows][64][2] per-block (sum, sum of squares) of the stored values,
  * rows = ldm_op_conv3d_block_stats_rows(D, H, W, th); th = 8 (4 x 8 x 16 blocks) or 4 (4 x 4 x 16). */
+/* The same for 128 output channels (conv3_block128_kernel): w packed [27][128][cin], out / residual [N*D*H*W][128], bias [128],
+ * stats [N * ldm_op_conv3d_block_stats_rows(D, H, W, 8)][128][2]. */
+int ldm_op_conv3d_block128(const void* x, int cin, const void* w, const float* bias, const float* temb, int temb_stride, const void* residual,
+                           void* out, float* stats, int N, int D, int H, int W, void* stream) {
+    if (!x || !w || !out || N < 1 || D < 1 || H < 1 || W < 1 || cin < 32 || cin % 32) return fail(LDM_ERR_BAD_ARG, "bad argument");
+    if ((long)N * D * H * W * cin * 2 >= (1L << 32)) return fail(LDM_ERR_BAD_ARG, "the input tensor exceeds 4 GiB (split the batch)");
+    BlockParams q{}; q.x = (const bf16_t*)x; q.w = (const bf16_t*)w; q.bias = bias; q.temb = temb; q.temb_stride = temb_stride;
+    q.residual = (const bf16_t*)residual; q.out = (bf16_t*)out; q.stats = stats; q.N = N; q.D = D; q.H = H; q.W = W; q.Cin = cin;
+    HIP_TRY(launch_conv_block128(q, (hipStream_t)stream));
+    return 0;
+}
 /* tests only: the grid of conv3_block_kernel's tile loop (0 = two workgroups per CU); returns the previous value */
 int ldm_debug_conv_block_slots(int slots) { const int old = g_block_slots; g_block_slots = slots < 0 ? 0 : slots; return old; }
 int ldm_op_conv3d_block_stats_rows(int D, int H, int W, int th) {

@@ -240,6 +240,11 @@ int ldm_op_conv3d(const void* xa, int ca, const void* xb, int cb, const void* w,
  *      (4, th, 16) block of output voxels per workgroup, its input halo copied into LDS once per 32 input channels.  x [N][D][H][W][cin],
  *      w packed [27][64][cin], out [N*D*H*W][64]; stats (optional) [N * rows][64][2], rows = ldm_op_conv3d_block_stats_rows; th = 8 | 4. */
 int ldm_op_conv3d_block_stats_rows(int D, int H, int W, int th);
+/*      the same for 128 OUTPUT channels (conv3_block128_kernel: eight waves per workgroup, double-buffered halo chunks; the AutoencoderKL's
+ *      half-resolution ResBlocks at num_channels[1] = 128): w packed [27][128][cin], out / residual [N*D*H*W][128],
+ *      stats [N * ldm_op_conv3d_block_stats_rows(D, H, W, 8)][128][2]. */
+int ldm_op_conv3d_block128(const void* x, int cin, const void* w, const float* bias, const float* temb, int temb_stride, const void* residual,
+                           void* out, float* stats, int N, int D, int H, int W, void* stream);
 /* tests only: number of workgroups of conv3_block_kernel's tile loop (0 = default: two per CU; a multiple of 8); returns the previous value */
 int ldm_debug_conv_block_slots(int slots);
 int ldm_op_conv3d_block(const void* x, int cin, const void* w, const float* bias, const float* temb, int temb_stride, const void* residual,
@@ -333,7 +338,7 @@ int ldm_op_attention_bwd(const void* qkv, const void* o, const void* d_o, const 
  *      (wgm x wgn waves, K depth bk), recorded on the launch stream.  stop() fills
  *      out = {instrumented launches, their total ms, their algorithmic FLOPs, all conv launches, all conv FLOPs}.
  *      plan_conv_cfgs lists the {wgm, wgn, bk | halo << 8, splitk} the planner chose per conv of a plan ("unet"|"enc"|"dec");
- *      halo: 0 = conv_igemm_kernel, 1 / 2 = conv3_halo_kernel (126 x 128 / 254 x 64 tiles), 3 = conv3_block_kernel. -- */
+ *      halo: 0 = conv_igemm_kernel, 1 / 2 = conv3_halo_kernel (126 x 128 / 254 x 64 tiles), 3 = conv3_block_kernel, 4 = conv3_block128_kernel. -- */
 int ldm_profile_start(int wgm, int wgn, int bk, int max_launches);
 int ldm_profile_detail(double* flops, double* ms, int max);   /* per instrumented launch; call before ldm_profile_stop; returns their number */
 int ldm_profile_stop(double out[5]);

@@ -263,6 +263,9 @@ def test_planner_rules_added_in_round_3(built_lib, monkeypatch):
     assert sum(1 for c in dec if c[3] == 3) == 3 and sum(1 for c in dec if c[3] == 2) == 1, dec
     enc = _bf16_conv_launches(AutoencoderKL(**cfgs.VAE_FULL), b"enc", 1, (96, 96, 96))
     assert sum(1 for c in enc if c[3] == 3) >= 3, enc
+    # the 48^3 level's plain convs with 128 output channels and Cin <= 128 on conv3_block128_kernel (halo code 4): 64 -> 128, 128 -> 128 x 2 in the
+    # encoder (the fused-skip conv stays on the halo kernel), 128 -> 128 x 2 in the decoder (256 -> 128 stays: the halo tile gains with K)
+    assert sum(1 for c in enc if c[3] == 4) == 3 and sum(1 for c in dec if c[3] == 4) == 2, (enc, dec)
 
 
 def test_shapes_the_networks_cannot_take_fail_loudly(built_lib):

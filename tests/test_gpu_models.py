@@ -495,9 +495,9 @@ print(json.dumps({"sum": float(a.double().sum()), "abs": float(a.double().abs().
 
 
 def test_block_conv_plans_match_the_halo_plans_forward_and_gradients(cuda):
-    """conv3_block_kernel inside the launch plans (inference AND training: forward convs, data-gradient convs, GroupNorm partials per block):
-    an AutoencoderKL with 64 channels at full resolution on a ragged 12 x 20 x 24 volume, batch 2, with the kernel forced on
-    (LDM_CONV_BLOCK_MIN=1; the plans use it from 512 blocks up) against the same run with LDM_CONV_BLOCK=0.  Both are bf16 evaluations with
+    """conv3_block_kernel / conv3_block128_kernel inside the launch plans (inference AND training: forward convs, data-gradient convs, GroupNorm
+    partials per block): an AutoencoderKL with 64 channels at full resolution and 128 below on a ragged 12 x 20 x 24 volume, batch 2, with the
+    kernels forced on (LDM_CONV_BLOCK_MIN=1, LDM_CONV_BLOCK128_MIN=1; the plans use them from 512 / 128 blocks up) against the same run with both off.  Both are bf16 evaluations with
     the same rounding points: they agree to the network's bf16 floor, and both sit equally close to the fp32 CPU oracle.  Child processes: the knobs are read
     once per process."""
     import json
@@ -513,7 +513,7 @@ from ldm3d import _lib
 from ldm3d.networks import AutoencoderKL
 from oracle import autoencoder as oa
 from oracle.unet import init_state_dict
-cfg = dict(spatial_dims=3, in_channels=1, out_channels=1, latent_channels=4, channels=[64, 64, 128], num_res_blocks=[2, 1, 1],
+cfg = dict(spatial_dims=3, in_channels=1, out_channels=1, latent_channels=4, channels=[64, 128, 128], num_res_blocks=[2, 2, 1],
            norm_num_groups=16, norm_eps=1e-6, attention_levels=[False, False, False], with_encoder_nonlocal_attn=False,
            with_decoder_nonlocal_attn=False)
 sd = init_state_dict(oa.ae_param_shapes(cfg), 3, gain=0.7)
@@ -530,7 +530,7 @@ with torch.no_grad():
 L = _lib.lib()
 buf = (__import__("ctypes").c_int * 2048)()
 n = L.ldm_model_plan_conv_cfgs(m._h, b"enc", 2, *dims, buf, 512)
-blocks = sum(1 for i in range(n) if (buf[4 * i + 2] >> 8) == 3)
+blocks = sum(1 for i in range(n) if (buf[4 * i + 2] >> 8) in (3, 4))
 m.train()
 recon, mu2, sigma2 = m(x.to(dev), eps=eps.to(dev))
 loss = F.l1_loss(recon, x.to(dev)) + 1e-3 * oa.kl_loss(mu2, sigma2).mean()
@@ -553,11 +553,11 @@ print(json.dumps({"blocks": blocks, "rec": rec.flatten()[::7].double().cpu().tol
                   "e_rec": rel(rec, o_dec), "e_mu": rel(mu, o_mu.detach()), "e_grads": rel(grads, o_grads), "o_loss": float(o_loss)}))
 '''
     recs = {}
-    for tag, env in (("halo", {"LDM_CONV_BLOCK": "0"}), ("block", {"LDM_CONV_BLOCK_MIN": "1"})):
+    for tag, env in (("halo", {"LDM_CONV_BLOCK": "0", "LDM_CONV_BLOCK128": "0"}), ("block", {"LDM_CONV_BLOCK_MIN": "1", "LDM_CONV_BLOCK128_MIN": "1"})):
         r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         recs[tag] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-    assert recs["halo"]["blocks"] == 0 and recs["block"]["blocks"] >= 3, (recs["halo"]["blocks"], recs["block"]["blocks"])
+    assert recs["halo"]["blocks"] == 0 and recs["block"]["blocks"] >= 6, (recs["halo"]["blocks"], recs["block"]["blocks"])
     errs = {}
     for k in ("rec", "mu", "grads"):
         a, b = torch.tensor(recs["halo"][k], dtype=torch.float64), torch.tensor(recs["block"][k], dtype=torch.float64)

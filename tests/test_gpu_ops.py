@@ -653,3 +653,52 @@ def test_conv3_block_kernel(cuda, built_lib, cin, cout, dims, n, th, temb, resid
     tot = stats.double().view(n, rows, 64, 2).sum(1)
     assert torch.allclose(tot[..., 0], o.sum(1), rtol=1e-4, atol=1e-2)
     assert torch.allclose(tot[..., 1], (o * o).sum(1), rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize("cin,cout,dims,n,temb,residual", [
+    (128, 128, (8, 16, 32), 1, False, False),       # whole blocks, four chunks through both buffers
+    (64, 128, (5, 11, 20), 2, True, True),          # ragged in every dimension, two samples, two chunks
+    (32, 100, (3, 3, 3), 1, True, False),           # one chunk (no second buffer), smaller than a block, real couts < 128
+    (96, 128, (4, 9, 17), 1, False, True),          # three chunks (the buffers end on the one they started with)
+    (256, 128, (12, 16, 16), 1, False, False),      # eight chunks (the decoder's 256 -> 128)
+])
+def test_conv3_block128_kernel(cuda, built_lib, cin, cout, dims, n, temb, residual):
+    """conv3_block128_kernel (128 output channels: eight waves per workgroup, double-buffered halo chunks copied piece by piece under the K
+    loop of the chunk before; the AutoencoderKL's half-resolution ResBlock convs) against F.conv3d on the same bf16-rounded operands; its
+    per-block GroupNorm partials are the sums of the stored values."""
+    from ldm3d import _lib
+    g = torch.Generator().manual_seed(cin + dims[2] + 128)
+    x = torch.randn((n, cin, *dims), generator=g)
+    w = torch.randn((cout, cin, 3, 3, 3), generator=g) / (cin * 27) ** 0.5
+    b = 0.1 * torch.randn((cout,), generator=g)
+    ref = F.conv3d(bf16_round(x), bf16_round(w), b, padding=1)
+    te = None
+    if temb:
+        tv = torch.randn((n, 128), generator=g)
+        tv[:, cout:] = 0.0
+        ref = ref + tv[:, :cout, None, None, None]
+        te = tv.to(cuda)
+    res = None
+    if residual:
+        rv = bf16_round(torch.randn(ref.shape, generator=g))
+        ref = ref + rv
+        res = to_ndhwc_bf16(rv, 128).to(cuda)
+    xa = to_ndhwc_bf16(x).to(cuda)
+    wp = pack_conv_weight(w, cin, 128).to(cuda)
+    bp = pad_vec(b, 128).to(cuda)
+    rows = built_lib.ldm_op_conv3d_block_stats_rows(*dims, 8)
+    out = torch.full((n, *dims, 128), float("nan"), dtype=torch.bfloat16, device=cuda)
+    stats = torch.full((n * rows, 128, 2), float("nan"), device=cuda)
+    _lib.check(built_lib.ldm_op_conv3d_block128(xa.data_ptr(), cin, wp.data_ptr(), bp.data_ptr(), None if te is None else te.data_ptr(), 128,
+                                                None if res is None else res.data_ptr(), out.data_ptr(), stats.data_ptr(), n, *dims,
+                                                torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()
+    err = rel_l2(from_ndhwc(out.cpu(), cout), bf16_round(ref))
+    assert err <= TOL_SAME_ROUNDING, err
+    if cout < 128:
+        assert float(out[..., cout:].float().abs().max()) == 0.0, "channel padding must be written as zeros"
+    o = out.double().view(n, -1, 128)
+    tot = stats.double().view(n, rows, 128, 2).sum(1)
+    assert torch.allclose(tot[..., 0], o.sum(1), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(tot[..., 1], (o * o).sum(1), rtol=1e-4, atol=1e-2)

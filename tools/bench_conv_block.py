@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """conv3_block_kernel alone (csrc/conv_block.h): the AutoencoderKL's full-resolution 3^3 conv, Cin -> 64 channels, against the 254 x 64 halo tile.
 
-    python tools/bench_conv_block.py [D,H,W] [cin] [th]"""
+    python tools/bench_conv_block.py [D,H,W] [cin] [th] [cout = 64 | 128]"""
 import os
 import sys
 
@@ -17,26 +17,30 @@ def main():
     dims = [int(a) for a in (sys.argv[1] if len(sys.argv) > 1 else "96,96,96").split(",")]
     cin = int(sys.argv[2]) if len(sys.argv) > 2 else 64
     th = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+    cout = int(sys.argv[4]) if len(sys.argv) > 4 else 64
     L = _lib.lib()
     dev = torch.device("cuda:0")
     m = dims[0] * dims[1] * dims[2]
     x = torch.randn((1, *dims, cin), device=dev).to(torch.bfloat16)
-    w = (torch.randn((27, 64, cin), device=dev) / (27 * cin) ** 0.5).to(torch.bfloat16)
-    b = torch.randn((64,), device=dev)
-    out = torch.empty((1, *dims, 64), dtype=torch.bfloat16, device=dev)
+    w = (torch.randn((27, cout, cin), device=dev) / (27 * cin) ** 0.5).to(torch.bfloat16)
+    b = torch.randn((cout,), device=dev)
+    out = torch.empty((1, *dims, cout), dtype=torch.bfloat16, device=dev)
     rows = L.ldm_op_conv3d_block_stats_rows(*dims, th)
-    stats = torch.empty((rows, 64, 2), device=dev)
+    stats = torch.empty((rows, cout, 2), device=dev)
     st = torch.cuda.current_stream().cuda_stream
-    gflop = 2.0 * m * 64 * cin * 27 / 1e9
+    gflop = 2.0 * m * cout * cin * 27 / 1e9
 
     def block():
+        if cout == 128:
+            _lib.check(L.ldm_op_conv3d_block128(x.data_ptr(), cin, w.data_ptr(), b.data_ptr(), None, 0, None, out.data_ptr(), stats.data_ptr(), 1, *dims, st))
+            return
         _lib.check(L.ldm_op_conv3d_block(x.data_ptr(), cin, w.data_ptr(), b.data_ptr(), None, 0, None, out.data_ptr(), stats.data_ptr(), 1, *dims, th, st))
 
-    scratch = torch.empty((256,), dtype=torch.uint8, device=dev)
+    scratch = torch.empty((64 * m * cout * 4 + 256,), dtype=torch.uint8, device=dev)
 
     def halo():
-        _lib.check(L.ldm_op_conv3d(x.data_ptr(), cin, None, 0, w.data_ptr(), b.data_ptr(), None, 0, None, 0, None, None, None, 64, None, out.data_ptr(), None,
-                                   1, *dims, 3, 1, 1, 0, 64, 64, 0, 0, scratch.data_ptr(), scratch.numel(), st))
+        _lib.check(L.ldm_op_conv3d(x.data_ptr(), cin, None, 0, w.data_ptr(), b.data_ptr(), None, 0, None, 0, None, None, None, cout, None, out.data_ptr(), None,
+                                   1, *dims, 3, 1, 1, 0, cout, cout, 0, 0, scratch.data_ptr(), scratch.numel(), st))
 
     for name, fn in (("conv3_block_kernel", block), ("planner's choice through ldm_op_conv3d", halo)):
         for _ in range(5):
