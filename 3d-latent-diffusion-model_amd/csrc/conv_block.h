@@ -69,7 +69,6 @@ __global__ __launch_bounds__(256, TH == 8 ? 2 : 3) void conv3_block_kernel(const
     // cycles per read) at every alignment; columns in voxel order cost 8 (MI355X_MICROARCH.md, LDS)
     const int wm = fr < 4 ? 2 * fr : fr < 12 ? 2 * (fr - 4) + 1 : 2 * (fr - 8);
     const int hv_base = wave * G::HH * G::HW + wm;
-    const int cb = 16 * fg;
 
     // tile state (wave-uniform).  A halo copy works out this lane's voxel of each of the wave's DMA pieces as it goes (nothing kept across
     // the K loop: the kernel sits at the 256-register line): piece q covers halo voxels 16 q .. 16 q + 15, lane = (voxel L >> 2, slot L & 3);
