@@ -255,7 +255,8 @@ __global__ __launch_bounds__(256, TH == 8 ? 2 : 3) void conv3_block_kernel(const
 // way, the copies are not what this kernel waits for).  Only a tile's first chunk is exposed.
 // Measured at 48^3 (tools/bench_conv_block.py, random data): 64 -> 128: 70 vs 80 us on the halo tile; 128 -> 128: 131 vs 125; 256 -> 128: 243 vs
 // 212 -- per MFMA it runs at the 64-cout kernel's rate (0.30 of peak), the halo tile gains with K.  Inside the AutoencoderKL (same-box A/B,
-// Cin <= 128 here): encode 2.37 -> 2.34 ms, decode 3.30 -> 3.27 ms (fewer GroupNorm partial rows behind it).
+// Cin <= 128 here): encode 2.37 -> 2.34 ms, decode 3.30 -> 3.27 ms (fewer GroupNorm partial rows behind it); at the configs[3] patch (693 tiles =
+// 2.7 rounds of one workgroup per CU) it LOSES 3.5 %, so the plans use it only where the tiles fit one round (ldm3d.hip).
 #ifndef BLK128_BURST_AT
 #define BLK128_BURST_AT 0
 #endif

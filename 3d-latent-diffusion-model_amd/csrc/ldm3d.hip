@@ -88,6 +88,13 @@ static hipError_t launch_conv_block(const BlockParams& q0, int TH, hipStream_t s
     else hipLaunchKernelGGL((conv3_block_kernel<4, 0, false>), dim3(grid), dim3(256), BlkGeom<4>::LDS_ALL, s, q);
     return hipGetLastError();
 }
+// CUs of the current device (256 when there is none: the planner also runs on hosts without a GPU, tests/test_abi_and_host.py)
+static int device_cus() {
+    static int tab[32] = {};
+    int d = 0; if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 32) return 256;
+    if (!tab[d]) { hipDeviceProp_t pr; tab[d] = (hipGetDeviceProperties(&pr, d) == hipSuccess && pr.multiProcessorCount >= 8) ? pr.multiProcessorCount : 256; }
+    return tab[d];
+}
 static hipError_t launch_conv_block128(const BlockParams& q0, hipStream_t s) {
     BlockParams q = q0;
     q.td = (q.D + BLK_TD - 1) / BLK_TD; q.th = (q.H + 7) / 8; q.tw = (q.W + BLK_TW - 1) / BLK_TW;
@@ -810,7 +817,11 @@ struct Builder {
             w.cout_pad == 128 && rup(w.cout, 32) == 128 && cin0 <= conv_block128_max_cin() && a.w_over.base == BASE_NULL && a.xa.D == a.Do && a.xa.H == a.Ho && a.xa.W == a.Wo) {
             const int td = (a.Do + BLK_TD - 1) / BLK_TD, th = (a.Ho + 7) / 8, tw = (a.Wo + BLK_TW - 1) / BLK_TW;
             static const long min_blocks = [] { const char* e = getenv("LDM_CONV_BLOCK128_MIN"); return e ? atol(e) : 128L; }();
-            if ((long)N * td * th * tw >= min_blocks) {
+            // one eight-wave workgroup per CU: it pays where the tiles fit ONE round (48^3: 216 tiles: AutoencoderKL 96^3 encode 2.37 -> 2.34 ms) and
+            // loses where they need several (72 x 88 x 56: 693 tiles = 2.7 rounds that take 3: configs[3] encode 6.65 -> 6.89 ms), so: <= CUs tiles
+            static const long max_blocks = [] { const char* e = getenv("LDM_CONV_BLOCK128_MAX"); return e ? atol(e) : 0L; }();
+            const long tiles128 = (long)N * td * th * tw;
+            if (tiles128 >= min_blocks && tiles128 <= (max_blocks > 0 ? max_blocks : (long)device_cus())) {
                 Act out = new_act(N, a.Do, a.Ho, a.Wo, 128);
                 if (a.want_stats) { out.stats_off = pool.alloc((size_t)N * td * th * tw * 128 * 2 * 4); out.has_stats = true; out.stats_nrb = td * th * tw; }
                 Op op{}; op.kind = OP_CONV_BLOCK;
