@@ -816,7 +816,7 @@ struct Builder {
         if (conv_block128_enabled() && a.k == 3 && a.stride == 1 && a.pad == 1 && a.ups == 0 && !a.exact && !a.xb.valid && !a.w1 && !a.f32_out &&
             w.cout_pad == 128 && rup(w.cout, 32) == 128 && cin0 <= conv_block128_max_cin() && a.w_over.base == BASE_NULL && a.xa.D == a.Do && a.xa.H == a.Ho && a.xa.W == a.Wo) {
             const int td = (a.Do + BLK_TD - 1) / BLK_TD, th = (a.Ho + 7) / 8, tw = (a.Wo + BLK_TW - 1) / BLK_TW;
-            static const long min_blocks = [] { const char* e = getenv("LDM_CONV_BLOCK128_MIN"); return e ? atol(e) : 128L; }();
+            static const long min_blocks = [] { const char* e = getenv("LDM_CONV_BLOCK128_MIN"); return e ? atol(e) : 192L; }();   // 128 tiles (32^3 x batch 2) leave half the CUs idle: AutoencoderKL training step 18.4 vs 18.6 ms
             // one eight-wave workgroup per CU: it pays where the tiles fit ONE round (48^3: 216 tiles: AutoencoderKL 96^3 encode 2.37 -> 2.34 ms) and
             // loses where they need several (72 x 88 x 56: 693 tiles = 2.7 rounds that take 3: configs[3] encode 6.65 -> 6.89 ms), so: <= CUs tiles
             static const long max_blocks = [] { const char* e = getenv("LDM_CONV_BLOCK128_MAX"); return e ? atol(e) : 0L; }();
