@@ -2092,8 +2092,12 @@ static inline int grid_for(long total, int per_block = 256, int cap = 4096) {
 }
 
 // voxel-range split of the weight-gradient GEMM: enough workgroups for 2 waves of 256 CUs, at least 16 K steps each
+static bool wgrad_pair(int taps, int cin, bool hp) {       // conv_wgrad_kernel's two-taps-per-workgroup form (WgradParams::pair)
+    static const int on = [] { const char* e = getenv("LDM_WGRAD_PAIR"); return e ? atoi(e) : 1; }();
+    return on && !hp && taps == 27 && cin <= 64;
+}
 static int wgrad_ksplit(long M, int taps, int cout, int cin, bool hp) {
-    const long wgs = (long)taps * ((cout + 127) / 128) * ((cin + 127) / 128);
+    const long wgs = (long)(wgrad_pair(taps, cin, hp) ? (taps + 1) / 2 : taps) * ((cout + 127) / 128) * ((cin + 127) / 128);
     const long steps = (M + 63) / 64;
     const char* e = getenv("LDM_WGRAD_WGS");                 // tuning knob: workgroups aimed at (default: one round of 256 CUs;
     const long target = e ? atol(e) : (hp ? 768 : 256);      // the fp32 kernel, latency bound on its operand loads, wants three per CU: 49.3 -> 46.6 ms per step)
@@ -2102,17 +2106,20 @@ static int wgrad_ksplit(long M, int taps, int cout, int cin, bool hp) {
     if (k > 16) k = 16;
     return (int)(k < 1 ? 1 : k);
 }
-static int launch_wgrad(const WgradParams& p, hipStream_t s) {
-    constexpr int LDS = 4 * 2 * 64 * 256 + 3 * 128 * 4;        // ring + triple-buffered source-offset table
+static int launch_wgrad(const WgradParams& p0, hipStream_t s) {
+    WgradParams p = p0;
+    p.pair = wgrad_pair(p.ksize * p.ksize * p.ksize, p.Cin, false) && p.cx <= 64 ? 1 : 0;
+    const int tg_ = p.pair ? (p.ksize * p.ksize * p.ksize + 1) / 2 : p.ksize * p.ksize * p.ksize;
+    constexpr int LDS = 4 * 2 * 64 * 256 + 3 * 192 * 4;        // ring + triple-buffered source-offset table (three sections in the pair form)
     static bool attr_tab[32] = {}; bool& attr_set = attr_flag(attr_tab);   // per device
     if (!attr_set) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr_set = true; }
     { const char* e = getenv("LDM_CONV_DBG"); const int dbg = e ? atoi(e) : 0;      // timing ablations (results are wrong)
 #define W1_ABL(A) if (dbg == A) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<A>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); \
-          hipLaunchKernelGGL(conv_wgrad_kernel<A>, dim3(p.co_tiles * p.ci_tiles * p.ksize * p.ksize * p.ksize * p.ksplit), dim3(512), LDS, s, p); return 0; }
+          hipLaunchKernelGGL(conv_wgrad_kernel<A>, dim3(p.co_tiles * p.ci_tiles * tg_ * p.ksplit), dim3(512), LDS, s, p); return 0; }
       W1_ABL(4) W1_ABL(8) W1_ABL(16) W1_ABL(12) W1_ABL(20) W1_ABL(24)
 #undef W1_ABL
     }
-    hipLaunchKernelGGL(conv_wgrad_kernel<0>, dim3(p.co_tiles * p.ci_tiles * p.ksize * p.ksize * p.ksize * p.ksplit), dim3(512), LDS, s, p);
+    hipLaunchKernelGGL(conv_wgrad_kernel<0>, dim3(p.co_tiles * p.ci_tiles * tg_ * p.ksplit), dim3(512), LDS, s, p);
     return 0;
 }
 
