@@ -2103,7 +2103,10 @@ static int wgrad_ksplit(long M, int taps, int cout, int cin, bool hp) {
     const long target = e ? atol(e) : (hp ? 768 : 256);      // the fp32 kernel, latency bound on its operand loads, wants three per CU: 49.3 -> 46.6 ms per step)
     long k = (target + wgs / 2) / wgs;                       // nearest count of whole rounds
     if (k > steps / 16) k = steps / 16;
-    if (k > 16) k = 16;
+    // at most 16 copies of a 3^3 weight-sized matrix for the export to fold; a 1x1 conv's matrix is 27 x smaller and its grid is ksplit
+    // workgroups in all (nin_shortcut 128 -> 64 over 64^3 voxels: 16 workgroups ran 147 us on 6 % of the chip), so: up to 64 there
+    const long cap = taps == 1 ? 64 : 16;
+    if (k > cap) k = cap;
     return (int)(k < 1 ? 1 : k);
 }
 static int launch_wgrad(const WgradParams& p0, hipStream_t s) {
