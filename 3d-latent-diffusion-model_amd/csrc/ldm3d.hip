@@ -753,18 +753,20 @@ struct Builder {
                                       a.w1 ? std::max(M * a.g1a.C, a.g1b.valid ? M * a.g1b.C : 0L) : 0L) * 2;
             if (big >= (1L << 32)) { err = "conv " + tag + ": a source tensor exceeds 4 GiB (split the batch)"; return Act(); }
         }
-        {   // the networks' last layer (Cout <= 4, fp32 NCDHW output) in inference plans: conv_thin.h
+        {   // the networks' last layer (Cout <= 4, fp32 NCDHW output): conv_thin.h; inference plans and (round 4) the training forward too
             static const int thin = [] { const char* e = getenv("LDM_CONV_THIN"); return e ? atoi(e) : 1; }();
+            static const long thin_min = [] { const char* e = getenv("LDM_CONV_THIN_MIN"); return e ? atol(e) : 512L; }();
             const int cr = a.cout_real ? a.cout_real : w.cout;
-            if (thin && !train && a.f32_out && a.k == 3 && a.stride == 1 && a.pad == 1 && !a.ups && !a.exact && !a.xb.valid && !a.w1 &&
+            if (thin && a.f32_out && a.k == 3 && a.stride == 1 && a.pad == 1 && !a.ups && !a.exact && !a.xb.valid && !a.w1 &&
                 a.temb.base == BASE_NULL && !a.residual.valid && a.w_over.base == BASE_NULL && cr <= 4 && cin0 % 32 == 0 && cin0 <= 128 &&
                 a.xa.D == a.Do && a.xa.H == a.Ho && a.xa.W == a.Wo &&
                 // enough blocks to fill the chip and few channel chunks: measured 64 -> 1 at 96^3 247 -> ~100 us; 256 -> 4 at 24^3 (72 blocks, 8 chunks) 22 -> 44 us
-                (long)N * ((a.Do + THIN_TD - 1) / THIN_TD) * ((a.Ho + THIN_TH - 1) / THIN_TH) * ((a.Wo + THIN_TW - 1) / THIN_TW) >= 512) {
+                (long)N * ((a.Do + THIN_TD - 1) / THIN_TD) * ((a.Ho + THIN_TH - 1) / THIN_TH) * ((a.Wo + THIN_TW - 1) / THIN_TW) >= thin_min) {
                 Op op{}; op.kind = OP_CONV_THIN;
                 op.r[0] = ws_ref(a.xa.off); op.r[2] = w_ref(w.w_off); op.r[6] = a.no_bias ? Ref() : w_ref(w.b_off); op.r[10] = a.out_ref;
                 op.i[0] = N; op.i[1] = a.xa.D; op.i[2] = a.xa.H; op.i[3] = a.xa.W; op.i[4] = cin0; op.i[5] = w.cout_pad; op.i[6] = cr;
                 plan->ops.push_back(op);
+                if (recording) { Tape t; t.kind = 0; t.c = a; t.out = Act(); tape.push_back(t); }
                 return Act();
             }
         }

@@ -497,7 +497,8 @@ print(json.dumps({"sum": float(a.double().sum()), "abs": float(a.double().abs().
 def test_block_conv_plans_match_the_halo_plans_forward_and_gradients(cuda):
     """conv3_block_kernel / conv3_block128_kernel inside the launch plans (inference AND training: forward convs, data-gradient convs, GroupNorm
     partials per block): an AutoencoderKL with 64 channels at full resolution and 128 below on a ragged 12 x 20 x 24 volume, batch 2, with the
-    kernels forced on (LDM_CONV_BLOCK_MIN=1, LDM_CONV_BLOCK128_MIN=1; the plans use them from 512 / 128 blocks up) against the same run with both off.  Both are bf16 evaluations with
+    kernels forced on (LDM_CONV_BLOCK_MIN=1, LDM_CONV_BLOCK128_MIN=1, and LDM_CONV_THIN_MIN=1 for the last layer's conv3_thin_kernel, which the
+    training forward uses too; the plans use them from 512 / 192 / 512 blocks up) against the same run with all three off.  Both are bf16 evaluations with
     the same rounding points: they agree to the network's bf16 floor, and both sit equally close to the fp32 CPU oracle.  Child processes: the knobs are read
     once per process."""
     import json
@@ -553,7 +554,7 @@ print(json.dumps({"blocks": blocks, "rec": rec.flatten()[::7].double().cpu().tol
                   "e_rec": rel(rec, o_dec), "e_mu": rel(mu, o_mu.detach()), "e_grads": rel(grads, o_grads), "o_loss": float(o_loss)}))
 '''
     recs = {}
-    for tag, env in (("halo", {"LDM_CONV_BLOCK": "0", "LDM_CONV_BLOCK128": "0"}), ("block", {"LDM_CONV_BLOCK_MIN": "1", "LDM_CONV_BLOCK128_MIN": "1"})):
+    for tag, env in (("halo", {"LDM_CONV_BLOCK": "0", "LDM_CONV_BLOCK128": "0", "LDM_CONV_THIN": "0"}), ("block", {"LDM_CONV_BLOCK_MIN": "1", "LDM_CONV_BLOCK128_MIN": "1", "LDM_CONV_THIN_MIN": "1"})):
         r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         recs[tag] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
