@@ -2104,7 +2104,10 @@ static int wgrad_ksplit(long M, int taps, int cout, int cin, bool hp) {
     const char* e = getenv("LDM_WGRAD_WGS");                 // tuning knob: workgroups aimed at (default: one round of 256 CUs;
     const long target = e ? atol(e) : (hp ? 768 : 256);      // the fp32 kernel, latency bound on its operand loads, wants three per CU: 49.3 -> 46.6 ms per step)
     long k = (target + wgs / 2) / wgs;                       // nearest count of whole rounds
-    if (k > steps / 16) k = steps / 16;
+    // at least 16 K steps per workgroup for a 3^3 conv (prologue and ring fill amortised); a 1x1 conv at 12^3 is 27 steps on 4 - 12 workgroups
+    // in all (24.7 us of serial K loop, 20 such launches per UNet training step): there 4 steps per workgroup are enough
+    const long min_steps = taps == 1 ? 4 : 16;
+    if (k > steps / min_steps) k = steps / min_steps;
     // at most 16 copies of a 3^3 weight-sized matrix for the export to fold; a 1x1 conv's matrix is 27 x smaller and its grid is ksplit
     // workgroups in all (nin_shortcut 128 -> 64 over 64^3 voxels: 16 workgroups ran 147 us on 6 % of the chip), so: up to 64 there
     const long cap = taps == 1 ? 64 : 16;
