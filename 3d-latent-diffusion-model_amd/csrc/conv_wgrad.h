@@ -39,9 +39,10 @@ struct WgradParams {
     int M, co_tiles, ci_tiles;
     int dbg;                          // 2048 never set: feeds the opaque per-step branch
     int ksplit; long slab_stride;     // voxel range split over `ksplit` workgroups, each writing its own [taps][Cout][ld] slab
-    int pair;                         // Cin <= 64 (one 128-byte half of an X row): the tile's cins 64 .. 127 carry the NEXT tap's X rows, so a
+    int pair;                         // 1: Cin <= 64 (one 128-byte half of an X row): the tile's cins 64 .. 127 carry the NEXT tap's X rows, so a
                                       // workgroup computes taps (2 t, 2 t + 1) and the cin half of the MFMA work that was padding does real
                                       // work (the AutoencoderKL's 64-channel level: 40 % of its training step was this kernel at 25 % useful MFMAs)
+                                      // 2: Cout <= 64 as well (stride 1, no upsample): three taps per workgroup, see the kernel
 };
 
 template <int ABL1 = 0>
@@ -63,15 +64,19 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradParams p)
     const int ci_t = bid % p.ci_tiles; bid /= p.ci_tiles;
     const int co_t = bid % p.co_tiles; bid /= p.co_tiles;
     const int taps = p.ksize * p.ksize * p.ksize;
-    const bool pair = p.pair != 0;                                                     // workgroup-uniform
-    const int tgroups = pair ? (taps + 1) / 2 : taps;
+    const bool pair = p.pair != 0, triple = p.pair == 2;                               // workgroup-uniform
+    // triple (Cout <= 64 too, stride 1, no upsample): the tile's couts 64 .. 127 are the dY rows of the NEXT voxel of the line (zero at the line's
+    // end), its cins (0 .. 63, 64 .. 127) the X rows of taps (kd, kh, 1) and (kd, kh, 2): quadrant (couts a, cins a) is tap kw = 1, (a, b) kw = 2 and
+    // (b, a) -- dY[m + 1] against X[src(m, kw = 1)] = dY[m'] against X[src(m', kw = 0)] -- kw = 0; (b, b) repeats kw = 1 and is dropped: one workgroup
+    // per (kd, kh), three quarters of the MFMAs useful
+    const int tgroups = triple ? taps / 3 : pair ? (taps + 1) / 2 : taps;
     const int tidx = bid % tgroups; const int split = bid / tgroups;
-    const int tap = pair ? 2 * tidx : tidx;
+    const int tap = triple ? 3 * tidx + 1 : pair ? 2 * tidx : tidx;
     const int kk = p.ksize * p.ksize;
     const int kd = tap / kk, kh = (tap - kd * kk) / p.ksize, kw = tap - kd * kk - kh * p.ksize;
-    const int tap2 = tap + 1;                                                          // pair mode: the tap of the tile's cins 64 .. 127
+    const int tap2 = tap + 1;                                                          // pair / triple: the tap of the tile's cins 64 .. 127
     const int kd2 = tap2 / kk, kh2 = (tap2 - kd2 * kk) / p.ksize, kw2 = tap2 - kd2 * kk - kh2 * p.ksize;
-    const int TABW = pair ? 3 * KV : 2 * KV;                                           // table entries per buffer: dY rows, X rows (, X rows of tap2)
+    const int TABW = triple ? 4 * KV : pair ? 3 * KV : 2 * KV;                         // table entries per buffer: dY rows, X rows (, X rows of tap2 (, dY rows one voxel on))
     const int DinU = p.Din << p.ups, HinU = p.Hin << p.ups, WinU = p.Win << p.ups;
     const int HWo = p.Hout * p.Wout, DHWo = p.Dout * HWo;
     const int steps_all = (p.M + KV - 1) / KV;
@@ -86,8 +91,9 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradParams p)
     //      K step is one basic block in which copies and fragment reads ride between the MFMAs.  Three table buffers: a fast
     //      wave may publish for step k + 1 while a slow one still reads the table of step k - 1.
     unsigned* const tab = reinterpret_cast<unsigned*>(smem + NS * STAGE);
-    const bool owner = tid < TABW, own_x = tid >= KV, own_x2 = tid >= 2 * KV;
-    const int own_row = own_x2 ? tid - 2 * KV : own_x ? tid - KV : tid;
+    const bool own_y2 = tid >= 3 * KV;                                                 // triple: dY rows shifted by one voxel along the line
+    const bool owner = tid < TABW, own_x = tid >= KV && !own_y2, own_x2 = tid >= 2 * KV && !own_y2;
+    const int own_row = own_y2 ? tid - 3 * KV : own_x2 ? tid - 2 * KV : own_x ? tid - KV : tid;
     const int okd = own_x2 ? kd2 : kd, okh = own_x2 ? kh2 : kh, okw = own_x2 ? kw2 : kw;
     const bool otap_ok = own_x2 ? tap2 < taps : true;
     int vw = 0, vh = 0, vd = 0, vn = 0, vm = s_begin * KV + own_row;
@@ -101,7 +107,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradParams p)
 #define WG_PUBLISH(PAR) do {                                                                                  \
         if (owner) {                                                                                          \
             unsigned off_ = 0xFFFFFFFFu;                                                                      \
-            if (!own_x) { if (vm < p.M) off_ = (unsigned)vm * (unsigned)(p.cdy * 2); }                        \
+            if (own_y2) { if (vm + 1 < p.M && vw + 1 < p.Wout) off_ = (unsigned)(vm + 1) * (unsigned)(p.cdy * 2); } \
+            else if (!own_x) { if (vm < p.M) off_ = (unsigned)vm * (unsigned)(p.cdy * 2); }                   \
             else {                                                                                            \
                 const int id = vd * p.stride + okd - p.pad, ih = vh * p.stride + okh - p.pad, iw = vw * p.stride + okw - p.pad; \
                 const bool ok_ = otap_ok & (vm < p.M) & ((unsigned)id < (unsigned)DinU) & ((unsigned)ih < (unsigned)HinU) & ((unsigned)iw < (unsigned)WinU); \
@@ -120,7 +127,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradParams p)
     // lane -> (row = lane / 16 inside the piece, physical 16-B chunk = lane % 16); 32-byte blocks are XOR-swizzled by
     // f(row) = (row & 3) + 4 * ((row >> 3) & 1) so the transposed reads below are bank-conflict free.
     const int prow = lane >> 4, pch = lane & 15;
-    int l_row[2], l_xsel[2]; unsigned l_ady[2], l_ax[2];     // voxel row inside the step, table section of its X row, channel byte added to the row offset (or OOB)
+    int l_row[2], l_xsel[2], l_ysel[2]; unsigned l_ady[2], l_ax[2];     // voxel row inside the step, table sections of its X / dY row, channel byte added to the row offset (or OOB)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int row = (wave * 2 + j) * 4 + prow;
@@ -135,6 +142,12 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradParams p)
             l_ax[j] = kbx < (unsigned)p.cx * 2u ? kbx : 0xFFFFFFFFu;
             l_xsel[j] = kb >= 128u ? 2 * KV : KV;
         }
+        l_ysel[j] = 0;
+        if (triple) {                            // bytes 128 .. 255 of the dY tile row = couts 0 .. 63 of the next voxel's dY row
+            const unsigned kby = kb & 127u;
+            l_ady[j] = kby < (unsigned)p.cdy * 2u ? kby : 0xFFFFFFFFu;
+            l_ysel[j] = kb >= 128u ? 3 * KV : 0;
+        }
     }
     __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (int)((unsigned)p.M * (unsigned)p.cdy * 2u), 0x00020000);
     __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
@@ -144,7 +157,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradParams p)
     // table reads of one step's four copies (issued ahead of the waits), then the copies themselves
 #define WG_TAB(T, PAR) do {                                                                                   \
         _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                       \
-            T[2 * j] = tab[(PAR) * TABW + l_row[j]]; T[2 * j + 1] = tab[(PAR) * TABW + l_xsel[j] + l_row[j]]; \
+            T[2 * j] = tab[(PAR) * TABW + l_ysel[j] + l_row[j]]; T[2 * j + 1] = tab[(PAR) * TABW + l_xsel[j] + l_row[j]]; \
         }                                                                                                     \
     } while (0)
 #define WG_COPIES(T) do {                                                                                     \
@@ -289,7 +302,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradParams p)
     __syncthreads();
     if (grp == 0) {
         // accumulator: col = lane & 15 -> cin, row = 4 fg + r -> cout
-        const int tap_w = pair ? tap + wb : tap;               // pair mode: the cin half of the tile is the second tap
+        int tap_w = pair ? tap + wb : tap;                     // pair mode: the cin half of the tile is the second tap
+        if (triple) { if (wa == 1 && wb == 1) return; if (wa == 1) tap_w = tap - 1; }   // (b, a) = kw 0; (b, b) repeats kw 1
         if (tap_w >= taps) return;
         const size_t tap_off = (size_t)split * p.slab_stride + (size_t)tap_w * p.Cout * p.dw_ld + p.dw_ci_off;
 #pragma unroll
@@ -299,7 +313,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradParams p)
                 const int ci = pair ? b * 16 + fi : ci_t * 128 + wb * 64 + b * 16 + fi;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int co = co_t * 128 + wa * 64 + a * 16 + 4 * fg + r;
+                    const int co = triple ? a * 16 + 4 * fg + r : co_t * 128 + wa * 64 + a * 16 + 4 * fg + r;
                     const float v = acc[a][b][r] + xch[((wq * 64) + (a * 4 + b) * 4 + r) * 64 + lane];
                     if (co < p.Cout && ci < p.Cin) p.dw[tap_off + (size_t)co * p.dw_ld + ci] = v;
                 }

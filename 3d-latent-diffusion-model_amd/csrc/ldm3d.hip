@@ -393,7 +393,7 @@ struct ldm_model {
 };
 
 // ================================================================================================ builder
-static int wgrad_ksplit(long M, int taps, int cout, int cin, bool hp = false);
+static int wgrad_ksplit(long M, int taps, int cout, int cin, bool hp = false, int stride = 1, int ups = 0);
 
 struct Builder {
     ldm_model* m; Plan* plan; Pool pool;
@@ -1356,7 +1356,7 @@ struct Builder {
         if (a.w1) export_bias(*a.w1);
         if (a.temb_row >= 0) emit_colsum(dout, true, ws_ref(dtemb_off + (size_t)a.temb_row * 4), w.cout, tproj_stride);
         // weights
-        cur_ksplit = wgrad_ksplit(dout.rows(), a.k * a.k * a.k, w.cout, cin_real, hp);
+        cur_ksplit = wgrad_ksplit(dout.rows(), a.k * a.k * a.k, w.cout, cin_real, hp, a.stride, a.ups);
         cur_rows_total = w.cout;
         dw_off = pool.alloc((size_t)cur_ksplit * a.k * a.k * a.k * w.cout * cin_real * 4);
         if (a.xb.valid) {
@@ -2094,12 +2094,14 @@ static inline int grid_for(long total, int per_block = 256, int cap = 4096) {
 }
 
 // voxel-range split of the weight-gradient GEMM: enough workgroups for 2 waves of 256 CUs, at least 16 K steps each
-static bool wgrad_pair(int taps, int cin, bool hp) {       // conv_wgrad_kernel's two-taps-per-workgroup form (WgradParams::pair)
-    static const int on = [] { const char* e = getenv("LDM_WGRAD_PAIR"); return e ? atoi(e) : 1; }();
-    return on && !hp && taps == 27 && cin <= 64;
+static int wgrad_pair(int taps, int cout, int cin, int stride, int ups, bool hp) {   // conv_wgrad_kernel's forms with several taps per workgroup (WgradParams::pair): 0 | 1 | 2 (three taps)
+    static const int on = [] { const char* e = getenv("LDM_WGRAD_PAIR"); return e ? atoi(e) : 2; }();
+    if (!on || hp || taps != 27 || cin > 64) return 0;
+    return (on >= 2 && cout <= 64 && stride == 1 && ups == 0) ? 2 : 1;
 }
-static int wgrad_ksplit(long M, int taps, int cout, int cin, bool hp) {
-    const long wgs = (long)(wgrad_pair(taps, cin, hp) ? (taps + 1) / 2 : taps) * ((cout + 127) / 128) * ((cin + 127) / 128);
+static int wgrad_ksplit(long M, int taps, int cout, int cin, bool hp, int stride, int ups) {
+    const int pm = wgrad_pair(taps, cout, cin, stride, ups, hp);
+    const long wgs = (long)(pm == 2 ? taps / 3 : pm == 1 ? (taps + 1) / 2 : taps) * ((cout + 127) / 128) * ((cin + 127) / 128);
     const long steps = (M + 63) / 64;
     const char* e = getenv("LDM_WGRAD_WGS");                 // tuning knob: workgroups aimed at (default: one round of 256 CUs;
     const long target = e ? atol(e) : (hp ? 768 : 256);      // the fp32 kernel, latency bound on its operand loads, wants three per CU: 49.3 -> 46.6 ms per step)
@@ -2110,15 +2112,17 @@ static int wgrad_ksplit(long M, int taps, int cout, int cin, bool hp) {
     if (k > steps / min_steps) k = steps / min_steps;
     // at most 16 copies of a 3^3 weight-sized matrix for the export to fold; a 1x1 conv's matrix is 27 x smaller and its grid is ksplit
     // workgroups in all (nin_shortcut 128 -> 64 over 64^3 voxels: 16 workgroups ran 147 us on 6 % of the chip), so: up to 64 there
-    const long cap = taps == 1 ? 64 : 16;
+    const long cap = taps == 1 ? 64 : pm == 2 ? 32 : 16;     // the three-tap form has 9 workgroups per voxel range (and a 64 x 64 matrix per tap): 28 ranges fill the chip
     if (k > cap) k = cap;
     return (int)(k < 1 ? 1 : k);
 }
 static int launch_wgrad(const WgradParams& p0, hipStream_t s) {
     WgradParams p = p0;
-    p.pair = wgrad_pair(p.ksize * p.ksize * p.ksize, p.Cin, false) && p.cx <= 64 ? 1 : 0;
-    const int tg_ = p.pair ? (p.ksize * p.ksize * p.ksize + 1) / 2 : p.ksize * p.ksize * p.ksize;
-    constexpr int LDS = 4 * 2 * 64 * 256 + 3 * 192 * 4;        // ring + triple-buffered source-offset table (three sections in the pair form)
+    const int taps_ = p.ksize * p.ksize * p.ksize;
+    p.pair = p.cx <= 64 ? wgrad_pair(taps_, p.Cout, p.Cin, p.stride, p.ups, false) : 0;
+    if (p.pair == 2 && p.cdy > 64) p.pair = 1;
+    const int tg_ = p.pair == 2 ? taps_ / 3 : p.pair ? (taps_ + 1) / 2 : taps_;
+    constexpr int LDS = 4 * 2 * 64 * 256 + 3 * 256 * 4;        // ring + triple-buffered source-offset table (up to four sections)
     static bool attr_tab[32] = {}; bool& attr_set = attr_flag(attr_tab);   // per device
     if (!attr_set) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr_set = true; }
     { const char* e = getenv("LDM_CONV_DBG"); const int dbg = e ? atoi(e) : 0;      // timing ablations (results are wrong)
