@@ -797,7 +797,7 @@ struct Builder {
         }
         // 64 output channels over a large grid (the AutoencoderKL's full-resolution level): one halo block in LDS per workgroup (conv_block.h)
         if (conv_block_enabled() && a.k == 3 && a.stride == 1 && a.pad == 1 && a.ups == 0 && !a.exact && !a.xb.valid && !a.w1 && !a.f32_out &&
-            w.cout_pad == 64 && rup(w.cout, 32) == 64 && cin0 <= conv_block_max_cin() && a.w_over.base == BASE_NULL &&
+            w.cout_pad == 64 && rup(w.cout, 32) == 64 && cin0 <= conv_block_max_cin() &&      // (w_over: the data-gradient convs' flipped weights, same layout)
             a.xa.D == a.Do && a.xa.H == a.Ho && a.xa.W == a.Wo) {
             const int TH = conv_block_th();
             const int td = (a.Do + BLK_TD - 1) / BLK_TD, th = (a.Ho + TH - 1) / TH, tw = (a.Wo + BLK_TW - 1) / BLK_TW;
@@ -806,7 +806,7 @@ struct Builder {
                 Act out = new_act(N, a.Do, a.Ho, a.Wo, 64);
                 if (a.want_stats) { out.stats_off = pool.alloc((size_t)N * td * th * tw * 64 * 2 * 4); out.has_stats = true; out.stats_nrb = td * th * tw; }
                 Op op{}; op.kind = OP_CONV_BLOCK;
-                op.r[0] = ws_ref(a.xa.off); op.r[2] = w_ref(w.w_off); op.r[6] = a.no_bias ? Ref() : w_ref(w.b_off); op.r[8] = a.temb;
+                op.r[0] = ws_ref(a.xa.off); op.r[2] = a.w_over.base != BASE_NULL ? a.w_over : w_ref(w.w_off); op.r[6] = a.no_bias ? Ref() : w_ref(w.b_off); op.r[8] = a.temb;
                 op.r[9] = a.residual.valid ? ws_ref(a.residual.off) : Ref(); op.r[10] = ws_ref(out.off); op.r[12] = out.has_stats ? ws_ref(out.stats_off) : Ref();
                 op.i[0] = N; op.i[1] = a.Do; op.i[2] = a.Ho; op.i[3] = a.Wo; op.i[4] = cin0; op.i[5] = TH; op.i[6] = a.temb_stride;
                 plan->ops.push_back(op);
@@ -816,7 +816,7 @@ struct Builder {
         }
         // 128 output channels (the AutoencoderKL's half-resolution level): eight-wave block kernel with double-buffered halo chunks (conv_block.h)
         if (conv_block128_enabled() && a.k == 3 && a.stride == 1 && a.pad == 1 && a.ups == 0 && !a.exact && !a.xb.valid && !a.w1 && !a.f32_out &&
-            w.cout_pad == 128 && rup(w.cout, 32) == 128 && cin0 <= conv_block128_max_cin() && a.w_over.base == BASE_NULL && a.xa.D == a.Do && a.xa.H == a.Ho && a.xa.W == a.Wo) {
+            w.cout_pad == 128 && rup(w.cout, 32) == 128 && cin0 <= conv_block128_max_cin() && a.xa.D == a.Do && a.xa.H == a.Ho && a.xa.W == a.Wo) {
             const int td = (a.Do + BLK_TD - 1) / BLK_TD, th = (a.Ho + 7) / 8, tw = (a.Wo + BLK_TW - 1) / BLK_TW;
             static const long min_blocks = [] { const char* e = getenv("LDM_CONV_BLOCK128_MIN"); return e ? atol(e) : 192L; }();   // 128 tiles (32^3 x batch 2) leave half the CUs idle: AutoencoderKL training step 18.4 vs 18.6 ms
             // one eight-wave workgroup per CU: it pays where the tiles fit ONE round (48^3: 216 tiles: AutoencoderKL 96^3 encode 2.37 -> 2.34 ms) and
@@ -827,7 +827,7 @@ struct Builder {
                 Act out = new_act(N, a.Do, a.Ho, a.Wo, 128);
                 if (a.want_stats) { out.stats_off = pool.alloc((size_t)N * td * th * tw * 128 * 2 * 4); out.has_stats = true; out.stats_nrb = td * th * tw; }
                 Op op{}; op.kind = OP_CONV_BLOCK;
-                op.r[0] = ws_ref(a.xa.off); op.r[2] = w_ref(w.w_off); op.r[6] = a.no_bias ? Ref() : w_ref(w.b_off); op.r[8] = a.temb;
+                op.r[0] = ws_ref(a.xa.off); op.r[2] = a.w_over.base != BASE_NULL ? a.w_over : w_ref(w.w_off); op.r[6] = a.no_bias ? Ref() : w_ref(w.b_off); op.r[8] = a.temb;
                 op.r[9] = a.residual.valid ? ws_ref(a.residual.off) : Ref(); op.r[10] = ws_ref(out.off); op.r[12] = out.has_stats ? ws_ref(out.stats_off) : Ref();
                 op.i[0] = N; op.i[1] = a.Do; op.i[2] = a.Ho; op.i[3] = a.Wo; op.i[4] = cin0; op.i[5] = 8; op.i[6] = a.temb_stride; op.i[7] = 128;
                 plan->ops.push_back(op);
