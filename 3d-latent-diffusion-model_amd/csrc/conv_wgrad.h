@@ -43,6 +43,7 @@ struct WgradParams {
                                       // workgroup computes taps (2 t, 2 t + 1) and the cin half of the MFMA work that was padding does real
                                       // work (the AutoencoderKL's 64-channel level: 40 % of its training step was this kernel at 25 % useful MFMAs)
                                       // 2: Cout <= 64 as well (stride 1, no upsample): three taps per workgroup, see the kernel
+                                      // 3: Cout <= 64 < Cin: the cout half alone is paired (two workgroups per (kd, kh))
 };
 
 template <int ABL1 = 0>
@@ -64,19 +65,22 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradParams p)
     const int ci_t = bid % p.ci_tiles; bid /= p.ci_tiles;
     const int co_t = bid % p.co_tiles; bid /= p.co_tiles;
     const int taps = p.ksize * p.ksize * p.ksize;
-    const bool pair = p.pair != 0, triple = p.pair == 2;                               // workgroup-uniform
+    // workgroup-uniform: xpair = the cin half of the tile is the next tap (modes 1, 2), ypair = the cout half is the next voxel's dY (modes 2, 3)
+    const bool pair = p.pair == 1 || p.pair == 2, triple = p.pair == 2, ypair = p.pair >= 2, ysolo = p.pair == 3;
     // triple (Cout <= 64 too, stride 1, no upsample): the tile's couts 64 .. 127 are the dY rows of the NEXT voxel of the line (zero at the line's
     // end), its cins (0 .. 63, 64 .. 127) the X rows of taps (kd, kh, 1) and (kd, kh, 2): quadrant (couts a, cins a) is tap kw = 1, (a, b) kw = 2 and
     // (b, a) -- dY[m + 1] against X[src(m, kw = 1)] = dY[m'] against X[src(m', kw = 0)] -- kw = 0; (b, b) repeats kw = 1 and is dropped: one workgroup
     // per (kd, kh), three quarters of the MFMAs useful
-    const int tgroups = triple ? taps / 3 : pair ? (taps + 1) / 2 : taps;
+    // mode 3 (Cout <= 64 < Cin, stride 1, no upsample): all 128 cins are real, two workgroups per (kd, kh): X rows of kw = 1 (quadrants a = kw 1,
+    // b = kw 0) and X rows of kw = 2 (a = kw 2; b would repeat kw 1 and is dropped)
+    const int tgroups = ysolo ? 2 * (taps / 3) : triple ? taps / 3 : pair ? (taps + 1) / 2 : taps;
     const int tidx = bid % tgroups; const int split = bid / tgroups;
-    const int tap = triple ? 3 * tidx + 1 : pair ? 2 * tidx : tidx;
+    const int tap = ysolo ? 3 * (tidx >> 1) + 1 + (tidx & 1) : triple ? 3 * tidx + 1 : pair ? 2 * tidx : tidx;
     const int kk = p.ksize * p.ksize;
     const int kd = tap / kk, kh = (tap - kd * kk) / p.ksize, kw = tap - kd * kk - kh * p.ksize;
     const int tap2 = tap + 1;                                                          // pair / triple: the tap of the tile's cins 64 .. 127
     const int kd2 = tap2 / kk, kh2 = (tap2 - kd2 * kk) / p.ksize, kw2 = tap2 - kd2 * kk - kh2 * p.ksize;
-    const int TABW = triple ? 4 * KV : pair ? 3 * KV : 2 * KV;                         // table entries per buffer: dY rows, X rows (, X rows of tap2 (, dY rows one voxel on))
+    const int TABW = ypair ? 4 * KV : pair ? 3 * KV : 2 * KV;                         // table entries per buffer: dY rows, X rows (, X rows of tap2 (, dY rows one voxel on))
     const int DinU = p.Din << p.ups, HinU = p.Hin << p.ups, WinU = p.Win << p.ups;
     const int HWo = p.Hout * p.Wout, DHWo = p.Dout * HWo;
     const int steps_all = (p.M + KV - 1) / KV;
@@ -143,7 +147,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradParams p)
             l_xsel[j] = kb >= 128u ? 2 * KV : KV;
         }
         l_ysel[j] = 0;
-        if (triple) {                            // bytes 128 .. 255 of the dY tile row = couts 0 .. 63 of the next voxel's dY row
+        if (ypair) {                            // bytes 128 .. 255 of the dY tile row = couts 0 .. 63 of the next voxel's dY row
             const unsigned kby = kb & 127u;
             l_ady[j] = kby < (unsigned)p.cdy * 2u ? kby : 0xFFFFFFFFu;
             l_ysel[j] = kb >= 128u ? 3 * KV : 0;
@@ -304,6 +308,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradParams p)
         // accumulator: col = lane & 15 -> cin, row = 4 fg + r -> cout
         int tap_w = pair ? tap + wb : tap;                     // pair mode: the cin half of the tile is the second tap
         if (triple) { if (wa == 1 && wb == 1) return; if (wa == 1) tap_w = tap - 1; }   // (b, a) = kw 0; (b, b) repeats kw 1
+        if (ysolo && wa == 1) { if (tidx & 1) return; tap_w = tap - 1; }                // X of kw 1: b = kw 0; X of kw 2: b repeats kw 1
         if (tap_w >= taps) return;
         const size_t tap_off = (size_t)split * p.slab_stride + (size_t)tap_w * p.Cout * p.dw_ld + p.dw_ci_off;
 #pragma unroll
@@ -313,7 +318,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const WgradParams p)
                 const int ci = pair ? b * 16 + fi : ci_t * 128 + wb * 64 + b * 16 + fi;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int co = triple ? a * 16 + 4 * fg + r : co_t * 128 + wa * 64 + a * 16 + 4 * fg + r;
+                    const int co = ypair ? a * 16 + 4 * fg + r : co_t * 128 + wa * 64 + a * 16 + 4 * fg + r;
                     const float v = acc[a][b][r] + xch[((wq * 64) + (a * 4 + b) * 4 + r) * 64 + lane];
                     if (co < p.Cout && ci < p.Cin) p.dw[tap_off + (size_t)co * p.dw_ld + ci] = v;
                 }

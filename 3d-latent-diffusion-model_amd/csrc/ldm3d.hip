@@ -2095,13 +2095,15 @@ static inline int grid_for(long total, int per_block = 256, int cap = 4096) {
 
 // voxel-range split of the weight-gradient GEMM: enough workgroups for 2 waves of 256 CUs, at least 16 K steps each
 static int wgrad_pair(int taps, int cout, int cin, int stride, int ups, bool hp) {   // conv_wgrad_kernel's forms with several taps per workgroup (WgradParams::pair): 0 | 1 | 2 (three taps)
-    static const int on = [] { const char* e = getenv("LDM_WGRAD_PAIR"); return e ? atoi(e) : 2; }();
-    if (!on || hp || taps != 27 || cin > 64) return 0;
-    return (on >= 2 && cout <= 64 && stride == 1 && ups == 0) ? 2 : 1;
+    static const int on = [] { const char* e = getenv("LDM_WGRAD_PAIR"); return e ? atoi(e) : 3; }();
+    if (!on || hp || taps != 27) return 0;
+    const bool y = on >= 2 && cout <= 64 && stride == 1 && ups == 0;
+    if (cin > 64) return (y && on >= 3) ? 3 : 0;
+    return y ? 2 : 1;
 }
 static int wgrad_ksplit(long M, int taps, int cout, int cin, bool hp, int stride, int ups) {
     const int pm = wgrad_pair(taps, cout, cin, stride, ups, hp);
-    const long wgs = (long)(pm == 2 ? taps / 3 : pm == 1 ? (taps + 1) / 2 : taps) * ((cout + 127) / 128) * ((cin + 127) / 128);
+    const long wgs = (long)(pm == 3 ? 2 * (taps / 3) : pm == 2 ? taps / 3 : pm == 1 ? (taps + 1) / 2 : taps) * ((cout + 127) / 128) * ((cin + 127) / 128);
     const long steps = (M + 63) / 64;
     const char* e = getenv("LDM_WGRAD_WGS");                 // tuning knob: workgroups aimed at (default: one round of 256 CUs;
     const long target = e ? atol(e) : (hp ? 768 : 256);      // the fp32 kernel, latency bound on its operand loads, wants three per CU: 49.3 -> 46.6 ms per step)
@@ -2119,9 +2121,11 @@ static int wgrad_ksplit(long M, int taps, int cout, int cin, bool hp, int stride
 static int launch_wgrad(const WgradParams& p0, hipStream_t s) {
     WgradParams p = p0;
     const int taps_ = p.ksize * p.ksize * p.ksize;
-    p.pair = p.cx <= 64 ? wgrad_pair(taps_, p.Cout, p.Cin, p.stride, p.ups, false) : 0;
+    p.pair = wgrad_pair(taps_, p.Cout, p.Cin, p.stride, p.ups, false);
+    if ((p.pair == 1 || p.pair == 2) && p.cx > 64) p.pair = 0;      // stored channels decide what fits a half row
     if (p.pair == 2 && p.cdy > 64) p.pair = 1;
-    const int tg_ = p.pair == 2 ? taps_ / 3 : p.pair ? (taps_ + 1) / 2 : taps_;
+    if (p.pair == 3 && p.cdy > 64) p.pair = 0;
+    const int tg_ = p.pair == 3 ? 2 * (taps_ / 3) : p.pair == 2 ? taps_ / 3 : p.pair ? (taps_ + 1) / 2 : taps_;
     constexpr int LDS = 4 * 2 * 64 * 256 + 3 * 256 * 4;        // ring + triple-buffered source-offset table (up to four sections)
     static bool attr_tab[32] = {}; bool& attr_set = attr_flag(attr_tab);   // per device
     if (!attr_set) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr_set = true; }
