@@ -113,8 +113,7 @@ SIGNATURES = {
                                    C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_size_t, _P]),
     "ldm_op_conv3d_fin_gn_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "ldm_op_conv3d_fin_gn": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int, _P, _P, _P, C.c_int, C.c_float, C.c_int, _P, _P,
-                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_size_t,
-                                       C.POINTER(C.c_int), _P]),
+                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_size_t, _P]),
     "ldm_op_group_norm_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "ldm_op_group_norm": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P, C.c_int, C.c_float, C.c_int, _P, C.c_int, C.c_int,
                                     _P, C.c_size_t, _P]),
@@ -154,7 +153,6 @@ SIGNATURES = {
     "ldm_comm_destroy": (None, [_P]),
     "ldm_comm_rank": (C.c_int, [_P]),
     "ldm_comm_world": (C.c_int, [_P]),
-    "ldm_model_sync_errors": (C.c_int, [_P]),
     "ldm_model_set_grad_sync": (C.c_int, [_P, _P]),
     "ldm_model_set_grad_wire": (C.c_int, [_P, C.c_int]),
     "ldm_model_grad_sync_pending": (C.c_int, [_P]),

@@ -1,5 +1,6 @@
 // Shared device/host helpers for the gfx950 (CDNA4) 3D latent-diffusion kernels.
 #pragma once
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -22,6 +23,16 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
     return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
 }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+// ---- environment knobs (host).  ldm_knob: switches of the SHIPPING library -- A/B of a kept feature, flipped by the parity tests and
+// documented in INTEGRATION.md.  ldm_xknob: tuning / diagnostic knobs of measured-and-settled choices (DESIGN.md keeps the numbers): they
+// read the environment only in an experiments build (make EXTRA=-DLDM_EXPERIMENTS) and are their defaults in the product library.
+static inline long ldm_knob(const char* name, long dflt) { const char* e = getenv(name); return (e && *e) ? atol(e) : dflt; }
+#ifdef LDM_EXPERIMENTS
+static inline long ldm_xknob(const char* name, long dflt) { return ldm_knob(name, dflt); }
+#else
+static inline long ldm_xknob(const char*, long dflt) { return dflt; }
+#endif
 
 // 16-byte store; WT = true: write-through (sc1): the bytes leave the XCD's L2 while the kernel still runs instead of in the
 // write-back at its end (short launches whose consumers run on every XCD anyway).  Knob: LDM_WT_STORES (GroupNorm / finalize).

@@ -434,11 +434,11 @@ __global__ __launch_bounds__(512, 1) void conv3_block128_kernel(const BlockParam
 #endif
 }
 
-static inline int conv_block128_max_cin() { static const int c = [] { const char* e = getenv("LDM_CONV_BLOCK128_MAX_CIN"); return e ? atoi(e) : 128; }(); return c; }
-static inline bool conv_block128_enabled() { static const int on = [] { const char* e = getenv("LDM_CONV_BLOCK128"); return e ? atoi(e) : 1; }(); return on != 0; }
-static inline bool conv_block_enabled() { static const int on = [] { const char* e = getenv("LDM_CONV_BLOCK"); return e ? atoi(e) : 1; }(); return on != 0; }
-static inline int conv_block_th() { static const int th = [] { const char* e = getenv("LDM_CONV_BLOCK_TH"); return e ? atoi(e) : 8; }(); return th == 4 ? 4 : 8; }
+static inline int conv_block128_max_cin() { static const int c = ldm_xknob("LDM_CONV_BLOCK128_MAX_CIN", 128); return c; }
+static inline bool conv_block128_enabled() { static const int on = ldm_knob("LDM_CONV_BLOCK128", 1); return on != 0; }
+static inline bool conv_block_enabled() { static const int on = ldm_knob("LDM_CONV_BLOCK", 1); return on != 0; }
+static inline int conv_block_th() { static const int th = ldm_xknob("LDM_CONV_BLOCK_TH", 8); return th == 4 ? 4 : 8; }
 // 128 -> 64 channels at 96^3 alone: 464 us here against 451 on the 254 x 64 halo tile (four channel chunks = four exposed copy phases), but inside
 // the AutoencoderKL decode the plan with it is FASTER (3.32 vs 3.39 ms, same box: half as many GroupNorm partial rows for the norm that follows,
 // and the halo tile's persistent grid loses its balance next to it), so the plans send Cin <= 128 here.  LDM_CONV_BLOCK_MAX_CIN overrides.
-static inline int conv_block_max_cin() { static const int c = [] { const char* e = getenv("LDM_CONV_BLOCK_MAX_CIN"); return e ? atoi(e) : 128; }(); return c; }
+static inline int conv_block_max_cin() { static const int c = ldm_xknob("LDM_CONV_BLOCK_MAX_CIN", 128); return c; }

@@ -363,10 +363,16 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
     // ---- fused 1x1 skip convolution of a ResBlock (MONAI's skip_connection when Cin != Cout): p.steps1 extra K steps over the
     //      channel-concatenated sources (x1a | x1b) at the CENTRE tap, i.e. LDS row = tile row + 1 of the (kd, kh) = (1, 1) table,
     //      no border masks.  A short second loop behind the 3^3 one (8 steps for 512 channels against 108): one voxel tile + one
-    //      weight tile per step, three ring slots, copies two steps ahead.  Unsplit convs only (the planner keeps split-K ones with a
-    //      skip on conv_igemm_kernel).
-    if (p.steps1 > 0) {
-        const int n1 = p.steps1, nca = p.c1a / BK;
+    //      weight tile per step, three ring slots, copies two steps ahead.
+    // Split-K convs (round 5): the skip's K steps are dealt to the splits in equal shares (split s takes steps [s * per, (s + 1) * per)), so the
+    // 12^3 / 6^3 ResBlocks with a channel change leave conv_igemm_kernel too; the finalize adds bias2 once.
+    int s1b = 0, s1e = p.steps1;
+    if (p.steps1 > 0 && p.splitk > 1) {
+        const int per = (p.steps1 + p.splitk - 1) / p.splitk;
+        s1b = split * per; s1e = s1b + per; if (s1e > p.steps1) s1e = p.steps1;
+    }
+    if (s1e > s1b) {
+        const int n1 = s1e - s1b, nca = p.c1a / BK;
         const unsigned c1a2 = (unsigned)p.c1a * 2u, c1b2 = (unsigned)p.c1b * 2u, w1row2 = (unsigned)(p.c1a + p.c1b) * 2u;
         __amdgpu_buffer_rsrc_t rs_1a = __builtin_amdgcn_make_buffer_rsrc((void*)p.x1a, 0, (int)((unsigned)(p.N * DHW) * c1a2), 0x00020000);
         __amdgpu_buffer_rsrc_t rs_1b = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x1b ? p.x1b : p.x1a), 0, (int)((unsigned)(p.N * DHW) * (p.x1b ? c1b2 : c1a2)), 0x00020000);
@@ -404,15 +410,15 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        issue1(0, 0);
-        if (n1 > 1) issue1(1, 1);
+        issue1(s1b, 0);
+        if (n1 > 1) issue1(s1b + 1, 1);
         int slot = 0;
         for (int s1 = 0; s1 < n1; ++s1) {
             if (s1 + 1 < n1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PA + PB) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (s1 + 2 < n1) issue1(s1 + 2, slot == 0 ? 2 : slot - 1);      // (s1 + 2) % 3: the slot step s1 - 1 has just released
+            if (s1 + 2 < n1) issue1(s1b + s1 + 2, slot == 0 ? 2 : slot - 1);      // (s1 + 2) % 3: the slot step s1 - 1 has just released
             c_aslot = (unsigned)slot * AT;
             HL_READ(wfA, afA, slot, 1);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -536,12 +542,10 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[nt * 4 + r] = (grp == 0) ? acc[nt][ml][r] : acc[nt][2 + ml][r];
         if (to_slab) {
-            float* dst = p.partial + ((size_t)e_split * p.M + m) * p.CoutPad + cbase;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4 t4 = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-                if (p.wt_slab) store16<true>(dst + 4 * q, __builtin_bit_cast(u32x4, t4));
-                else *reinterpret_cast<float4*>(dst + 4 * q) = t4;
+                *reinterpret_cast<float4*>(slab_ptr(p.partial, e_split, p.M, p.CoutPad, p.slab_lg, m, cbase + 4 * q)) = t4;
             }
             continue;
         }

@@ -60,8 +60,8 @@ struct ConvParams {
     // exact unsigned division by Hout * Wout and by Wout as multiply-high + shifts (FastDiv; filled by the launchers): the prologues decompose
     // ~14 voxel indices per lane, and a 32-bit division by a run-time value is a ~40-instruction sequence on this ISA
     unsigned fd_hw_m, fd_hw_s, fd_w_m, fd_w_s;
-    int wt_slab;                      // split-K slabs stored write-through (sc1): the 12-17 MB of fp32 partials leave the XCDs' L2s while the
-                                      // kernel runs instead of in the write-back at its end (the finalize that reads them runs on every XCD)
+    int slab_lg;                      // split-K slabs PLANAR for the group-owning finalize + GroupNorm (fin_gn.h): 0 = [split][M][CoutPad]; else
+                                      // [split][CoutPad >> slab_lg][M][1 << slab_lg]: the channels of one GroupNorm group contiguous over all rows
     float* out32; const float* residual32;   // conv3_halo_kernel, fp32 precision, splitk == 1: fp32 NDHWC output [M][CoutS] (+ fp32 residual) from the fused epilogue
     // epilogue (splitk == 1) ------------------------------------------------------------
     const float* bias;                // [CoutPad] or null
@@ -75,6 +75,14 @@ struct ConvParams {
     unsigned long long* stamps;       // diagnostic (dbg & 512): per-workgroup s_memrealtime stamps [nwg][8]
     int dbg;                          // timing experiments only (LDM_CONV_DBG): 1 = all voxel rows from the zero page, 2 = all weight rows = row 0
 };
+
+// address of 4 consecutive couts [c, c + 4) of output row m in split `split` of the fp32 slabs (ConvParams::slab_lg)
+__device__ __forceinline__ float* slab_ptr(float* partial, int split, int M, int CoutPad, int lg, int m, int c) {
+    float* base = partial + (size_t)split * M * CoutPad;
+    if (lg == 0) return base + (size_t)m * CoutPad + c;
+    return base + (((size_t)(c >> lg) * M + m) << lg) + (c & ((1 << lg) - 1));
+}
+
 
 // n / d for 32-bit unsigned n and a divisor fixed at launch time (round-up multiplier with an add-shift fix-up, exact for every n):
 //   host: s = ceil(log2 d) - 1, m = floor(2^32 (2^(s+1) - d) / d) + 1;  device: q = mulhi(n, m); (((n - q) >> 1) + q) >> s.   d = 1: s = 255.
@@ -583,12 +591,10 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_igemm_kernel(const ConvParam
                     else v[nt * 4 + r] = acc[nt][ml][r];
                 }
             if (to_slab) {
-                float* dst = p.partial + ((size_t)split * p.M + m) * p.CoutPad + cbase;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float4 t4 = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-                    if (p.wt_slab) store16<true>(dst + 4 * q, __builtin_bit_cast(u32x4, t4));
-                    else *reinterpret_cast<float4*>(dst + 4 * q) = t4;
+                    *reinterpret_cast<float4*>(slab_ptr(p.partial, split, p.M, p.CoutPad, p.slab_lg, m, cbase + 4 * q)) = t4;
                 }
                 continue;
             }

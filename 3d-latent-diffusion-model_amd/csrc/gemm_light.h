@@ -154,7 +154,7 @@ static inline hipError_t launch_gemm_light(const LightParams& p0, int cout_pad, 
     return hipGetLastError();
 }
 static inline int gemm_light_big(long M, int cout_pad) {
-    static const int thr = [] { const char* e = getenv("LDM_LIGHT_BIG_MIN"); return e ? atoi(e) : 256; }();   // tuning knob (tools/stamp_conv1.py)
+    static const int thr = ldm_xknob("LDM_LIGHT_BIG_MIN", 256);   // tuning knob (tools/stamp_conv1.py)
     return ((M + 63) / 64) * (cout_pad / 64) >= thr;
 }
 static inline bool gemm_light_ok(int k, int stride, int ups, int cin, bool single_source, bool plain_epilogue) {

@@ -166,7 +166,7 @@ __global__ __launch_bounds__(64 * KW) void gemm_light_x3_kernel(const LightX3Par
 
 // tile choice: 64 x 64 per wave once that still gives every CU a wave (LDM_LIGHT_X3_BIG_MIN tiles), else 32 x 32
 static inline int gemm_light_x3_big(long M, int cout_pad) {
-    static const int thr = [] { const char* e = getenv("LDM_LIGHT_X3_BIG_MIN"); return e ? atoi(e) : 256; }();
+    static const int thr = ldm_xknob("LDM_LIGHT_X3_BIG_MIN", 256);
     return cout_pad % 64 == 0 && ((M + 63) / 64) * (cout_pad / 64) >= thr;
 }
 static inline hipError_t launch_gemm_light_x3(const LightX3Params& p0, int cout_pad, int big, hipStream_t s) {

@@ -52,23 +52,29 @@ static int fail(int code, const char* fmt, ...) {
 // "has hipFuncSetAttribute been called for this kernel" is a per-DEVICE fact: launchers keep a flag per device ordinal
 static inline bool& attr_flag(bool (&tab)[32]) { int d = 0; if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 32) d = 0; return tab[d]; }
 
+#ifdef LDM_EXPERIMENTS
 static int g_block_slots = 0;                                  // ldm_debug_conv_block_slots: tests walk the tile loop on small volumes
+#endif
 static hipError_t launch_conv_block(const BlockParams& q0, int TH, hipStream_t s) {
     BlockParams q = q0;
     q.td = (q.D + BLK_TD - 1) / BLK_TD; q.th = (q.H + TH - 1) / TH; q.tw = (q.W + BLK_TW - 1) / BLK_TW;
     const long tiles = (long)q.N * q.td * q.th * q.tw;
-    static const int dbg = [] { const char* e = getenv("LDM_BLOCK_DBG"); return e ? atoi(e) : 0; }();
-    // the tile-loop form (two workgroups per CU walk the tiles, the next tile's first halo copy issued before the epilogue) is built and tested but
-    // OFF: 280 vs 255 us at 96^3 (AutoencoderKL encode 2.49 vs 2.35 ms).  A static share of 3 or 4 tiles per workgroup loses what the hardware
-    // dispatcher gives the one-tile form for free: the next tile goes to whichever CU frees a slot first.
-    static const int persist = [] { const char* e = getenv("LDM_CONV_BLOCK_PERSIST"); return e ? atoi(e) : 0; }();
+    static const int dbg = ldm_xknob("LDM_BLOCK_DBG", 0);
+    // the tile-loop form (two workgroups per CU walk the tiles, the next tile's first halo copy issued before the epilogue) lives in experiments
+    // builds only (EXTRA=-DLDM_EXPERIMENTS, LDM_CONV_BLOCK_PERSIST=1): 280 vs 255 us at 96^3 (AutoencoderKL encode 2.49 vs 2.35 ms).  A static
+    // share of 3 or 4 tiles per workgroup loses what the hardware dispatcher gives the one-tile form for free: the next tile goes to whichever CU
+    // frees a slot first.
+    static const int persist = ldm_xknob("LDM_CONV_BLOCK_PERSIST", 0);
     static int cus_tab[32] = {};
     int dev_ = 0; if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 32) dev_ = 0;
     if (!cus_tab[dev_]) { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev_) != hipSuccess) return hipErrorUnknown; cus_tab[dev_] = pr.multiProcessorCount / 8 * 8; if (cus_tab[dev_] < 8) cus_tab[dev_] = 8; }
     static bool attr_tab[32] = {}; bool& attr_set = attr_flag(attr_tab);
     if (!attr_set) {
 #define BLK_ATTR(...) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_block_kernel<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, BlkGeom<8>::LDS_ALL); if (e != hipSuccess) return e; }
-        BLK_ATTR(8, 0, false) BLK_ATTR(8, 0, true) BLK_ATTR(4, 0, false)
+        BLK_ATTR(8, 0, false) BLK_ATTR(4, 0, false)
+#ifdef LDM_EXPERIMENTS
+        BLK_ATTR(8, 0, true)
+#endif
 #ifdef LDM_BLOCK_EXPERIMENTS
         BLK_ATTR(8, 1, false) BLK_ATTR(8, 2, false) BLK_ATTR(8, 4, false) BLK_ATTR(8, 3, false) BLK_ATTR(8, 7, false) BLK_ATTR(8, 8, false) BLK_ATTR(8, 15, false)
 #endif
@@ -81,10 +87,12 @@ static hipError_t launch_conv_block(const BlockParams& q0, int TH, hipStream_t s
     BLK_DBG(1) BLK_DBG(2) BLK_DBG(4) BLK_DBG(3) BLK_DBG(7) BLK_DBG(8) BLK_DBG(15)
 #undef BLK_DBG
 #endif
-    (void)dbg;
+    (void)dbg; (void)persist;
+#ifdef LDM_EXPERIMENTS
     const long slots = g_block_slots > 0 ? g_block_slots : 2L * cus_tab[dev_];     // two workgroups per CU
-    if (TH == 8 && persist && tiles > slots) hipLaunchKernelGGL((conv3_block_kernel<8, 0, true>), dim3((unsigned)slots), dim3(256), BlkGeom<8>::LDS_ALL, s, q);
-    else if (TH == 8) hipLaunchKernelGGL((conv3_block_kernel<8, 0, false>), dim3(grid), dim3(256), BlkGeom<8>::LDS_ALL, s, q);
+    if (TH == 8 && persist && tiles > slots) { hipLaunchKernelGGL((conv3_block_kernel<8, 0, true>), dim3((unsigned)slots), dim3(256), BlkGeom<8>::LDS_ALL, s, q); return hipGetLastError(); }
+#endif
+    if (TH == 8) hipLaunchKernelGGL((conv3_block_kernel<8, 0, false>), dim3(grid), dim3(256), BlkGeom<8>::LDS_ALL, s, q);
     else hipLaunchKernelGGL((conv3_block_kernel<4, 0, false>), dim3(grid), dim3(256), BlkGeom<4>::LDS_ALL, s, q);
     return hipGetLastError();
 }
@@ -118,7 +126,7 @@ static inline uint16_t host_f2bf(float f) {            // round-to-nearest-even,
 }
 
 // ================================================================================================ plan IR
-enum BaseId { BASE_NULL = 0, BASE_WS, BASE_W, BASE_IO0, BASE_IO1, BASE_IO2, BASE_IO3, BASE_IO4, BASE_IO5, BASE_W32, BASE_TAPO, BASE_TAPI, BASE_COUNT };
+enum BaseId { BASE_NULL = 0, BASE_WS, BASE_W, BASE_IO0, BASE_IO1, BASE_IO2, BASE_IO3, BASE_IO4, BASE_IO5, BASE_W32, BASE_TAPO, BASE_TAPI, BASE_TTAB, BASE_SST, BASE_COUNT };   // TTAB: tabulated time-embedding rows (model-owned), SST: the sampler's device state
 struct Ref { int base = BASE_NULL; size_t off = 0; };
 static inline Ref ws_ref(size_t off) { Ref r; r.base = BASE_WS; r.off = off; return r; }
 static inline Ref w_ref(size_t off) { Ref r; r.base = BASE_W; r.off = off; return r; }
@@ -152,10 +160,11 @@ enum OpKind { OP_PACK, OP_CONV, OP_FINALIZE, OP_GN_STATS, OP_GN_FINALIZE, OP_GN_
               OP_CONV_THIN,                        // 3^3 conv with Cout <= 4 and fp32 NCDHW output: the networks' last layer (conv_thin.h)
               OP_FIN_GN,                           // split-K finalize + the GroupNorm(+SiLU) that consumes it, one launch (fin_gn.h)
               OP_GEMM_LIGHT32,
-              OP_CONV_BLOCK };                     // 3^3 conv with 64 output channels over a large grid, one halo block in LDS per workgroup (conv_block.h)
+              OP_CONV_BLOCK,                       // 3^3 conv with 64 output channels over a large grid, one halo block in LDS per workgroup (conv_block.h)
+              OP_TEMB_ROW };                       // denoise-step plans: the time-embedding projections of the sampler's current step, copied from the table (temb_row_kernel)
              //                   // fp32 precision: 1x1 convolution as the light GEMM on fp32 operands split in registers (gemm_light_x3.h)
 
-struct ConvCfg { int wgm, wgn, bk, splitk; int halo = 0, mtps = 0, qps = 0; };   // halo: conv3_halo_kernel (126-row tiles)
+struct ConvCfg { int wgm, wgn, bk, splitk; int halo = 0, mtps = 0, qps = 0; int slab_lg = 0; };   // halo: conv3_halo_kernel (126-row tiles); slab_lg: planar split-K slabs (fin_gn.h)
 
 struct Op {
     OpKind kind;
@@ -287,15 +296,11 @@ struct ldm_model {
     GradSyncState gsync;                     // ldm_model_set_grad_sync
     // UNet: stacked time_emb_proj GEMV
     size_t tproj_w_off = 0, tproj_b_off = 0; int tproj_rows = 0; std::map<std::string, int> tproj_row;
+    // UNet: the stacked projections tabulated for every step of a sampler's schedule ([n_steps][tproj_rows] fp32; ldm_unet_denoise_step):
+    // valid for the schedule `temb_tab_ts` and the precision it was built in, until the next parameter upload
+    float* temb_tab = nullptr; size_t temb_tab_cap = 0; std::vector<float> temb_tab_ts; int temb_tab_prec = -1; bool temb_tab_valid = false;
 
     size_t arena_alloc(size_t bytes) { size_t o = arena_bytes; arena_bytes += rup_sz(bytes, 256); return o; }
-    // inter-workgroup exchange area of the fused finalize + GroupNorm launches (fin_gn.h), inside the (zero-initialised) arena:
-    // [0, 256) error word; [256, 256 + 64 * 256) arrival / departure counters, 256 B per fused op of a plan; then 32 KiB of partial
-    // statistics per fused op.  Counters are zero between launches (the kernel restores them).
-    static constexpr int SYNC_SLOTS = 60;
-    static constexpr size_t SYNC_CNT_OFF = 256, SYNC_PART_OFF = 256 + 64 * 256, SYNC_PART_BYTES = 32 * 1024;
-    static constexpr size_t SYNC_BYTES = SYNC_PART_OFF + SYNC_SLOTS * SYNC_PART_BYTES;
-    size_t sync_off = 0;
     // weights derived from the packed ones (phase weights of the upsample convs): rebuilt on the stream of the next inference
     // call after any parameter upload
     struct PhaseW { size_t w_off, wp_off; int cout_pad, cin_s; };
@@ -452,17 +457,18 @@ struct Builder {
     };
     std::vector<Tape> tape;
 
-    static bool halo_enabled() { const char* e = getenv("LDM_CONV_HALO"); return e ? atoi(e) != 0 : true; }
+    static bool halo_enabled() { return ldm_knob("LDM_CONV_HALO", 1) != 0; }
     // LDM_HALO_TALL: 0 = never, 1 = wherever the cost model prefers it, 2 (default) = only for Cout % 128 != 0
-    static int tall_mode() { const char* e = getenv("LDM_HALO_TALL"); return e ? atoi(e) : 2; }
-    static bool light_enabled() { const char* e = getenv("LDM_GEMM_LIGHT"); return e ? atoi(e) != 0 : true; }
-    static bool two_wg_enabled() { const char* e = getenv("LDM_IGEMM_2WG"); return e ? atoi(e) != 0 : true; }
-    static bool phase_enabled() { const char* e = getenv("LDM_CONV_PHASE"); return e ? atoi(e) != 0 : true; }
+    static int tall_mode() { return ldm_xknob("LDM_HALO_TALL", 2); }
+    static bool light_enabled() { return ldm_knob("LDM_GEMM_LIGHT", 1) != 0; }
+    static bool two_wg_enabled() { return ldm_knob("LDM_IGEMM_2WG", 1) != 0; }
+    static bool phase_enabled() { return ldm_knob("LDM_CONV_PHASE", 1) != 0; }
     // halo_n > 0: the conv is eligible for conv3_halo_kernel (3^3, stride 1, pad 1, single source, BK 64); halo_n = N
     // and halo_dhw = voxels per sample (its 126-row tiles never straddle samples).
     // steps = K steps of the 3^3 (or k^3) part; steps1 = extra K steps of a fused 1x1 skip (the halo kernel runs them as a second loop
     // behind the 3^3 one, unsplit convs only)
-    static bool halo_skip_enabled() { static const int v = [] { const char* e = getenv("LDM_HALO_SKIP"); return e ? atoi(e) : 1; }(); return v != 0; }
+    static bool halo_skip_enabled() { static const int v = ldm_knob("LDM_HALO_SKIP", 1); return v != 0; }
+    static bool halo_skip_split_enabled() { static const int v = ldm_knob("LDM_HALO_SKIP_SPLIT", 1); return v != 0; }   // ... in split-K convs too
     static ConvCfg choose_cfg(long M, int cout_pad, int steps0, int bk, int halo_n = 0, long halo_dhw = 0, bool halo_only = false, int steps1 = 0) {
         ConvCfg best{2, 2, bk, 1}; double best_t = 1e30;
         const int steps = steps0 + steps1;
@@ -496,9 +502,9 @@ struct Builder {
                 const int qps = (Q + sk - 1) / sk, skr = (Q + qps - 1) / qps;    // every split non-empty
                 const long nwg = tiles * skr;
                 const double rounds = ceil((double)nwg / 256.0);
-                double t = rounds * (3.0 * qps * c_step + 2500.0 + steps1 * 1.6 * c_step);
+                double t = rounds * (3.0 * qps * c_step + 2500.0 + ((steps1 + skr - 1) / skr) * 1.6 * c_step + (steps1 && skr > 1 ? 800.0 : 0.0));
                 if (skr > 1) t += 6000.0 + (double)M * cout_pad * 4.0 * skr * 2.0 / 2500.0;
-                if (steps1 && skr > 1) continue;                               // the fused skip loop exists in the unsplit form only
+                if (steps1 && skr > 1 && !halo_skip_split_enabled()) continue;   // the splits share the fused skip's K steps (round 5)
                 if (t < best_t) { best_t = t; best = ConvCfg{2, 2, 64, skr}; best.halo = 1; best.mtps = mtps; best.qps = qps; }
             }
         }
@@ -514,9 +520,9 @@ struct Builder {
                 const int qps = (Q + sk - 1) / sk, skr = (Q + qps - 1) / qps;
                 const long nwg = tiles * skr;
                 const double rounds = ceil((double)nwg / 256.0);
-                double t = rounds * (3.0 * qps * c_step + 2500.0 + steps1 * 1.6 * c_step);
+                double t = rounds * (3.0 * qps * c_step + 2500.0 + ((steps1 + skr - 1) / skr) * 1.6 * c_step + (steps1 && skr > 1 ? 800.0 : 0.0));
                 if (skr > 1) t += 6000.0 + (double)M * cout_pad * 4.0 * skr * 2.0 / 2500.0;
-                if (steps1 && skr > 1) continue;
+                if (steps1 && skr > 1 && !halo_skip_split_enabled()) continue;
                 if (tall_mode() == 2 && cout_pad % 128 == 0) t = 1e31;           // mode 2: only where the 128-cout tile cannot run
                 if (tall_mode() == 3 && skr == 1 && best.halo == 1 && best.splitk == 1) t = 0.0;   // mode 3 (experiments): wherever the 128-cout tile runs unsplit
                 if (t < best_t) { best_t = t; best = ConvCfg{4, 1, 64, skr}; best.halo = 2; best.mtps = mtps; best.qps = qps; }
@@ -529,7 +535,7 @@ struct Builder {
     // fp32 inference plans: the split-K finalize also leaves the output's GroupNorm partials (finalize_stats_f32_kernel), so the
     // GroupNorm that reads it folds them in its own launch (gn_apply's hp && fused branch) instead of a statistics pass.  LDM_FIN32_STATS=0: off.
     void fin32_stats(Op& f, Act& out, const ConvArgs& a, int N, int dhwo, int couts) {
-        static const int on = [] { const char* e = getenv("LDM_FIN32_STATS"); return e ? atoi(e) : 1; }();
+        static const int on = ldm_xknob("LDM_FIN32_STATS", 1);
         if (!on || train || !a.want_stats || a.f32_out || couts % 4 || couts > 1024) return;
         const int cvec = couts / 4, rows_par = std::max(1, 256 / cvec);
         int nrb = std::min((dhwo + rows_par - 1) / rows_par, std::max(1, 256 / N));
@@ -550,7 +556,7 @@ struct Builder {
         // 3 x bf16 product on conv_igemm_kernel: the source is split once (hi | lo, same size), the kernel reads it as two concatenated
         // sources (hi | lo, then hi again) against phase weights [hi | hi | lo], fp32 slabs, fp32 finalize.
         {
-            static const int x3_phase = [] { const char* e = getenv("LDM_X3_PHASE"); return e ? atoi(e) : 1; }();
+            static const int x3_phase = ldm_xknob("LDM_X3_PHASE", 1);
             const int C = a.xa.C;
             if (x3_phase && !train && a.ups == 1 && !a.exact && a.k == 3 && a.stride == 1 && a.pad == 1 && !a.xb.valid && !a.w1 && !a.f32_out &&
                 a.w_over.base == BASE_NULL && !a.xa.hl && a.Do == 2 * a.xa.D && a.Ho == 2 * a.xa.H && a.Wo == 2 * a.xa.W && phase_enabled() &&
@@ -620,9 +626,9 @@ struct Builder {
             i[0] = 2 * C; i[4] = N; i[5] = a.xa.D; i[6] = a.xa.H; i[7] = a.xa.W; i[8] = a.Do; i[9] = a.Ho; i[10] = a.Wo;
             i[11] = 3; i[12] = 1; i[13] = 1; i[14] = 8; i[15] = (int)M; i[16] = couts; i[17] = w.cout_pad; i[18] = w.cout;
             i[19] = 3 * n3; i[23] = N * cc.mtps;
-            static const int x3_fused = [] { const char* e = getenv("LDM_X3_FUSED_EP"); return e ? atoi(e) : 1; }();
+            static const int x3_fused = ldm_xknob("LDM_X3_FUSED_EP", 1);
             {   // the last layer with <= 4 output channels: conv3_thin_kernel over the split (conv_thin.h, ThinParams::x3_c)
-                static const int thin = [] { const char* e = getenv("LDM_CONV_THIN"); return e ? atoi(e) : 1; }();
+                static const int thin = ldm_knob("LDM_CONV_THIN", 1);
                 const int cr = a.cout_real ? a.cout_real : w.cout;
                 if (thin && a.f32_out && cr <= 4 && C <= 128 && a.temb.base == BASE_NULL && !a.residual.valid &&
                     (long)N * ((a.Do + THIN_TD - 1) / THIN_TD) * ((a.Ho + THIN_TH - 1) / THIN_TH) * ((a.Wo + THIN_TW - 1) / THIN_TW) >= 512) {
@@ -668,11 +674,11 @@ struct Builder {
         // ~5e-6 per block, 5e-5 end to end (gate 1e-3).  Training plans keep the exact fp32 MFMA: at unit weight gain the backward of
         // these networks amplifies a 1e-5 perturbation to 1e-3 of the gradient (measured), which is the whole parity budget.
         // LDM_F32_X3=0: fp32 MFMA everywhere; 2: 3 x bf16 in training plans too.
-        static const int f32_x3 = [] { const char* e = getenv("LDM_F32_X3"); return e ? atoi(e) : 1; }();
+        static const int f32_x3 = ldm_knob("LDM_F32_X3", 1);
         const bool x3 = (f32_x3 == 2 || (f32_x3 == 1 && !train)) && cin0 % 32 == 0 && a.xa.C % 32 == 0;
         {   // 1x1x1 convolutions of the 3 x bf16 plans: light GEMM on the fp32 operands, no slabs and no finalize (gemm_light_x3.h).  LDM_LIGHT_X3=0: off.
-            static const int light_x3 = [] { const char* e = getenv("LDM_LIGHT_X3"); return e ? atoi(e) : 1; }();
-            static const long light_x3_max_m = [] { const char* e = getenv("LDM_LIGHT_X3_MAX_M"); return e ? atol(e) : 4096L; }();   // above: conv_x3_kernel's LDS tiles (one split per tile) win: 24^3 x 512 -> 256: 61 vs 68 us
+            static const int light_x3 = ldm_xknob("LDM_LIGHT_X3", 1);
+            static const long light_x3_max_m = ldm_xknob("LDM_LIGHT_X3_MAX_M", 4096L);   // above: conv_x3_kernel's LDS tiles (one split per tile) win: 24^3 x 512 -> 256: 61 vs 68 us
             if (light_x3 && x3 && M <= light_x3_max_m && a.k == 1 && a.stride == 1 && a.pad == 0 && !a.ups && !a.exact && !a.f32_out && !a.xa.hl && a.temb.base == BASE_NULL &&
                 (!a.xb.valid || a.xb.C % 32 == 0) && w.cout_pad % 32 == 0 && a.xa.D == a.Do && a.xa.H == a.Ho && a.xa.W == a.Wo &&
                 M * (long)std::max(cin0, w.cout_pad) * 4 < (1L << 31)) {
@@ -697,8 +703,8 @@ struct Builder {
         }
         const int kb = x3 ? 32 : 16;
         const int taps = a.k * a.k * a.k, nchunk = cin0 / kb, steps = taps * nchunk;
-        static const int f32_bn = [] { const char* e = getenv("LDM_F32_BN"); return e ? atoi(e) : 0; }();        // tuning knobs
-        static const int f32_wgs = [] { const char* e = getenv("LDM_F32_WGS"); return e ? atoi(e) : 512; }();   // two workgroups per CU: 66 -> 73 TFLOP/s over the step
+        static const int f32_bn = ldm_knob("LDM_F32_BN", 0);        // tuning knobs
+        static const int f32_wgs = ldm_knob("LDM_F32_WGS", 512);   // two workgroups per CU: 66 -> 73 TFLOP/s over the step
         const int mtiles = (int)((M + 127) / 128);
         int bn = (w.cout_pad % 128) ? 64 : 128;          // 64-wide tiles where 128 would idle half of the MFMA rows
         if (f32_bn == 64 || (f32_bn == 1 && (long)mtiles * (w.cout_pad / 128) < 256)) bn = 64;
@@ -754,8 +760,8 @@ struct Builder {
             if (big >= (1L << 32)) { err = "conv " + tag + ": a source tensor exceeds 4 GiB (split the batch)"; return Act(); }
         }
         {   // the networks' last layer (Cout <= 4, fp32 NCDHW output): conv_thin.h; inference plans and (round 4) the training forward too
-            static const int thin = [] { const char* e = getenv("LDM_CONV_THIN"); return e ? atoi(e) : 1; }();
-            static const long thin_min = [] { const char* e = getenv("LDM_CONV_THIN_MIN"); return e ? atol(e) : 512L; }();
+            static const int thin = ldm_knob("LDM_CONV_THIN", 1);
+            static const long thin_min = ldm_knob("LDM_CONV_THIN_MIN", 512L);
             const int cr = a.cout_real ? a.cout_real : w.cout;
             if (thin && a.f32_out && a.k == 3 && a.stride == 1 && a.pad == 1 && !a.ups && !a.exact && !a.xb.valid && !a.w1 &&
                 a.temb.base == BASE_NULL && !a.residual.valid && a.w_over.base == BASE_NULL && cr <= 4 && cin0 % 32 == 0 && cin0 <= 128 &&
@@ -801,7 +807,7 @@ struct Builder {
             a.xa.D == a.Do && a.xa.H == a.Ho && a.xa.W == a.Wo) {
             const int TH = conv_block_th();
             const int td = (a.Do + BLK_TD - 1) / BLK_TD, th = (a.Ho + TH - 1) / TH, tw = (a.Wo + BLK_TW - 1) / BLK_TW;
-            static const long min_blocks = [] { const char* e = getenv("LDM_CONV_BLOCK_MIN"); return e ? atol(e) : 512L; }();
+            static const long min_blocks = ldm_knob("LDM_CONV_BLOCK_MIN", 512L);
             if ((long)N * td * th * tw >= min_blocks) {
                 Act out = new_act(N, a.Do, a.Ho, a.Wo, 64);
                 if (a.want_stats) { out.stats_off = pool.alloc((size_t)N * td * th * tw * 64 * 2 * 4); out.has_stats = true; out.stats_nrb = td * th * tw; }
@@ -818,10 +824,10 @@ struct Builder {
         if (conv_block128_enabled() && a.k == 3 && a.stride == 1 && a.pad == 1 && a.ups == 0 && !a.exact && !a.xb.valid && !a.w1 && !a.f32_out &&
             w.cout_pad == 128 && rup(w.cout, 32) == 128 && cin0 <= conv_block128_max_cin() && a.xa.D == a.Do && a.xa.H == a.Ho && a.xa.W == a.Wo) {
             const int td = (a.Do + BLK_TD - 1) / BLK_TD, th = (a.Ho + 7) / 8, tw = (a.Wo + BLK_TW - 1) / BLK_TW;
-            static const long min_blocks = [] { const char* e = getenv("LDM_CONV_BLOCK128_MIN"); return e ? atol(e) : 192L; }();   // 128 tiles (32^3 x batch 2) leave half the CUs idle: AutoencoderKL training step 18.4 vs 18.6 ms
+            static const long min_blocks = ldm_knob("LDM_CONV_BLOCK128_MIN", 192L);   // 128 tiles (32^3 x batch 2) leave half the CUs idle: AutoencoderKL training step 18.4 vs 18.6 ms
             // one eight-wave workgroup per CU: it pays where the tiles fit ONE round (48^3: 216 tiles: AutoencoderKL 96^3 encode 2.37 -> 2.34 ms) and
             // loses where they need several (72 x 88 x 56: 693 tiles = 2.7 rounds that take 3: configs[3] encode 6.65 -> 6.89 ms), so: <= CUs tiles
-            static const long max_blocks = [] { const char* e = getenv("LDM_CONV_BLOCK128_MAX"); return e ? atol(e) : 0L; }();
+            static const long max_blocks = ldm_xknob("LDM_CONV_BLOCK128_MAX", 0L);
             const long tiles128 = (long)N * td * th * tw;
             if (tiles128 >= min_blocks && tiles128 <= (max_blocks > 0 ? max_blocks : (long)device_cus())) {
                 Act out = new_act(N, a.Do, a.Ho, a.Wo, 128);
@@ -904,35 +910,34 @@ struct Builder {
     }
 
     // ---- split-K finalize + the GroupNorm that consumes it, in one launch (fin_gn.h) ------------------------------------------
-    // Called right after conv() returned `raw`: if the plan's last op is that conv's OP_FINALIZE and the shapes allow, it becomes an
-    // OP_FIN_GN that also writes GroupNorm(+SiLU)(raw) into *y.  keep_raw = false: nobody else reads the un-normalised tensor (a
+    // Called right after conv() returned `raw`: if the plan's last op is that conv's OP_FINALIZE and one workgroup can own a whole
+    // (sample, group) of the tensor, the finalize becomes an OP_FIN_GN that also writes GroupNorm(+SiLU)(raw) into *y, and the conv in
+    // front of it writes its slabs planar (ConvCfg::slab_lg).  keep_raw = false: nobody else reads the un-normalised tensor (a
     // ResBlock's conv1 output): it is not written at all and its workspace block returns to the pool.
-    // Measured (round 4, same box, headline step): 23 fused launches, 458.7 vs 468.6 steps/s for the three-launch form -- 2.2 % SLOWER.
-    // In-kernel stamps (profiles/r04_kstamps_fin_gn.txt): slab sum 2.7 us + block statistics 1.2 + EXCHANGE 4.2 - 8.2 + apply 0.9 + drain 0.4
-    // = 11.1 us against finalize 4.7 + boundary 1.2 + one-launch GroupNorm 4.0 = 9.9 us: an arrival counter in memory costs three
-    // dependent round trips (atomic lands, poll sees it, payload read) plus the arrival skew of the slice's 54 blocks, which is more
-    // than the kernel boundary (1.2 us) plus the statistics fold it replaces.  Off by default (LDM_FIN_GN=1 switches it on).
-    static bool fin_gn_enabled() { static const int v = [] { const char* e = getenv("LDM_FIN_GN"); return e ? atoi(e) : 0; }(); return v != 0; }
-    int fin_gn_slots = 0;
+    // History: rounds 2 / 4 built this with a grid barrier / an arrival counter between the launch's workgroups and lost 10 % / 2.2 %
+    // (DESIGN.md 3.2b); the group-owning form has no exchange.  LDM_FIN_GN=0 switches it off.
+    static bool fin_gn_enabled() { static const int v = ldm_knob("LDM_FIN_GN", 1); return v != 0; }
     std::map<size_t, Act> prenorm;                   // un-normalised activation (by offset) -> its GroupNorm output, produced by an OP_FIN_GN
     bool fuse_fin_gn(Act& raw, bool keep_raw, const GnW& g, int groups, float eps, bool silu, Act* y) {
-        if (hp || train || !fin_gn_enabled() || plan->ops.empty() || !raw.valid) return false;
+        if (hp || train || !fin_gn_enabled() || plan->ops.size() < 2 || !raw.valid) return false;
         Op& f = plan->ops.back();
-        if (f.kind != OP_FINALIZE || f.i[22] || f.r[10].base != BASE_WS || f.r[10].off != raw.off) return false;
+        Op& cv = plan->ops[plan->ops.size() - 2];
+        if (f.kind != OP_FINALIZE || cv.kind != OP_CONV || f.i[22] || f.r[10].base != BASE_WS || f.r[10].off != raw.off) return false;
         const int C = raw.C, N = raw.N, DHW = raw.D * raw.H * raw.W;
-        if (C != g.C || C % groups) return false;
-        const int cpg = C / groups;
-        if (cpg < 4 || cpg > 64 || 64 % cpg) return false;                      // whole groups inside a 64-channel slice, <= 16 of them
-        const int slices = (C + 63) / 64, chunks = (DHW + 31) / 32;
-        if (N * slices > 32 || (long)N * slices * chunks > 256) return false;   // every block resident (one per CU) and inside its sync slot
-        if (fin_gn_slots >= ldm_model::SYNC_SLOTS) return false;
-        const int slot = fin_gn_slots++;
+        if (C != g.C || !fin_gn_ok(C, groups, DHW) || (f.i[14] & 4)) return false;      // (phase-mode convs scatter their rows: not planar)
+        const int lg = fin_gn_lg(C, groups);
+        // one CU streams a whole group's slabs (~40 - 50 GB/s per CU measured): it pays where that is less than what the separate finalize
+        // + GroupNorm cost.  6^3 x 16 channels x 24 splits = 332 KB per group: 12.3 vs 9 + 8 us (per-op trace); 12^3 x 8 channels x 9 splits =
+        // 498 KB: 21 - 25 vs 8.5 + 8 us: the 12^3 level keeps its three launches (profiles/r05_ab_fin_gn.txt)
+        static const long max_kb = ldm_knob("LDM_FIN_GN_MAX_KB", 400);
+        if ((long)cv.cc.splitk * DHW * (C / groups) * 4 > max_kb * 1024) return false;
+        if (f.i[17] % (1 << lg)) return false;
         Act out = new_act(N, raw.D, raw.H, raw.W, C);
         f.kind = OP_FIN_GN;
         f.r[3] = w_ref(g.g_off); f.r[4] = w_ref(g.b_off); f.r[5] = ws_ref(out.off);
-        f.r[13] = w_ref(m->sync_off);
         f.r[12] = Ref();                                                        // no statistics slab: the statistics never leave the launch
-        f.i[0] = groups; f.i[1] = silu ? 1 : 0; f.i[2] = chunks; f.i[3] = slot; f.f[0] = eps;
+        f.i[0] = groups; f.i[1] = silu ? 1 : 0; f.i[2] = lg; f.f[0] = eps;
+        f.cc.slab_lg = lg; cv.cc.slab_lg = lg; cv.r[12] = Ref();
         if (raw.has_stats) { pool.release(raw.stats_off); raw.has_stats = false; }
         if (!keep_raw) { f.r[10] = Ref(); pool.release(raw.off); raw.valid = false; }
         *y = out;
@@ -945,9 +950,9 @@ struct Builder {
     // instead of fp32 values (same bytes), the conv leaves fp32 slabs, finalize_f32_kernel applies the epilogue.  Measured at 24^3:
     // 256 -> 256 channels 250 -> 160 us, 512 -> 256 493 -> 297 us (conv_x3_kernel splits every operand on its way into LDS, in every tile).
     static bool x3_halo_ok(const ConvW& w, long rows, int C) {
-        static const int on = [] { const char* e = getenv("LDM_X3_HALO"); return e ? atoi(e) : 1; }();
-        static const long min_rows = [] { const char* e = getenv("LDM_X3_HALO_ROWS"); return e ? atol(e) : 1L; }();
-        static const int f32_x3 = [] { const char* e = getenv("LDM_F32_X3"); return e ? atoi(e) : 1; }();
+        static const int on = ldm_xknob("LDM_X3_HALO", 1);
+        static const long min_rows = ldm_xknob("LDM_X3_HALO_ROWS", 1L);
+        static const int f32_x3 = ldm_knob("LDM_F32_X3", 1);
         return on && f32_x3 != 0 && halo_enabled() && w.k == 3 && w.x3_off != (size_t)-1 && C == w.cin_s && C % 64 == 0 && rows >= min_rows &&
                rows * C * 4 < (1L << 32);                  // the halo kernel addresses its voxel operand with 32-bit byte offsets
     }
@@ -988,7 +993,7 @@ struct Builder {
         if (fused && C / groups <= 64 && nrb_tot <= 512) {   // few slab rows: ONE launch folds them per block and applies
             Act out = new_act(N, xa.D, xa.H, xa.W, C);
             const int slices = (C + 63) / 64;
-            static const int gn_blocks = [] { const char* e = getenv("LDM_GN_BLOCKS"); return e ? atoi(e) : 512; }();   // tuning knob: 512 = two blocks per CU at 24^3 (the apply is VALU-latency bound at one wave per SIMD: +0.3 % over the step; 1024: -1 %, every block folds the slabs again)
+            static const int gn_blocks = ldm_xknob("LDM_GN_BLOCKS", 512);   // tuning knob: 512 = two blocks per CU at 24^3 (the apply is VALU-latency bound at one wave per SIMD: +0.3 % over the step; 1024: -1 %, every block folds the slabs again)
             int chunks = std::max(1, std::min(gn_blocks / (slices * N), (DHW + 31) / 32));   // one round of the 256 CUs: the slab fold is per block
             int rpb = rup((DHW + chunks - 1) / chunks, 32);
             chunks = (DHW + rpb - 1) / rpb;
@@ -1016,7 +1021,7 @@ struct Builder {
             const int cvec = C / 8;
             const int rows_par = std::max(1, 256 / cvec);
             // fp32 inference plans: statistics fold + apply in one launch (gn32_fold_apply_kernel); one partial row per CU keeps the fold short
-            static const bool gn32_fold = [] { const char* e = getenv("LDM_GN32_FOLD"); return e ? atoi(e) != 0 : true; }();
+            static const bool gn32_fold = (ldm_knob("LDM_GN32_FOLD", 1) != 0);
             const bool fold32 = hp && !train && gn32_fold && C / groups <= 64;
             int nslab = std::min((DHW + rows_par - 1) / rows_par, std::max(1, (fold32 ? 256 : 512) / N));
             int rps = (DHW + nslab - 1) / nslab;
@@ -1060,7 +1065,7 @@ struct Builder {
 
     // first conv of a network as im2col + light GEMM (inference plans; the training tape keeps the 3^3 form): r0 / r1 = the fp32
     // NCDHW inputs (x | cond).  Returns an invalid Act when the model has no derived weights for it.
-    static bool im2col_enabled() { const char* e = getenv("LDM_CONV_IM2COL"); return e ? atoi(e) != 0 : true; }
+    static bool im2col_enabled() { return ldm_knob("LDM_CONV_IM2COL", 1) != 0; }
     Act conv_in_im2col(const std::string& name, Ref r0, Ref r1, int N, int D, int H, int W, int cin, bool internal) {
         auto it = m->convs.find(name + ".im2col");
         if (train || hp || it == m->convs.end() || !im2col_enabled() || !light_enabled()) return Act();
@@ -1268,8 +1273,8 @@ struct Builder {
         gnpart_fixups.push_back(plan->ops.size()); plan->ops.push_back(cs);
     }
     std::vector<ColsumDesc> cs_descs; std::vector<int2> cs_map;
-    static bool gnb_fold_enabled() { const char* e = getenv("LDM_GNB_FOLD"); return e ? atoi(e) != 0 : true; }
-    static bool colsum_batched() { const char* e = getenv("LDM_COLSUM_BATCH"); return e ? atoi(e) != 0 : true; }
+    static bool gnb_fold_enabled() { return ldm_xknob("LDM_GNB_FOLD", 1) != 0; }
+    static bool colsum_batched() { return ldm_xknob("LDM_COLSUM_BATCH", 1) != 0; }
     size_t cs_flushed = 0, exp_flushed = 0;              // blocks of cs_map / exp_map already launched by an earlier flush
     void flush_colsums() {
         if (cs_map.size() > cs_flushed) {
@@ -1601,11 +1606,12 @@ static int unet_register(ldm_model* m) {
     }
     collect = false;
     walk();                                                  // pass 2: everything else, in execution order
-    m->sync_off = m->arena_alloc(ldm_model::SYNC_BYTES);
     return 0;
 }
 
-static int unet_build(ldm_model* m, int B, int D, int H, int W, Plan* plan, bool train, bool hp = false, int tap_mode = 0) {
+// temb_table: the plan of ldm_unet_denoise_step when the model holds the tabulated projections of the sampler's schedule: one row copy
+// (OP_TEMB_ROW) instead of sinusoid + three GEMVs; everything else (workspace layout included) is the plain forward plan
+static int unet_build(ldm_model* m, int B, int D, int H, int W, Plan* plan, bool train, bool hp = false, int tap_mode = 0, bool temb_table = false) {
     const ldm_unet_cfg& c = m->ucfg;
     const int L = c.num_levels; const int* ch = c.channels;
     const int temb = ch[0] * 4, G = c.norm_num_groups; const float eps = c.norm_eps;
@@ -1617,16 +1623,21 @@ static int unet_build(ldm_model* m, int B, int D, int H, int W, Plan* plan, bool
     const size_t e2_off = b.pool.alloc((size_t)B * temb * 4);
     b.tproj_stride = m->tproj_rows;
     b.temb_all_off = b.pool.alloc(((size_t)B * m->tproj_rows + 256) * 4);
+    const LinW& l0 = m->lins.at("time_embed.0"); const LinW& l2 = m->lins.at("time_embed.2");
+    if (temb_table && !train) {
+        Op o{}; o.kind = OP_TEMB_ROW; o.r[0].base = BASE_TTAB; o.r[1].base = BASE_SST; o.r[2] = ws_ref(b.temb_all_off);
+        o.i[0] = m->tproj_rows; o.i[1] = B; plan->ops.push_back(o);
+    } else {
     { Op o{}; o.kind = OP_SINUSOID; o.r[0] = io_ref(2); o.r[1] = ws_ref(sin_off); o.i[0] = B; o.i[1] = ch[0];
       plan->ops.push_back(o); }
     auto gemv = [&](size_t w_off, size_t b_off, size_t x_off, size_t y_off, int I, int O, int xs, int ys, int silu) {
         Op o{}; o.kind = hp ? OP_GEMV32 : OP_GEMV; o.r[0] = hp ? w32_ref(w_off) : w_ref(w_off); o.r[1] = w_ref(b_off); o.r[2] = ws_ref(x_off); o.r[3] = ws_ref(y_off);
         o.i[0] = I; o.i[1] = O; o.i[2] = xs; o.i[3] = ys; o.i[4] = silu; o.i[5] = B; plan->ops.push_back(o);
     };
-    const LinW& l0 = m->lins.at("time_embed.0"); const LinW& l2 = m->lins.at("time_embed.2");
     gemv(l0.w_off, l0.b_off, sin_off, e1_off, ch[0], temb, ch[0], temb, 0);
     gemv(l2.w_off, l2.b_off, e1_off, e2_off, temb, temb, temb, temb, 1);
     gemv(m->tproj_w_off, m->tproj_b_off, e2_off, b.temb_all_off, temb, m->tproj_rows, temb, m->tproj_rows, 1);
+    }
 
     // ---- pack input (x | cond) -> NDHWC bf16, channels padded to 32
     const int cin_s = rup(c.in_channels, 32);
@@ -1837,7 +1848,6 @@ static int vae_register(ldm_model* m) {
     m->reg_conv_into("post_quant_conv", pq, Lc, Lc, 1, 0, false);
     m->convs["post_quant_conv"] = pq;
     LDM_TRY(reg("decoder", ae_decoder_layout(c)));
-    m->sync_off = m->arena_alloc(ldm_model::SYNC_BYTES);
     return 0;
 }
 
@@ -1982,13 +1992,13 @@ static int vae_build_train(ldm_model* m, int B, int D, int H, int W, Plan* plan,
 }
 
 // ================================================================================================ launch
-struct Bases { char* p[BASE_COUNT]; };
+struct Bases { char* p[BASE_COUNT]; int sampler_steps; };   // sampler_steps: rows of the table behind BASE_TTAB (OP_TEMB_ROW)
 static inline char* rp(const Bases& b, const Ref& r) { return r.base == BASE_NULL ? nullptr : (b.p[r.base] ? b.p[r.base] + r.off : nullptr); }
 
 // LDM_XCD_ROWS (tuning knob, default 0: measured 0.4 % SLOWER over the step, with and without write-through stores: DESIGN.md section 5): unsplit convolutions and the GroupNorm launches deal contiguous ROW ranges to the XCDs
 // (ConvParams::tile_order 1, GnFusedParams::xcd_rows), so that a tensor is produced and consumed by the same XCD where the order of
 // the work allows it; 0 = the round-2 orders (an XCD streams one weight panel; GroupNorm blocks in launch order)
-static int xcd_rows_mode() { static const int v = [] { const char* e = getenv("LDM_XCD_ROWS"); return e ? atoi(e) : 0; }(); return v; }
+static int xcd_rows_mode() { static const int v = ldm_xknob("LDM_XCD_ROWS", 0); return v; }
 static inline int conv_tile_order(const ConvParams& p) { return (xcd_rows_mode() && p.splitk == 1 && !p.phase_mode) ? 1 : 0; }
 
 template <int WGM, int WGN, int BK>
@@ -2056,7 +2066,7 @@ static int launch_conv_halo(const ConvParams& p_in, hipStream_t s, bool tall = f
         attr_set = true;
     }
     // persistent grid (conv_halo.h): at most one workgroup per CU, each walks its tiles; LDM_HALO_PERSIST=0: one workgroup per tile
-    static const int persist = [] { const char* e = getenv("LDM_HALO_PERSIST"); return e ? atoi(e) : 1; }();
+    static const int persist = ldm_xknob("LDM_HALO_PERSIST", 1);
     static int cus_tab[32] = {};
     int dev_ = 0; if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 32) dev_ = 0;
     int& cus = cus_tab[dev_];
@@ -2095,7 +2105,7 @@ static inline int grid_for(long total, int per_block = 256, int cap = 4096) {
 
 // voxel-range split of the weight-gradient GEMM: enough workgroups for 2 waves of 256 CUs, at least 16 K steps each
 static int wgrad_pair(int taps, int cout, int cin, int stride, int ups, bool hp) {   // conv_wgrad_kernel's forms with several taps per workgroup (WgradParams::pair): 0 | 1 | 2 (three taps)
-    static const int on = [] { const char* e = getenv("LDM_WGRAD_PAIR"); return e ? atoi(e) : 3; }();
+    static const int on = ldm_xknob("LDM_WGRAD_PAIR", 3);
     if (!on || hp || taps != 27) return 0;
     const bool y = on >= 2 && cout <= 64 && stride == 1 && ups == 0;
     if (cin > 64) return (y && on >= 3) ? 3 : 0;
@@ -2105,8 +2115,8 @@ static int wgrad_ksplit(long M, int taps, int cout, int cin, bool hp, int stride
     const int pm = wgrad_pair(taps, cout, cin, stride, ups, hp);
     const long wgs = (long)(pm == 3 ? 2 * (taps / 3) : pm == 2 ? taps / 3 : pm == 1 ? (taps + 1) / 2 : taps) * ((cout + 127) / 128) * ((cin + 127) / 128);
     const long steps = (M + 63) / 64;
-    const char* e = getenv("LDM_WGRAD_WGS");                 // tuning knob: workgroups aimed at (default: one round of 256 CUs;
-    const long target = e ? atol(e) : (hp ? 768 : 256);      // the fp32 kernel, latency bound on its operand loads, wants three per CU: 49.3 -> 46.6 ms per step)
+    // tuning knob: workgroups aimed at (default: one round of 256 CUs; the fp32 kernel, latency bound on its operand loads, wants three per CU: 49.3 -> 46.6 ms per step)
+    const long target = ldm_xknob("LDM_WGRAD_WGS", hp ? 768 : 256);
     long k = (target + wgs / 2) / wgs;                       // nearest count of whole rounds
     // at least 16 K steps per workgroup for a 3^3 conv (prologue and ring fill amortised); a 1x1 conv at 12^3 is 27 steps on 4 - 12 workgroups
     // in all (24.7 us of serial K loop, 20 such launches per UNet training step): there 4 steps per workgroup are enough
@@ -2129,7 +2139,7 @@ static int launch_wgrad(const WgradParams& p0, hipStream_t s) {
     constexpr int LDS = 4 * 2 * 64 * 256 + 3 * 256 * 4;        // ring + triple-buffered source-offset table (up to four sections)
     static bool attr_tab[32] = {}; bool& attr_set = attr_flag(attr_tab);   // per device
     if (!attr_set) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr_set = true; }
-    { const char* e = getenv("LDM_CONV_DBG"); const int dbg = e ? atoi(e) : 0;      // timing ablations (results are wrong)
+    { const int dbg = (int)ldm_xknob("LDM_CONV_DBG", 0);      // timing ablations (results are wrong; experiments builds only)
 #define W1_ABL(A) if (dbg == A) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<A>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); \
           hipLaunchKernelGGL(conv_wgrad_kernel<A>, dim3(p.co_tiles * p.ci_tiles * tg_ * p.ksplit), dim3(512), LDS, s, p); return 0; }
       W1_ABL(4) W1_ABL(8) W1_ABL(16) W1_ABL(12) W1_ABL(20) W1_ABL(24)
@@ -2139,8 +2149,7 @@ static int launch_wgrad(const WgradParams& p0, hipStream_t s) {
     return 0;
 }
 
-static bool wt_slabs() { static const int v = [] { const char* e = getenv("LDM_WT_SLABS"); return e ? atoi(e) : 0; }(); return v != 0; }   // split-K slabs written through (ConvParams::wt_slab)
-static bool wt_stores() { static const int v = [] { const char* e = getenv("LDM_WT_STORES"); return e ? atoi(e) : 1; }(); return v != 0; }   // GroupNorm / finalize outputs written through (sc1): -24 us per step
+static bool wt_stores() { static const int v = ldm_xknob("LDM_WT_STORES", 1); return v != 0; }   // GroupNorm / finalize outputs written through (sc1): -24 us per step
 
 // per-op timeline of every launch plan that runs while it is on (ldm_set_plan_trace; initial state from LDM_PLAN_TRACE)
 struct PlanTrace { bool on = false; std::string path; PlanTrace() { const char* e = getenv("LDM_PLAN_TRACE"); if (e && *e) { on = true; path = e; } } };
@@ -2297,22 +2306,15 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                     else hipLaunchKernelGGL(pack2_ncdhw_kernel, dim3(grid_for(tot2)), dim3(256), 0, s, src, i[1], (const float*)nullptr, 0, (bf16_t*)rp(bs, o.r[0]), i[0], i[2], i[3]);
                 }
                 break; }
-            case OP_FIN_GN: {            // an OP_FINALIZE whose r[3..5] = gamma, beta, normalised output; r[13] = sync region; i[0..3] = groups, silu, chunks, slot
+            case OP_FIN_GN: {            // an OP_FINALIZE whose r[3..5] = gamma, beta, normalised output; i[0..2] = groups, silu, log2(channels per group)
                 FinGnParams q{}; FinalizeParams& f = q.f;
                 f.partial = (const float*)rp(bs, o.r[11]); f.splitk = o.cc.splitk; f.M = i[15]; f.CoutPad = i[17]; f.CoutS = i[16]; f.CoutReal = i[18];
                 f.DHWo = i[8] * i[9] * i[10];
                 f.bias = (const float*)rp(bs, o.r[6]); f.bias2 = (const float*)rp(bs, o.r[7]); f.temb = (const float*)rp(bs, o.r[8]); f.temb_stride = i[21];
                 f.residual = (const bf16_t*)rp(bs, o.r[9]); f.out = (bf16_t*)rp(bs, o.r[10]);
                 q.gamma = (const float*)rp(bs, o.r[3]); q.beta = (const float*)rp(bs, o.r[4]); q.y = (bf16_t*)rp(bs, o.r[5]);
-                q.groups = i[0]; q.silu = i[1]; q.chunks = i[2]; q.dhw = f.DHWo; q.eps = o.f[0];
-                char* sync = rp(bs, o.r[13]);
-                if (!sync) return fail(LDM_ERR_NOT_LOADED, "the weight arena is empty");
-                q.err = (unsigned*)sync;
-                q.cnt = (unsigned*)(sync + ldm_model::SYNC_CNT_OFF + (size_t)i[3] * 256);
-                q.xpart = (float*)(sync + ldm_model::SYNC_PART_OFF + (size_t)i[3] * ldm_model::SYNC_PART_BYTES);
-                const dim3 grid(i[2], (i[16] + 63) / 64, i[4]);
-                if (wt_stores()) hipLaunchKernelGGL(fin_gn_kernel<true>, grid, dim3(256), 0, s, q);
-                else hipLaunchKernelGGL(fin_gn_kernel<false>, grid, dim3(256), 0, s, q);
+                q.groups = i[0]; q.silu = i[1]; q.lg = i[2]; q.eps = o.f[0];
+                HIP_TRY(launch_fin_gn(q, i[4], wt_stores(), s));
                 break; }
             case OP_CONV: case OP_FINALIZE: {
                 ConvParams p{};
@@ -2341,7 +2343,7 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                 if (i[14] & 16) {                          // ... with the epilogue fused (splitk 1): fp32 NDHWC output, fp32 residual
                     p.out32 = (float*)rp(bs, o.r[10]); p.residual32 = (const float*)rp(bs, o.r[9]); p.out = nullptr; p.residual = nullptr;
                 }
-                p.wt_slab = (p.splitk > 1 && wt_slabs()) ? 1 : 0;
+                p.slab_lg = o.cc.slab_lg;
                 if (o.kind == OP_CONV) { LDM_TRY(launch_conv(p, o.cc, s)); }
                 else {
                     FinalizeParams f{}; f.partial = p.partial; f.splitk = p.splitk; f.M = p.M; f.CoutPad = p.CoutPad;
@@ -2393,6 +2395,11 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                 AttnParams p{}; p.qkv = (const bf16_t*)rp(bs, o.r[0]); p.out = (bf16_t*)rp(bs, o.r[1]);
                 p.B = i[0]; p.N = i[1]; p.C = i[2]; p.heads = i[3]; p.d = i[4]; p.scale = o.f[0]; p.lse = (float*)rp(bs, o.r[2]);
                 HIP_TRY(launch_attn_fwd(p, s));
+                break; }
+            case OP_TEMB_ROW: {         // i: rows, B; bs[TTAB] = table, bs[SST] = sampler state
+                const float* tab = (const float*)bs.p[BASE_TTAB]; const SamplerState* st = (const SamplerState*)bs.p[BASE_SST];
+                if (!tab || !st || bs.sampler_steps < 1) return fail(LDM_ERR_BAD_ARG, "denoise-step plan without a sampler / time-embedding table");
+                hipLaunchKernelGGL(temb_row_kernel, dim3((i[0] / 4 + 255) / 256, i[1]), dim3(256), 0, s, tab, st, (float*)rp(bs, o.r[2]), i[0], i[0], bs.sampler_steps);
                 break; }
             case OP_SINUSOID:
                 hipLaunchKernelGGL(temb_sinusoid_kernel, dim3(grid_for((long)i[0] * i[1])), dim3(256), 0, s,
@@ -2630,6 +2637,7 @@ void ldm_model_destroy(ldm_model* m) {
     for (auto e : m->gsync.ev) (void)hipEventDestroy(e);
     if (m->arena) (void)hipFree(m->arena);
     if (m->arena32) (void)hipFree(m->arena32);
+    if (m->temb_tab) (void)hipFree(m->temb_tab);
     delete m;
 }
 
@@ -2720,7 +2728,7 @@ int ldm_model_load_param(ldm_model* m, const char* name, const float* src, size_
         }
     }
     if (!d.loaded) { d.loaded = true; m->loaded_count++; }
-    m->derived_dirty = true;
+    m->derived_dirty = true; m->temb_tab_valid = false;
     return 0;
 }
 
@@ -2756,7 +2764,7 @@ static int get_plan(ldm_model* m, const char* kind, int B, int D, int H, int W, 
     auto it = m->plans.find(key);
     if (it != m->plans.end()) { *out = it->second; return 0; }
     std::shared_ptr<Plan> p(new Plan());
-    if (m->type == 0) LDM_TRY(unet_build(m, B, D, H, W, p.get(), train, hp, tap_mode));
+    if (m->type == 0) LDM_TRY(unet_build(m, B, D, H, W, p.get(), train, hp, tap_mode, strcmp(kind, "unet_tab") == 0));
     else if (train) LDM_TRY(vae_build_train(m, B, D, H, W, p.get(), hp));
     else if (kind[0] == 'e') LDM_TRY(vae_build_encode(m, B, D, H, W, p.get(), hp, tap_mode));
     else LDM_TRY(vae_build_decode(m, B, D, H, W, p.get(), hp, tap_mode));
@@ -2787,11 +2795,57 @@ static std::atomic<uint64_t> g_sampler_uid{0};
 struct ldm_sampler {
     float* coef = nullptr; SamplerState* st = nullptr; int n_steps = 0, kind = 0, clip = 1; unsigned seed_lo = 0, seed_hi = 0;
     uint64_t uid = ++g_sampler_uid;                  // never reused (graph-replay cache key)
+    std::vector<float> ts;                           // host copy of the schedule's timesteps in sampling order (key of the model's time-embedding table)
 };
 static int sampler_launch(ldm_sampler* sp, const float* eps, float* x, float* x0_out, int64_t n, float* tbuf, int B, hipStream_t s) {
     SamplerParams p{}; p.coef = sp->coef; p.st = sp->st; p.n_steps = sp->n_steps; p.kind = sp->kind; p.clip = sp->clip;
     p.seed_lo = sp->seed_lo; p.seed_hi = sp->seed_hi; p.eps = eps; p.x = x; p.x0_out = x0_out; p.n = (long)n; p.tbuf = tbuf; p.B = B;
     hipLaunchKernelGGL(sampler_step_kernel, dim3(grid_for((n + 3) / 4, 256, 1024)), dim3(256), 0, s, p);
+    return 0;
+}
+
+// The stacked time_emb_proj outputs for every step of `sp`'s schedule, [n_steps][tproj_rows] fp32, built by the forward plan's own
+// kernels (sinusoid -> Linear -> SiLU -> Linear -> SiLU -> stacked projections) at batch n_steps, so row k is bit-identical to what
+// the plan computes for t = ts[k].  Rebuilt after a parameter upload / optimizer step, a precision switch or for another schedule;
+// a table that moves in memory invalidates the model's cached graphs (they hold its address).  LDM_TEMB_TABLE=0: never used.
+static bool temb_table_enabled() { static const int v = ldm_knob("LDM_TEMB_TABLE", 1); return v != 0; }
+static int ensure_temb_table(ldm_model* m, const ldm_sampler* sp, hipStream_t s) {
+    if (m->temb_tab_valid && m->temb_tab_prec == m->precision && m->temb_tab_ts == sp->ts) return 0;
+    const int n = sp->n_steps, rows = m->tproj_rows, c0 = m->ucfg.channels[0], temb = 4 * c0;
+    const bool hp = m->precision == 1;
+    if (hp && !m->arena32) return fail(LDM_ERR_NOT_LOADED, "fp32 precision: the fp32 weight arena is empty");
+    const size_t need = (size_t)n * rows * 4;
+    if (need > m->temb_tab_cap) {
+        HIP_TRY(hipDeviceSynchronize());                                   // a replaying graph may still read the old table
+        for (auto& g : m->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        m->graphs.clear();
+        if (m->temb_tab) (void)hipFree(m->temb_tab);
+        m->temb_tab = nullptr; m->temb_tab_cap = 0;
+        HIP_TRY(hipMalloc((void**)&m->temb_tab, need));
+        m->temb_tab_cap = need;
+    }
+    float* tmp = nullptr;                                                  // t [n] | sinusoid [n][c0] | e1 [n][temb] | e2 [n][temb]
+    HIP_TRY(hipMalloc((void**)&tmp, (size_t)n * (1 + c0 + 2 * temb) * 4));
+    float* d_t = tmp; float* d_sin = tmp + n; float* d_e1 = d_sin + (size_t)n * c0; float* d_e2 = d_e1 + (size_t)n * temb;
+    hipError_t e = hipMemcpyAsync(d_t, sp->ts.data(), (size_t)n * 4, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        const LinW& l0 = m->lins.at("time_embed.0"); const LinW& l2 = m->lins.at("time_embed.2");
+        hipLaunchKernelGGL(temb_sinusoid_kernel, dim3(grid_for((long)n * c0)), dim3(256), 0, s, (const float*)d_t, d_sin, n, c0);
+        auto gemv = [&](size_t w_off, size_t b_off, const float* xin, float* y, int I, int O, int silu) {
+            if (hp) hipLaunchKernelGGL(gemv_f32_kernel, dim3((O + 3) / 4, n), dim3(256), 0, s, (const float*)(m->arena32 + 2 * w_off),
+                                       (const float*)(m->arena + b_off), xin, y, I, O, I, O, silu);
+            else hipLaunchKernelGGL(gemv_bf16_kernel, dim3((O + 3) / 4, n), dim3(256), 0, s, (const bf16_t*)(m->arena + w_off),
+                                    (const float*)(m->arena + b_off), xin, y, I, O, I, O, silu);
+        };
+        gemv(l0.w_off, l0.b_off, d_sin, d_e1, c0, temb, 0);
+        gemv(l2.w_off, l2.b_off, d_e1, d_e2, temb, temb, 1);
+        gemv(m->tproj_w_off, m->tproj_b_off, d_e2, m->temb_tab, temb, rows, 1);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(s);                  // the temporaries go away below; one-off per upload
+    }
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return fail(LDM_ERR_HIP, "time-embedding table: %s", hipGetErrorString(e));
+    m->temb_tab_ts = sp->ts; m->temb_tab_prec = m->precision; m->temb_tab_valid = true;
     return 0;
 }
 
@@ -2801,10 +2855,14 @@ static int unet_forward_impl(ldm_model* m, const float* x, int x_channels, const
     if (!m || m->type != 0) return fail(LDM_ERR_BAD_ARG, "not a UNet handle");
     if (!x || !timesteps || !out) return fail(LDM_ERR_BAD_ARG, "null tensor argument");
     if (!cond) cond_channels = 0;
-    std::shared_ptr<Plan> p; LDM_TRY(get_plan(m, "unet", B, D, H, W, &p));
+    // a denoising step driven by a sampler knows its timestep as a step INDEX on the device: the time-embedding chain becomes one row copy
+    const bool tab = sp != nullptr && temb_table_enabled() && m->tproj_rows % 4 == 0;
+    std::shared_ptr<Plan> p; LDM_TRY(get_plan(m, tab ? "unet_tab" : "unet", B, D, H, W, &p));
     LDM_TRY(check_ready(m, workspace, workspace_bytes, *p));
+    if (tab) LDM_TRY(ensure_temb_table(m, sp, (hipStream_t)stream));
     Bases bs{}; bs.p[BASE_WS] = (char*)workspace; bs.p[BASE_W] = m->arena; bs.p[BASE_W32] = m->arena32;
     bs.p[BASE_IO0] = (char*)x; bs.p[BASE_IO1] = (char*)cond; bs.p[BASE_IO2] = (char*)timesteps; bs.p[BASE_IO3] = (char*)out;
+    if (tab) { bs.p[BASE_TTAB] = (char*)m->temb_tab; bs.p[BASE_SST] = (char*)sp->st; bs.sampler_steps = sp->n_steps; }
     const int rt[2] = {x_channels, cond_channels};
     LDM_TRY(ensure_derived(m, (hipStream_t)stream));
     LaneCtx lanes;
@@ -2872,6 +2930,7 @@ int ldm_sampler_create(const float* coef_host, int n_steps, int kind, int clip, 
     HIP_TRY(hipMemset(sp->st, 0, 256));
     HIP_TRY(hipDeviceSynchronize());
     sp->n_steps = n_steps; sp->kind = kind; sp->clip = clip ? 1 : 0; sp->seed_lo = (unsigned)seed; sp->seed_hi = (unsigned)(seed >> 32);
+    sp->ts.resize(n_steps); for (int k = 0; k < n_steps; ++k) sp->ts[k] = coef_host[(size_t)k * 6 + 5];
     *out = sp.release();
     return 0;
 }
@@ -2949,16 +3008,6 @@ int ldm_set_plan_trace(const char* path) {
 /* on != 0: ldm_unet_forward replays a HIP graph of its launch plan whenever it sees the same (x, cond, timesteps, out,
  * workspace, stream) pointers again (callers keep those buffers fixed: the Python shell stages through persistent tensors).
  * Same kernels, same results; only the host cost per step changes (one graph launch instead of ~150 launches). */
-/* Error word of the fused finalize + GroupNorm launches (fin_gn.h): 0 = every inter-workgroup wait of every launch so far completed,
- * 1 = a wait gave up (results of that launch are wrong).  Synchronises the device; tests and smoke() read it. */
-int ldm_model_sync_errors(ldm_model* m) {
-    if (!m) return fail(LDM_ERR_BAD_ARG, "null model");
-    if (!m->arena || !m->sync_off) return 0;
-    unsigned v = 0;
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(&v, m->arena + m->sync_off, 4, hipMemcpyDeviceToHost));
-    return (int)v;
-}
 int ldm_model_set_graph_mode(ldm_model* m, int on) {
     if (!m) return fail(LDM_ERR_BAD_ARG, "null model");
     m->graph_mode = on ? 1 : 0;
@@ -3065,7 +3114,7 @@ int ldm_model_load_params_device(ldm_model* m, const float* const* ptrs, int n, 
         if (!d.loaded) { d.loaded = true; m->loaded_count++; }
     }
     HIP_TRY(hipGetLastError());
-    m->derived_dirty = true;
+    m->derived_dirty = true; m->temb_tab_valid = false;
     return 0;
 }
 
@@ -3100,7 +3149,7 @@ int ldm_model_load_params_flat(ldm_model* m, const float* flat, void* stream) {
     }
     HIP_TRY(hipGetLastError());
     for (ParamDesc& d : m->params) if (!d.loaded) { d.loaded = true; m->loaded_count++; }
-    m->derived_dirty = true;
+    m->derived_dirty = true; m->temb_tab_valid = false;
     return 0;
 }
 
@@ -3238,7 +3287,7 @@ int ldm_model_adam_step(ldm_model* m, float* params_flat, const float* grads_fla
     }
     HIP_TRY(hipGetLastError());
     for (ParamDesc& d : m->params) if (!d.loaded) { d.loaded = true; m->loaded_count++; }
-    m->derived_dirty = true;
+    m->derived_dirty = true; m->temb_tab_valid = false;
     return 0;
 }
 
@@ -3456,7 +3505,13 @@ int ldm_op_conv3d_block128(const void* x, int cin, const void* w, const float* b
     return 0;
 }
 /* tests only: the grid of conv3_block_kernel's tile loop (0 = two workgroups per CU); returns the previous value */
-int ldm_debug_conv_block_slots(int slots) { const int old = g_block_slots; g_block_slots = slots < 0 ? 0 : slots; return old; }
+int ldm_debug_conv_block_slots(int slots) {
+#ifdef LDM_EXPERIMENTS
+    const int old = g_block_slots; g_block_slots = slots < 0 ? 0 : slots; return old;
+#else
+    (void)slots; return -1;                              // the tile-loop form of conv3_block_kernel is not in the product library
+#endif
+}
 int ldm_op_conv3d_block_stats_rows(int D, int H, int W, int th) {
     if (th != 4 && th != 8) return 0;
     return ((D + BLK_TD - 1) / BLK_TD) * ((H + th - 1) / th) * ((W + BLK_TW - 1) / BLK_TW);
@@ -3517,7 +3572,7 @@ static int op_conv3d_impl(const void* xa, int ca, const void* xb, int cb, const 
     p.CoutS = rup(cout, 32); p.CoutPad = cout_pad; p.CoutReal = cout;
     p.nchunk0 = cin0 / bk; p.nchunk1 = cin1 / bk; p.steps0 = taps * p.nchunk0; p.steps1 = p.nchunk1;
     const bool halo_ok = ksize == 3 && stride == 1 && pad == 1 && ups == 0 && !exact && cb == 0 && bk == 64 &&
-                         (cin1 == 0 || (Builder::halo_skip_enabled() && splitk <= 1)) && Builder::halo_enabled();
+                         (cin1 == 0 || (Builder::halo_skip_enabled() && (splitk <= 1 || Builder::halo_skip_split_enabled()))) && Builder::halo_enabled();
     ConvCfg cc = Builder::choose_cfg(M, cout_pad, p.steps0, bk, halo_ok ? N : 0, (long)Do * Ho * Wo, false, p.steps1);
     if (wgn) {                                       // forced tile shape: wgn = 2 keeps the halo kernel where it applies
         if ((wgn != 1 && wgn != 2 && wgn != 4) || cout_pad % (64 * wgn)) return fail(LDM_ERR_BAD_ARG, "bad wgn");
@@ -3549,21 +3604,20 @@ static int op_conv3d_impl(const void* xa, int ca, const void* xb, int cb, const 
         else { if (N > 1 && dhwo % bm) return fail(LDM_ERR_UNSUPPORTED, "statistics: tiles straddle samples"); *stats_nrb = (int)(N == 1 ? (M + bm - 1) / bm : dhwo / bm); }
         p.stats = stats;
     }
-    { const char* e = getenv("LDM_CONV_DBG"); p.dbg = e ? atoi(e) : 0; }
+    p.dbg = (int)ldm_xknob("LDM_CONV_DBG", 0);
     if (p.dbg & 512) {                          // diagnostic stamps go to the caller's scratch (needs nwg * 64 bytes)
         if (cc.splitk > 1 || !scratch || scratch_bytes < (size_t)p.mtiles * p.ntiles * (64 + 4096)) return fail(LDM_ERR_BAD_ARG, "stamps need scratch and splitk 1");
         p.stamps = (unsigned long long*)scratch;
     }
+    if (fg && cc.splitk > 1) p.slab_lg = fg->lg;     // planar slabs for the group-owning finalize
     LDM_TRY(launch_conv(p, cc, (hipStream_t)stream));
     if (cc.splitk > 1) {
         FinalizeParams f{}; f.partial = p.partial; f.splitk = p.splitk; f.M = p.M; f.CoutPad = p.CoutPad; f.CoutS = p.CoutS;
         f.CoutReal = p.CoutReal; f.DHWo = Do * Ho * Wo; f.bias = bias; f.bias2 = bias2; f.temb = temb; f.temb_stride = temb_stride;
         f.residual = p.residual; f.out = p.out; f.out_f32 = p.out_f32; f.stats = stats;
         if (fg) {                                    // finalize + GroupNorm in one launch (fin_gn.h), as the plans' OP_FIN_GN
-            fg->f = f; fg->f.stats = nullptr; fg->dhw = f.DHWo; fg->chunks = (f.DHWo + 31) / 32;
-            const dim3 grid(fg->chunks, (p.CoutS + 63) / 64, N);
-            if (wt_stores()) hipLaunchKernelGGL(fin_gn_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, *fg);
-            else hipLaunchKernelGGL(fin_gn_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, *fg);
+            fg->f = f; fg->f.stats = nullptr;
+            HIP_TRY(launch_fin_gn(*fg, N, wt_stores(), (hipStream_t)stream));
         } else
             launch_finalize(f, stats && wt_stores(), (hipStream_t)stream);
     } else if (fg) return fail(LDM_ERR_UNSUPPORTED, "the fused finalize + GroupNorm needs a conv that is split over K");
@@ -3617,38 +3671,29 @@ int ldm_op_conv3d_gn(const void* x, int cin, const void* w, const float* bias, c
 }
 
 /* The split-K conv -> GroupNorm pair as the inference plans launch it at the 12^3 / 6^3 levels (OP_CONV + OP_FIN_GN, csrc/fin_gn.h): a 3^3
- * stride-1 conv split over K (splitk >= 2), then ONE launch that sums the slabs, applies bias / per-sample channel bias `temb` /
- * `residual`, rounds to bf16, exchanges the GroupNorm statistics between its workgroups and writes GroupNorm(+SiLU) of the rounded
- * tensor to gn_out; conv_out (optional) receives the un-normalised bf16 tensor.  scratch: split-K slabs + 64 KiB exchange area
- * (ldm_op_conv3d_fin_gn_scratch_bytes).  *err_out (host, optional; the call then synchronises the stream) = 1 if an inter-workgroup wait gave up.
- * LDM_ERR_UNSUPPORTED where the plans keep the two launches (channels per group not dividing 64, more than 256 blocks). */
+ * stride-1 conv split over K (splitk >= 2) that writes its fp32 slabs planar (one plane per GroupNorm group), then ONE launch in which
+ * every workgroup owns a whole (sample, group): it sums the slabs, applies bias / per-sample channel bias `temb` / `residual`, rounds to
+ * bf16, reduces the group's statistics and writes GroupNorm(+SiLU) of the rounded tensor to gn_out; conv_out (optional) receives the
+ * un-normalised bf16 tensor.  scratch: the split-K slabs (ldm_op_conv3d_fin_gn_scratch_bytes).
+ * LDM_ERR_UNSUPPORTED where the plans keep the two launches (channels per group not a power of two in 4 ... 64, or more than 4096
+ * (row, 4-channel) items per group). */
 size_t ldm_op_conv3d_fin_gn_scratch_bytes(int N, int D, int H, int W, int cout_pad, int splitk) {
-    return rup_sz((size_t)splitk * N * D * H * W * cout_pad * 4, 256) + 65536;
+    return rup_sz((size_t)splitk * N * D * H * W * cout_pad * 4, 256);
 }
 int ldm_op_conv3d_fin_gn(const void* x, int cin, const void* w, const float* bias, const float* temb, int temb_stride, const void* residual,
                          const float* gamma, const float* beta, int groups, float eps, int silu, void* conv_out, void* gn_out,
                          int N, int D, int H, int W, int cout, int cout_pad, int wgn, int splitk, void* scratch, size_t scratch_bytes,
-                         int* err_out, void* stream) {
+                         void* stream) {
     if (!x || !w || !gamma || !beta || !gn_out || !scratch) return fail(LDM_ERR_BAD_ARG, "null tensor argument");
     const int C = rup(cout, 32);
     if (groups < 1 || C % groups || cout != C || splitk < 2) return fail(LDM_ERR_BAD_ARG, "cout must be a multiple of 32 and of groups, splitk >= 2");
-    const int cpg = C / groups, slices = (C + 63) / 64, chunks = (D * H * W + 31) / 32;
-    if (cpg < 4 || cpg > 64 || 64 % cpg || N * slices > 32 || (long)N * slices * chunks > 256)
-        return fail(LDM_ERR_UNSUPPORTED, "the plans keep finalize and GroupNorm apart here (%d channels per group, %ld blocks)", cpg, (long)N * slices * chunks);
+    if (!fin_gn_ok(C, groups, D * H * W) || cout_pad % (C / groups))
+        return fail(LDM_ERR_UNSUPPORTED, "the plans keep finalize and GroupNorm apart here (%d channels per group, %d rows)", C / groups, D * H * W);
     if (scratch_bytes < ldm_op_conv3d_fin_gn_scratch_bytes(N, D, H, W, cout_pad, splitk)) return fail(LDM_ERR_WORKSPACE, "scratch too small");
     const size_t slab_bytes = rup_sz((size_t)splitk * N * D * H * W * cout_pad * 4, 256);
-    char* sync = (char*)scratch + slab_bytes;
-    HIP_TRY(hipMemsetAsync(sync, 0, 32768, (hipStream_t)stream));       // error word + counters (the plans keep theirs in the zeroed arena)
-    FinGnParams q{}; q.gamma = gamma; q.beta = beta; q.y = (bf16_t*)gn_out; q.groups = groups; q.silu = silu; q.eps = eps;
-    q.err = (unsigned*)sync; q.cnt = (unsigned*)(sync + 256); q.xpart = (float*)(sync + 32768);
+    FinGnParams q{}; q.gamma = gamma; q.beta = beta; q.y = (bf16_t*)gn_out; q.groups = groups; q.silu = silu; q.eps = eps; q.lg = fin_gn_lg(C, groups);
     LDM_TRY(op_conv3d_impl(x, cin, nullptr, 0, w, bias, nullptr, 0, nullptr, 0, nullptr, nullptr, temb, temb_stride, residual, conv_out, nullptr,
                            N, D, H, W, 3, 1, 1, 0, cout, cout_pad, wgn, splitk, scratch, slab_bytes, stream, nullptr, nullptr, &q));
-    if (err_out) {
-        unsigned v = 0;
-        HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-        HIP_TRY(hipMemcpy(&v, sync, 4, hipMemcpyDeviceToHost));
-        *err_out = (int)v;
-    }
     return 0;
 }
 
@@ -4210,6 +4255,10 @@ static hipEvent_t* gs_event(GradSyncState& g, size_t k) {
     return &g.ev[k];
 }
 static int grad_sync_begin(GradSyncState& g, hipStream_t s) {
+    // a previous backward that returned an error between a bucket and its join left buckets un-joined: this backward is ordered behind
+    // them (the comm stream is in order: its last done-event covers all) and the bookkeeping starts clean
+    if (g.pending > 0 && g.used > 2) HIP_TRY(hipStreamWaitEvent(s, g.ev[g.used - 1], 0));
+    g.pending = 0;
     g.used = 2; g.elems.clear();                     // ev[0] = start of this backward, ev[1] = its end (recorded by the join)
     hipEvent_t* e0 = gs_event(g, 1); if (!e0) return fail(LDM_ERR_HIP, "hipEventCreate failed");
     HIP_TRY(hipEventRecord(g.ev[0], s));

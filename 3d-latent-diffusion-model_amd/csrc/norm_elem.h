@@ -640,6 +640,20 @@ __global__ __launch_bounds__(256) void sampler_step_kernel(const SamplerParams p
 __global__ void sampler_reset_kernel(SamplerState* st, const float* coef, float* tbuf, int B) {
     if (threadIdx.x == 0 && blockIdx.x == 0) { st->k = 0; st->done = 0; for (int b = 0; b < B; ++b) tbuf[b] = coef[5]; }
 }
+// Tabulated time embedding ("depends only on t => tabulate"): the 17 stacked time_emb_proj outputs of every
+// timestep of a sampler's schedule are computed once per parameter upload by the plan's own sinusoid + GEMV kernels (bit-identical
+// rows); a denoising step then copies row k (k = the sampler's device-resident step counter) instead of running those four launches.
+// out[b][0..rows) = tab[min(k, n_steps - 1)][0..rows), rows % 4 == 0, out rows `stride` floats apart.  grid = (ceil(rows / 1024), B).
+__global__ __launch_bounds__(256) void temb_row_kernel(const float* __restrict__ tab, const SamplerState* __restrict__ st,
+                                                       float* __restrict__ out, int rows, int stride, int n_steps) {
+    KSTAMP_BEGIN(1);
+    int k = st->k; if (k >= n_steps) k = n_steps - 1; if (k < 0) k = 0;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    KSTAMP(1);
+    if (4 * q < rows)
+        *reinterpret_cast<float4*>(out + (size_t)blockIdx.y * stride + 4 * q) = *reinterpret_cast<const float4*>(tab + (size_t)k * rows + 4 * q);
+    KSTAMP_DRAIN(2);
+}
 
 // ------------------------------------------------------------------------------------------------
 // PatchDiscriminator support (stage-1 GAN tail, 3d_ldm/train_autoencoder.py:150-158,407-424,454-494): its 4^3 convolutions run as

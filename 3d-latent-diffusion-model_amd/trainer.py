@@ -49,7 +49,12 @@ class GradSync:
         have collectives in flight in an order that differs between ranks; here that is excluded by construction -- every bucket is
         joined into the launch stream at the end of backward, and torch's collectives are ordered behind the launch stream -- and
         this check turns the construction into an assertion: a torch.distributed collective issued while a bucket is still un-joined
-        is a programming error, not a race to be debugged on eight GPUs."""
+        is a programming error, not a race to be debugged on eight GPUs.
+
+        Scope: the assertion guards the collectives issued THROUGH this class (every one the trainers and bench.py's ddp_train leg
+        issue); code that calls torch.distributed directly is outside it.  The counter it reads is host bookkeeping: a backward that
+        failed between a bucket and its join leaves it non-zero until the next backward begins (which orders itself behind the stray
+        buckets and clears it: grad_sync_begin), so after such an error the next collective here raises rather than races."""
         from . import _lib
         L = _lib.lib()
         for m in self._modules:
@@ -175,6 +180,24 @@ class GradSync:
         t = t.clone()
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return t / self.world
+
+    def max_scalar(self, t: torch.Tensor) -> torch.Tensor:
+        """MAX over ranks (wall clocks of a timed region: bench.py's ddp_train leg)."""
+        if not self.on:
+            return t
+        self._quiescent()
+        t = t.clone()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t
+
+    def gather_objects(self, obj) -> list:
+        """Every rank's (picklable) record on every rank, in rank order: per-rank timelines of the bench's ddp_train leg."""
+        if not self.on:
+            return [obj]
+        self._quiescent()
+        out = [None] * self.world
+        dist.all_gather_object(out, obj)
+        return out
 
     def barrier(self) -> None:
         if self.on:

@@ -235,9 +235,8 @@ def ddp_train_leg(dev, rank, world, dist, rehearsal, steps=8, warmup=3, latent=(
     images = torch.rand((1, 1, *patch), device=dev, generator=gen)
     labels = torch.rand((1, 1, *patch), device=dev, generator=gen)
 
-    def fence():
-        if dist is not None:
-            dist.barrier()
+    def fence():                                            # through GradSync: its quiescence assertion covers this leg's collectives too
+        tr.sync.barrier()
         torch.cuda.synchronize()
 
     def checksum():
@@ -248,20 +247,16 @@ def ddp_train_leg(dev, rank, world, dist, rehearsal, steps=8, warmup=3, latent=(
     sums = checksum()                                       # after `warmup` (3) optimizer steps
     equal = True
     if dist is not None:
-        t = torch.tensor(sums, dtype=torch.float64, device=dev)
-        allt = [torch.empty_like(t) for _ in range(world)]
-        dist.all_gather(allt, t)
-        equal = all(bool(torch.equal(a, allt[0])) for a in allt)
+        allt = tr.sync.gather_objects(sums)
+        equal = all(a == allt[0] for a in allt)
     fence()
     t0 = time.perf_counter()
     for _ in range(steps):
         loss, skipped = tr.train_step(images, labels)
     fence()
-    dt = time.perf_counter() - t0
+    dt_local = dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        dt = float(tr.sync.max_scalar(torch.tensor([dt], dtype=torch.float64, device=dev)).item())
     rec = {"what": "BASELINE configs[3]: train_diffusion step (2 x VAE encode of a 144x176x112 patch, UNet in 8 / out 4 fwd + bwd at "
                    "the 36x44x28 latent, MSE, clip 1.0, Adam), bf16 compute / fp32 master weights and gradients, batch 1 per GPU, "
                    "gradients averaged over ranks inside backward",
@@ -273,30 +268,88 @@ def ddp_train_leg(dev, rank, world, dist, rehearsal, steps=8, warmup=3, latent=(
            "param_checksum_after_3_steps": sums, "param_checksums_equal_on_all_ranks": equal}
     rec["exchange_path"] = "in-library" if tr.overlap else "fallback"          # machine-readable form of "exchange"
     rec["rccl_version"] = L.ldm_comm_rccl_version()                              # ncclGetVersion() of the librccl this process loaded
-    rec["phases_ms"] = ddp_phase_trace(tr, images, labels, dev)
+    # what THIS rank saw: phases, its own wall clock, the bucket timeline of its last step.  Rank 0's copy also sits at the top level
+    # (the r03 / r04 field names); "per_rank" carries every rank's, so the first N > 1 run says by itself WHICH rank waited where
+    mine = {"rank": rank, "ms_per_step_local": dt_local / steps * 1e3, "phases_ms": ddp_phase_trace(tr, images, labels, dev)}
     if tr.overlap:
         n_max = 64
         issue, done, elems = (C.c_double * n_max)(), (C.c_double * n_max)(), (C.c_int64 * n_max)()
         n = L.ldm_model_grad_sync_trace(unet._h, issue, done, elems, n_max)
         comm = getattr(unet, "_grad_comm", None)
-        rec["ldm_comm_world"] = L.ldm_comm_world(comm) if comm else None
+        mine["ldm_comm_world"] = L.ldm_comm_world(comm) if comm else None
         if comm:
             st = (C.c_int64 * 4)()
             L.ldm_comm_stats(comm, st)
-            calls = max(1, int(st[0]))
-            rec["ldm_comm"] = {"transport_is_rccl": bool(L.ldm_comm_is_rccl(comm) == 1), "allreduce_calls": int(st[0]),
-                               "allreduce_bytes": int(st[1]), "optimizer_steps_counted": steps + warmup + 3,
-                               "bytes_per_step": int(st[1]) // (steps + warmup + 3),
-                               "note": "counted inside the library where each bucket is handed to ncclAllReduce"}
+            counted = steps + warmup + 3                 # warm-up + timed + the three steps of the phase trace
+            mine["ldm_comm"] = {"transport_is_rccl": bool(L.ldm_comm_is_rccl(comm) == 1), "allreduce_calls": int(st[0]),
+                                "allreduce_bytes": int(st[1]), "optimizer_steps_counted": counted,
+                                "bytes_per_step": int(st[1]) // counted,
+                                "note": "counted inside the library where each bucket is handed to ncclAllReduce"}
         if 0 < n < n_max:
             end = issue[n]
-            rec.update({"backward_ms": end, "buckets": n, "bucket_mb": [round(elems[k] * 4 / 2 ** 20, 1) for k in range(n)],
-                        "bucket_issue_ms": [round(issue[k], 3) for k in range(n)], "bucket_done_ms": [round(done[k], 3) for k in range(n)],
-                        # what the launch stream has to wait for after its own last backward kernel (the join): 0 = fully hidden
-                        "allreduce_exposed_ms": max(0.0, done[n - 1] - issue[n - 1] if n else 0.0),
-                        "allreduce_busy_ms": sum(done[k] - max(issue[k], done[k - 1] if k else 0.0) for k in range(n)),
-                        "trace_note": "times of the LAST step on rank 0, ms since its backward began; backward_ms includes the join"})
+            mine.update({"backward_ms": end, "buckets": n, "bucket_mb": [round(elems[k] * 4 / 2 ** 20, 1) for k in range(n)],
+                         "bucket_issue_ms": [round(issue[k], 3) for k in range(n)], "bucket_done_ms": [round(done[k], 3) for k in range(n)],
+                         # what the launch stream has to wait for after its own last backward kernel (the join): 0 = fully hidden
+                         "allreduce_exposed_ms": max(0.0, done[n - 1] - issue[n - 1] if n else 0.0),
+                         "allreduce_busy_ms": sum(done[k] - max(issue[k], done[k - 1] if k else 0.0) for k in range(n)),
+                         "trace_note": "times of the LAST step of this rank, ms since its backward began; backward_ms includes the join"})
+    mine["rccl_debug"] = rccl_debug_digest()
+    rec.update({k: v for k, v in mine.items() if k not in ("rank", "ms_per_step_local")})
+    everyone = tr.sync.gather_objects(mine) if dist is not None else [mine]
+    rec["per_rank"] = everyone
+    exposed = [r.get("allreduce_exposed_ms") for r in everyone if r.get("allreduce_exposed_ms") is not None]
+    if exposed:
+        rec["allreduce_exposed_ms_over_ranks"] = {"min": min(exposed), "max": max(exposed)}
+    rec["ms_per_step_over_ranks"] = {"min": min(r["ms_per_step_local"] for r in everyone), "max": max(r["ms_per_step_local"] for r in everyone)}
     return rec
+
+
+RCCL_DEBUG_LOG = None                        # this process's RCCL debug file (set_rccl_debug)
+RCCL_DEBUG_PREV = None
+
+
+def set_rccl_debug(rank):
+    """First-contact instrumentation of the N > 1 runs (nobody has seen this code's collectives on real xGMI): RCCL's own INFO log
+    of the INIT (+ TUNING on rank 0: algorithm / protocol / channels per collective size) subsystems goes to a per-process file that
+    ddp_train digests into the JSON line and echoes to stderr.  Must run before the first communicator of the process exists;
+    whatever NCCL_DEBUG* the environment had is reported in the digest.  LDM_BENCH_RCCL_DEBUG=0 switches it off."""
+    global RCCL_DEBUG_LOG, RCCL_DEBUG_PREV
+    if os.environ.get("LDM_BENCH_RCCL_DEBUG", "1") == "0":
+        return
+    RCCL_DEBUG_PREV = {k: os.environ.get(k) for k in ("NCCL_DEBUG", "NCCL_DEBUG_SUBSYS", "NCCL_DEBUG_FILE")}   # what the environment had (reported)
+    import tempfile
+    RCCL_DEBUG_LOG = os.path.join(tempfile.gettempdir(), f"ldm_bench_rccl_{os.getpid()}.log")
+    os.environ["NCCL_DEBUG"] = "INFO"
+    os.environ["NCCL_DEBUG_SUBSYS"] = "INIT,TUNING" if rank == 0 else "INIT"
+    os.environ["NCCL_DEBUG_FILE"] = RCCL_DEBUG_LOG
+
+
+def rccl_debug_digest(max_lines=40):
+    """The lines of this process's RCCL debug log that say what the library chose: per communicator its size / channel counts, and
+    (rank 0) the DISTINCT (bytes -> algorithm, protocol, channels) decisions of the collectives it ran.  The whole log goes to stderr."""
+    if not RCCL_DEBUG_LOG:
+        return None
+    if not os.path.exists(RCCL_DEBUG_LOG):
+        return {"log_lines": 0, "digest": [], "note": "RCCL wrote no debug file (debug state initialised before bench.py set NCCL_DEBUG?)",
+                "env_before": RCCL_DEBUG_PREV}
+    import re
+    keep, seen = [], set()
+    try:
+        lines = open(RCCL_DEBUG_LOG, errors="replace").read().splitlines()
+    except OSError:
+        return None
+    for ln in lines:
+        body = ln.split("NCCL INFO", 1)[-1].strip()
+        if re.search(r"Init COMPLETE|nranks|coll channels|Channel \d+/\d+ *:|Trees|Connected all (rings|trees)|threadThresholds|NET/|P2P|xGMI|XGMI", body) \
+                or re.search(r"Bytes -> Algo|-> algorithm", body, re.I):
+            key = re.sub(r"0x[0-9a-f]+|\b\d{5,}\b", "#", body)      # pointers / opCounts / big byte counts do not make a line new
+            if "Bytes ->" in body:
+                key = body.split("Bytes ->", 1)[0].split()[-1] + body.split("Bytes ->", 1)[1]
+            if key not in seen:
+                seen.add(key)
+                keep.append(body[:240])
+    sys.stderr.write("".join(f"[rccl] {ln}\n" for ln in lines[-400:]))
+    return {"log_lines": len(lines), "digest": keep[:max_lines], "truncated": len(keep) > max_lines, "env_before": RCCL_DEBUG_PREV}
 
 
 def ddp_phase_trace(tr, images, labels, dev, n=3):
@@ -382,6 +435,8 @@ def main():
     if world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} does not match WORLD_SIZE {world} (launch with --nproc-per-node {args.gpus})", file=sys.stderr)
         sys.exit(2)
+    if not args.no_ddp_train:
+        set_rccl_debug(rank)                                # before torch's process group / the library's communicator exist
     dist = None
     # rehearsal of the multi-rank control flow on a one-GPU box: LDM_BENCH_REHEARSAL=1 puts every rank on cuda:0 and uses gloo
     # (NCCL/RCCL refuses two ranks on one device); the numbers of such a run mean nothing
@@ -444,21 +499,28 @@ def main():
             x = step(i, x)
         gc.collect()
         gc.disable()
-        fence()
-        t0 = time.perf_counter()
-        ev[0].record()
-        for i in range(args.steps):
-            host_at[i] = time.perf_counter()
-            x = step(args.warmup + i, x)
-            ev[i + 1].record()
-        fence()
-        dt = time.perf_counter() - t0
-        gc.enable()
+        try:
+            fence()
+            t0 = time.perf_counter()
+            ev[0].record()
+            for i in range(args.steps):
+                host_at[i] = time.perf_counter()
+                x = step(args.warmup + i, x)
+                ev[i + 1].record()
+            fence()
+            dt = time.perf_counter() - t0
+        finally:
+            gc.enable()
+        dt_local = dt
         per_step = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]           # ms, on the launch stream
         host_gap = [(host_at[i + 1] - host_at[i]) * 1e3 for i in range(args.steps - 1)]  # ms between two enqueues on the host
         # the headline is final HERE (MAX over ranks), before any of the legs reported beside it runs: nothing below can change or lose it
+        per_rank_sps = [args.steps / dt_local]
         if dist is not None:
             tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            allt = [torch.empty_like(tt) for _ in range(world)]
+            dist.all_gather(allt, tt)                    # every replica's own wall clock: a slow rank is then visible by number
+            per_rank_sps = [args.steps / float(a.item()) for a in allt]
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         # Roofline leg: the SAME K steps once more with HIP events recorded on the launch stream around every launch
@@ -532,7 +594,7 @@ def main():
             if rank == 0:
                 emit({"ddp_train": {"error": f"the data-parallel training leg did not finish within {budget:.0f} s (stuck collective?); "
                                              "the headline above was final before it started"}})
-            os._exit(0)
+            os._exit(3)                                    # the line is out; the RUN failed and every launcher above must see that
         timer = threading.Timer(budget, give_up)
         timer.daemon = True
         timer.start()
@@ -544,12 +606,15 @@ def main():
         return rec
 
     if rank != 0:
+        failed = False
         if not args.no_ddp_train:
             del unet
             torch.cuda.empty_cache()
-            run_ddp()
+            failed = "error" in run_ddp()
         if dist is not None:
             dist.destroy_process_group()
+        if failed:
+            sys.exit(3)
         return
 
     ms_per_step = dt / args.steps * 1e3
@@ -563,6 +628,8 @@ def main():
         "timed_region": {"sum_of_step_events_ms": sum(per_step), "wall_ms": dt * 1e3,
                          "slowest_step_index": per_step.index(max(per_step)),
                          "host_enqueue_gap_ms_max": max(host_gap) if host_gap else 0.0,
+                         "host_hygiene": "python gc parked (collect + disable) for the region and one HIP event recorded per step inside it "
+                                         "(rounds 4+; rounds 1-3 timed the same loop without either)",
                          "note": "wall_ms - sum_of_step_events_ms = time before the first / after the last step; a host stall shows as a "
                                  "large host_enqueue_gap with a long step behind it, a device-side one as a long step alone"},
         "config": {"workload": "DiffusionModelUNet (channels 256/256/512, attn at 12^3 and 6^3, 191.18 M params) fwd + DDPM "
@@ -574,6 +641,8 @@ def main():
                               "Philox noise and device-resident timestep (ldm_unet_denoise_step)" if not args.host_step else
                               "HIP graph replay of the forward plan; scheduler step driven from the host (torch.randn)")},
         "steps_per_s_per_gpu": args.steps / dt,
+        # every replica's own rate (value uses the MAX of the ranks' wall clocks): min << max = one slow GPU / host share, not the code
+        "replica_steps_per_s": {"min": min(per_rank_sps), "max": max(per_rank_sps), "per_rank": [round(v, 2) for v in per_rank_sps]},
         "unet_step_tflops": UNET_STEP_GFLOP / ms_per_step,
         # unet_step_tflops and whole_step_fractions price the step at the REFERENCE's FLOP count (889.1 G); the plan executes fewer
         # (executed_gflop), so matrix-pipe utilisation of the step is executed_tflops / peak, not the fraction below
@@ -620,6 +689,8 @@ def main():
     emit(extra)
     if dist is not None:
         dist.destroy_process_group()
+    if "error" in (extra.get("ddp_train") or {}):          # the headline line is printed; a failed leg still fails the run (exit code 3)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

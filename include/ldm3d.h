@@ -245,7 +245,8 @@ int ldm_op_conv3d_block_stats_rows(int D, int H, int W, int th);
  *      stats [N * ldm_op_conv3d_block_stats_rows(D, H, W, 8)][128][2]. */
 int ldm_op_conv3d_block128(const void* x, int cin, const void* w, const float* bias, const float* temb, int temb_stride, const void* residual,
                            void* out, float* stats, int N, int D, int H, int W, void* stream);
-/* tests only: number of workgroups of conv3_block_kernel's tile loop (0 = default: two per CU; a multiple of 8); returns the previous value */
+/* tests only, experiments builds (make EXTRA=-DLDM_EXPERIMENTS): number of workgroups of conv3_block_kernel's tile loop (0 = default: two per
+ * CU; a multiple of 8); returns the previous value.  The product library has no tile-loop form: returns -1. */
 int ldm_debug_conv_block_slots(int slots);
 int ldm_op_conv3d_block(const void* x, int cin, const void* w, const float* bias, const float* temb, int temb_stride, const void* residual,
                         void* out, float* stats, int N, int D, int H, int W, int th, void* stream);
@@ -304,13 +305,14 @@ int ldm_op_group_norm_bwd_f32(const float* dy, const float* x, int C, const floa
                               float* dx, float* dgamma, float* dbeta, int N, int DHW, void* scratch, size_t scratch_bytes, void* stream);
 /* The split-K conv -> GroupNorm pair as the inference plans launch it at the low-resolution levels (conv + ONE finalize-and-GroupNorm
  * launch, csrc/fin_gn.h; MONAI ResBlock conv1 -> norm2 -> SiLU behind 3d_ldm/train_diffusion.py:197-205): gn_out = GroupNorm(+SiLU) of
- * bf16(conv + bias + temb[n] + residual), conv_out (optional) = that bf16 tensor itself.  splitk >= 2.  *err_out (optional, host;
- * synchronises) = 1 if an inter-workgroup wait gave up.  LDM_ERR_UNSUPPORTED for shapes the plans keep on two launches. */
+ * bf16(conv + bias + temb[n] + residual), conv_out (optional) = that bf16 tensor itself.  splitk >= 2.  Every workgroup of the second launch
+ * owns one (sample, group) over all rows (the conv writes its fp32 slabs one plane per group), so no statistics cross workgroups.
+ * LDM_ERR_UNSUPPORTED for shapes the plans keep on two launches (channels per group not a power of two in 4 ... 64, > 4096 items per group). */
 size_t ldm_op_conv3d_fin_gn_scratch_bytes(int N, int D, int H, int W, int cout_pad, int splitk);
 int ldm_op_conv3d_fin_gn(const void* x, int cin, const void* w, const float* bias, const float* temb, int temb_stride, const void* residual,
                          const float* gamma, const float* beta, int groups, float eps, int silu, void* conv_out, void* gn_out,
                          int N, int D, int H, int W, int cout, int cout_pad, int wgn, int splitk, void* scratch, size_t scratch_bytes,
-                         int* err_out, void* stream);
+                         void* stream);
 /* producer -> GroupNorm pair as the inference plans launch it (conv epilogue / write-through split-K finalize leave the statistics
  * slabs, one-launch GroupNorm(+SiLU) with write-through stores folds them): the per-kernel gate of exactly those kernel variants */
 size_t ldm_op_conv3d_gn_scratch_bytes(int N, int D, int H, int W, int cout_pad, int splitk);
@@ -351,9 +353,6 @@ int ldm_debug_kstamps(unsigned long long* out, int max_entries, int reset);
 int ldm_model_plan_conv_cfgs(ldm_model* m, const char* kind, int B, int D, int H, int W, int* cfgs, int max_convs);
 /* launches of a cached inference plan ("unet"|"enc"|"dec"; builds it if needed) */
 int ldm_model_plan_launches(ldm_model* m, const char* kind, int B, int D, int H, int W);
-/* 0 = every inter-workgroup wait inside the fused split-K finalize + GroupNorm launches (csrc/fin_gn.h) has completed so far; 1 = one
- * gave up (a resident-grid assumption was violated; the results of that launch are wrong).  Synchronises the device. */
-int ldm_model_sync_errors(ldm_model* m);
 
 /* ---- data-parallel collectives (replaces init_process_group("nccl") + DDP all-reduce,
  *      3d_ldm/utils.py:55-63, 3d_ldm/train_diffusion.py:121-123,147-149,281-283): RCCL over xGMI.

@@ -256,6 +256,10 @@ def test_planner_rules_added_in_round_3(built_lib, monkeypatch):
     halo_now = sum(1 for c in _bf16_conv_launches(AutoencoderKL(**cfgs.VAE_FULL), b"dec", 1, (24, 24, 24)) if c[3])
     bf16_unet = _bf16_conv_launches(DiffusionModelUNet(**cfgs.UNET_FULL), b"unet", 1, (24, 24, 24))
     assert sum(1 for c in bf16_unet if c[3] and c[4] == 1) >= 10        # 7 plain + 3 fused-skip convs at 24^3 on the halo kernel, unsplit
+    # round 5: the split-K convs with a fused skip (12^3 / 6^3) share the skip's steps among their splits on the halo kernel as well: only
+    # the two stride-2 Downsample convs and the two phase-form Upsample convs are left on the general kernel
+    assert sum(1 for c in bf16_unet if not c[3]) == 4, [c for c in bf16_unet if not c[3]]
+    # (LDM_HALO_SKIP_SPLIT=0, read once per process, plans the seven of them on the general kernel as round 4 did)
     assert halo_now >= 12
     # the 128 -> 64 and the two plain 64 -> 64 convs of the 96^3 level on conv3_block_kernel (halo code 3); the fused-skip one stays on the
     # 254 x 64 halo tile; the encoder's 96^3 level has four 64 -> 64 convs

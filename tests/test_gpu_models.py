@@ -9,9 +9,14 @@ How the gate is stated (DESIGN.md "Parity"):
     implementations that sum in different orders are therefore two independent draws of the same rounding noise,
     and no end-to-end 1e-3 bound can hold between them.  The end-to-end gate is the NOISE FLOOR itself:
         floor   = rel-L2(oracle bf16-emulated, oracle fp32)          (what bf16 costs the CPU reference)
-        rel-L2(GPU, oracle fp32)          <= 2.0 * floor + 1e-3      (GPU is as close to fp32 as the CPU bf16 path)
-        rel-L2(GPU, oracle bf16-emulated) <= 2.5 * floor + 1e-3      (two draws of the same noise: ~sqrt(2) * floor)
-    A plumbing bug (wrong skip, wrong tap, wrong head) gives O(1) errors and cannot hide under that.
+        rel-L2(GPU, oracle fp32)          <= FLOOR_FACTOR_FP32 * floor + 1e-3      (GPU is as close to fp32 as the CPU bf16 path)
+        rel-L2(GPU, oracle bf16-emulated) <= FLOOR_FACTOR_BF16 * floor + 1e-3      (two draws of the same noise: ~sqrt(2) * floor)
+    The factors are the measured ratios plus margin.  Round 5 printed the ratio of all 57 calls (gpurun_out/r05b_floor_ratios.txt):
+    GPU vs fp32 oracle 0.34 - 1.37 x floor (median 1.00; the two above 1.25 are small random-weight cases -- the concat-conditioned tiny
+    UNet 1.37, one step of the 16^3 DDIM chain 1.29 -- i.e. draws of the noise, not defects: the 24^3 headline network sits at 0.98),
+    GPU vs bf16 oracle 0.42 - 1.20.  tests/test_gpu_negative_controls.py shows what a defect in ONE layer does to the same ratio: a
+    zeroed conv tap 7.1 x, a GroupNorm epsilon off by 10 x 12.8 x, two swapped attention heads 11.9 x floor -- all fail this gate and
+    the per-block one.
 """
 import pytest
 import torch
@@ -22,13 +27,18 @@ from util import rel_l2
 pytestmark = pytest.mark.gpu
 
 
+FLOOR_FACTOR_FP32 = 1.5         # GPU vs fp32 oracle, in units of the CPU oracle's own bf16 floor (measured <= 1.37; round 4: 2.0)
+FLOOR_FACTOR_BF16 = 1.5         # GPU vs bf16-emulating oracle: two draws of the same rounding noise (measured <= 1.20; round 4: 2.5)
+
+
 def floor_gate(got, ref_bf, ref_32, what):
     floor = rel_l2(ref_bf, ref_32)
     e_bf, e_32 = rel_l2(got, ref_bf), rel_l2(got, ref_32)
-    print(f"{what}: bf16 floor {floor:.2e} | GPU vs fp32-oracle {e_32:.2e} | GPU vs bf16-oracle {e_bf:.2e}")
+    print(f"FLOOR_GATE {what}: bf16 floor {floor:.2e} | GPU vs fp32-oracle {e_32:.2e} = {e_32 / floor:.2f} x floor | "
+          f"GPU vs bf16-oracle {e_bf:.2e} = {e_bf / floor:.2f} x floor")
     assert torch.isfinite(got).all(), what
-    assert e_32 <= 2.0 * floor + 1e-3, (what, e_32, floor)
-    assert e_bf <= 2.5 * floor + 1e-3, (what, e_bf, floor)
+    assert e_32 <= FLOOR_FACTOR_FP32 * floor + 1e-3, (what, e_32, floor, e_32 / floor)
+    assert e_bf <= FLOOR_FACTOR_BF16 * floor + 1e-3, (what, e_bf, floor, e_bf / floor)
     return floor, e_32, e_bf
 
 
@@ -448,10 +458,10 @@ def test_vae_full_size_96cube_golden(cuda):
 
 
 def test_fused_finalize_group_norm_plan_matches_the_default_plan(cuda):
-    """LDM_FIN_GN=1 (off by default: measured 2 % slower, csrc/fin_gn.h) turns every split-K finalize -> GroupNorm pair of the inference
-    plan into ONE launch whose workgroups exchange the statistics behind an arrival counter.  Same rounding points as the default plan:
-    the benchmark UNet's output at 16^3 agrees to the bf16 noise floor of the network, the plan has 23 launches fewer, the error word of
-    the exchange stays 0 over repeated graph replays.  Runs in a child process: the knob is read once per process."""
+    """The inference plans run every split-K finalize -> GroupNorm pair as ONE launch in which a workgroup owns a whole (sample, group)
+    (csrc/fin_gn.h; LDM_FIN_GN=0 keeps the three-launch form).  Same rounding points as the three-launch plan: the benchmark UNet's
+    output at 16^3 agrees to a few bf16 ulps of a few elements amplified by the network, the plan has >= 15 launches fewer, graph
+    replays are bit-stable.  Runs in child processes: the knob is read once per process."""
     import json
     import os
     import subprocess
@@ -477,7 +487,7 @@ with torch.no_grad():
     outs = [m(x=x, timesteps=t).clone() for _ in range(20)]
 L = _lib.lib()
 print(json.dumps({"sum": float(a.double().sum()), "abs": float(a.double().abs().sum()), "replays_equal": all(bool(torch.equal(o, a)) for o in outs),
-                  "launches": L.ldm_model_plan_launches(m._h, b"unet", 1, 16, 16, 16), "err": L.ldm_model_sync_errors(m._h),
+                  "launches": L.ldm_model_plan_launches(m._h, b"unet", 1, 16, 16, 16),
                   "out": a.flatten()[::97].cpu().tolist()}))
 '''
     recs = {}
@@ -488,7 +498,6 @@ print(json.dumps({"sum": float(a.double().sum()), "abs": float(a.double().abs().
     a, b = torch.tensor(recs["0"]["out"]), torch.tensor(recs["1"]["out"])
     rel = float((a - b).norm() / a.norm())
     print(f"fused finalize + GroupNorm plan vs default: rel-L2 {rel:.2e}, launches {recs['0']['launches']} -> {recs['1']['launches']}")
-    assert recs["1"]["err"] == 0 and recs["0"]["err"] == 0
     assert recs["0"]["replays_equal"] and recs["1"]["replays_equal"]
     assert recs["1"]["launches"] <= recs["0"]["launches"] - 15
     assert rel <= 5e-2                       # two correct bf16 evaluations of this network (statistics folded in another order): its noise floor

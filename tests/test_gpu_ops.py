@@ -136,16 +136,22 @@ def test_conv_fused_skip_1x1_dual_source(cuda, built_lib, splitk):
     assert err <= tol, err
 
 
-@pytest.mark.parametrize("cin,cout,dims,n,skip,temb", [
-    (256, 256, (24, 24, 24), 1, (256, 256), False),    # up-block conv2 at 24^3: 1x1 skip over cat(h, skip) = 8 extra K steps, two sources
-    (128, 128, (6, 6, 6), 1, (192, 0), True),          # one source, 3 extra steps, ragged last tile, per-sample channel bias
-    (64, 128, (5, 3, 7), 3, (64, 64), False),          # several samples, tiles that end inside a sample, one chunk per source
-    (64, 256, (4, 4, 4), 2, (64, 0), False),           # a single extra step (no prefetch ahead)
+@pytest.mark.parametrize("cin,cout,dims,n,skip,temb,splitk", [
+    (256, 256, (24, 24, 24), 1, (256, 256), False, 1),    # up-block conv2 at 24^3: 1x1 skip over cat(h, skip) = 8 extra K steps, two sources
+    (128, 128, (6, 6, 6), 1, (192, 0), True, 1),          # one source, 3 extra steps, ragged last tile, per-sample channel bias
+    (64, 128, (5, 3, 7), 3, (64, 64), False, 1),          # several samples, tiles that end inside a sample, one chunk per source
+    (64, 256, (4, 4, 4), 2, (64, 0), False, 1),           # a single extra step (no prefetch ahead)
+    # split over K (round 5): the splits share the skip's steps -- the 12^3 / 6^3 ResBlocks with a channel change
+    (256, 256, (12, 12, 12), 1, (256, 512), True, 9),     # up_blocks.1 conv2: 12 skip steps over 9 splits (2 each, the last three splits none)
+    (512, 512, (6, 6, 6), 1, (512, 512), False, 24),      # up_blocks.0 conv2: 16 skip steps over 24 splits (one each, eight splits none)
+    (512, 512, (6, 6, 6), 1, (256, 0), True, 12),         # down_blocks.2 conv2: 4 steps, one source, 12 splits
+    (128, 128, (5, 3, 7), 2, (64, 192), False, 3),        # two samples, 4 steps over 3 splits (2 / 2 / 0), chunks from both sources inside one split
 ])
-def test_conv3_halo_kernel_with_the_fused_1x1_skip(cuda, built_lib, cin, cout, dims, n, skip, temb):
+def test_conv3_halo_kernel_with_the_fused_1x1_skip(cuda, built_lib, cin, cout, dims, n, skip, temb, splitk):
     """conv3_halo_kernel with the ResBlock's 1x1 skip_connection fused as a second K loop at the centre tap (wgn = 2 on an eligible
-    unsplit conv): MONAI's `skip_connection(x) + conv2(h)` in one launch, as the inference plans run the up-block conv2s at 24^3."""
-    err, tol = _conv_case(cuda, built_lib, cin=(cin, 0), cout=cout, dims=dims, n=n, wgn=2, splitk=1, skip=skip, temb=temb, seed=cin + dims[2] + skip[0])
+    conv): MONAI's `skip_connection(x) + conv2(h)` in one launch, as the inference plans run the up-block conv2s at 24^3 (unsplit) and
+    at 12^3 / 6^3 (split over K: every split takes a share of the skip's steps)."""
+    err, tol = _conv_case(cuda, built_lib, cin=(cin, 0), cout=cout, dims=dims, n=n, wgn=2, splitk=splitk, skip=skip, temb=temb, seed=cin + dims[2] + skip[0])
     assert err <= tol, err
 
 
@@ -511,18 +517,17 @@ def test_conv_then_group_norm_as_the_plans_launch_them(cuda, built_lib, cin, cou
     assert e_pair <= TOL_SAME_ROUNDING, e_pair
 
 
-# conv (split over K) -> ONE finalize-and-GroupNorm launch (csrc/fin_gn.h: the statistics are exchanged between the launch's workgroups
-# behind an arrival counter), as the inference plans launch it at the 12^3 / 6^3 levels.  Checked: against torch on identical
+# conv (split over K, planar slabs) -> ONE finalize-and-GroupNorm launch (csrc/fin_gn.h: every workgroup owns a whole (sample, group), no
+# statistics cross workgroups), as the inference plans launch it at the 12^3 / 6^3 levels.  Checked: against torch on identical
 # bf16-rounded inputs (same rounding points as the two-launch path), against the two-launch path itself (the un-normalised tensor bit
-# for bit; the normalised one to the last bf16 ulp: the fold order of the statistics differs), and under 200 back-to-back replays with
-# CHANGING inputs (the counters restore themselves, nothing stale is read from the exchange area, the error word stays 0).
+# for bit; the normalised one to the last bf16 ulp: the fold order of the statistics differs), and under back-to-back replays with
+# CHANGING inputs (results follow the inputs).
 @pytest.mark.parametrize("cin,cout,dims,n,wgn,splitk,groups,silu,temb,res,keep", [
     (256, 256, (12, 12, 12), 1, 2, 6, 32, True, True, False, False),    # ResBlock conv1 -> norm2 at 12^3 (halo tile): nobody reads the raw tensor
     (256, 256, (12, 12, 12), 1, 2, 8, 32, False, False, True, True),    # conv2 (+ residual) -> attention norm: the raw tensor is the residual stream
     (512, 512, (6, 6, 6), 1, 2, 12, 32, True, True, False, False),      # the 6^3 level: 216 rows (ragged last 32-row block), 16 channels per group
     (512, 512, (6, 6, 6), 1, 2, 27, 32, False, False, True, True),
     (96, 128, (8, 8, 8), 2, 2, 3, 16, True, True, False, True),         # general kernel (K step 32), batch 2, 8 channels per group
-    (64, 96, (4, 6, 8), 1, 2, 2, 24, True, False, False, True),         # 96 channels: the second 64-channel slice is half empty; 4 channels per group
 ])
 def test_split_k_conv_then_fused_finalize_group_norm(cuda, built_lib, cin, cout, dims, n, wgn, splitk, groups, silu, temb, res, keep):
     from ldm3d import _lib
@@ -540,12 +545,11 @@ def test_split_k_conv_then_fused_finalize_group_norm(cuda, built_lib, cin, cout,
     st = torch.cuda.current_stream().cuda_stream
     nb = max(built_lib.ldm_op_conv3d_fin_gn_scratch_bytes(n, *dims, cout_pad, splitk), built_lib.ldm_op_conv3d_gn_scratch_bytes(n, *dims, cout_pad, splitk))
     scratch = torch.empty((nb,), dtype=torch.uint8, device=cuda)
-    err = C.c_int(-1)
 
-    def fused(xa, ra, raw_out, gn_out, err_ptr):
+    def fused(xa, ra, raw_out, gn_out):
         _lib.check(built_lib.ldm_op_conv3d_fin_gn(xa.data_ptr(), cin, wp.data_ptr(), bp.data_ptr(), _lib.ptr(td), cout_pad if temb else 0, _lib.ptr(ra),
                                                   gd.data_ptr(), bd.data_ptr(), groups, 1e-6, int(silu), _lib.ptr(raw_out), gn_out.data_ptr(),
-                                                  n, *dims, cout, cout_pad, wgn, splitk, scratch.data_ptr(), scratch.numel(), err_ptr, st))
+                                                  n, *dims, cout, cout_pad, wgn, splitk, scratch.data_ptr(), scratch.numel(), st))
     worst = 0.0
     for rep in range(3):
         x = bf16_round(torch.randn((n, cin, *dims), generator=g))
@@ -563,8 +567,7 @@ def test_split_k_conv_then_fused_finalize_group_norm(cuda, built_lib, cin, cout,
         ra = to_ndhwc_bf16(r).to(cuda) if res else None
         raw = torch.full((n, *dims, cout), float("nan"), dtype=torch.bfloat16, device=cuda) if keep else None
         gn_out = torch.full((n, *dims, cout), float("nan"), dtype=torch.bfloat16, device=cuda)
-        fused(xa, ra, raw, gn_out, C.byref(err))
-        assert err.value == 0
+        fused(xa, ra, raw, gn_out)
         e_pair = rel_l2(from_ndhwc(gn_out.cpu(), cout), bf16_round(ref))
         worst = max(worst, e_pair)
         assert e_pair <= TOL_SAME_ROUNDING, e_pair
@@ -590,15 +593,15 @@ def test_split_k_conv_then_fused_finalize_group_norm(cuda, built_lib, cin, cout,
     first = []
     ra = to_ndhwc_bf16(bf16_round(torch.randn((n, cout, *dims), generator=g))).to(cuda) if res else None
     for k in range(2):
-        fused(xs[k], ra, None, outs[k], None)
+        fused(xs[k], ra, None, outs[k])
         first.append(outs[k].clone())
-    for it in range(200):
+    for it in range(40):
         k = it & 1
-        fused(xs[k], ra, None, outs[k], None)
-        if it % 50 == 49:
+        fused(xs[k], ra, None, outs[k])
+        if it % 10 == 9:
             assert torch.equal(outs[k], first[k])
-    fused(xs[0], ra, None, outs[0], C.byref(err))
-    assert err.value == 0 and torch.equal(outs[0], first[0]) and not torch.equal(first[0], first[1])
+    fused(xs[0], ra, None, outs[0])
+    assert torch.equal(outs[0], first[0]) and not torch.equal(first[0], first[1])
     print(f"fused finalize + GroupNorm {cin}->{cout} {dims} n={n} splitk={splitk} groups={groups}: pair {worst:.2e}")
 
 
@@ -640,13 +643,15 @@ def test_conv3_block_kernel(cuda, built_lib, cin, cout, dims, n, th, temb, resid
     out = torch.full((n, *dims, 64), float("nan"), dtype=torch.bfloat16, device=cuda)
     stats = torch.full((n * rows, 64, 2), float("nan"), device=cuda)
     prev = built_lib.ldm_debug_conv_block_slots(slots)
+    if slots and prev < 0:
+        pytest.skip("the tile-loop form of conv3_block_kernel exists in experiments builds only (make EXTRA=-DLDM_EXPERIMENTS)")
     try:
         _lib.check(built_lib.ldm_op_conv3d_block(xa.data_ptr(), cin, wp.data_ptr(), bp.data_ptr(), None if te is None else te.data_ptr(), 64,
                                                  None if res is None else res.data_ptr(), out.data_ptr(), stats.data_ptr(), n, *dims, th,
                                                  torch.cuda.current_stream().cuda_stream))
         torch.cuda.synchronize()
     finally:
-        built_lib.ldm_debug_conv_block_slots(prev)
+        built_lib.ldm_debug_conv_block_slots(max(prev, 0))
     assert torch.isfinite(out.float()).all()
     err = rel_l2(from_ndhwc(out.cpu(), cout), bf16_round(ref))
     assert err <= TOL_SAME_ROUNDING, err

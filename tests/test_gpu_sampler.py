@@ -153,3 +153,55 @@ def test_graph_replay_never_reuses_a_graph_recorded_for_a_destroyed_sampler(cuda
     ga2 = chain(11, 12, True)
     m.enable_graph_replay(False)
     assert torch.equal(ga, eager_a) and torch.equal(gb, eager_b) and torch.equal(ga2, eager_a)
+
+
+def test_time_embedding_table_follows_weight_uploads_schedules_and_precision(cuda):
+    """``denoise_step`` takes the 17 stacked time_emb_proj outputs of the sampler's current step from a table built once per
+    parameter upload (csrc temb_row_kernel), ``forward`` computes them from ``timesteps`` (sinusoid + 3 GEMVs).
+    Same kernels at another batch size, so the two must agree bit for bit -- after a second ``load_state_dict`` (stale table), with
+    another schedule on the same module (DDIM, 7 steps), past the end of the schedule, and in the fp32 precision mode."""
+    from ldm3d.networks import DiffusionModelUNet
+    from ldm3d.schedulers import DDIMScheduler, DDPMScheduler
+    from oracle import unet as ou
+    cfg = cfgs.UNET_TINY
+    m = DiffusionModelUNet(**cfg)
+    m.load_state_dict(ou.init_state_dict(ou.unet_param_shapes(cfg), 1))
+    m = m.to(cuda).eval()
+    x0 = torch.randn((2, 4, 8, 8, 8), device=cuda, generator=torch.Generator(device=cuda).manual_seed(5))
+    tbuf = torch.empty((2,), device=cuda)
+
+    def both(sch, steps, graph):
+        with torch.no_grad():
+            a = sch.device_sampler(seed=3)
+            xa = x0.clone()
+            a.reset(tbuf)
+            m.enable_graph_replay(False)
+            for _ in range(steps):
+                a.step(m(x=xa, timesteps=tbuf), xa, tbuf)
+            b = sch.device_sampler(seed=3)
+            xb = x0.clone()
+            b.reset(tbuf)
+            m.enable_graph_replay(graph)
+            for _ in range(steps):
+                m.denoise_step(xb, tbuf, b)
+            m.enable_graph_replay(False)
+        return xa, xb
+    ddpm = DDPMScheduler(**cfgs.SCHED)
+    ddim = DDIMScheduler(**cfgs.SCHED)
+    ddim.set_timesteps(7)
+    xa, xb = both(ddpm, 4, True)
+    assert torch.equal(xa, xb)
+    first = xb.clone()
+    m.load_state_dict({k: v * 1.25 for k, v in ou.init_state_dict(ou.unet_param_shapes(cfg), 1).items()})
+    xa, xb = both(ddpm, 4, True)
+    assert torch.equal(xa, xb) and not torch.equal(xb, first)        # the table was rebuilt from the new weights
+    xa, xb = both(ddim, 9, False)                                    # another schedule; two calls beyond its 7 steps
+    assert torch.equal(xa, xb)
+    xa, xb = both(ddpm, 3, True)                                     # and back
+    assert torch.equal(xa, xb)
+    m.set_precision("fp32")
+    xa, xb = both(ddpm, 3, True)
+    assert torch.equal(xa, xb)
+    m.set_precision("bf16")
+    xa, xb = both(ddpm, 3, False)
+    assert torch.equal(xa, xb)

@@ -77,7 +77,7 @@ def test_vae_decode_config5_volume(cuda):
         small = v.decode_stage_2_outputs(zs.to(cuda)).cpu()
     ref_bf, ref_32 = oa.decode(sd, cfgs.VAE_FULL, zs, True), oa.decode(sd, cfgs.VAE_FULL, zs, False)
     floor = rel_l2(ref_bf, ref_32)
-    assert rel_l2(small, ref_32) <= 2.0 * floor + 1e-3
+    assert rel_l2(small, ref_32) <= 1.5 * floor + 1e-3
 
 
 def test_vae_encode_brats_patch(cuda):

@@ -66,8 +66,8 @@ def test_unet_parameter_gradients_match_oracle_autograd(cuda, name, dims, b, con
     worst = max(((rel_l2(got[n], g32[n]), n) for n in names if g32[n].norm() > 1e-3 * r.norm()), default=(0.0, ""))
     print(f"{name}: loss gpu {float(loss):.5f} / fp32 {loss32:.5f} / bf16 {lossbf:.5f}; grad floor {floor:.2e}, "
           f"GPU vs fp32 {e32:.2e}, vs bf16-oracle {ebf:.2e}, cosine {cos:.5f}, worst tensor {worst[0]:.2e} ({worst[1]})")
-    assert e32 <= 2.0 * floor + 2e-3, (e32, floor)
-    assert ebf <= 2.5 * floor + 2e-3, (ebf, floor)
+    assert e32 <= 1.5 * floor + 2e-3, (e32, floor)     # measured 0.98 - 1.04 x floor (round 5; round 4 allowed 2.0 / 2.5)
+    assert ebf <= 1.5 * floor + 2e-3, (ebf, floor)
     assert cos >= 1.0 - 2.0 * (2.0 * floor + 2e-3) ** 2
     # every family of parameters individually (catches a wrong export / layout that is small in the global norm)
     for fam in ("conv.weight", "conv.bias", "norm", "time_emb", "time_embed", "to_q", "to_k", "to_v", "out_proj", "skip_connection"):
@@ -106,7 +106,7 @@ def test_unit_gain_gradients_sit_on_the_bf16_floor(cuda):
     cos_gpu, cos_bf = float(a @ r / (a.norm() * r.norm())), float(bfo @ r / (bfo.norm() * r.norm()))
     print(f"unit gain: oracle bf16-vs-fp32 floor {floor:.2e} (cosine {cos_bf:.4f}); GPU vs fp32 {rel_l2(a, r):.2e} (cosine {cos_gpu:.4f})")
     assert torch.isfinite(a).all()
-    assert rel_l2(a, r) <= 2.0 * floor + 2e-3
+    assert rel_l2(a, r) <= 1.5 * floor + 2e-3              # measured 1.12 x floor
     assert cos_gpu >= cos_bf - 0.1
 
 
@@ -350,8 +350,8 @@ def test_autoencoder_parameter_gradients_match_oracle_autograd(cuda, name, dims,
     cos = float((a @ r) / (a.norm() * r.norm()))
     print(f"{name} {dims}: loss gpu {float(loss):.5f} / fp32 {l32:.5f} / bf16 {lbf:.5f}; grad floor {floor:.2e}, GPU vs fp32 {e32:.2e}, "
           f"vs bf16-oracle {ebf:.2e}, cosine {cos:.5f}")
-    assert e32 <= 2.0 * floor + 5e-3, (e32, floor)
-    assert ebf <= 2.5 * floor + 5e-3, (ebf, floor)
+    assert e32 <= 1.5 * floor + 5e-3, (e32, floor)     # measured 0.83 - 1.18 x floor
+    assert ebf <= 1.5 * floor + 5e-3, (ebf, floor)
     for fam in ("encoder", "decoder", "quant_conv_mu", "quant_conv_log_sigma", "post_quant_conv", "norm", "nin_shortcut", "attn.to_", "attn.out_proj"):
         sel = [n for n in names if fam in n]
         if sel and _cat(g32, sel).norm() > 0:
@@ -473,7 +473,7 @@ def test_training_step_matches_committed_golden(cuda):
     en = float((gn - rn).norm() / rn.norm())
     print(f"golden train step: loss {float(loss):.6f} vs {gold['loss_fp32']:.6f}; projection rel-L2 {e32:.2e} (bf16 floor {floor:.2e}); "
           f"per-tensor norm rel-L2 {en:.2e}")
-    assert e32 <= 2.0 * floor + 5e-3, (e32, floor)
+    assert e32 <= 1.5 * floor + 5e-3, (e32, floor)     # measured 0.99 x floor
     assert en <= 2e-2
     total = float(opt.grad_norm())
     assert abs(total - gold["total_grad_norm_fp32"]) <= 2e-2 * gold["total_grad_norm_fp32"]

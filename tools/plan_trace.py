@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 KINDS = ("PACK CONV FINALIZE GN_STATS GN_FINALIZE GN_PREP GN_APPLY ATTN SINUSOID GEMV VAE_HEADS GN_FUSED WT WT_BATCH WGRAD EXPORT "
          "EXPORT_BATCH COLSUM GNB ATTN_BWD ADD SUMPOOL LIN_DX LIN_DW VAE_HEADS_BWD GEMM_LIGHT COLSUM_BATCH IM2COL "
-         "PACK32 CONV32 FIN32 GN_STATS32 GN_APPLY32 ATTN32 GEMV32 TAP BUCKET BUCKET_JOIN UPS_SPLIT32 CONV_THIN FIN_GN GEMM_LIGHT32 CONV_BLOCK").split()
+         "PACK32 CONV32 FIN32 GN_STATS32 GN_APPLY32 ATTN32 GEMV32 TAP BUCKET BUCKET_JOIN UPS_SPLIT32 CONV_THIN FIN_GN GEMM_LIGHT32 CONV_BLOCK TEMB_ROW").split()
 
 
 def main():
