@@ -25,6 +25,9 @@
 #include "attention.h"
 #include "conv_igemm.h"
 #include "conv_halo.h"
+#ifdef LDM_EXPERIMENTS
+#include "conv_halo_rw.h"                // register-fed weights: built, parity-green, slower
+#endif
 #include "conv_thin.h"
 #include "gemm_light.h"
 #include "gemm_light_x3.h"
@@ -2079,6 +2082,26 @@ static int launch_conv_halo(const ConvParams& p_in, hipStream_t s, bool tall = f
         else hipLaunchKernelGGL((conv3_halo_kernel<6, 0, true>), dim3(grid), dim3(512), LDS_TALL, s, p);
         return 0;
     }
+#ifdef LDM_EXPERIMENTS
+    // EXPERIMENTS BUILD ONLY (LDM_HALO_RW=1): the 126 x 128 tile with register-fed weights and one barrier per macro step (conv_halo_rw.h).
+    // Parity-green on every conv operator test (gpurun_out/r05h_rw_ops.txt) and 22 % SLOWER than conv3_halo_kernel at 24^3 (59.1 vs 47.2 us;
+    // headline 443.8 vs 484.5 steps/s, profiles/r05_ab_halo_rw.txt): 16 KiB of weight fragments per K step through the vector L1 as half
+    // cache lines cost ~350 cycles per step, and ONE barrier per macro step still costs ~250 cycles per step (profiles/r05_halo_ablations.txt).
+    static const int rw = ldm_xknob("LDM_HALO_RW", 0);
+    if (rw && !p.x3_n && !p.out_f32 && !p.out32 && !p.raw_partial && p.CoutPad % 128 == 0 && (p.out || p.splitk > 1)) {
+        static bool rw_attr_tab[32] = {}; bool& rw_attr = attr_flag(rw_attr_tab);
+        if (!rw_attr) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_halo_rw_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, HRW_LDS));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_halo_rw_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, HRW_LDS));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_halo_rw_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, HRW_LDS));
+            rw_attr = true;
+        }
+        if ((p.dbg & 124) == 64) { hipLaunchKernelGGL((conv3_halo_rw_kernel<64>), dim3(tiles), dim3(512), HRW_LDS, s, p); return 0; }
+        if ((p.dbg & 124) == 4) { hipLaunchKernelGGL((conv3_halo_rw_kernel<4>), dim3(tiles), dim3(512), HRW_LDS, s, p); return 0; }
+        hipLaunchKernelGGL((conv3_halo_rw_kernel<0>), dim3(tiles), dim3(512), HRW_LDS, s, p);
+        return 0;
+    }
+#endif
     if (p.dbg & (4 | 8 | 16 | 32 | 64)) {                  // timing ablations (operator-level API + LDM_CONV_DBG only)
 #define ABL_CASE(A) if ((p.dbg & 124) == A) { \
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_halo_kernel<6, A>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); \

@@ -26,9 +26,11 @@ def main():
     ap.add_argument("--shapes", default="plain,wide,skip")
     ap.add_argument("--stamps", action="store_true")
     ap.add_argument("--iters", type=int, default=0, help="fixed launch count instead of a duration (PMC passes)")
+    ap.add_argument("--dbg", type=int, default=0, help="extra LDM_CONV_DBG bits (experiments build; results are wrong): 1 = voxel copies from 1024 "
+                    "L2-resident rows, 2 = weight copies out of range (no bytes move), 4 / 8 / 16 / 32 / 64 = conv_halo.h's compile-time ablations")
     args = ap.parse_args()
-    if args.stamps:
-        os.environ["LDM_CONV_DBG"] = "512"
+    if args.stamps or args.dbg:
+        os.environ["LDM_CONV_DBG"] = str((512 if args.stamps else 0) | args.dbg)
     import torch
     from ldm3d import _lib
     dev = torch.device("cuda:0")
@@ -74,7 +76,7 @@ def main():
         gf = 2.0 * M * cout * (27 * cin + 2 * cskip) / 1e9
         us = dt / n * 1e6
         line = (f"{name:5s} {cin}->{cout}{' +skip ' + str(2 * cskip) if cskip else ''} @24^3: {n} launches in {dt:.2f} s = {us:.2f} us per launch, "
-                f"{gf / us * 1e-3:.3f} PFLOP/s = {gf / us * 1e-3 / 2.5:.3f} of the bf16 MFMA peak")
+                f"{gf / us:.3f} PFLOP/s = {gf / us / 2.5:.3f} of the bf16 MFMA peak")
         if args.stamps:
             s8 = scratch.view(torch.int64).view(-1, 8).cpu().double()
             s8 = s8[s8[:, 0] > 0]
