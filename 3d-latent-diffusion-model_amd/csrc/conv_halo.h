@@ -27,7 +27,7 @@
 // 32 / 3 KiB of voxels = 18.7 KiB.
 // PERSIST: the tile loop below exists (launches with more tiles than CUs); false = one tile per workgroup, straight-line code (every conv
 // of the B = 1 UNet step: the loop form keeps per-lane constants live across the K loop and costs registers that launch does not have)
-template <int NSB, int ABL = 0, bool TALL = false, bool PERSIST = false>
+template <int NSB, int ABL = 0, bool TALL = false, bool PERSIST = false, bool MASK_INLINE = false>
 __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int BM = TALL ? 256 : 128, TM = BM - 2, BN = TALL ? 64 : 128, BK = 64, RB = 128;
@@ -221,9 +221,25 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(vm_) : "memory");                                  \
         if (!(ABL & 64)) __builtin_amdgcn_s_barrier();                                              \
         asm volatile("" ::: "memory");                                                              \
-        HL_MASK(AC, kw_);                                                                           \
         HL_ISSUE(kw_, (J));                                    /* step S+6 refills the weight slot of step S */ \
         HL_READ(WN, AN, ((J) + 1) % NSB, kn_);                                                      \
+        if (MASK_INLINE) {                                                                          \
+            /* round 5: the W-border masks of a voxel fragment sit right in front of the four MFMAs that read it (voxel tile outer, cout  \
+               tile inner) instead of all 16 v_cndmask in front of the step's first MFMA, where both waves of a SIMD executed them at the  \
+               same moment behind the barrier with the matrix pipe idle */                                                              \
+            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                      \
+                if (kw_ != 1 && ((wmask >> ((kw_ == 0 ? 0 : 4) + mt)) & 1u)) AC[mt] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0}; \
+                if (!(ABL & 8)) _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                    \
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WC[nt], AC[mt], acc[nt][mt], 0, 0, 0); \
+            }                                                                                       \
+            _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {                                     \
+                if (kw_ != 1 && (i_ & 3) == 0) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                  \
+                if (i_ < nc_) { __builtin_amdgcn_sched_group_barrier(0x004, 2, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); } \
+                else if (i_ < nc_ + 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);           \
+            }                                                                                       \
+        } else {                                                                                    \
+        HL_MASK(AC, kw_);                                                                           \
         HL_MFMA(WC, AC);                                                                            \
         /* one scheduling region: every copy / LDS read rides in the shadow of an MFMA (border masks float freely) */ \
         _Pragma("unroll") for (int i_ = 0; i_ < nc_; ++i_) {                                        \
@@ -236,6 +252,7 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                      \
         }                                                                                           \
         __builtin_amdgcn_sched_group_barrier(0x008, 16 - nc_ - 8, 0);                               \
+        }                                                                                           \
     } while (0)
 
     // diagnostic (dbg & 512, operator-level API): shader-clock and 100 MHz stamps around the K loop -> effective clock

@@ -2077,8 +2077,19 @@ static int launch_conv_halo(const ConvParams& p_in, hipStream_t s, bool tall = f
     const int tiles = p.mtiles * p.ntiles * p.splitk;
     const int grid = (persist && tiles > cus) ? cus : tiles;
     const bool loop = grid < tiles;                  // more tiles than workgroups: the persistent instantiation walks them
+    static const int mi = ldm_knob("LDM_HALO_MASK_INLINE", 1);    // W-border masks between the MFMAs (conv_halo.h, MASK_INLINE)
+    if (mi) {
+        static bool mi_attr_tab[32] = {}; bool& mi_attr = attr_flag(mi_attr_tab);
+        if (!mi_attr) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_halo_kernel<6, 0, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_halo_kernel<6, 0, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TALL));
+            mi_attr = true;
+        }
+    }
     if (tall) {
+        // (the tile-loop instantiations keep the masks in front: inline they push 35 - 53 registers into scratch)
         if (loop) hipLaunchKernelGGL((conv3_halo_kernel<6, 0, true, true>), dim3(grid), dim3(512), LDS_TALL, s, p);
+        else if (mi) hipLaunchKernelGGL((conv3_halo_kernel<6, 0, true, false, true>), dim3(grid), dim3(512), LDS_TALL, s, p);
         else hipLaunchKernelGGL((conv3_halo_kernel<6, 0, true>), dim3(grid), dim3(512), LDS_TALL, s, p);
         return 0;
     }
@@ -2110,6 +2121,7 @@ static int launch_conv_halo(const ConvParams& p_in, hipStream_t s, bool tall = f
 #undef ABL_CASE
     }
     if (loop) hipLaunchKernelGGL((conv3_halo_kernel<6, 0, false, true>), dim3(grid), dim3(512), LDS, s, p);
+    else if (mi) hipLaunchKernelGGL((conv3_halo_kernel<6, 0, false, false, true>), dim3(grid), dim3(512), LDS, s, p);
     else hipLaunchKernelGGL((conv3_halo_kernel<6>), dim3(grid), dim3(512), LDS, s, p);
     return 0;
 }

@@ -44,7 +44,7 @@ def test_hot_kernels_do_not_spill(isa):
             continue
         seen += 1
         m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b)
-        if re.search(r"conv3_halo_kernelILi6ELi0ELb[01]ELb1E", name):
+        if re.search(r"conv3_halo_kernelILi6ELi0ELb[01]ELb1ELb[01]EEv", name):     # <NSB, ABL, TALL, PERSIST = true, MASK_INLINE>
             continue                                       # the persistent (tile-loop) instantiations: checked loop by loop below
         assert m and int(m.group(1)) == 0, (name, m and m.group(1))
     assert seen >= 11
@@ -58,7 +58,7 @@ def test_persistent_halo_kernels_keep_scratch_out_of_their_k_loops(isa):
     one-tile-per-workgroup instantiations (every conv of the B = 1 UNet step) must not touch scratch at all (test above)."""
     lines, res = isa
     for tall in "01":
-        start = next(i for i, l in enumerate(lines) if l.startswith(f"_Z17conv3_halo_kernelILi6ELi0ELb{tall}ELb1EEv10ConvParams:"))
+        start = next(i for i, l in enumerate(lines) if l.startswith(f"_Z17conv3_halo_kernelILi6ELi0ELb{tall}ELb1ELb0EEv10ConvParams:"))
         end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
         body = lines[start:end]
         labels = {m.group(1): i for i, l in enumerate(body) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
