@@ -673,6 +673,11 @@ def main():
             "how": "HIP events on the launch stream around every launch of this kernel, second pass of the same K steps; "
                    "traffic = HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), read side x2 per "
                    "the gfx950 FETCH_SIZE correction",
+            # two per-launch figures exist and differ by method: THIS one (events around eager launches: each carries ~3 us of event
+            # and launch-gap overhead, so frac reads ~8 % low) and the rocprofv3 kernel trace of the graph-replayed step in profiles/
+            "authoritative": "profiles/<newest r*_summary.md>: rocprofv3 --kernel-trace avg duration of this kernel under graph replay "
+                             "(no per-launch events); 'achieved' / 'frac' in this line are the live HIP-event measurement the contract asks "
+                             "for and read ~8 % lower by method; by_shape has the same bias per shape",
         }
     if fp32_leg is not None:
         out["fp32_mode"] = fp32_leg

@@ -307,3 +307,15 @@ def test_launcher_script_uses_torchrun_and_keeps_peer_to_peer_on():
     assert any("HSA_ENABLE_IPC_MODE_LEGACY" in ln for ln in code)
     for stage in ("train_autoencoder.py", "train_diffusion.py"):
         assert any(stage in ln for ln in code) and os.path.exists(os.path.join(ROOT, stage))
+
+
+def test_launcher_refuses_shared_stage_flags_before_training_anything():
+    """`-s both` with trailing `-- flags` would hand the autoencoder stage's options to the diffusion stage's strict parser AFTER stage 1
+    has trained: the launcher refuses up front and names -A / -D; per-stage flags reach only their stage."""
+    import subprocess
+    path = os.path.join(ROOT, "train_LDM.sh")
+    r = subprocess.run(["bash", path, "-n", "1", "-s", "both", "--", "--no-images"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "-A" in r.stderr and "-D" in r.stderr, (r.returncode, r.stderr[-300:])
+    text = open(path).read()
+    assert "train_autoencoder.py $AE_FLAGS" in text and "train_diffusion.py $DM_FLAGS" in text
+    assert ">/dev/null" not in text.replace("2>/dev/null", "")          # a failing build must show its log
