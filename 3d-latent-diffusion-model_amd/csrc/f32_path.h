@@ -592,7 +592,18 @@ __global__ __launch_bounds__(256) void x3_phase_weights_kernel(const float* __re
 // A wave owns 32 queries; per 32-key tile  S^T = K Q^T  (32x32x2 MFMA over d) lands with the query on the lane and 16 of the 32 keys
 // in the lane's registers (the other 16 in lane ^ 32), so the softmax needs one cross-lane exchange per row statistic and P feeds
 // O^T += V^T P^T  as the B operand straight from those registers (k order permuted identically on the V^T operand).
-struct Attn32Params { const float* qkv; float* out; int B, N, C, heads, d; float scale; float* lse; };   // lse (optional): [B][heads][N] natural log-sum-exp of the scaled scores
+struct Attn32Params { const float* qkv; float* out; int B, N, C, heads, d; float scale; float* lse; int x3; };   // lse (optional): [B][heads][N] natural log-sum-exp of the scaled scores; x3: the 3 x bf16 form of both products (inference plans)
+
+// x = hi + lo with hi = bf16(x), lo = bf16(x - hi): |x - hi - lo| <= 2^-18 |x|.  Eight consecutive k of one MFMA operand row.
+__device__ __forceinline__ void split8_bf16(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
+    u32x4 h, l;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        h[q] = pack2bf(x[2 * q], x[2 * q + 1]);
+        l[q] = pack2bf(x[2 * q] - __uint_as_float(h[q] << 16), x[2 * q + 1] - __uint_as_float(h[q] & 0xffff0000u));
+    }
+    hi = __builtin_bit_cast(bf16x8, h); lo = __builtin_bit_cast(bf16x8, l);
+}
 
 template <int DT>                                        // DT = d / 32
 __global__ __launch_bounds__(256) void attn_f32_kernel(const Attn32Params p) {
@@ -690,7 +701,11 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const Attn32Params p) {
 // The same attention with the KEY range split over the workgroup's four waves (d <= 64): the plain kernel gives one wave per 32 queries,
 // i.e. 216 waves for 4 heads x 1728 tokens on a chip with 1024 SIMDs; here the four waves of a workgroup share the 32 queries, wave w
 // walks key tiles w, w + 4, ... with its own K / V images, and the (max, sum, O) partials are merged through LDS in a fixed order.
-template <int DT>
+// X3 (round 5, inference plans): both products as three bf16 MFMAs (32x32x16) on hi / lo splits of the fp32 operands -- hi*lo + lo*hi + hi*hi,
+// fp32 accumulate, the dropped lo*lo term is <= 2^-18 of the product -- instead of the 32x32x2 fp32 MFMA (1/16 of the bf16 rate): per
+// 32-key tile 12 + 12 MFMAs of 32 cycles instead of 32 + 32 of 64.  The softmax stays fp32; P is split in registers (the lane that holds a
+// query's 16 scores feeds them as the B operand with the k order (r & 3) + 8 (r >> 2) + 4 fh applied to the V^T operand as well).
+template <int DT, bool X3 = false>
 __global__ __launch_bounds__(256) void attn_f32_split_kernel(const Attn32Params p) {
     constexpr int D = DT * 32, LDQ = D + 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -731,6 +746,17 @@ __global__ __launch_bounds__(256) void attn_f32_split_kernel(const Attn32Params 
         }
     };
     if (wave < ntile) fetch(wave);
+    bf16x8 qh[X3 ? D / 16 : 1], ql[X3 ? D / 16 : 1];       // X3: this lane's Q fragments (query fr, k = 16 ks + 8 fh ..), split once
+    if constexpr (X3) {
+        __syncthreads();                                 // Q is in LDS
+#pragma unroll
+        for (int ks = 0; ks < D / 16; ++ks) {
+            float qx[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qx[j] = sQ[fr * LDQ + 16 * ks + 8 * fh + j];
+            split8_bf16(qx, qh[ks], ql[ks]);
+        }
+    }
     for (int it = 0; it < nround; ++it) {
         const int t = it * 4 + wave, k0 = t * 32;
         __syncthreads();                                 // Q written (first round) / the previous tile's reads are done
@@ -748,10 +774,23 @@ __global__ __launch_bounds__(256) void attn_f32_split_kernel(const Attn32Params 
         f32x16 s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        if constexpr (X3) {
+#pragma unroll
+            for (int ks = 0; ks < D / 16; ++ks) {
+                float kx[8]; bf16x8 kh, kl;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) kx[j] = sK[fr * LDQ + 16 * ks + 8 * fh + j];
+                split8_bf16(kx, kh, kl);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[ks], s, 0, 0, 0);       // small terms first
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[ks], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[ks], s, 0, 0, 0);
+            }
+        } else {
         const float* kq = sK + fr * LDQ + fh;
         const float* qq = sQ + fr * LDQ + fh;
 #pragma unroll 8
         for (int kk = 0; kk < D / 2; ++kk) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kq[2 * kk], qq[2 * kk], s, 0, 0, 0);
+        }
         float mx = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -771,11 +810,31 @@ __global__ __launch_bounds__(256) void attn_f32_split_kernel(const Attn32Params 
         for (int tt = 0; tt < DT; ++tt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[tt][r] *= alpha;
+        if constexpr (X3) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {             // k slot (ks, fh, j) <-> key (r & 3) + 8 (r >> 2) + 4 fh with r = 8 ks + j, on BOTH operands
+                float px[8]; bf16x8 ph, pl;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) px[j] = s[8 * ks + j];
+                split8_bf16(px, ph, pl);
+#pragma unroll
+                for (int tt = 0; tt < DT; ++tt) {
+                    float vx[8]; bf16x8 vh, vl;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { const int r = 8 * ks + j; vx[j] = sV[((r & 3) + 8 * (r >> 2) + 4 * fh) * LDQ + 32 * tt + fr]; }
+                    split8_bf16(vx, vh, vl);
+                    o[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, o[tt], 0, 0, 0);
+                    o[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, o[tt], 0, 0, 0);
+                    o[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, o[tt], 0, 0, 0);
+                }
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const float* vrow = sV + ((j & 3) + 8 * (j >> 2) + 4 * fh) * LDQ + fr;
 #pragma unroll
             for (int tt = 0; tt < DT; ++tt) o[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[32 * tt], s[j], o[tt], 0, 0, 0);
+        }
         }
     }
     // ---- merge the four waves' partials (waves 1..3 publish, wave 0 folds them in wave order: reproducible)
@@ -818,7 +877,11 @@ static hipError_t launch_attn_f32(const Attn32Params& p, hipStream_t s) {
     if (p.d <= 64 && p.N >= 128) {                        // key range split over the four waves of a workgroup
         const int lds = (32 + 4 * 64) * (p.d + 1) * 4;
         const dim3 grid((p.N + 31) / 32, p.heads, p.B);
-        if (p.d == 64) {
+        if (p.d == 64 && p.x3) {
+            static bool set64x = false;
+            if (!set64x) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f32_split_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e; set64x = true; }
+            hipLaunchKernelGGL((attn_f32_split_kernel<2, true>), grid, dim3(256), lds, s, p);
+        } else if (p.d == 64) {
             static bool set64 = false;
             if (!set64) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f32_split_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) return e; set64 = true; }
             hipLaunchKernelGGL(attn_f32_split_kernel<2>, grid, dim3(256), lds, s, p);

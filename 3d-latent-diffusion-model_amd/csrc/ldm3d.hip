@@ -1154,6 +1154,9 @@ struct Builder {
         Act o = new_act(x.N, x.D, x.H, x.W, C);
         Op at{}; at.kind = OP_ATTN32; at.r[0] = ws_ref(qkv.off); at.r[1] = ws_ref(o.off);
         at.i[0] = x.N; at.i[1] = x.D * x.H * x.W; at.i[2] = C; at.i[3] = C / head_ch; at.i[4] = head_ch; at.f[0] = 1.0f / sqrtf((float)head_ch);
+        // inference plans: QK^T and PV as 3 x bf16 MFMAs on hi / lo splits (f32_path.h, X3), like their convolutions; LDM_ATTN_X3=0: the exact fp32 MFMA
+        static const int attn_x3 = ldm_knob("LDM_ATTN_X3", 1);
+        at.i[5] = (!train && attn_x3 && ldm_knob("LDM_F32_X3", 1) != 0) ? 1 : 0;
         size_t lse_off = 0;
         if (train) {
             lse_off = pool.alloc((size_t)x.N * (C / head_ch) * at.i[1] * 4); at.r[2] = ws_ref(lse_off);
@@ -2319,7 +2322,7 @@ static int run_plan(const Plan& plan, const Bases& bs, const int* rt, hipStream_
                 break; }
             case OP_ATTN32: {
                 Attn32Params p{}; p.qkv = (const float*)rp(bs, o.r[0]); p.out = (float*)rp(bs, o.r[1]);
-                p.B = i[0]; p.N = i[1]; p.C = i[2]; p.heads = i[3]; p.d = i[4]; p.scale = o.f[0]; p.lse = (float*)rp(bs, o.r[2]);
+                p.B = i[0]; p.N = i[1]; p.C = i[2]; p.heads = i[3]; p.d = i[4]; p.scale = o.f[0]; p.lse = (float*)rp(bs, o.r[2]); p.x3 = i[5];
                 HIP_TRY(launch_attn_f32(p, s));
                 break; }
             case OP_GEMV32: {

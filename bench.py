@@ -345,6 +345,8 @@ def rccl_debug_digest(max_lines=40):
             key = re.sub(r"0x[0-9a-f]+|\b\d{5,}\b", "#", body)      # pointers / opCounts / big byte counts do not make a line new
             if "Bytes ->" in body:
                 key = body.split("Bytes ->", 1)[0].split()[-1] + body.split("Bytes ->", 1)[1]
+            elif re.match(r"Channel \d+/\d+", body):                 # one line per channel (128 of them at world 1): keep the first, count the rest
+                key = "Channel " + re.sub(r"^Channel \d+", "", body).split(":")[0]
             if key not in seen:
                 seen.add(key)
                 keep.append(body[:240])
