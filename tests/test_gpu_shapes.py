@@ -44,7 +44,11 @@ def test_unet_brats_latent_batch_independence(cuda):
         both32 = m(x=x, timesteps=t, cond=c)
         one32 = m(x=x[1:], timesteps=t[1:], cond=c[1:])
         zero32 = m(x=x[:1], timesteps=t[:1], cond=c[:1])
-    assert rel_l2(both32[1:], one32) < 2e-5 and rel_l2(both32[:1], zero32) < 2e-5
+    e1, e0 = rel_l2(both32[1:], one32), rel_l2(both32[:1], zero32)
+    print(f"fp32 mode, batch 2 vs batch 1 of the same samples: {e1:.2e} / {e0:.2e}")
+    # round 5: 5e-5 (was 2e-5, measured 1.9e-5 then): the inference plans' 3 x bf16 products (convolutions, and since round 5 the attention
+    # products) carry 2^-18 terms that a different split-K / tile decomposition sums in another order: measured 2.2e-5; the parity bar is 1e-3
+    assert e1 < 5e-5 and e0 < 5e-5, (e1, e0)
     assert rel_l2(both[1:], one32) < 8e-2                     # and the bf16 batch result sits within its floor of the fp32 one
 
 
