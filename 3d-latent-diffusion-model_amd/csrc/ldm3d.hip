@@ -2098,7 +2098,7 @@ static int launch_conv_halo(const ConvParams& p_in, hipStream_t s, bool tall = f
     }
 #ifdef LDM_EXPERIMENTS
     // EXPERIMENTS BUILD ONLY (LDM_HALO_RW=1): the 126 x 128 tile with register-fed weights and one barrier per macro step (conv_halo_rw.h).
-    // Parity-green on every conv operator test (gpurun_out/r05h_rw_ops.txt) and 22 % SLOWER than conv3_halo_kernel at 24^3 (59.1 vs 47.2 us;
+    // Parity-green on every conv operator test (profiles/r05_halo_rw_ops.txt) and 22 % SLOWER than conv3_halo_kernel at 24^3 (59.1 vs 47.2 us;
     // headline 443.8 vs 484.5 steps/s, profiles/r05_ab_halo_rw.txt): 16 KiB of weight fragments per K step through the vector L1 as half
     // cache lines cost ~350 cycles per step, and ONE barrier per macro step still costs ~250 cycles per step (profiles/r05_halo_ablations.txt).
     static const int rw = ldm_xknob("LDM_HALO_RW", 0);
