@@ -26,6 +26,7 @@
 #include "conv_igemm.h"
 #include "conv_halo.h"
 #ifdef LDM_EXPERIMENTS
+#include "conv_halo_pp.h"                // alternating K steps per wave group, one barrier per six K steps (experiments builds)
 #include "conv_halo_rw.h"                // register-fed weights: built, parity-green, slower
 #endif
 #include "conv_thin.h"
@@ -2101,6 +2102,20 @@ static int launch_conv_halo(const ConvParams& p_in, hipStream_t s, bool tall = f
     // Parity-green on every conv operator test (profiles/r05_halo_rw_ops.txt) and 22 % SLOWER than conv3_halo_kernel at 24^3 (59.1 vs 47.2 us;
     // headline 443.8 vs 484.5 steps/s, profiles/r05_ab_halo_rw.txt): 16 KiB of weight fragments per K step through the vector L1 as half
     // cache lines cost ~350 cycles per step, and ONE barrier per macro step still costs ~250 cycles per step (profiles/r05_halo_ablations.txt).
+    // LDM_HALO_PP=1: alternating K steps per wave group, one barrier per six K steps, weights as whole cache lines into registers
+    // (conv_halo_pp.h): parity-green, 1133 cycles per K step against 823 -- bound by the vector L1's ingest of the weights
+    // (profiles/r05_halo_pp_ablations.txt).  LDM_CONV_DBG bits 4 .. 256 pick its timing ablations.
+    static const int pp = ldm_xknob("LDM_HALO_PP", 0);
+    if (pp && !p.x3_n && !p.out_f32 && !p.out32 && !p.raw_partial && p.steps1 == 0 && p.CoutPad % 128 == 0 && (p.out || p.splitk > 1)) {
+#define PP_CASE(A) if ((p.dbg & 508) == A) { \
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_halo_pp_kernel<A>), hipFuncAttributeMaxDynamicSharedMemorySize, HPP_LDS)); \
+            hipLaunchKernelGGL((conv3_halo_pp_kernel<A>), dim3(tiles), dim3(512), HPP_LDS, s, p); return 0; }
+        PP_CASE(4) PP_CASE(16) PP_CASE(64) PP_CASE(20) PP_CASE(68) PP_CASE(84) PP_CASE(80) PP_CASE(128) PP_CASE(256) PP_CASE(384) PP_CASE(464) PP_CASE(400) PP_CASE(208)
+#undef PP_CASE
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_halo_pp_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, HPP_LDS));
+        hipLaunchKernelGGL((conv3_halo_pp_kernel<0>), dim3(tiles), dim3(512), HPP_LDS, s, p);
+        return 0;
+    }
     static const int rw = ldm_xknob("LDM_HALO_RW", 0);
     if (rw && !p.x3_n && !p.out_f32 && !p.out32 && !p.raw_partial && p.CoutPad % 128 == 0 && (p.out || p.splitk > 1)) {
         static bool rw_attr_tab[32] = {}; bool& rw_attr = attr_flag(rw_attr_tab);
