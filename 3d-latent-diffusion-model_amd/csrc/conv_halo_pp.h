@@ -40,7 +40,7 @@ constexpr int HPP_LDS = 65536 + 2 * HPP_TILE;
 static_assert(HPP_ROFF + 2048 <= 65536, "LDS layout");
 
 template <int ABL = 0>
-__global__ __launch_bounds__(512, 2) void conv3_halo_pp_kernel(const ConvParams p) {
+__global__ __launch_bounds__((ABL & 1024) ? 768 : 512, (ABL & 1024) ? 3 : 2) void conv3_halo_pp_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int BM = 128, TM = BM - 2, BN = 128, BK = 64, RB = 128;
     constexpr int AT = HPP_TILE;
@@ -50,7 +50,13 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_pp_kernel(const ConvParams 
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2, wn = wave & 3;                  // K-step group; 32-cout quarter of the tile
+    // ABL & 1024 (timing experiment, 768 threads): waves 8 - 11 are PRODUCERS, one per SIMD -- they issue every tile copy of the workgroup
+    // (a quarter each) plus, per K step, 4 more 1 KiB copies each out of the weight tensor into a scratch area (the 16 KiB of weights per
+    // step conv3_halo_kernel moves by LDS-DMA: 21.3 pieces per K step in all) and no MFMA; in the epilogue they shadow waves 0 - 3
+    constexpr bool PROD = (ABL & 1024) != 0;
+    const bool producer = PROD && wave >= 8;
+    const int cwave = producer ? wave - 8 : wave;
+    const int grp = cwave >> 2, wn = cwave & 3;                // K-step group; 32-cout quarter of the tile
     const int nwg = p.mtiles * p.ntiles * p.splitk;
     const int DHW = p.Dout * p.Hout * p.Wout, HW = p.Hout * p.Wout;
     const int nch = p.nchunk0, Q = 9 * nch;                    // macro steps: (kd, kh) x Cin chunk
@@ -94,6 +100,22 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_pp_kernel(const ConvParams 
     // the tile of macro step q0 + QREL -> LDS at byte offset DST (zeros when the step is outside the K range)
 #define PP_ISSUE_TILE(QREL, DST) do {                                                               \
         if (ABL & 256) break;                                                                       \
+        if (PROD) {                                                                                 \
+            if (producer) {                                                                         \
+                PP_PC(QREL)                                                                         \
+                const bool live_ = (q0 + (QREL) < q_end) && !(ABL & 4);                             \
+                const int pc_ = p_ < 9 ? p_ : 8;                                                    \
+                int v4_[4];                                                                         \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) v4_[j] = tab[pc_ * BM + (cwave * 4 + j) * 8 + prow]; \
+                __builtin_amdgcn_sched_barrier(0);                                                  \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                     \
+                    const int row_ = (cwave * 4 + j) * 8 + prow;                                    \
+                    const unsigned vo_ = (live_ && v4_[j] >= 0) ? (unsigned)v4_[j] * cin2 + (unsigned)((pchunk ^ (row_ & 7)) * 16) : 0xFFFFFFFFu; \
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr_t)(smem + (DST) + (cwave * 4 + j) * 1024), 16, vo_, (unsigned)__builtin_amdgcn_readfirstlane(c_ * (BK * 2)), 0, 0); \
+                }                                                                                   \
+            }                                                                                       \
+            break;                                                                                  \
+        }                                                                                           \
         PP_PC(QREL)                                                                                 \
         const bool live_ = (q0 + (QREL) < q_end) && !(ABL & 4);                                     \
         const int pc_ = p_ < 9 ? p_ : 8;                                                            \
@@ -120,6 +142,18 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_pp_kernel(const ConvParams 
         for (int a = 0; a < 12; ++a) wf[a / 4][(a >> 1) & 1][a & 1] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
     }
 #define PP_WLOAD(SET, QREL, KW) do {                                                                \
+        if (PROD) {                                            /* called 3 x per super step: 8 scratch copies each = 4 per K step */ \
+            if (producer && !(ABL & 2)) {                                                           \
+                PP_PC(QREL)                                                                         \
+                if (p_ > 8) p_ = 8;                                                                 \
+                _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                     \
+                    const unsigned so_ = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(p_ * 3 + (j % 3)) * wtap + (unsigned)c_ * (BK * 2))); \
+                    const unsigned vo_ = (ABL & 32) ? 0xFFFFFFFFu : (unsigned)(n0 + (cwave * 8 + j) * 8 + (lane >> 3)) * cin2 + (unsigned)((lane & 7) * 16); \
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(smem + 100 * 1024 + (cwave * 8 + j) * 1024), 16, vo_, so_, 0, 0); \
+                }                                                                                   \
+            }                                                                                       \
+            break;                                                                                  \
+        }                                                                                           \
         if (ABL & 128) break;                                                                       \
         PP_PC(QREL)                                                                                 \
         if (p_ > 8) p_ = 8;                                    /* past the end: a valid row, multiplied by a tile of zeros */ \
@@ -197,6 +231,7 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_pp_kernel(const ConvParams 
         if (!(ABL & 16)) _Pragma("unroll") for (int t = 0; t < 8; ++t) XF[t] = *(lds_frag_t)(unsigned)(pre[I][t] ^ ((KS) * 64)); \
     } while (0)
 #define PP_MFMA16(I, KS, XF) do {                                                                   \
+        if (PROD && producer) break;                                                                \
         if (!(ABL & 8)) _Pragma("unroll") for (int mt = 0; mt < 8; ++mt)                            \
             _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                        \
                 acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[I][nt][KS], XF[mt], acc[nt][mt], 0, 0, 0); \
@@ -255,7 +290,8 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_pp_kernel(const ConvParams 
         // in front of the LAST half step of the super step: this wave's fragment reads of the slot are complete and its copies of the next
         // tiles have landed (8 younger weight loads may stay in flight); behind the barrier that holds for every wave, so the first
         // fragments of the next super step are read from the other slot under the last 16 MFMAs
-        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        if (PROD) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");    /* producers: the tile copies landed, the 16 younger scratch copies fly */
+        else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
         if (!(ABL & 64)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         xslot ^= 0x10000;

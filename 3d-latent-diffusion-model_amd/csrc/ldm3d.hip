@@ -34,6 +34,7 @@
 #include "gemm_light_x3.h"
 #include "conv_block.h"
 #include "conv_wgrad.h"
+#include "conv_wgrad_kw3.h"            // 3^3 stride-1 weight gradient, three kw taps per workgroup over one shared X tile
 #include "norm_elem.h"
 #include "fin_gn.h"
 #include "f32_path.h"
@@ -2110,7 +2111,20 @@ static int launch_conv_halo(const ConvParams& p_in, hipStream_t s, bool tall = f
 #define PP_CASE(A) if ((p.dbg & 508) == A) { \
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_halo_pp_kernel<A>), hipFuncAttributeMaxDynamicSharedMemorySize, HPP_LDS)); \
             hipLaunchKernelGGL((conv3_halo_pp_kernel<A>), dim3(tiles), dim3(512), HPP_LDS, s, p); return 0; }
-        PP_CASE(4) PP_CASE(16) PP_CASE(64) PP_CASE(20) PP_CASE(68) PP_CASE(84) PP_CASE(80) PP_CASE(128) PP_CASE(256) PP_CASE(384) PP_CASE(464) PP_CASE(400) PP_CASE(208)
+        if (p.dbg & 1024) {                                  // producer-wave timing experiment: 12 waves, waves 8 - 11 issue every copy (results are wrong)
+            constexpr int LDSP = 100 * 1024 + 32 * 1024;
+            if (p.dbg & 32) {
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_halo_pp_kernel<1200>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSP));
+                hipLaunchKernelGGL((conv3_halo_pp_kernel<1200>), dim3(tiles), dim3(768), LDSP, s, p); return 0;
+            }
+            if (p.dbg & 2) {
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_halo_pp_kernel<1170>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSP));
+                hipLaunchKernelGGL((conv3_halo_pp_kernel<1170>), dim3(tiles), dim3(768), LDSP, s, p); return 0;
+            }
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_halo_pp_kernel<1168>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSP));
+            hipLaunchKernelGGL((conv3_halo_pp_kernel<1168>), dim3(tiles), dim3(768), LDSP, s, p); return 0;
+        }
+        PP_CASE(144) PP_CASE(4) PP_CASE(16) PP_CASE(64) PP_CASE(20) PP_CASE(68) PP_CASE(84) PP_CASE(80) PP_CASE(128) PP_CASE(256) PP_CASE(384) PP_CASE(464) PP_CASE(400) PP_CASE(208)
 #undef PP_CASE
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_halo_pp_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, HPP_LDS));
         hipLaunchKernelGGL((conv3_halo_pp_kernel<0>), dim3(tiles), dim3(512), HPP_LDS, s, p);
@@ -2164,9 +2178,25 @@ static int wgrad_pair(int taps, int cout, int cin, int stride, int ups, bool hp)
     if (cin > 64) return (y && on >= 3) ? 3 : 0;
     return y ? 2 : 1;
 }
+// conv_wgrad_kw3_kernel (three kw taps of a (kd, kh) per workgroup, 128 couts x 64 cins, one shared X tile): 3^3, stride 1, both channel
+// counts above 64 (below, the pair forms of conv_wgrad_kernel fill the tile better).  launch_wgrad also asks for pad 1 and W >= 8.
+// EXPERIMENTS BUILDS ONLY (LDM_WGRAD_KW3=1): parity-green on 11 operator cases and no faster (81.4 vs 83.8 us at 256 -> 256, 24^3): 24 % fewer
+// copied bytes per MFMA bought nothing because the step is a serial sum -- copies 500 + fragment reads 500 + masks 340 + barrier 250 +
+// MFMAs 900 cycles (profiles/r05_wgrad_kw3.txt), the copies at the ~145 cycles a wave needs to issue one 1 KiB LDS-DMA piece
+// (profiles/r05_producer_wave_experiment.txt).
+static bool wgrad_kw3(int taps, int cout, int cin, int stride, int ups, bool hp) {
+#ifdef LDM_EXPERIMENTS
+    static const int on = ldm_xknob("LDM_WGRAD_KW3", 0);
+    return on && !hp && taps == 27 && stride == 1 && ups == 0 && cin > 64 && cout > 64;
+#else
+    return false;
+#endif
+}
 static int wgrad_ksplit(long M, int taps, int cout, int cin, bool hp, int stride, int ups) {
     const int pm = wgrad_pair(taps, cout, cin, stride, ups, hp);
-    const long wgs = (long)(pm == 3 ? 2 * (taps / 3) : pm == 2 ? taps / 3 : pm == 1 ? (taps + 1) / 2 : taps) * ((cout + 127) / 128) * ((cin + 127) / 128);
+    const bool k3 = wgrad_kw3(taps, cout, cin, stride, ups, hp);
+    const long wgs = k3 ? 9L * ((cout + 127) / 128) * ((cin + 63) / 64)
+                        : (long)(pm == 3 ? 2 * (taps / 3) : pm == 2 ? taps / 3 : pm == 1 ? (taps + 1) / 2 : taps) * ((cout + 127) / 128) * ((cin + 127) / 128);
     const long steps = (M + 63) / 64;
     // tuning knob: workgroups aimed at (default: one round of 256 CUs; the fp32 kernel, latency bound on its operand loads, wants three per CU: 49.3 -> 46.6 ms per step)
     const long target = ldm_xknob("LDM_WGRAD_WGS", hp ? 768 : 256);
@@ -2188,6 +2218,21 @@ static int launch_wgrad(const WgradParams& p0, hipStream_t s) {
     if ((p.pair == 1 || p.pair == 2) && p.cx > 64) p.pair = 0;      // stored channels decide what fits a half row
     if (p.pair == 2 && p.cdy > 64) p.pair = 1;
     if (p.pair == 3 && p.cdy > 64) p.pair = 0;
+#ifdef LDM_EXPERIMENTS
+    if (p.pair == 0 && wgrad_kw3(taps_, p.Cout, p.Cin, p.stride, p.ups, false) && p.pad == 1 && p.Wout >= 8 && p.Dout == p.Din && p.Hout == p.Hin && p.Wout == p.Win) {
+        p.ci_tiles = (p.Cin + 63) / 64;
+        static bool attr3_tab[32] = {}; bool& attr3 = attr_flag(attr3_tab);
+        if (!attr3) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kw3_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, WG3_LDS)); attr3 = true; }
+        { const int dbg = (int)ldm_xknob("LDM_CONV_DBG", 0);  // timing ablations (results are wrong): 4 no copies, 8 no MFMAs, 16 no fragment reads, 32 no masks, 64 no per-step barrier
+#define W3_ABL(A) if (dbg == A) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kw3_kernel<A>), hipFuncAttributeMaxDynamicSharedMemorySize, WG3_LDS)); \
+          hipLaunchKernelGGL(conv_wgrad_kw3_kernel<A>, dim3(p.co_tiles * p.ci_tiles * 9 * p.ksplit), dim3(512), WG3_LDS, s, p); return 0; }
+          W3_ABL(4) W3_ABL(8) W3_ABL(16) W3_ABL(32) W3_ABL(64) W3_ABL(20) W3_ABL(52) W3_ABL(116) W3_ABL(48) W3_ABL(112) W3_ABL(96)
+#undef W3_ABL
+        }
+        hipLaunchKernelGGL(conv_wgrad_kw3_kernel<0>, dim3(p.co_tiles * p.ci_tiles * 9 * p.ksplit), dim3(512), WG3_LDS, s, p);
+        return 0;
+    }
+#endif
     const int tg_ = p.pair == 3 ? 2 * (taps_ / 3) : p.pair == 2 ? taps_ / 3 : p.pair ? (taps_ + 1) / 2 : taps_;
     constexpr int LDS = 4 * 2 * 64 * 256 + 3 * 256 * 4;        // ring + triple-buffered source-offset table (up to four sections)
     static bool attr_tab[32] = {}; bool& attr_set = attr_flag(attr_tab);   // per device

@@ -302,6 +302,21 @@ def test_conv_wgrad(cuda, built_lib, cin, cout, dims, k, stride, pad, n, ups):
     assert err <= 2e-5, err
 
 
+@pytest.mark.parametrize("cin,cout,dims,n,ksplit", [
+    (128, 256, (5, 7, 9), 2, 1), (192, 128, (4, 6, 8), 2, 2), (96, 160, (6, 6, 12), 1, 1), (256, 256, (12, 12, 12), 1, 3),
+    (128, 128, (2, 2, 8), 1, 1), (128, 128, (3, 3, 8), 2, 4), (160, 96, (3, 5, 17), 1, 2), (128, 128, (24, 24, 24), 1, 3),
+    (128, 128, (1, 1, 8), 1, 1), (128, 128, (4, 4, 64), 1, 1), (128, 128, (2, 2, 32), 3, 2)])
+def test_conv_wgrad_wide_channels_w_borders_and_splits(cuda, built_lib, cin, cout, dims, n, ksplit):
+    """3^3 stride-1 weight gradients with both channel counts above 64 (the UNet's 256 / 512-channel levels) over the shapes where a W-halo
+    form would have to get its border pairs right: W not a divisor of 64, W = 8, W = 64 and 32, batches (the voxel before sample n's first
+    is sample n - 1's last), voxel ranges that are no multiple of 64, splits that end up empty, channel counts that leave the last tile part
+    empty, volumes smaller than one K step.  The product library runs conv_wgrad_kernel on them; an experiments build with
+    LDM_WGRAD_KW3=1 runs conv_wgrad_kw3_kernel (three kw taps per workgroup over one shared X tile, csrc/conv_wgrad_kw3.h; no faster,
+    profiles/r05_wgrad_kw3.txt)."""
+    err = _wgrad_case(cuda, built_lib, cin, cout, dims, 3, 1, 1, n, 0, ksplit=ksplit)
+    assert err <= 2e-5, err
+
+
 @pytest.mark.parametrize("dims,n,ksplit", [((12, 12, 12), 1, 3), ((6, 6, 6), 1, 4), ((2, 2, 2), 2, 1), ((5, 3, 2), 1, 2), ((24, 24, 24), 1, 5)])
 def test_conv_wgrad_voxel_split_and_tiny_volumes(cuda, built_lib, dims, n, ksplit):
     """Voxel range split over workgroups (partial matrices summed by the caller), including splits that end up empty
