@@ -219,7 +219,17 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const ConvParams p) 
         __builtin_amdgcn_sched_barrier(0);                                                          \
         __builtin_amdgcn_s_waitcnt(0xC07F);                    /* fragments of step S have arrived */ \
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(vm_) : "memory");                                  \
-        if (!(ABL & 64)) __builtin_amdgcn_s_barrier();                                              \
+        if ((ABL & 384) == 384) {                              /* timing: a barrier with SLACK -- go on once every wave has reached step S - slack */ \
+            volatile int* const cnt_ = reinterpret_cast<volatile int*>(smem + TOFF + 9 * BM * 4);   \
+            if (lane == 0) cnt_[wave] = s + (J) + 1;                                                \
+            const int need_ = s + (J) + 1 - ((ABL & 1) ? 2 : 1);                                    \
+            for (int it_ = 0; it_ < 100000; ++it_) {                                                \
+                const int v_ = cnt_[lane & 7];                                                      \
+                if (__builtin_amdgcn_ballot_w64(v_ < need_) == 0) break;                            \
+                __builtin_amdgcn_s_sleep(1);                                                        \
+            }                                                                                       \
+        } else                                                                                      \
+        if (!(ABL & 64) && !((ABL & 128) && ((J) & 1)) && !((ABL & 256) && (J) % 3 != 0)) __builtin_amdgcn_s_barrier();   /* ABL 128 / 256: every 2nd / 3rd step only (timing) */ \
         asm volatile("" ::: "memory");                                                              \
         HL_ISSUE(kw_, (J));                                    /* step S+6 refills the weight slot of step S */ \
         HL_READ(WN, AN, ((J) + 1) % NSB, kn_);                                                      \

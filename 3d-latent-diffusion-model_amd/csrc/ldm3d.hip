@@ -2145,11 +2145,20 @@ static int launch_conv_halo(const ConvParams& p_in, hipStream_t s, bool tall = f
         return 0;
     }
 #endif
-    if (p.dbg & (4 | 8 | 16 | 32 | 64)) {                  // timing ablations (operator-level API + LDM_CONV_DBG only)
-#define ABL_CASE(A) if ((p.dbg & 124) == A) { \
+    if (p.dbg & (4 | 8 | 16 | 32 | 64 | 128 | 256)) {      // timing ablations (operator-level API + LDM_CONV_DBG only)
+#define ABL_CASE(A) if ((p.dbg & 508) == A) { \
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_halo_kernel<6, A>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); \
             hipLaunchKernelGGL((conv3_halo_kernel<6, A>), dim3(p.mtiles * p.ntiles * p.splitk), dim3(512), LDS, s, p); return 0; }
-        ABL_CASE(4) ABL_CASE(8) ABL_CASE(16) ABL_CASE(12) ABL_CASE(20) ABL_CASE(24) ABL_CASE(32) ABL_CASE(40) ABL_CASE(84) ABL_CASE(68) ABL_CASE(64)
+        if ((p.dbg & 508) == 384) {                            // barrier with slack 1 (dbg & 2048: slack 2): timing only, the ring protocol is NOT adapted
+            constexpr int LDSX = LDS + 64;
+            if (p.dbg & 2048) {
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_halo_kernel<6, 385>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSX));
+                hipLaunchKernelGGL((conv3_halo_kernel<6, 385>), dim3(p.mtiles * p.ntiles * p.splitk), dim3(512), LDSX, s, p); return 0;
+            }
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_halo_kernel<6, 384>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSX));
+            hipLaunchKernelGGL((conv3_halo_kernel<6, 384>), dim3(p.mtiles * p.ntiles * p.splitk), dim3(512), LDSX, s, p); return 0;
+        }
+        ABL_CASE(4) ABL_CASE(8) ABL_CASE(16) ABL_CASE(12) ABL_CASE(20) ABL_CASE(24) ABL_CASE(32) ABL_CASE(40) ABL_CASE(84) ABL_CASE(68) ABL_CASE(64) ABL_CASE(128) ABL_CASE(256)
 #undef ABL_CASE
     }
     if (loop) hipLaunchKernelGGL((conv3_halo_kernel<6, 0, false, true>), dim3(grid), dim3(512), LDS, s, p);
