@@ -34,6 +34,7 @@
 #include "gemm_light_x3.h"
 #include "conv_block.h"
 #include "conv_wgrad.h"
+#include "conv_wgrad_w16.h"            // sixteen-wave form of the weight gradient for the wide-channel convs
 #include "conv_wgrad_kw3.h"            // 3^3 stride-1 weight gradient, three kw taps per workgroup over one shared X tile
 #include "norm_elem.h"
 #include "fin_gn.h"
@@ -2238,6 +2239,12 @@ static int launch_wgrad(const WgradParams& p0, hipStream_t s) {
           W3_ABL(4) W3_ABL(8) W3_ABL(16) W3_ABL(32) W3_ABL(64) W3_ABL(20) W3_ABL(52) W3_ABL(116) W3_ABL(48) W3_ABL(112) W3_ABL(96)
 #undef W3_ABL
         }
+        if (ldm_xknob("LDM_WGRAD_KW3", 0) == 2) {           // sixteen-wave form
+            static bool attr3w_tab[32] = {}; bool& attr3w = attr_flag(attr3w_tab);
+            if (!attr3w) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kw3w16_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, WG3_LDS)); attr3w = true; }
+            hipLaunchKernelGGL(conv_wgrad_kw3w16_kernel<0>, dim3(p.co_tiles * p.ci_tiles * 9 * p.ksplit), dim3(1024), WG3_LDS, s, p);
+            return 0;
+        }
         hipLaunchKernelGGL(conv_wgrad_kw3_kernel<0>, dim3(p.co_tiles * p.ci_tiles * 9 * p.ksplit), dim3(512), WG3_LDS, s, p);
         return 0;
     }
@@ -2251,6 +2258,13 @@ static int launch_wgrad(const WgradParams& p0, hipStream_t s) {
           hipLaunchKernelGGL(conv_wgrad_kernel<A>, dim3(p.co_tiles * p.ci_tiles * tg_ * p.ksplit), dim3(512), LDS, s, p); return 0; }
       W1_ABL(4) W1_ABL(8) W1_ABL(16) W1_ABL(12) W1_ABL(20) W1_ABL(24)
 #undef W1_ABL
+    }
+    static const int w16 = ldm_knob("LDM_WGRAD_W16", 1);     // sixteen waves per workgroup where no several-taps form applies (conv_wgrad_w16.h)
+    if (w16 && p.pair == 0) {
+        static bool attr16_tab[32] = {}; bool& attr16 = attr_flag(attr16_tab);
+        if (!attr16) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_w16_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr16 = true; }
+        hipLaunchKernelGGL(conv_wgrad_w16_kernel<0>, dim3(p.co_tiles * p.ci_tiles * tg_ * p.ksplit), dim3(1024), LDS, s, p);
+        return 0;
     }
     hipLaunchKernelGGL(conv_wgrad_kernel<0>, dim3(p.co_tiles * p.ci_tiles * tg_ * p.ksplit), dim3(512), LDS, s, p);
     return 0;
