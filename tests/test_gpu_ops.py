@@ -293,11 +293,13 @@ def _wgrad_case(cuda, lib, cin, cout, dims, k, stride, pad, n=1, ups=0, seed=0, 
     (64, 64, (6, 6, 6), 3, 1, 1, 1, 0), (128, 256, (5, 7, 6), 3, 1, 1, 2, 0), (256, 128, (8, 8, 8), 1, 1, 0, 1, 0),
     (64, 64, (8, 8, 8), 3, 2, 1, 1, 0), (4, 64, (8, 8, 8), 3, 1, 1, 1, 0), (64, 4, (6, 6, 6), 3, 1, 1, 1, 0),
     (64, 64, (4, 4, 4), 3, 1, 1, 1, 1), (96, 160, (6, 6, 6), 3, 1, 1, 1, 0), (32, 160, (5, 7, 6), 3, 1, 1, 2, 0),
-    (128, 64, (6, 5, 7), 3, 1, 1, 2, 0), (160, 40, (4, 6, 9), 3, 1, 1, 1, 0)])
+    (128, 64, (6, 5, 7), 3, 1, 1, 2, 0), (160, 40, (4, 6, 9), 3, 1, 1, 1, 0),
+    (128, 160, (8, 8, 8), 3, 2, 1, 1, 0), (128, 128, (4, 4, 4), 3, 1, 1, 1, 1), (192, 128, (6, 6, 6), 1, 1, 0, 2, 0)])
 def test_conv_wgrad(cuda, built_lib, cin, cout, dims, k, stride, pad, n, ups):
     """fp32 output, fp32 accumulation over voxels: only summation order separates it from autograd.  The 3^3 cases with Cin <= 64 run
     the forms with several taps per workgroup (WgradParams::pair: 1 = taps (2 t, 2 t + 1) share a tile, the 27th tap's partner is empty;
-    2 = Cout <= 64 too: all three kw of a (kd, kh); 3 = Cout <= 64 < Cin, the last two cases: kw pairs through the shifted dY rows alone)."""
+    2 = Cout <= 64 too: all three kw of a (kd, kh); 3 = Cout <= 64 < Cin: kw pairs through the shifted dY rows alone).  Both channel counts above
+    64 (no several-taps form): the sixteen-wave kernel conv_wgrad_w16_kernel, here also at stride 2, behind a nearest upsample and as a 1x1."""
     err = _wgrad_case(cuda, built_lib, cin, cout, dims, k, stride, pad, n, ups)
     assert err <= 2e-5, err
 
