@@ -29,22 +29,10 @@ __global__ __launch_bounds__(1024, 4) void conv_wgrad_w16_kernel(const WgradPara
     const int ci_t = bid % p.ci_tiles; bid /= p.ci_tiles;
     const int co_t = bid % p.co_tiles; bid /= p.co_tiles;
     const int taps = p.ksize * p.ksize * p.ksize;
-    // workgroup-uniform: xpair = the cin half of the tile is the next tap (modes 1, 2), ypair = the cout half is the next voxel's dY (modes 2, 3)
-    constexpr bool pair = false, triple = false, ypair = false, ysolo = false;   // the several-taps-per-workgroup forms stay with conv_wgrad_kernel
-    // triple (Cout <= 64 too, stride 1, no upsample): the tile's couts 64 .. 127 are the dY rows of the NEXT voxel of the line (zero at the line's
-    // end), its cins (0 .. 63, 64 .. 127) the X rows of taps (kd, kh, 1) and (kd, kh, 2): quadrant (couts a, cins a) is tap kw = 1, (a, b) kw = 2 and
-    // (b, a) -- dY[m + 1] against X[src(m, kw = 1)] = dY[m'] against X[src(m', kw = 0)] -- kw = 0; (b, b) repeats kw = 1 and is dropped: one workgroup
-    // per (kd, kh), three quarters of the MFMAs useful
-    // mode 3 (Cout <= 64 < Cin, stride 1, no upsample): all 128 cins are real, two workgroups per (kd, kh): X rows of kw = 1 (quadrants a = kw 1,
-    // b = kw 0) and X rows of kw = 2 (a = kw 2; b would repeat kw 1 and is dropped)
-    const int tgroups = ysolo ? 2 * (taps / 3) : triple ? taps / 3 : pair ? (taps + 1) / 2 : taps;
-    const int tidx = bid % tgroups; const int split = bid / tgroups;
-    const int tap = ysolo ? 3 * (tidx >> 1) + 1 + (tidx & 1) : triple ? 3 * tidx + 1 : pair ? 2 * tidx : tidx;
+    const int tap = bid % taps; const int split = bid / taps;          // one tap per workgroup (the several-taps forms stay with conv_wgrad_kernel)
     const int kk = p.ksize * p.ksize;
     const int kd = tap / kk, kh = (tap - kd * kk) / p.ksize, kw = tap - kd * kk - kh * p.ksize;
-    const int tap2 = tap + 1;                                                          // pair / triple: the tap of the tile's cins 64 .. 127
-    const int kd2 = tap2 / kk, kh2 = (tap2 - kd2 * kk) / p.ksize, kw2 = tap2 - kd2 * kk - kh2 * p.ksize;
-    const int TABW = ypair ? 4 * KV : pair ? 3 * KV : 2 * KV;                         // table entries per buffer: dY rows, X rows (, X rows of tap2 (, dY rows one voxel on))
+    constexpr int TABW = 2 * KV;                                                       // table entries per buffer: dY rows, X rows
     const int DinU = p.Din << p.ups, HinU = p.Hin << p.ups, WinU = p.Win << p.ups;
     const int HWo = p.Hout * p.Wout, DHWo = p.Dout * HWo;
     const int steps_all = (p.M + KV - 1) / KV;
@@ -59,11 +47,8 @@ __global__ __launch_bounds__(1024, 4) void conv_wgrad_w16_kernel(const WgradPara
     //      K step is one basic block in which copies and fragment reads ride between the MFMAs.  Three table buffers: a fast
     //      wave may publish for step k + 1 while a slow one still reads the table of step k - 1.
     unsigned* const tab = reinterpret_cast<unsigned*>(smem + NS * STAGE);
-    const bool own_y2 = tid >= 3 * KV;                                                 // triple: dY rows shifted by one voxel along the line
-    const bool owner = tid < TABW, own_x = tid >= KV && !own_y2, own_x2 = tid >= 2 * KV && !own_y2;
-    const int own_row = own_y2 ? tid - 3 * KV : own_x2 ? tid - 2 * KV : own_x ? tid - KV : tid;
-    const int okd = own_x2 ? kd2 : kd, okh = own_x2 ? kh2 : kh, okw = own_x2 ? kw2 : kw;
-    const bool otap_ok = own_x2 ? tap2 < taps : true;
+    const bool owner = tid < TABW, own_x = tid >= KV;
+    const int own_row = own_x ? tid - KV : tid;
     int vw = 0, vh = 0, vd = 0, vn = 0, vm = s_begin * KV + own_row;
     if (owner) {
         int m = vm;
@@ -75,11 +60,10 @@ __global__ __launch_bounds__(1024, 4) void conv_wgrad_w16_kernel(const WgradPara
 #define WG_PUBLISH(PAR) do {                                                                                  \
         if (owner) {                                                                                          \
             unsigned off_ = 0xFFFFFFFFu;                                                                      \
-            if (own_y2) { if (vm + 1 < p.M && vw + 1 < p.Wout) off_ = (unsigned)(vm + 1) * (unsigned)(p.cdy * 2); } \
-            else if (!own_x) { if (vm < p.M) off_ = (unsigned)vm * (unsigned)(p.cdy * 2); }                   \
+            if (!own_x) { if (vm < p.M) off_ = (unsigned)vm * (unsigned)(p.cdy * 2); }                   \
             else {                                                                                            \
-                const int id = vd * p.stride + okd - p.pad, ih = vh * p.stride + okh - p.pad, iw = vw * p.stride + okw - p.pad; \
-                const bool ok_ = otap_ok & (vm < p.M) & ((unsigned)id < (unsigned)DinU) & ((unsigned)ih < (unsigned)HinU) & ((unsigned)iw < (unsigned)WinU); \
+                const int id = vd * p.stride + kd - p.pad, ih = vh * p.stride + kh - p.pad, iw = vw * p.stride + kw - p.pad; \
+                const bool ok_ = (vm < p.M) & ((unsigned)id < (unsigned)DinU) & ((unsigned)ih < (unsigned)HinU) & ((unsigned)iw < (unsigned)WinU); \
                 const int src_ = ((vn * p.Din + (id >> p.ups)) * p.Hin + (ih >> p.ups)) * p.Win + (iw >> p.ups); \
                 if (ok_) off_ = (unsigned)src_ * (unsigned)(p.cx * 2);                                        \
             }                                                                                                 \
@@ -91,51 +75,31 @@ __global__ __launch_bounds__(1024, 4) void conv_wgrad_w16_kernel(const WgradPara
         }                                                                                                     \
     } while (0)
 
-    // ---- loader lanes: each wave copies 2 pieces (4 voxel rows x 256 B) of the dY tile and 2 of the X tile per step.
+    // ---- loader lanes: each wave copies ONE piece (4 voxel rows x 256 B) of the dY tile and one of the X tile per step.
     // lane -> (row = lane / 16 inside the piece, physical 16-B chunk = lane % 16); 32-byte blocks are XOR-swizzled by
     // f(row) = (row & 3) + 4 * ((row >> 3) & 1) so the transposed reads below are bank-conflict free.
     const int prow = lane >> 4, pch = lane & 15;
-    int l_row[1], l_xsel[1], l_ysel[1]; unsigned l_ady[1], l_ax[1];     // voxel row inside the step, table sections of its X / dY row, channel byte added to the row offset (or OOB)
-#pragma unroll
-    for (int j = 0; j < 1; ++j) {
-        const int row = (wave + j) * 4 + prow;
-        const int f = (row & 3) + 4 * ((row >> 3) & 1);
+    const int l_row = wave * 4 + prow;                                   // voxel row inside the step
+    unsigned l_ady, l_ax;                                                // channel byte added to the row offset (or out of range)
+    {
+        const int f = (l_row & 3) + 4 * ((l_row >> 3) & 1);
         const unsigned kb = (unsigned)(((((pch >> 1) ^ f) << 1) | (pch & 1)) * 16);
-        l_row[j] = row;
-        l_ady[j] = ((unsigned)co_t * 256u + kb < (unsigned)p.cdy * 2u) ? (unsigned)co_t * 256u + kb : 0xFFFFFFFFu;
-        l_ax[j] = ((unsigned)ci_t * 256u + kb < (unsigned)p.cx * 2u) ? (unsigned)ci_t * 256u + kb : 0xFFFFFFFFu;
-        l_xsel[j] = KV;
-        if (pair) {                              // bytes 128 .. 255 of the tile row = channels 0 .. 63 of the X row of tap2
-            const unsigned kbx = kb & 127u;
-            l_ax[j] = kbx < (unsigned)p.cx * 2u ? kbx : 0xFFFFFFFFu;
-            l_xsel[j] = kb >= 128u ? 2 * KV : KV;
-        }
-        l_ysel[j] = 0;
-        if (ypair) {                            // bytes 128 .. 255 of the dY tile row = couts 0 .. 63 of the next voxel's dY row
-            const unsigned kby = kb & 127u;
-            l_ady[j] = kby < (unsigned)p.cdy * 2u ? kby : 0xFFFFFFFFu;
-            l_ysel[j] = kb >= 128u ? 3 * KV : 0;
-        }
+        l_ady = ((unsigned)co_t * 256u + kb < (unsigned)p.cdy * 2u) ? (unsigned)co_t * 256u + kb : 0xFFFFFFFFu;
+        l_ax = ((unsigned)ci_t * 256u + kb < (unsigned)p.cx * 2u) ? (unsigned)ci_t * 256u + kb : 0xFFFFFFFFu;
     }
     __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (int)((unsigned)p.M * (unsigned)p.cdy * 2u), 0x00020000);
     __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
         (void*)p.x, 0, (int)((unsigned)(p.N * p.Din * p.Hin * p.Win) * (unsigned)p.cx * 2u), 0x00020000);
     int ld_s = 0;
 
-    // table reads of one step's four copies (issued ahead of the waits), then the copies themselves
-#define WG_TAB(T, PAR) do {                                                                                   \
-        _Pragma("unroll") for (int j = 0; j < 1; ++j) {                                                       \
-            T[2 * j] = tab[(PAR) * TABW + l_ysel[j] + l_row[j]]; T[2 * j + 1] = tab[(PAR) * TABW + l_xsel[j] + l_row[j]]; \
-        }                                                                                                     \
-    } while (0)
+    // table reads of one step's two copies (issued ahead of the waits), then the copies themselves
+#define WG_TAB(T, PAR) do { T[0] = tab[(PAR) * TABW + l_row]; T[1] = tab[(PAR) * TABW + KV + l_row]; } while (0)
 #define WG_COPIES(T) do {                                                                                     \
         char* st_ = smem + (ld_s % NS) * STAGE;                                                               \
-        _Pragma("unroll") for (int j = 0; j < 1; ++j) {                                                       \
-            const unsigned vo_dy = ((T[2 * j] == 0xFFFFFFFFu) | (l_ady[j] == 0xFFFFFFFFu)) ? 0xFFFFFFFFu : T[2 * j] + l_ady[j]; \
-            const unsigned vo_x = ((T[2 * j + 1] == 0xFFFFFFFFu) | (l_ax[j] == 0xFFFFFFFFu)) ? 0xFFFFFFFFu : T[2 * j + 1] + l_ax[j]; \
-            if (!(ABL1 & 4)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, (lds_ptr_t)(st_ + (wave + j) * 1024), 16, vo_dy, 0, 0, 0); \
-            if (!(ABL1 & 4)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(st_ + KV * TR + (wave + j) * 1024), 16, vo_x, 0, 0, 0); \
-        }                                                                                                     \
+        const unsigned vo_dy = ((T[0] == 0xFFFFFFFFu) | (l_ady == 0xFFFFFFFFu)) ? 0xFFFFFFFFu : T[0] + l_ady; \
+        const unsigned vo_x = ((T[1] == 0xFFFFFFFFu) | (l_ax == 0xFFFFFFFFu)) ? 0xFFFFFFFFu : T[1] + l_ax;    \
+        if (!(ABL1 & 4)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, (lds_ptr_t)(st_ + wave * 1024), 16, vo_dy, 0, 0, 0); \
+        if (!(ABL1 & 4)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(st_ + KV * TR + wave * 1024), 16, vo_x, 0, 0, 0); \
         ++ld_s;                                                                                               \
     } while (0)
 
@@ -189,7 +153,7 @@ __global__ __launch_bounds__(1024, 4) void conv_wgrad_w16_kernel(const WgradPara
         if (dbgf & 2048) asm volatile("s_nop 0");              /* opaque branch: one basic block per step */ \
         WG_PUBLISH(((S) + NS + 1) % 3);                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                          \
-        unsigned t_[4];                                                                             \
+        unsigned t_[2];                                                                             \
         WG_TAB(t_, ((S) + NS) % 3);                            /* published one barrier ago: readable ahead of the waits */ \
         __builtin_amdgcn_s_waitcnt(0xC07F);                    /* fragments of step S, table values, own table write retired */ \
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF - 1) * LPS) : "memory");                       \
@@ -217,7 +181,7 @@ __global__ __launch_bounds__(1024, 4) void conv_wgrad_w16_kernel(const WgradPara
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                   \
             __builtin_amdgcn_s_barrier();                                                           \
             asm volatile("" ::: "memory");                                                          \
-            if (ld_s < nsteps) { unsigned t_[4]; WG_TAB(t_, ((S) + NS) % 3); WG_COPIES(t_); }       \
+            if (ld_s < nsteps) { unsigned t_[2]; WG_TAB(t_, ((S) + NS) % 3); WG_COPIES(t_); }       \
             WG_READ(AN, BN, ((S) + 1) % NS);                                                        \
             WG_PUBLISH(((S) + NS + 1) % 3);                                                         \
         }                                                                                           \
@@ -229,7 +193,7 @@ __global__ __launch_bounds__(1024, 4) void conv_wgrad_w16_kernel(const WgradPara
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
-        if (i < nsteps) { unsigned t_[4]; WG_TAB(t_, i % 3); WG_COPIES(t_); }
+        if (i < nsteps) { unsigned t_[2]; WG_TAB(t_, i % 3); WG_COPIES(t_); }
         __syncthreads();                                       // table #i read by every wave
         WG_PUBLISH((i + 1) % 3);                               // #1 .. #NS
         __syncthreads();
@@ -273,11 +237,7 @@ __global__ __launch_bounds__(1024, 4) void conv_wgrad_w16_kernel(const WgradPara
     __syncthreads();
     if (grp == 0) {
         // accumulator: col = lane & 15 -> cin, row = 4 fg + r -> cout
-        int tap_w = pair ? tap + wb : tap;                     // pair mode: the cin half of the tile is the second tap
-        if (triple) { if (wa == 1 && wb == 1) return; if (wa == 1) tap_w = tap - 1; }   // (b, a) = kw 0; (b, b) repeats kw 1
-        if (ysolo && wa == 1) { if (tidx & 1) return; tap_w = tap - 1; }                // X of kw 1: b = kw 0; X of kw 2: b repeats kw 1
-        if (tap_w >= taps) return;
-        const size_t tap_off = (size_t)split * p.slab_stride + (size_t)tap_w * p.Cout * p.dw_ld + p.dw_ci_off;
+        const size_t tap_off = (size_t)split * p.slab_stride + (size_t)tap * p.Cout * p.dw_ld + p.dw_ci_off;
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
