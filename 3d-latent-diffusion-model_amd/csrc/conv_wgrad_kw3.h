@@ -330,6 +330,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kw3_kernel(const WgradParam
 
 // ---- sixteen-wave form: wave = (K group of 2) x (cout quarter of 4: 32 couts) x (cin half of 2: 32 cins) x 3 kw, 48 accumulator registers,
 //      four waves per SIMD: a wave issues 1 - 2 copies, 20 fragment reads and 12 MFMAs per K step (conv_wgrad_w16.h says why)
+//      ONE fragment set (the reads of step s + 1 follow the MFMAs of step s; two sets spill 155 registers at the 128 a wave has here).
+//      MEASURED (profiles/r05_wgrad_w16.txt): parity-green, 90.6 us against the eight-wave form's 80.5 at 256 -> 256, 24^3: slower.  LDM_WGRAD_KW3=2.
 template <int ABL1 = 0>
 __global__ __launch_bounds__(1024, 4) void conv_wgrad_kw3w16_kernel(const WgradParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
